@@ -1,0 +1,394 @@
+"""TEST INFRASTRUCTURE — CPU oracle (NumPy, float64) for the wind-farm step hot path.
+
+This file is the checker, never the product: only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import it.  The product path
+(wfcrl-env_amd/) must never import anything under oracle/.
+
+What it restates
+----------------
+One farm step of the reference's FLORIS backend:
+  reference wfcrl/interface.py:557-586  FlorisInterface.update_command
+  reference wfcrl/interface.py:622-623  avg_powers        -> fi.get_turbine_powers()
+  reference wfcrl/interface.py:629-637  local_load_proxies
+  reference wfcrl/interface.py:639-648  local_wind_measurements
+  reference wfcrl/interface.py:663-671  update_wind       (wd % 360)
+The arithmetic behind `fi.calculate_wake` lives in the third-party package
+FLORIS==3.5 (reference requirements.txt:8), which is NOT vendored under
+/root/reference and not installable here.  Its published algorithm — the
+sequential Gauss-Curl-Hybrid solver configured by
+reference wfcrl/simulators/floris/inputs/template/case.yaml:14-89 — is restated
+below following SURVEY.md Appendix A (sections cited per function as [A.x]).
+
+Parity pin
+----------
+PINNED (yaw = 0 only): the single known-answer vector the reference holds,
+reference examples/demo.ipynb:137-139 (Ablaincourt, ws 6.48958384,
+wd 266.363907, yaw 0) -> 7 local wind speeds + 7 local wind directions, is
+reproduced to <= 1e-8 relative (tests/test_oracle_kat.py).
+PARITY UNPINNED beyond that: the reference has no tests and no other stored
+outputs; yaw != 0 results, powers, load proxies and the Ct/Cp table outside
+4.5-6.5 m/s rest on this restatement alone.
+
+Layout conventions: all per-turbine grids are (N, 3, 3) arrays indexed
+[turbine, j (lateral, y), k (vertical, z)]  [A.1-3].
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# Model constants  (reference case.yaml:14-89 + FLORIS turbine library `nrel_5MW`, [A.5])
+# --------------------------------------------------------------------------------------
+
+# nrel_5MW power/thrust table [A.5]: values from 3.0 m/s in 0.5 m/s steps.
+_CT_FROM_3 = [
+    0.99, 0.99, 0.97373036, 0.92826162, 0.89210543, 0.86100905, 0.835423, 0.81237673,
+    0.79225789, 0.77584769, 0.7629228, 0.76156073, 0.76261984, 0.76169723, 0.75232027,
+    0.74026851, 0.72987175, 0.70701647, 0.54054532, 0.45509459, 0.39343381, 0.34250785,
+    0.30487242, 0.27164979, 0.24361964, 0.21973831, 0.19918151, 0.18131868, 0.16537679,
+    0.15103727, 0.13998636, 0.1289037, 0.11970413, 0.11087113, 0.10339901, 0.09617888,
+    0.09009926, 0.08395078, 0.0791188, 0.07448356, 0.07050731, 0.06684119, 0.06345518,
+    0.06032267, 0.05741999,
+]
+_CP_FROM_3 = [
+    0.1780851, 0.28907459, 0.34902166, 0.3847278, 0.40605878, 0.4202279, 0.42882274,
+    0.43387274, 0.43622267, 0.43684468, 0.43657497, 0.43651053, 0.4365612, 0.43651728,
+    0.43590309, 0.43467276, 0.43322955, 0.43003137, 0.37655587, 0.33328466, 0.29700574,
+    0.26420779, 0.23839379, 0.21459275, 0.19382354, 0.1756635, 0.15970926, 0.14561785,
+    0.13287856, 0.12130194, 0.11219941, 0.10311631, 0.09545392, 0.08813781, 0.08186763,
+    0.07585005, 0.07071926, 0.06557558, 0.06148104, 0.05755207, 0.05413366, 0.05097969,
+    0.04806545, 0.04536883, 0.04287006,
+]
+# wind-speed knots: 0, 2, 2.5 (zeros: below cut-in), 3.0 ... 25.0, then the cut-out tail.
+# The tail (25.01, 25.02, 50.0 -> 0) is [unpinned] in SURVEY A.5; kept as DATA.
+TABLE_WS = [0.0, 2.0, 2.5] + [3.0 + 0.5 * i for i in range(45)] + [25.01, 25.02, 50.0]
+TABLE_CT = [0.0, 0.0, 0.0] + _CT_FROM_3 + [0.0, 0.0, 0.0]
+TABLE_CP = [0.0, 0.0, 0.0] + _CP_FROM_3 + [0.0, 0.0, 0.0]
+
+
+@dataclass
+class ModelParams:
+    """All constants of the path [SURVEY §8 a10]."""
+
+    # solver / flow field (case.yaml:14-16, 30-39)
+    grid: int = 3
+    air_density: float = 1.225
+    ambient_ti: float = 0.06
+    shear: float = 0.12
+    veer: float = 0.0
+    # turbine nrel_5MW
+    D: float = 126.0
+    HH: float = 90.0
+    TSR: float = 8.0
+    pP: float = 1.88
+    pT: float = 1.88
+    gen_eff: float = 1.0
+    ref_density: float = 1.225
+    # gauss velocity + deflection (case.yaml:52-59, 76-80)
+    alpha: float = 0.58
+    beta: float = 0.077
+    ka: float = 0.38
+    kb: float = 0.004
+    ad: float = 0.0
+    bd: float = 0.0
+    dm: float = 1.0
+    # crespo-hernandez (case.yaml:84-89)
+    ch_initial: float = 0.1
+    ch_constant: float = 0.5
+    ch_ai: float = 0.8
+    ch_downstream: float = -0.32
+    # GCH internals [A.3]
+    eps_gain: float = 0.2
+    num_eps: float = 0.001
+    kappa: float = 0.41
+    gch_gain: float = 2.0
+    overlap_thresh: float = 0.05
+    near_wake_c: float = 0.501
+    # tables
+    table_ws: list = field(default_factory=lambda: list(TABLE_WS))
+    table_ct: list = field(default_factory=lambda: list(TABLE_CT))
+    table_cp: list = field(default_factory=lambda: list(TABLE_CP))
+
+    def power_table(self) -> np.ndarray:
+        """P_tab[m] = 1/2 * A * Cp[m] * eta * ws[m]^3   [A.4] (interpolated on POWER, not Cp)."""
+        ws = np.asarray(self.table_ws, dtype=np.float64)
+        cp = np.asarray(self.table_cp, dtype=np.float64)
+        area = math.pi * (self.D / 2.0) ** 2
+        return 0.5 * area * cp * self.gen_eff * ws**3
+
+
+def cosd(a):
+    return np.cos(np.radians(a))
+
+
+def sind(a):
+    return np.sin(np.radians(a))
+
+
+def _interp_fill(xq, xs, ys, lo, hi):
+    """scipy interp1d(linear, bounds_error=False, fill_value=(lo, hi)) equivalent."""
+    xs = np.asarray(xs, dtype=np.float64)
+    ys = np.asarray(ys, dtype=np.float64)
+    out = np.interp(xq, xs, ys)
+    out = np.where(xq < xs[0], lo, out)
+    out = np.where(xq > xs[-1], hi, out)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Geometry  [A.1]
+# --------------------------------------------------------------------------------------
+
+def rotate_layout(x, y, wd):
+    """Rotate the layout so the wind comes from -x (FLORIS `rotate_coordinates_rel_west`) [A.1-1]."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    dev = ((wd - 270.0) % 360.0 + 360.0) % 360.0
+    xc = (x.min() + x.max()) / 2.0
+    yc = (y.min() + y.max()) / 2.0
+    xo, yo = x - xc, y - yc
+    xr = xo * cosd(dev) - yo * sind(dev) + xc
+    yr = xo * sind(dev) + yo * cosd(dev) + yc
+    return xr, yr
+
+
+def sort_order(xr):
+    """Ascending x' [A.1-2].  FLORIS uses np.argsort default (ties implementation-defined);
+    this restatement fixes ties by original index (stable), and the HIP path does the same."""
+    return np.argsort(xr, kind="stable")
+
+
+# --------------------------------------------------------------------------------------
+# One farm step
+# --------------------------------------------------------------------------------------
+
+def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=False):
+    """One steady-state solve + measurement extraction for ONE farm.
+
+    x, y : (N,) layout [m];  ws [m/s];  wd [deg, meteorological];  yaw : (N,) absolute deg.
+    Returns dict with per-turbine (original order):
+      power [W], wind_speed [m/s], wind_direction [deg], load (N,4) = (TI, std u, std v, std w).
+    """
+    p = p or ModelParams()
+    assert p.grid == 3
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    yaw = np.asarray(yaw, dtype=np.float64)
+    N = x.shape[0]
+    D, HH, R = p.D, p.HH, p.D / 2.0
+    wd = wd % 360.0  # reference interface.py:664
+
+    # ---- geometry [A.1]
+    xr, yr = rotate_layout(x, y, wd)
+    order = sort_order(xr)
+    xs, ys, yaws = xr[order], yr[order], yaw[order]
+    off = np.linspace(-D / 4.0, D / 4.0, 3)  # radius_ratio 0.5 * R
+    X = np.broadcast_to(xs[:, None, None], (N, 3, 3)).copy()
+    Y = np.broadcast_to(ys[:, None, None] + off[None, :, None], (N, 3, 3)).copy()
+    Z = np.broadcast_to(HH + off[None, None, :], (N, 3, 3)).copy()
+
+    # ---- inflow [A.2]
+    Uinit = ws * (Z / HH) ** p.shear
+    dUdz = ws * p.shear * (1.0 / HH) ** p.shear * Z ** (p.shear - 1.0)
+    Uinf = Uinit.mean()
+    U = Uinit.copy()
+    V = np.zeros((N, 3, 3))
+    W = np.zeros((N, 3, 3))
+    wake = np.zeros((N, 3, 3))
+    TI = np.full((N, 3, 3), p.ambient_ti)
+
+    eps = p.eps_gain * D
+    vel_top = ((HH + R) / HH) ** p.shear
+    vel_bot = ((HH - R) / HH) ** p.shear
+    two_pi = 2.0 * np.pi
+    sqrt2 = np.sqrt(2.0)
+
+    def gamma(vel, ct):
+        return (np.pi / 8.0) * D * vel * Uinf * ct
+
+    def vortex(G, yL, zc, decay=1.0):
+        r = yL**2 + zc**2
+        core = 1.0 - np.exp(-r / eps**2)
+        k = G / (two_pi * r) * core * decay
+        return k * zc, -k * yL  # (v, w) of a REAL vortex; mirrors flip both signs
+
+    for i in range(N):
+        x_i, y_i = xs[i], ys[i]
+        g = yaws[i]
+        cg = cosd(g)
+
+        # 1. Ct / induction [A.3-1]
+        ubar = np.cbrt(np.mean(U[i] ** 3))
+        ct_tab = float(_interp_fill(ubar, p.table_ws, p.table_ct, 0.0001, 0.9999))
+        ct_tab = min(max(ct_tab, 0.0001), 0.9999)
+        ct = ct_tab * cg
+        a = 0.5 / cg * (1.0 - np.sqrt(1.0 - ct * cg))
+
+        G_wr = 0.25 * two_pi * D * (a - a * a) * ubar / p.TSR
+
+        # 2. secondary steering [A.3-2]  (own 9 points, no decay, no mirrors, no sin*cos)
+        yL_own = (Y[i] - y_i) + p.num_eps
+        v_top = np.mean(vortex(gamma(vel_top, ct), yL_own, Z[i] - (HH + R) + p.num_eps)[0])
+        v_bot = np.mean(vortex(-gamma(vel_bot, ct), yL_own, Z[i] - (HH - R) + p.num_eps)[0])
+        v_core = np.mean(vortex(G_wr, yL_own, Z[i] - HH + p.num_eps)[0])
+        val = 2.0 * (np.mean(V[i]) - v_core) / (v_top + v_bot)
+        val = min(max(val, -1.0), 1.0)
+        g_eff = g + np.degrees(0.5 * np.arcsin(val))
+
+        TI_i = TI[i][None, :, :]  # per grid point (j,k), broadcast against every target
+
+        # 3. deflection [A.3-3]  (uses -g_eff and TI BEFORE mixing)
+        gd = -g_eff
+        cgd = cosd(gd)
+        s_cc = np.sqrt(1.0 - ct * cgd)
+        s_c = np.sqrt(1.0 - ct)
+        uR = Uinit * ct * cgd / (2.0 * (1.0 - s_cc))
+        u0 = Uinit * s_c
+        x0 = D * cgd * (1.0 + s_cc) / (sqrt2 * (4.0 * p.alpha * TI_i + 2.0 * p.beta * (1.0 - s_c))) + x_i
+        ky = p.ka * TI_i + p.kb
+        kz = p.ka * TI_i + p.kb
+        C0 = 1.0 - u0 / Uinit
+        M0 = C0 * (2.0 - C0)
+        E0 = C0**2 - 3.0 * np.exp(1.0 / 12.0) * C0 + 3.0 * np.exp(1.0 / 3.0)
+        sz0 = D * 0.5 * np.sqrt(uR / (Uinit + u0))
+        sy0 = sz0 * cgd * cosd(p.veer)
+        th0 = p.dm * (0.3 * np.radians(gd) / cgd) * (1.0 - s_cc)
+        d0 = np.tan(th0) * (x0 - x_i)
+        lin = p.ad + p.bd * (X - x_i)
+        d_near = ((X - x_i) / (x0 - x_i)) * d0 + lin
+        d_near = d_near * (X >= x_i) * (X <= x0)
+        sy = np.where(X >= x0, ky * (X - x0) + sy0, sy0)
+        sz = np.where(X >= x0, kz * (X - x0) + sz0, sz0)
+        s = np.sqrt(sy * sz / (sy0 * sz0))
+        sM = np.sqrt(M0)
+        with np.errstate(all="ignore"):
+            ln_arg = ((1.6 + sM) * (1.6 * s - sM)) / ((1.6 - sM) * (1.6 * s + sM))
+            d_far = d0 + th0 * E0 / 5.2 * np.sqrt(sy0 * sz0 / (ky * kz * M0)) * np.log(ln_arg) + lin
+        d_far = np.where(X > x0, d_far, 0.0)
+        delta = d_near + d_far
+
+        # 4. transverse velocities over ALL targets [A.3-4]  (commanded yaw, sign not flipped)
+        sc = sind(g) * cg
+        G_t = sc * gamma(vel_top, ct)
+        G_b = -sc * gamma(vel_bot, ct)
+        dx = X - x_i
+        yL = (Y - y_i) + p.num_eps
+        lm = p.kappa * Z / (1.0 + p.kappa * Z / (D / 8.0))
+        nu = lm**2 * np.abs(dUdz)
+        with np.errstate(all="ignore"):
+            decay = eps**2 / (4.0 * nu * dx / Uinf + eps**2)
+        vw = np.zeros((N, 3, 3))
+        ww = np.zeros((N, 3, 3))
+        for G, h in ((G_t, HH + R), (G_b, HH - R), (G_wr, HH)):
+            v, w = vortex(G, yL, Z - h + p.num_eps, decay)
+            vw += v
+            ww += w
+            v, w = vortex(G, yL, Z + h + p.num_eps, decay)  # ground mirror: both signs flip
+            vw -= v
+            ww -= w
+        vw = np.where(dx < 0.0, 0.0, vw)
+        ww = np.where(dx < 0.0, 0.0, ww)
+        ww = np.where(ww < 0.0, 0.0, ww)  # quirk (5) [A.6]
+
+        # 5. yaw-added recovery [A.3-5]
+        I = TI[i, 0, 0]
+        k_tke = (ubar * I) ** 2 / (2.0 / 3.0)
+        vbar = np.mean(V[i] + vw[i])
+        wbar = np.mean(W[i] + ww[i])
+        I_tot = np.sqrt((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar**2 + wbar**2)) / ubar
+        I_mix = I_tot - I
+        TI[i] = TI[i] + p.gch_gain * I_mix
+        TI_i = TI[i][None, :, :]
+
+        # 6. velocity deficit [A.3-6]  (uses -g commanded and TI AFTER mixing)
+        gv = -g
+        cgv = cosd(gv)
+        uR = Uinit * ct / (2.0 * (1.0 - s_c))
+        u0 = Uinit * s_c
+        sz0 = D * 0.5 * np.sqrt(uR / (Uinit + u0))
+        sy0 = sz0 * cgv * cosd(p.veer)
+        x0 = D * cgv * (1.0 + s_c) / (sqrt2 * (4.0 * p.alpha * TI_i + 2.0 * p.beta * (1.0 - s_c))) + x_i
+        near = (X > x_i + 0.1) & (X < x0)
+        far = X >= x0
+
+        def r_and_C(sy, sz):
+            r = (Y - y_i - delta) ** 2 / (2.0 * sy**2) + (Z - HH) ** 2 / (2.0 * sz**2)
+            dd = np.clip(1.0 - ct * cgv / (8.0 * sy * sz / (D * D)), 0.0, 1.0)
+            return r, 1.0 - np.sqrt(dd)
+
+        deficit = np.zeros((N, 3, 3))
+        with np.errstate(all="ignore"):
+            up = (X - x_i) / (x0 - x_i)
+            dn = (x0 - X) / (x0 - x_i)
+            sy = dn * p.near_wake_c * D * np.sqrt(ct / 2.0) + up * sy0
+            sz = dn * p.near_wake_c * D * np.sqrt(ct / 2.0) + up * sz0
+            r, C = r_and_C(sy, sz)
+            deficit += np.where(near, C * np.exp(-r), 0.0)
+            ky = p.ka * TI_i + p.kb
+            sy = ky * (X - x0) + sy0
+            sz = ky * (X - x0) + sz0
+            r, C = r_and_C(sy, sz)
+            deficit += np.where(far, C * np.exp(-r), 0.0)
+
+        # 7. SOSFS combination [A.3-7]
+        wake = np.hypot(wake, deficit * Uinit)
+
+        # 8. Crespo-Hernandez wake-added turbulence with overlap gating [A.3-8]
+        upm = (dx <= 0.1).astype(np.float64)
+        dnm = (dx > -0.1).astype(np.float64)
+        dxp = dx * dnm + upm
+        with np.errstate(all="ignore"):
+            ti = p.ch_constant * a**p.ch_ai * p.ambient_ti**p.ch_initial * (dxp / D) ** p.ch_downstream * dnm
+        ti = np.nan_to_num(ti, posinf=0.0)
+        overlap = np.sum(deficit * Uinit > p.overlap_thresh, axis=(1, 2)) / 9.0
+        ti_added = overlap[:, None, None] * ti * (X > x_i) * (np.abs(y_i - Y) < 2.0 * D) * (X <= x_i + 15.0 * D)
+        TI = np.maximum(np.sqrt(ti_added**2 + p.ambient_ti**2), TI)
+
+        # 9. field update [A.3-9]
+        U = Uinit - wake
+        V = V + vw
+        W = W + ww
+
+    # ---- outputs [A.4], unsorted back to the caller's turbine order
+    inv = np.empty(N, dtype=np.int64)
+    inv[order] = np.arange(N)
+    U, V, W, TI = U[inv], V[inv], W[inv], TI[inv]
+    wind_speed = np.cbrt(np.mean(U**3, axis=(1, 2)))
+    wind_direction = np.mean(wd - np.degrees(np.arctan2(V, U)), axis=(1, 2))
+    v_eff = wind_speed * cosd(yaw) ** (p.pP / 3.0)
+    v_eff = (p.air_density / p.ref_density) ** (1.0 / 3.0) * v_eff
+    power = p.ref_density * _interp_fill(v_eff, p.table_ws, p.power_table(), 0.0, 0.0)
+    load = np.stack(
+        [TI.mean(axis=(1, 2)), U.std(axis=(1, 2)), V.std(axis=(1, 2)), W.std(axis=(1, 2))], axis=1
+    )
+    out = {
+        "power": power,
+        "wind_speed": wind_speed,
+        "wind_direction": wind_direction,
+        "load": load,
+    }
+    if return_fields:
+        out.update(U=U, V=V, W=W, TI=TI, order=order)
+    return out
+
+
+def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None):
+    """Loop `farm_step` over a batch: ws, wd scalars or (B,), yaw (B, N). Small B only."""
+    yaw = np.atleast_2d(np.asarray(yaw, dtype=np.float64))
+    B, N = yaw.shape
+    ws = np.broadcast_to(np.asarray(ws, dtype=np.float64), (B,))
+    wd = np.broadcast_to(np.asarray(wd, dtype=np.float64), (B,))
+    out = {
+        "power": np.empty((B, N)),
+        "wind_speed": np.empty((B, N)),
+        "wind_direction": np.empty((B, N)),
+        "load": np.empty((B, N, 4)),
+    }
+    for b in range(B):
+        r = farm_step(x, y, float(ws[b]), float(wd[b]), yaw[b], p)
+        for k in out:
+            out[k][b] = r[k]
+    return out
