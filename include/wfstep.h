@@ -1,0 +1,129 @@
+/* wfstep.h — C ABI of libwfstep.so: the MI355X-native batched wind-farm step.
+ *
+ * Drop-in boundary: these entry points are what a binding for the reference's
+ * simulator-interface layer would call in place of the FLORIS calls made by
+ *   reference wfcrl/interface.py:444-671  (class FlorisInterface).
+ * One handle evaluates, for a batch of B independent farm instances that share one layout, the
+ * FLORIS-3.5 Gauss-Curl-Hybrid steady-state solve configured by
+ *   reference wfcrl/simulators/floris/inputs/template/case.yaml:14-89
+ * and the measurement extraction of interface.py:565-577, 622-648.
+ *
+ * Plain C types only: no C++ or torch types cross this boundary.  Device pointers are plain
+ * `float*` / `double*` in the caller's HIP context (e.g. torch.Tensor.data_ptr()).
+ *
+ * Units (same as the reference): yaw absolute degrees (FLORIS sign convention); wind speed m/s;
+ * wind direction meteorological degrees (270 = wind along +x); power W; loads = (TI [-], std u,
+ * std v, std w [m/s]) — i.e. local_load_proxies() WITHOUT the reference's x1e7 / /1e7 round trip
+ * (interface.py:575-577, mdp.py:281-283, net identity).
+ *
+ * Threading: a handle is not re-entrant; distinct handles may be used from distinct threads.
+ * All work of a handle is queued on the handle's HIP stream (own stream unless wf_set_stream).
+ */
+#ifndef WFSTEP_H
+#define WFSTEP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WF_ABI_VERSION 1
+
+/* status codes (0 = ok, negative = error; text via wf_last_error) */
+#define WF_OK 0
+#define WF_E_INVALID -1     /* bad argument / call order */
+#define WF_E_UNSUPPORTED -2 /* model option outside what the kernels implement */
+#define WF_E_NODEVICE -3    /* no HIP device / device id out of range */
+#define WF_E_HIP -4         /* a HIP runtime call failed */
+#define WF_E_NOMEM -5
+
+#define WF_MAX_TURBINES 256
+#define WF_MAX_TABLE 64
+
+typedef struct wf_handle wf_handle;
+
+/* Model constants.  Defaults (wf_default_model) are the values of the reference's case.yaml and of
+ * FLORIS 3.5's `nrel_5MW` turbine.  The power/thrust table is
+ * DATA: pass any FLORIS `power_thrust_table` (wind_speed, thrust=Ct, power=Cp). */
+typedef struct wf_model_params {
+  /* flow field — case.yaml:30-39 */
+  double air_density, ambient_ti, shear, veer; /* veer must be 0 */
+  /* turbine — FLORIS turbine_library/nrel_5MW */
+  double rotor_diameter, hub_height, tsr, pP, pT, gen_eff, ref_density;
+  /* gauss velocity / deflection — case.yaml:52-59,76-80 (both blocks carry the same values) */
+  double alpha, beta, ka, kb, ad, bd, dm;
+  /* crespo_hernandez — case.yaml:84-89 */
+  double ch_initial, ch_constant, ch_ai, ch_downstream;
+  /* GCH internals of FLORIS 3.5 */
+  double eps_gain, num_eps, kappa, gch_gain, overlap_thresh, near_wake_c;
+  /* power_thrust_table, n_table <= WF_MAX_TABLE, wind speeds strictly ascending */
+  int n_table;
+  const double* table_ws;
+  const double* table_ct;
+  const double* table_cp;
+} wf_model_params;
+
+int wf_version(void);
+
+/* Fill *p with the reference defaults; table pointers reference static storage inside the library. */
+int wf_default_model(wf_model_params* p);
+
+/* Replaces `tools.FlorisInterface(simul_file)` (interface.py:479): create a handle bound to HIP
+ * device `device_id`, with the default model.  Fails with WF_E_NODEVICE when no GPU is visible —
+ * there is no CPU fallback. */
+int wf_create(int device_id, wf_handle** out);
+int wf_destroy(wf_handle* h);
+
+/* Adopt an external hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
+int wf_set_stream(wf_handle* h, void* hip_stream);
+void* wf_get_stream(wf_handle* h);
+
+/* Replaces the model section of case.yaml (simul_utils.py:34-48 writes it, interface.py:479 reads it). */
+int wf_set_model(wf_handle* h, const wf_model_params* p);
+
+/* Replaces farm.layout_x / layout_y of case.yaml (simul_utils.py:39-40). n <= WF_MAX_TURBINES. */
+int wf_set_layout(wf_handle* h, int n_turbines, const double* x, const double* y);
+
+/* Number of independent farm instances evaluated per step (not in the reference: it holds one). */
+int wf_set_batch(wf_handle* h, int env_batch);
+
+/* Replaces FlorisInterface.update_wind -> fi.reinitialize (interface.py:663-671).
+ * count == 1: one (ws, wd) shared by the whole batch; count == env_batch: one per instance.
+ * Performs wd % 360, the layout rotation and the upstream->downstream sort on the device (float64).
+ * Host pointers unless on_device != 0. */
+int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int on_device);
+
+/* Replaces fi.calculate_wake(yaw_angles) + fi.get_turbine_powers() + local_wind_measurements() +
+ * local_load_proxies() (interface.py:564, 623, 629-648).
+ *   yaw        [B*N]    absolute yaw, degrees, caller's turbine order
+ *   power      [B*N]    W                         (may be NULL to skip the copy-out)
+ *   wind_speed [B*N]    m/s   cbrt(mean u^3)      (may be NULL)
+ *   wind_dir   [B*N]    deg   mean(wd - atan2(v,u)) (may be NULL)
+ *   load       [B*N*4]  (TI, std u, std v, std w) (may be NULL)
+ * on_device == 0: host pointers; inputs/outputs are staged through pinned buffers and the call
+ *                 returns after the results are in the caller's arrays.
+ * on_device != 0: device pointers; the call only enqueues work on the handle's stream. */
+int wf_step(wf_handle* h, const float* yaw, float* power, float* wind_speed, float* wind_dir, float* load,
+            int on_device);
+
+int wf_sync(wf_handle* h);
+
+/* HIP-event timing of the step kernel on the handle's stream (used by bench.py for the roofline
+ * object): wf_timing_begin records an event, wf_timing_end records another, synchronises, and
+ * returns the elapsed milliseconds between them. */
+int wf_timing_begin(wf_handle* h);
+int wf_timing_end(wf_handle* h, float* elapsed_ms);
+
+/* Introspection: which kernel variant serves the current layout (lanes per farm, target slots per
+ * lane), its register/LDS footprint and the launch geometry. */
+typedef struct wf_kernel_info {
+  int lanes_per_env, slots_per_lane, envs_per_block, threads_per_block, grid_blocks;
+  int vgprs, sgprs, lds_bytes, scratch_bytes;
+} wf_kernel_info;
+int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info);
+
+const char* wf_last_error(wf_handle* h); /* h may be NULL: last error of a failed wf_create */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFSTEP_H */

@@ -1,0 +1,23 @@
+"""Print a table of per-kernel register / spill / occupancy figures from hipcc's
+-Rpass-analysis=kernel-resource-usage for wf_kernels.hip (no GPU needed)."""
+import re, subprocess, sys
+from pathlib import Path
+src = Path(__file__).resolve().parents[1] / "wfcrl-env_amd" / "csrc"
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
+       "-c", "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", str(src / "wf_kernels.hip")] + sys.argv[1:]
+out = subprocess.run(cmd, capture_output=True, text=True).stderr
+rows, cur = [], None
+for line in out.splitlines():
+    m = re.search(r"remark:\s+(.*?)\s*\[-Rpass", line)
+    if not m: continue
+    t = m.group(1)
+    if t.startswith("Function Name:"):
+        name = t.split(":", 1)[1].strip()
+        g = re.search(r"wf_step_kernelILi(\d+)ELi(\d+)E", name)
+        cur = {"kernel": f"step<{g.group(1)},{g.group(2)}>" if g else name[:30]}
+        rows.append(cur)
+    elif cur is not None and ":" in t:
+        k, v = t.split(":", 1); cur[k.strip()] = v.strip()
+keys = ["kernel", "VGPRs", "AGPRs", "SGPRs", "VGPRs Spill", "SGPRs Spill", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]"]
+print(" | ".join(keys))
+for r in rows: print(" | ".join(str(r.get(k, "")) for k in keys))

@@ -1,0 +1,146 @@
+"""`WfStep` — thin object wrapper over the C ABI handle (one handle = one device + stream).
+
+Accepts NumPy arrays (host path: staged through pinned buffers inside the library) or torch CUDA
+tensors (device path: pointers handed over as-is, call is asynchronous on the handle's stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KernelInfo, ModelParams, check
+
+
+def _is_torch(a) -> bool:
+    return type(a).__module__.startswith("torch")
+
+
+def default_model() -> dict:
+    """Reference defaults (case.yaml + nrel_5MW) as a plain dict incl. the power/thrust table."""
+    p = ModelParams()
+    check(_lib.load().wf_default_model(C.byref(p)))
+    d = {n: getattr(p, n) for n in _lib._MODEL_DOUBLES}
+    n = p.n_table
+    d["table_ws"] = [p.table_ws[i] for i in range(n)]
+    d["table_ct"] = [p.table_ct[i] for i in range(n)]
+    d["table_cp"] = [p.table_cp[i] for i in range(n)]
+    return d
+
+
+class WfStep:
+    def __init__(self, xcoords, ycoords, env_batch: int = 1, device_id: int = 0, model: dict | None = None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.wf_create(int(device_id), C.byref(self._h)))
+        self.device_id = int(device_id)
+        self.num_turbines = 0
+        self.env_batch = 0
+        if model is not None:
+            self.set_model(model)
+        self.set_layout(xcoords, ycoords)
+        self.set_batch(env_batch)
+
+    # -- configuration ---------------------------------------------------------------------------
+    def set_model(self, model: dict):
+        base = default_model()
+        base.update(model)
+        p = ModelParams()
+        for n in _lib._MODEL_DOUBLES:
+            setattr(p, n, float(base[n]))
+        tws = np.ascontiguousarray(base["table_ws"], dtype=np.float64)
+        tct = np.ascontiguousarray(base["table_ct"], dtype=np.float64)
+        tcp = np.ascontiguousarray(base["table_cp"], dtype=np.float64)
+        if not (len(tws) == len(tct) == len(tcp)):
+            raise ValueError("power_thrust_table columns must have equal length")
+        p.n_table = len(tws)
+        dp = C.POINTER(C.c_double)
+        p.table_ws, p.table_ct, p.table_cp = tws.ctypes.data_as(dp), tct.ctypes.data_as(dp), tcp.ctypes.data_as(dp)
+        check(self._lib.wf_set_model(self._h, C.byref(p)), self._h)
+
+    def set_layout(self, xcoords, ycoords):
+        x = np.ascontiguousarray(xcoords, dtype=np.float64)
+        y = np.ascontiguousarray(ycoords, dtype=np.float64)
+        if x.ndim != 1 or x.shape != y.shape:
+            raise ValueError("xcoords and ycoords layout coordinates must have the same length")
+        check(self._lib.wf_set_layout(self._h, x.size, x.ctypes.data, y.ctypes.data), self._h)
+        self.num_turbines = int(x.size)
+
+    def set_batch(self, env_batch: int):
+        check(self._lib.wf_set_batch(self._h, int(env_batch)), self._h)
+        self.env_batch = int(env_batch)
+
+    def set_stream(self, hip_stream: int | None):
+        check(self._lib.wf_set_stream(self._h, C.c_void_p(hip_stream or 0)), self._h)
+
+    def set_wind(self, wind_speed, wind_direction):
+        """Scalar (shared by the batch) or one value per env; NumPy/float or torch float64 CUDA tensors."""
+        if _is_torch(wind_speed):
+            ws, wd = wind_speed.contiguous(), wind_direction.contiguous()
+            assert ws.dtype == wd.dtype and str(ws.dtype) == "torch.float64" and ws.is_cuda
+            check(self._lib.wf_set_wind(self._h, ws.data_ptr(), wd.data_ptr(), ws.numel(), 1), self._h)
+            return
+        ws = np.ascontiguousarray(np.atleast_1d(wind_speed), dtype=np.float64)
+        wd = np.ascontiguousarray(np.atleast_1d(wind_direction), dtype=np.float64)
+        if ws.shape != wd.shape:
+            raise ValueError("wind_speed and wind_direction must have the same shape")
+        check(self._lib.wf_set_wind(self._h, ws.ctypes.data, wd.ctypes.data, ws.size, 0), self._h)
+
+    # -- the step ----------------------------------------------------------------------------------
+    def step(self, yaw, out: dict | None = None):
+        """yaw: (B, N) absolute degrees.  Returns dict(power, wind_speed, wind_direction, load)."""
+        B, N = self.env_batch, self.num_turbines
+        if _is_torch(yaw):
+            import torch
+
+            assert yaw.is_cuda and yaw.dtype == torch.float32 and yaw.numel() == B * N
+            yaw = yaw.contiguous()
+            if out is None:
+                out = {
+                    "power": torch.empty((B, N), device=yaw.device, dtype=torch.float32),
+                    "wind_speed": torch.empty((B, N), device=yaw.device, dtype=torch.float32),
+                    "wind_direction": torch.empty((B, N), device=yaw.device, dtype=torch.float32),
+                    "load": torch.empty((B, N, 4), device=yaw.device, dtype=torch.float32),
+                }
+            check(self._lib.wf_step(self._h, yaw.data_ptr(), out["power"].data_ptr(), out["wind_speed"].data_ptr(),
+                                    out["wind_direction"].data_ptr(), out["load"].data_ptr(), 1), self._h)
+            return out
+        yaw = np.ascontiguousarray(yaw, dtype=np.float32).reshape(B, N)
+        if out is None:
+            out = {
+                "power": np.empty((B, N), np.float32),
+                "wind_speed": np.empty((B, N), np.float32),
+                "wind_direction": np.empty((B, N), np.float32),
+                "load": np.empty((B, N, 4), np.float32),
+            }
+        check(self._lib.wf_step(self._h, yaw.ctypes.data, out["power"].ctypes.data, out["wind_speed"].ctypes.data,
+                                out["wind_direction"].ctypes.data, out["load"].ctypes.data, 0), self._h)
+        return out
+
+    def sync(self):
+        check(self._lib.wf_sync(self._h), self._h)
+
+    def timing_begin(self):
+        check(self._lib.wf_timing_begin(self._h), self._h)
+
+    def timing_end(self) -> float:
+        ms = C.c_float()
+        check(self._lib.wf_timing_end(self._h, C.byref(ms)), self._h)
+        return float(ms.value)
+
+    def kernel_info(self) -> dict:
+        k = KernelInfo()
+        check(self._lib.wf_get_kernel_info(self._h, C.byref(k)), self._h)
+        return {n: getattr(k, n) for n, _ in KernelInfo._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.wf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

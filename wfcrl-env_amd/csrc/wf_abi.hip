@@ -1,0 +1,473 @@
+// wf_abi.hip — host side of libwfstep.so: the C ABI declared in include/wfstep.h.
+//
+// Replaces the FLORIS object the reference holds in FlorisInterface (reference
+// wfcrl/interface.py:479 `tools.FlorisInterface(simul_file)`) by a handle that owns device-resident
+// geometry, model constants and staging buffers.  No CPU fallback: without a HIP device wf_create
+// fails with WF_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/wfstep.h"
+#include "wf_device.h"
+
+extern "C" int wfk_num_variants();
+extern "C" void wfk_variant(int i, int* G, int* S, const void** fn);
+extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
+                                          const double* wd, double* gx, float* gy, int* gidx, hipStream_t s);
+extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
+                                      const float* gy, const int* gidx, int geom_stride, const double* ws,
+                                      const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
+                                      float* o_wd, float* load, int B, hipStream_t s, int* grid_out);
+
+namespace {
+
+// ---- nrel_5MW power/thrust table (DATA, replaceable via wf_set_model) ----
+const double kCtFrom3[45] = {
+    0.99,       0.99,       0.97373036, 0.92826162, 0.89210543, 0.86100905, 0.835423,   0.81237673, 0.79225789,
+    0.77584769, 0.7629228,  0.76156073, 0.76261984, 0.76169723, 0.75232027, 0.74026851, 0.72987175, 0.70701647,
+    0.54054532, 0.45509459, 0.39343381, 0.34250785, 0.30487242, 0.27164979, 0.24361964, 0.21973831, 0.19918151,
+    0.18131868, 0.16537679, 0.15103727, 0.13998636, 0.1289037,  0.11970413, 0.11087113, 0.10339901, 0.09617888,
+    0.09009926, 0.08395078, 0.0791188,  0.07448356, 0.07050731, 0.06684119, 0.06345518, 0.06032267, 0.05741999};
+const double kCpFrom3[45] = {
+    0.1780851,  0.28907459, 0.34902166, 0.3847278,  0.40605878, 0.4202279,  0.42882274, 0.43387274, 0.43622267,
+    0.43684468, 0.43657497, 0.43651053, 0.4365612,  0.43651728, 0.43590309, 0.43467276, 0.43322955, 0.43003137,
+    0.37655587, 0.33328466, 0.29700574, 0.26420779, 0.23839379, 0.21459275, 0.19382354, 0.1756635,  0.15970926,
+    0.14561785, 0.13287856, 0.12130194, 0.11219941, 0.10311631, 0.09545392, 0.08813781, 0.08186763, 0.07585005,
+    0.07071926, 0.06557558, 0.06148104, 0.05755207, 0.05413366, 0.05097969, 0.04806545, 0.04536883, 0.04287006};
+double g_tab_ws[51], g_tab_ct[51], g_tab_cp[51];
+bool g_tab_init = false;
+void init_default_table() {
+  if (g_tab_init) return;
+  int n = 0;
+  const double head[3] = {0.0, 2.0, 2.5};
+  for (int i = 0; i < 3; ++i) { g_tab_ws[n] = head[i]; g_tab_ct[n] = 0.0; g_tab_cp[n] = 0.0; ++n; }
+  for (int i = 0; i < 45; ++i) { g_tab_ws[n] = 3.0 + 0.5 * i; g_tab_ct[n] = kCtFrom3[i]; g_tab_cp[n] = kCpFrom3[i]; ++n; }
+  const double tail[3] = {25.01, 25.02, 50.0};
+  for (int i = 0; i < 3; ++i) { g_tab_ws[n] = tail[i]; g_tab_ct[n] = 0.0; g_tab_cp[n] = 0.0; ++n; }
+  g_tab_init = true;
+}
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct wf_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+
+  wf_model_params model{};
+  std::vector<double> tws, tct, tcp;
+  bool model_dirty = true;
+
+  int N = 0;
+  std::vector<double> lx, ly;
+  double xc = 0, yc = 0;
+  int B = 0;
+  int wind_count = 0;  // 0 = not set
+  int variant = -1;
+  int grid = 0;
+
+  WfConsts consts{};
+  // device memory
+  WfTables* d_tab = nullptr;
+  double *d_lx = nullptr, *d_ly = nullptr;
+  double *d_ws = nullptr, *d_wd = nullptr;  // [B]
+  double* d_gx = nullptr;                   // [B*N] (or [N] when wind is shared)
+  float* d_gy = nullptr;
+  int* d_gidx = nullptr;
+  float *d_yaw = nullptr, *d_out = nullptr;  // staging for host callers: yaw [B*N], out [B*N*7]
+  float *h_yaw = nullptr, *h_out = nullptr;  // pinned
+  size_t cap_env = 0, cap_bn = 0;
+};
+
+namespace {
+
+int fail(wf_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+#define WF_HIP(h, call)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) return fail(h, WF_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+void free_batch(wf_handle* h) {
+  hipFree(h->d_ws); hipFree(h->d_wd); hipFree(h->d_gx); hipFree(h->d_gy); hipFree(h->d_gidx);
+  hipFree(h->d_yaw); hipFree(h->d_out);
+  if (h->h_yaw) hipHostFree(h->h_yaw);
+  if (h->h_out) hipHostFree(h->h_out);
+  h->d_ws = h->d_wd = h->d_gx = nullptr; h->d_gy = nullptr; h->d_gidx = nullptr;
+  h->d_yaw = h->d_out = h->h_yaw = h->h_out = nullptr;
+  h->cap_env = h->cap_bn = 0;
+}
+
+// Kernel variant for N turbines: G lanes per env, S target slots per lane, G*S >= N.
+// Smaller G wastes fewer lanes on the triangular (upstream->downstream) structure; S is bounded by
+// the 256-VGPR budget that keeps two waves per SIMD resident.
+int pick_variant(int N) {
+  const char* ov = getenv("WF_KERNEL_GS");  // tuning override, e.g. "16x5"
+  int og = 0, os = 0;
+  if (ov && sscanf(ov, "%dx%d", &og, &os) == 2) {
+    for (int i = 0; i < wfk_num_variants(); ++i) {
+      int G, S; const void* fn;
+      wfk_variant(i, &G, &S, &fn);
+      if (G == og && S == os && G * S >= N) return i;
+    }
+  }
+  static const int pref[][3] = {  // {max N, G, S}
+      {4, 4, 1}, {8, 8, 1}, {16, 8, 2}, {24, 8, 3}, {32, 8, 4}, {48, 16, 3}, {64, 16, 4},
+      {80, 16, 5}, {96, 16, 6}, {128, 32, 4}, {192, 64, 3}, {256, 64, 4}};
+  for (auto& r : pref) {
+    if (N <= r[0]) {
+      for (int i = 0; i < wfk_num_variants(); ++i) {
+        int G, S; const void* fn;
+        wfk_variant(i, &G, &S, &fn);
+        if (G == r[1] && S == r[2]) return i;
+      }
+    }
+  }
+  return -1;
+}
+
+int build_consts(wf_handle* h) {
+  const wf_model_params& m = h->model;
+  if (m.veer != 0.0) return fail(h, WF_E_UNSUPPORTED, "wind_veer != 0 is not implemented");
+  const int n = (int)h->tws.size();
+  if (n < 2 || n > WF_MAX_TABLE - 1) return fail(h, WF_E_INVALID, "power_thrust_table needs 2..63 entries");
+  for (int i = 1; i < n; ++i)
+    if (!(h->tws[i] > h->tws[i - 1])) return fail(h, WF_E_INVALID, "table wind speeds must be strictly ascending");
+  if (!(m.rotor_diameter > 0) || !(m.hub_height > m.rotor_diameter / 2))
+    return fail(h, WF_E_INVALID, "need rotor_diameter > 0 and hub_height > rotor radius");
+
+  WfConsts& c = h->consts;
+  const double D = m.rotor_diameter, HH = m.hub_height, R = D / 2, eps = m.eps_gain * D, eps2 = eps * eps;
+  c.N = h->N;
+  c.D = (float)D; c.invD = (float)(1.0 / D);
+  const double off[3] = {-D / 4, 0.0, D / 4};
+  double shearf[3], uinf = 0;
+  for (int k = 0; k < 3; ++k) {
+    c.off[k] = (float)off[k];
+    c.yoff[k] = (float)(off[k] + m.num_eps);
+    shearf[k] = std::pow((HH + off[k]) / HH, m.shear);
+    c.shearf[k] = (float)shearf[k];
+    uinf += shearf[k] / 3.0;
+  }
+  c.uinf_f = (float)uinf;
+  for (int k = 0; k < 3; ++k) {
+    const double z = HH + off[k];
+    const double dudz = m.shear * std::pow(1.0 / HH, m.shear) * std::pow(z, m.shear - 1.0);  // per unit ws
+    const double lm = m.kappa * z / (1.0 + m.kappa * z / (D / 8.0));
+    const double nu = lm * lm * std::fabs(dudz);
+    c.decay_a[k] = (float)(4.0 * nu / uinf / eps2);
+  }
+  c.exp_c = (float)(1.4426950408889634 / eps2);
+  const double hs[3] = {HH + R, HH - R, HH};
+  double ks[3] = {0, 0, 0};
+  for (int v = 0; v < 3; ++v)
+    for (int k = 0; k < 3; ++k) {
+      const double z = HH + off[k];
+      const double zc = z - hs[v] + m.num_eps, zm = z + hs[v] + m.num_eps;
+      c.zc[v][k] = (float)zc; c.zc2[v][k] = (float)(zc * zc); c.ez[v][k] = (float)std::exp(-zc * zc / eps2);
+      c.zm[v][k] = (float)zm; c.zm2[v][k] = (float)(zm * zm); c.ezm[v][k] = (float)std::exp(-zm * zm / eps2);
+      for (int j = 0; j < 3; ++j) {  // secondary-steering means on the source's own grid [A.3-2]
+        const double yL = off[j] + m.num_eps;
+        const double r = yL * yL + zc * zc;
+        ks[v] += zc / r * (1.0 - std::exp(-r / eps2)) / 9.0;
+      }
+    }
+  c.ks_top = (float)ks[0]; c.ks_bot = (float)ks[1]; c.ks_core = (float)ks[2];
+  const double vel_top = std::pow((HH + R) / HH, m.shear), vel_bot = std::pow((HH - R) / HH, m.shear);
+  const double inv2pi = 1.0 / (2.0 * M_PI);
+  c.gam_top = (float)(inv2pi * (M_PI / 8.0) * D * vel_top * uinf);
+  c.gam_bot = (float)(inv2pi * (M_PI / 8.0) * D * vel_bot * uinf);
+  c.gam_wr = (float)(inv2pi * 0.25 * 2.0 * M_PI * D / m.tsr);
+  c.alpha4 = (float)(4.0 * m.alpha); c.beta2 = (float)(2.0 * m.beta);
+  c.ka = (float)m.ka; c.kb = (float)m.kb; c.ad = (float)m.ad; c.bd = (float)m.bd; c.dm03 = (float)(0.3 * m.dm);
+  c.e0c1 = (float)(3.0 * std::exp(1.0 / 12.0)); c.e0c2 = (float)(3.0 * std::exp(1.0 / 3.0));
+  c.sz0v = (float)(D / (2.0 * std::sqrt(2.0)));
+  c.near_c = (float)(m.near_wake_c * D);
+  c.kdef = (float)(D * D / 8.0);
+  c.ch_c = (float)(m.ch_constant * std::pow(m.ambient_ti, m.ch_initial));
+  c.ch_ai = (float)m.ch_ai; c.ch_down = (float)m.ch_downstream;
+  c.amb = (float)m.ambient_ti; c.amb2 = (float)(m.ambient_ti * m.ambient_ti);
+  c.gch_gain = (float)m.gch_gain; c.overlap_thr = (float)m.overlap_thresh;
+  c.twoD = (float)(2.0 * D); c.fifteenD = (float)(15.0 * D);
+  c.rho = (float)m.ref_density; c.pw = (float)(m.pP / 3.0);
+  c.dens_f = (float)std::cbrt(m.air_density / m.ref_density);
+
+  // table + bucket index
+  WfTables t;
+  const double area = M_PI * R * R;
+  std::vector<double> pwv(n);
+  for (int i = 0; i < n; ++i) pwv[i] = 0.5 * area * h->tcp[i] * m.gen_eff * h->tws[i] * h->tws[i] * h->tws[i];
+  for (int i = 0; i < WF_TABLE_PAD; ++i) {
+    const bool in = i < n;
+    t.knot[i] = in ? (float)h->tws[i] : 3.0e38f;
+    t.ct[i] = in ? (float)h->tct[i] : 0.f;
+    t.pw[i] = in ? (float)pwv[i] : 0.f;
+    const bool seg = i + 1 < n;
+    t.ct_slope[i] = seg ? (float)((h->tct[i + 1] - h->tct[i]) / (h->tws[i + 1] - h->tws[i])) : 0.f;
+    t.pw_slope[i] = seg ? (float)((pwv[i + 1] - pwv[i]) / (h->tws[i + 1] - h->tws[i])) : 0.f;
+  }
+  const double x0 = h->tws[0], x1 = h->tws[n - 1];
+  const double bh = (x1 - x0) / WF_BUCKETS;
+  c.n_table = n; c.bucket_x0 = (float)x0; c.bucket_h_inv = (float)(1.0 / bh);
+  // bucket[b] = last knot <= start of bucket b-1; the kernel probes forward from there.  One bucket of
+  // slack on either side absorbs float rounding of the bucket index computed on the device.
+  int max_probe = 1;
+  for (int b = 0; b < WF_BUCKETS; ++b) {
+    const double lo = x0 + (b - 1) * bh, hi = x0 + (b + 2) * bh;
+    int j = 0;
+    while (j + 1 < n && h->tws[j + 1] <= lo) ++j;
+    t.bucket[b] = (unsigned char)j;
+    int k = j;
+    while (k + 1 < n && h->tws[k + 1] <= hi) ++k;
+    if (k - j > max_probe) max_probe = k - j;
+  }
+  c.max_probe = max_probe;
+  hipError_t e = hipMemcpyAsync(h->d_tab, &t, sizeof(WfTables), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail(h, WF_E_HIP, std::string("table upload: ") + hipGetErrorString(e));
+  h->model_dirty = false;
+  return WF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wf_version(void) { return WF_ABI_VERSION; }
+
+int wf_default_model(wf_model_params* p) {
+  if (!p) return WF_E_INVALID;
+  init_default_table();
+  p->air_density = 1.225; p->ambient_ti = 0.06; p->shear = 0.12; p->veer = 0.0;
+  p->rotor_diameter = 126.0; p->hub_height = 90.0; p->tsr = 8.0; p->pP = 1.88; p->pT = 1.88;
+  p->gen_eff = 1.0; p->ref_density = 1.225;
+  p->alpha = 0.58; p->beta = 0.077; p->ka = 0.38; p->kb = 0.004; p->ad = 0.0; p->bd = 0.0; p->dm = 1.0;
+  p->ch_initial = 0.1; p->ch_constant = 0.5; p->ch_ai = 0.8; p->ch_downstream = -0.32;
+  p->eps_gain = 0.2; p->num_eps = 0.001; p->kappa = 0.41; p->gch_gain = 2.0; p->overlap_thresh = 0.05;
+  p->near_wake_c = 0.501;
+  p->n_table = 51; p->table_ws = g_tab_ws; p->table_ct = g_tab_ct; p->table_cp = g_tab_cp;
+  return WF_OK;
+}
+
+int wf_create(int device_id, wf_handle** out) {
+  if (!out) return fail(nullptr, WF_E_INVALID, "out == NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, WF_E_NODEVICE, std::string("no HIP device visible (") + hipGetErrorString(e) +
+                                            "); libwfstep has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, WF_E_NODEVICE, "device id out of range");
+  wf_handle* h = new (std::nothrow) wf_handle();
+  if (!h) return fail(nullptr, WF_E_NOMEM, "out of host memory");
+  h->device = device_id;
+  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
+      (e = hipMalloc(&h->d_tab, sizeof(WfTables))) != hipSuccess) {
+    std::string msg = std::string("wf_create: ") + hipGetErrorString(e);
+    delete h;
+    return fail(nullptr, WF_E_HIP, msg);
+  }
+  h->stream = h->own_stream;
+  wf_model_params p;
+  wf_default_model(&p);
+  h->model = p;
+  h->tws.assign(p.table_ws, p.table_ws + p.n_table);
+  h->tct.assign(p.table_ct, p.table_ct + p.n_table);
+  h->tcp.assign(p.table_cp, p.table_cp + p.n_table);
+  *out = h;
+  return WF_OK;
+}
+
+int wf_destroy(wf_handle* h) {
+  if (!h) return WF_OK;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  free_batch(h);
+  hipFree(h->d_tab); hipFree(h->d_lx); hipFree(h->d_ly);
+  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+  hipStreamDestroy(h->own_stream);
+  delete h;
+  return WF_OK;
+}
+
+int wf_set_stream(wf_handle* h, void* s) {
+  if (!h) return WF_E_INVALID;
+  hipStreamSynchronize(h->stream);
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return WF_OK;
+}
+void* wf_get_stream(wf_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int wf_set_model(wf_handle* h, const wf_model_params* p) {
+  if (!h || !p) return WF_E_INVALID;
+  if (p->n_table < 2 || p->n_table > WF_MAX_TABLE - 1 || !p->table_ws || !p->table_ct || !p->table_cp)
+    return fail(h, WF_E_INVALID, "power_thrust_table needs 2..63 entries");
+  if (p->veer != 0.0) return fail(h, WF_E_UNSUPPORTED, "wind_veer != 0 is not implemented");
+  h->model = *p;
+  h->tws.assign(p->table_ws, p->table_ws + p->n_table);
+  h->tct.assign(p->table_ct, p->table_ct + p->n_table);
+  h->tcp.assign(p->table_cp, p->table_cp + p->n_table);
+  h->model.table_ws = h->model.table_ct = h->model.table_cp = nullptr;
+  h->model_dirty = true;
+  return WF_OK;
+}
+
+int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
+  if (!h || !x || !y) return WF_E_INVALID;
+  if (n < 1 || n > WF_MAX_TURBINES) return fail(h, WF_E_INVALID, "n_turbines must be in 1..256");
+  WF_HIP(h, hipSetDevice(h->device));
+  const int v = pick_variant(n);
+  if (v < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
+  h->lx.assign(x, x + n); h->ly.assign(y, y + n);
+  double xmin = x[0], xmax = x[0], ymin = y[0], ymax = y[0];
+  for (int i = 1; i < n; ++i) {
+    xmin = std::fmin(xmin, x[i]); xmax = std::fmax(xmax, x[i]);
+    ymin = std::fmin(ymin, y[i]); ymax = std::fmax(ymax, y[i]);
+  }
+  h->xc = (xmin + xmax) / 2.0; h->yc = (ymin + ymax) / 2.0;  // centre of rotation [A.1-1]
+  hipFree(h->d_lx); hipFree(h->d_ly); h->d_lx = h->d_ly = nullptr;
+  WF_HIP(h, hipMalloc(&h->d_lx, sizeof(double) * n));
+  WF_HIP(h, hipMalloc(&h->d_ly, sizeof(double) * n));
+  WF_HIP(h, hipMemcpy(h->d_lx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  WF_HIP(h, hipMemcpy(h->d_ly, y, sizeof(double) * n, hipMemcpyHostToDevice));
+  if (n != h->N) { free_batch(h); h->B = 0; }
+  h->N = n; h->variant = v; h->wind_count = 0; h->model_dirty = true;
+  return WF_OK;
+}
+
+int wf_set_batch(wf_handle* h, int B) {
+  if (!h) return WF_E_INVALID;
+  if (h->N <= 0) return fail(h, WF_E_INVALID, "wf_set_layout must be called before wf_set_batch");
+  if (B < 1) return fail(h, WF_E_INVALID, "env_batch must be >= 1");
+  WF_HIP(h, hipSetDevice(h->device));
+  WF_HIP(h, hipStreamSynchronize(h->stream));
+  if ((size_t)B != h->cap_env) {
+    free_batch(h);
+    const size_t bn = (size_t)B * h->N;
+    WF_HIP(h, hipMalloc(&h->d_ws, sizeof(double) * B));
+    WF_HIP(h, hipMalloc(&h->d_wd, sizeof(double) * B));
+    WF_HIP(h, hipMalloc(&h->d_gx, sizeof(double) * bn));
+    WF_HIP(h, hipMalloc(&h->d_gy, sizeof(float) * bn));
+    WF_HIP(h, hipMalloc(&h->d_gidx, sizeof(int) * bn));
+    h->cap_env = B; h->cap_bn = bn;
+  }
+  h->B = B; h->wind_count = 0;
+  return WF_OK;
+}
+
+int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int on_device) {
+  if (!h || !ws || !wd) return WF_E_INVALID;
+  if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called before wf_set_wind");
+  if (count != 1 && count != h->B) return fail(h, WF_E_INVALID, "wind count must be 1 or env_batch");
+  WF_HIP(h, hipSetDevice(h->device));
+  if (!on_device)
+    for (int i = 0; i < count; ++i)
+      if (!(ws[i] > 0.0) || !std::isfinite(wd[i])) return fail(h, WF_E_INVALID, "wind speed must be > 0 and direction finite");
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  WF_HIP(h, hipMemcpyAsync(h->d_ws, ws, sizeof(double) * count, kind, h->stream));
+  WF_HIP(h, hipMemcpyAsync(h->d_wd, wd, sizeof(double) * count, kind, h->stream));
+  WF_HIP(h, wfk_launch_geometry(count, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+  if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));  // caller's host arrays may go away
+  h->wind_count = count;
+  return WF_OK;
+}
+
+int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, int on_device) {
+  if (!h || !yaw) return WF_E_INVALID;
+  if (h->wind_count == 0) return fail(h, WF_E_INVALID, "wf_set_wind must be called before wf_step");
+  WF_HIP(h, hipSetDevice(h->device));
+  if (h->model_dirty) {
+    int rc = build_consts(h);
+    if (rc != WF_OK) return rc;
+  }
+  const size_t bn = (size_t)h->B * h->N;
+  const int gstride = (h->wind_count == 1) ? 0 : h->N;
+  const int wstride = (h->wind_count == 1) ? 0 : 1;
+  if (on_device) {
+    float* scratch = nullptr;
+    if (!power || !wspd || !wdir || !load) {  // kernel always writes all outputs: park skipped ones in staging
+      if (!h->d_out) WF_HIP(h, hipMalloc(&h->d_out, sizeof(float) * bn * 7));
+      scratch = h->d_out;
+    }
+    WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
+                              wstride, yaw, power ? power : scratch, wspd ? wspd : scratch + bn,
+                              wdir ? wdir : scratch + 2 * bn, load ? load : scratch + 3 * bn, h->B, h->stream, &h->grid));
+    return WF_OK;
+  }
+  if (!h->d_yaw) {
+    WF_HIP(h, hipMalloc(&h->d_yaw, sizeof(float) * bn));
+    WF_HIP(h, hipHostMalloc(&h->h_yaw, sizeof(float) * bn, hipHostMallocDefault));
+  }
+  if (!h->d_out) WF_HIP(h, hipMalloc(&h->d_out, sizeof(float) * bn * 7));
+  if (!h->h_out) WF_HIP(h, hipHostMalloc(&h->h_out, sizeof(float) * bn * 7, hipHostMallocDefault));
+  std::memcpy(h->h_yaw, yaw, sizeof(float) * bn);
+  WF_HIP(h, hipMemcpyAsync(h->d_yaw, h->h_yaw, sizeof(float) * bn, hipMemcpyHostToDevice, h->stream));
+  WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
+                            wstride, h->d_yaw, h->d_out, h->d_out + bn, h->d_out + 2 * bn, h->d_out + 3 * bn, h->B,
+                            h->stream, &h->grid));
+  WF_HIP(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(float) * bn * 7, hipMemcpyDeviceToHost, h->stream));
+  WF_HIP(h, hipStreamSynchronize(h->stream));
+  if (power) std::memcpy(power, h->h_out, sizeof(float) * bn);
+  if (wspd) std::memcpy(wspd, h->h_out + bn, sizeof(float) * bn);
+  if (wdir) std::memcpy(wdir, h->h_out + 2 * bn, sizeof(float) * bn);
+  if (load) std::memcpy(load, h->h_out + 3 * bn, sizeof(float) * bn * 4);
+  return WF_OK;
+}
+
+int wf_sync(wf_handle* h) {
+  if (!h) return WF_E_INVALID;
+  WF_HIP(h, hipSetDevice(h->device));
+  WF_HIP(h, hipStreamSynchronize(h->stream));
+  return WF_OK;
+}
+
+int wf_timing_begin(wf_handle* h) {
+  if (!h) return WF_E_INVALID;
+  WF_HIP(h, hipSetDevice(h->device));
+  WF_HIP(h, hipEventRecord(h->ev0, h->stream));
+  return WF_OK;
+}
+
+int wf_timing_end(wf_handle* h, float* ms) {
+  if (!h || !ms) return WF_E_INVALID;
+  WF_HIP(h, hipSetDevice(h->device));
+  WF_HIP(h, hipEventRecord(h->ev1, h->stream));
+  WF_HIP(h, hipEventSynchronize(h->ev1));
+  WF_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return WF_OK;
+}
+
+int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
+  if (!h || !info) return WF_E_INVALID;
+  if (h->variant < 0) return fail(h, WF_E_INVALID, "wf_set_layout must be called first");
+  int G, S; const void* fn;
+  wfk_variant(h->variant, &G, &S, &fn);
+  hipFuncAttributes a;
+  WF_HIP(h, hipSetDevice(h->device));
+  WF_HIP(h, hipFuncGetAttributes(&a, fn));
+  info->lanes_per_env = G; info->slots_per_lane = S;
+  info->envs_per_block = 4 * (64 / G); info->threads_per_block = 256;
+  info->grid_blocks = h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0;
+  info->vgprs = a.numRegs; info->sgprs = 0;
+  info->lds_bytes = (int)a.sharedSizeBytes; info->scratch_bytes = (int)a.localSizeBytes;
+  return WF_OK;
+}
+
+const char* wf_last_error(wf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"

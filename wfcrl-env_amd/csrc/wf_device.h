@@ -1,0 +1,53 @@
+// wf_device.h — per-farm constants handed to the HIP kernels by value (kernarg segment -> SGPRs).
+//
+// Everything here is derived on the host in float64 from wf_model_params (include/wfstep.h) and
+// rounded once to float32.  Nothing depends on the wind speed: every quantity that FLORIS 3.5
+// scales by the inflow (Uinit, Uinf, dU/dz) is stored per unit wind speed.
+#pragma once
+
+#define WF_TABLE_PAD 64
+#define WF_BUCKETS 256
+
+struct WfConsts {
+  int N;             // turbines
+  float D, invD;     // rotor diameter
+  float off[3];      // rotor-grid offsets  -D/4, 0, +D/4            [A.1-3]
+  float yoff[3];     // off[j] + NUM_EPS                              [A.3-4]
+  float shearf[3];   // (z_k/HH)^shear : Uinit_k = ws*shearf[k]       [A.2]
+  float uinf_f;      // mean shearf    : Uinf    = ws*uinf_f
+  float decay_a[3];  // 4 nu_k / (Uinf eps^2) : decay_k = 1/(decay_a[k]*dx + 1)   [A.3-4]
+  float exp_c;       // log2(e)/eps^2  : exp(-r/eps^2) = exp2(-r*exp_c)
+  // the six vortices of the transverse-velocity model, per (vortex v, grid row k)     [A.3-4]
+  // v = 0 top (h = HH+R), 1 bottom (h = HH-R), 2 wake rotation (h = HH); m = ground mirror
+  float zc[3][3], zc2[3][3], ez[3][3];   // zc = z_k - h + eps ; ez = exp(-zc^2/eps^2)
+  float zm[3][3], zm2[3][3], ezm[3][3];  // zm = z_k + h + eps
+  float gam_top, gam_bot;  // (1/2pi)(pi/8) D vel_{top,bot} uinf_f : Gamma/(2pi) = gam*ws*ct
+  float gam_wr;            // (1/2pi) 0.25*2pi*D/TSR               : Gamma_wr/(2pi) = gam_wr*(a-a^2)*ubar
+  // secondary steering: mean_9( z/(r) * core ) on the source's own grid (dx = 0, dy = 0)   [A.3-2]
+  float ks_top, ks_bot, ks_core;
+  // gauss deflection / deficit                                                      [A.3-3, A.3-6]
+  float alpha4, beta2, ka, kb, ad, bd, dm03;
+  float e0c1, e0c2;        // 3 e^(1/12), 3 e^(1/3)
+  float sz0v;              // D/2 * sqrt(uR/(Uinf+u0)) of the deficit model == D/(2 sqrt 2)
+  float near_c;            // 0.501 * D
+  float kdef;              // D^2/8
+  // crespo-hernandez + overlap gating                                               [A.3-8]
+  float ch_c, ch_ai, ch_down;  // ch_c = constant * ambient^initial
+  float amb, amb2, gch_gain, overlap_thr, twoD, fifteenD;
+  // outputs                                                                         [A.4]
+  float rho, pw, dens_f;   // ref density, pP/3, (air_density/ref_density)^(1/3)
+  // power / thrust table
+  int n_table;
+  float bucket_h_inv, bucket_x0;
+  int max_probe;
+};
+
+// Power/thrust table in global memory, staged to LDS by each block.
+struct WfTables {
+  float knot[WF_TABLE_PAD];      // wind speeds, padded with +huge
+  float ct[WF_TABLE_PAD];        // Ct at knot
+  float ct_slope[WF_TABLE_PAD];  // (ct[j+1]-ct[j])/(knot[j+1]-knot[j])
+  float pw[WF_TABLE_PAD];        // 1/2 A Cp eta ws^3 at knot
+  float pw_slope[WF_TABLE_PAD];
+  unsigned char bucket[WF_BUCKETS];  // index of the last knot <= bucket start
+};

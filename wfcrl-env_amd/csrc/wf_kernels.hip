@@ -1,0 +1,470 @@
+// wf_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4) of the batched wind-farm step.
+//
+// What they replace: the arithmetic behind
+//   reference wfcrl/interface.py:564  fi.calculate_wake          (FLORIS 3.5 sequential GCH solve)
+//   reference wfcrl/interface.py:623  fi.get_turbine_powers
+//   reference wfcrl/interface.py:629-648  local_load_proxies / local_wind_measurements
+//   reference wfcrl/interface.py:663-671  update_wind -> fi.reinitialize (rotation + sort)
+// following SURVEY.md Appendix A ([A.x] tags below).
+//
+// Mapping: this is a VALU-bound pairwise recurrence, not a contraction — no MFMA.
+//   * one farm instance (env) is owned by a GROUP of G lanes of a 64-wide wavefront (64/G envs per
+//     wave); lane `sub` of the group owns the S target turbines  t = p*G + sub  (p = slot);
+//   * the per-turbine state (SOSFS wake^2, V, W on the 3x3 rotor grid, TI per grid column) lives in
+//     VGPRs for the whole solve; HBM is touched once for yaw in and once for the 7 outputs;
+//   * the upstream->downstream recurrence runs over sources i = 0..N-1; the source's scalars are
+//     broadcast inside the group with ds_bpermute (__shfl) and every lane evaluates the source's
+//     influence on its own targets; slots with no target downstream of the source are skipped by a
+//     wave-uniform branch; slots rotate so the source always sits in slot 0 (static register
+//     indices, no scratch).
+#include <hip/hip_runtime.h>
+
+#include "wf_device.h"
+
+namespace {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kDeg2Rad = kPi / 180.0f;
+constexpr float kRad2Deg = 180.0f / kPi;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
+
+// cube root of a positive number: exp2(log2(x)/3) polished by one Newton step (rel. err ~1e-7)
+__device__ __forceinline__ float fcbrt_pos(float x) {
+  float y = fexp2(flog2(x) * (1.0f / 3.0f));
+  float y2 = y * y;
+  return y - (y2 * y - x) * frcp(3.0f * y2);
+}
+
+struct TableLds {
+  float knot[WF_TABLE_PAD], ct[WF_TABLE_PAD], cts[WF_TABLE_PAD], pw[WF_TABLE_PAD], pws[WF_TABLE_PAD];
+  unsigned char bucket[WF_BUCKETS];
+};
+
+// index of the last knot <= v (v inside the table range)
+__device__ __forceinline__ int table_segment(const WfConsts& c, const TableLds& T, float v) {
+  int b = (int)((v - c.bucket_x0) * c.bucket_h_inv);
+  b = min(max(b, 0), WF_BUCKETS - 1);
+  int j = T.bucket[b];
+  for (int p = 0; p < c.max_probe; ++p)
+    if (T.knot[j + 1] <= v) ++j;
+  return min(j, c.n_table - 2);
+}
+
+// scipy interp1d(linear, fill_value=(lo,hi)) on the LDS copy of the table
+__device__ __forceinline__ float table_ct(const WfConsts& c, const TableLds& T, float v) {
+  int j = table_segment(c, T, v);
+  float r = fmaf(T.cts[j], v - T.knot[j], T.ct[j]);
+  r = (v < T.knot[0]) ? 0.0001f : r;
+  r = (v > T.knot[c.n_table - 1]) ? 0.9999f : r;
+  return fminf(fmaxf(r, 0.0001f), 0.9999f);
+}
+__device__ __forceinline__ float table_pw(const WfConsts& c, const TableLds& T, float v) {
+  int j = table_segment(c, T, v);
+  float r = fmaf(T.pws[j], v - T.knot[j], T.pw[j]);
+  r = (v < T.knot[0] || v > T.knot[c.n_table - 1]) ? 0.0f : r;
+  return r;
+}
+
+template <int S>
+struct Slots {
+  double x[S];   // sorted x' (float64: the sign of dx decides every upstream/downstream mask)
+  float y[S];    // sorted y' - yc
+  float yaw[S];  // commanded yaw, degrees
+  float wsq[S][9];  // SOSFS: sum of (deficit*Uinit)^2                 [A.3-7]
+  float V[S][9], W[S][9];
+  float TI[S][3];   // per grid column j (independent of k)            [A.3-8]
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Geometry: wd % 360, rotation about the layout's bounding-box centre, stable ascending sort [A.1]
+// One block per wind condition; float64 throughout.
+// ---------------------------------------------------------------------------------------------
+__global__ void wf_geometry_kernel(int N, const double* __restrict__ lx, const double* __restrict__ ly, double xc,
+                                   double yc, const double* __restrict__ wd, double* __restrict__ gx,
+                                   float* __restrict__ gy, int* __restrict__ gidx) {
+  __shared__ double sx[WF_TABLE_PAD * 4];
+  const int e = blockIdx.x;
+  const int t = threadIdx.x;
+  double w = fmod(wd[e], 360.0);
+  if (w < 0.0) w += 360.0;
+  double dev = fmod(w - 270.0, 360.0);
+  if (dev < 0.0) dev += 360.0;
+  dev = fmod(dev + 360.0, 360.0);
+  const double a = dev * (M_PI / 180.0);
+  const double ca = cos(a), sa = sin(a);
+  double xr = 0.0, yr = 0.0;
+  if (t < N) {
+    const double xo = lx[t] - xc, yo = ly[t] - yc;
+    xr = xo * ca - yo * sa + xc;
+    yr = xo * sa + yo * ca + yc;
+    sx[t] = xr;
+  }
+  __syncthreads();
+  if (t < N) {
+    int rank = 0;
+    for (int u = 0; u < N; ++u) {
+      const double xu = sx[u];
+      rank += (xu < xr) || (xu == xr && u < t);
+    }
+    const size_t o = (size_t)e * N + rank;
+    gx[o] = xr;
+    gy[o] = (float)(yr - yc);
+    gidx[o] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The farm step
+// ---------------------------------------------------------------------------------------------
+template <int G, int S>
+__global__ __launch_bounds__(256, 2) void wf_step_kernel(
+    const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const float* __restrict__ gy,
+    const int* __restrict__ gidx, int geom_stride, const double* __restrict__ ws_in, const double* __restrict__ wd_in,
+    int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power, float* __restrict__ o_ws,
+    float* __restrict__ o_wd, float* __restrict__ o_load, int B) {
+  constexpr int EPW = 64 / G;  // envs per wave
+  __shared__ TableLds T;
+  for (int k = threadIdx.x; k < WF_TABLE_PAD; k += blockDim.x) {
+    T.knot[k] = tab->knot[k];
+    T.ct[k] = tab->ct[k];
+    T.cts[k] = tab->ct_slope[k];
+    T.pw[k] = tab->pw[k];
+    T.pws[k] = tab->pw_slope[k];
+  }
+  for (int k = threadIdx.x; k < WF_BUCKETS; k += blockDim.x) T.bucket[k] = tab->bucket[k];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int sub = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int env_raw = (blockIdx.x * (blockDim.x >> 6) + wave) * EPW + lane / G;
+  const bool env_ok = env_raw < B;
+  const int env = env_ok ? env_raw : (B - 1);
+  const int N = c.N;
+
+  const float ws = (float)ws_in[(size_t)env * wind_stride];
+  const double wd_d = fmod(wd_in[(size_t)env * wind_stride], 360.0);
+  const float wd = (float)(wd_d < 0.0 ? wd_d + 360.0 : wd_d);
+  const float Ui[3] = {ws * c.shearf[0], ws * c.shearf[1], ws * c.shearf[2]};
+
+  const size_t gofs = (size_t)env * geom_stride;
+  const size_t yofs = (size_t)env * N;
+
+  Slots<S> st;
+#pragma unroll
+  for (int p = 0; p < S; ++p) {
+    const int t = p * G + sub;
+    const bool ok = t < N;
+    const int tt = ok ? t : 0;
+    st.x[p] = ok ? gx[gofs + tt] : -1.0e300;  // never downstream of anything
+    st.y[p] = gy[gofs + tt];
+    st.yaw[p] = yaw_in[yofs + gidx[gofs + tt]];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      st.wsq[p][q] = 0.0f;
+      st.V[p][q] = 0.0f;
+      st.W[p][q] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) st.TI[p][j] = c.amb;
+  }
+
+  const int nblk = (N + G - 1) / G;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int nsrc = min(G, N - blk * G);
+    for (int li = 0; li < nsrc; ++li) {
+      const int src = gbase + li;
+      // ---- A. the source's state (slot 0 of lane `li` of the group) ------------------------
+      float m3 = 0.0f, vsum = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const float u = Ui[q % 3] - fsqrt(st.wsq[0][q]);
+        m3 = fmaf(u * u, u, m3);
+        vsum += st.V[0][q];
+      }
+      m3 = __shfl(m3, src);
+      const float Vmean = __shfl(vsum, src) * (1.0f / 9.0f);
+      const double x_i = __shfl(st.x[0], src);
+      const float y_i = __shfl(st.y[0], src);
+      const float yaw_i = __shfl(st.yaw[0], src);
+      float TIs[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) TIs[j] = __shfl(st.TI[0][j], src);
+
+      // ---- B. source constants, part 1 [A.3-1 .. A.3-4] ------------------------------------
+      const float ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
+      float sg, cg;
+      sincosf(yaw_i * kDeg2Rad, &sg, &cg);
+      const float ct = table_ct(c, T, ubar) * cg;
+      const float sq1 = fsqrt(1.0f - ct * cg);
+      const float a = 0.5f * ct * frcp(1.0f + sq1);  // == 0.5/cg*(1 - sqrt(1 - ct*cg))
+      const float Gwr = c.gam_wr * (a - a * a) * ubar;
+      const float gt = c.gam_top * ws * ct, gb = c.gam_bot * ws * ct;
+      // secondary steering
+      float val = 2.0f * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
+      val = fminf(fmaxf(val, -1.0f), 1.0f);
+      const float gd = -(yaw_i * kDeg2Rad + 0.5f * asinf(val));  // radians, deflection sign convention
+      const float cgd = cosf(gd);
+      const float s_cc = fsqrt(1.0f - ct * cgd), s_c = fsqrt(1.0f - ct);
+      const float om_scc = ct * cgd * frcp(1.0f + s_cc);  // 1 - s_cc
+      const float om_sc = ct * frcp(1.0f + s_c);          // 1 - s_c  (== C0)
+      const float sM = fsqrt(ct);                         // sqrt(M0), M0 = C0(2-C0) = ct
+      const float E0 = fmaf(om_sc, om_sc, fmaf(-c.e0c1, om_sc, c.e0c2));
+      const float sz0d = 0.5f * c.D * fsqrt((1.0f + s_cc) * frcp(2.0f * (1.0f + s_c)));
+      const float sy0d = sz0d * cgd;
+      const float th0 = c.dm03 * gd * frcp(cgd) * om_scc;
+      const float tan_th0 = tanf(th0);
+      const float inv_s0d = frcp(sy0d * sz0d);
+      const float pfac = th0 * E0 * (1.0f / 5.2f) * fsqrt(sy0d * sz0d * frcp(ct)) * kLn2;  // * log2(arg)/ky
+      const float lnA = 1.6f + sM, lnB = 1.6f - sM;
+      float x0d[3], kyd[3], d0[3], pj[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        x0d[j] = c.D * cgd * (1.0f + s_cc) * frcp(1.41421356237f * fmaf(c.alpha4, TIs[j], c.beta2 * om_sc));
+        kyd[j] = fmaf(c.ka, TIs[j], c.kb);
+        d0[j] = tan_th0 * x0d[j];
+        pj[j] = pfac * frcp(kyd[j]);
+      }
+      // transverse circulations / (2 pi), commanded yaw
+      const float scg = sg * cg;
+      const float Gv[3] = {scg * gt, -scg * gb, Gwr};
+
+      // ---- C. pass 1: transverse velocities on every target at or downstream of the source --
+      float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
+#pragma unroll
+      for (int p = 0; p < S; ++p) {
+        const float dx = (float)(st.x[p] - x_i);
+        if (dx >= 0.0f) {
+          const float dy = st.y[p] - y_i;
+          float dec[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dec[k] = frcp(fmaf(c.decay_a[k], dx, 1.0f));
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float yL = dy + c.yoff[j];
+            const float yL2 = yL * yL;
+            const float Ey = fexp2(-yL2 * c.exp_c);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              float A = 0.0f, Bw = 0.0f;
+#pragma unroll
+              for (int v = 0; v < 3; ++v) {
+                const float tr = fmaf(-Ey, c.ez[v][k], 1.0f) * frcp(yL2 + c.zc2[v][k]);
+                const float tm = fmaf(-Ey, c.ezm[v][k], 1.0f) * frcp(yL2 + c.zm2[v][k]);
+                A = fmaf(Gv[v], fmaf(c.zc[v][k], tr, -c.zm[v][k] * tm), A);
+                Bw = fmaf(Gv[v], tr - tm, Bw);
+              }
+              const float vw = A * dec[k];
+              const float ww = fmaxf(-yL * Bw * dec[k], 0.0f);  // W[W<0] = 0, quirk (5)
+              st.V[p][j * 3 + k] += vw;
+              st.W[p][j * 3 + k] += ww;
+            }
+          }
+        }
+        if (p == 0) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            vbar += st.V[0][q];
+            wbar += st.W[0][q];
+          }
+        }
+      }
+      vbar = __shfl(vbar, src) * (1.0f / 9.0f);
+      wbar = __shfl(wbar, src) * (1.0f / 9.0f);
+
+      // ---- D. yaw-added recovery [A.3-5] and deficit constants [A.3-6] -----------------------
+      const float I0 = TIs[0];
+      const float uI = ubar * I0;
+      const float mix2 = (vbar * vbar + wbar * wbar) * (1.0f / 3.0f);
+      const float inv_ubar = frcp(ubar);
+      const float Itot = fsqrt(fmaf(uI, uI, mix2)) * inv_ubar;
+      const float Imix = mix2 * inv_ubar * inv_ubar * frcp(Itot + I0);  // == Itot - I0, no cancellation
+      const float dTI = c.gch_gain * Imix;
+      if (lane == src) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) st.TI[0][j] += dTI;
+      }
+      const float sy0v = c.sz0v * cg;
+      const float snw = c.near_c * fsqrt(0.5f * ct);
+      const float kdef = ct * cg * c.kdef;
+      const float ch_pref = c.ch_c * fexp2(c.ch_ai * flog2(a));
+      float x0v[3], ix0v[3], kyv[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float ti = TIs[j] + dTI;
+        x0v[j] = c.D * cg * (1.0f + s_c) * frcp(1.41421356237f * fmaf(c.alpha4, ti, c.beta2 * om_sc));
+        ix0v[j] = frcp(x0v[j]);
+        kyv[j] = fmaf(c.ka, ti, c.kb);
+      }
+
+      // ---- E. pass 2: deflection, deficit, SOSFS, wake-added turbulence ----------------------
+#pragma unroll
+      for (int p = 0; p < S; ++p) {
+        const float dx = (float)(st.x[p] - x_i);
+        if (dx > 0.0f) {
+          const float dy = st.y[p] - y_i;
+          const float lin = fmaf(c.bd, dx, c.ad);
+          const bool wake_on = dx > 0.1f;
+          int cnt = 0;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            // deflection (TI before mixing) [A.3-3]
+            const float xs = fmaxf(dx - x0d[j], 0.0f);
+            const float syd = fmaf(kyd[j], xs, sy0d), szd = fmaf(kyd[j], xs, sz0d);
+            const float s = fsqrt(syd * szd * inv_s0d);
+            const float arg = lnA * fmaf(1.6f, s, -sM) * frcp(lnB * fmaf(1.6f, s, sM));
+            const float d_far = fmaf(pj[j], flog2(arg), d0[j]);
+            const float d_near = dx * tan_th0;  // (dx/x0d)*d0
+            const float delta = ((dx > x0d[j]) ? d_far : d_near) + lin;
+            // deficit (TI after mixing) [A.3-6]
+            const bool far = dx >= x0v[j];
+            const float up = dx * ix0v[j];
+            const float xf = dx - x0v[j];
+            const float sy = far ? fmaf(kyv[j], xf, sy0v) : fmaf(up, sy0v - snw, snw);
+            const float sz = far ? fmaf(kyv[j], xf, c.sz0v) : fmaf(up, c.sz0v - snw, snw);
+            const float isy = frcp(sy), isz = frcp(sz);
+            const float xarg = kdef * isy * isz;
+            const float C = (xarg >= 1.0f) ? 1.0f : xarg * frcp(1.0f + fsqrt(fmaxf(1.0f - xarg, 0.0f)));
+            const float yy = (dy + c.off[j] - delta) * isy;
+            const float zz = c.off[2] * isz;
+            const float ry = 0.5f * kLog2e * yy * yy;
+            const float rz = 0.5f * kLog2e * zz * zz;
+            const float amp = wake_on ? C : 0.0f;
+            const float e1 = amp * fexp2(-ry);
+            const float e0 = amp * fexp2(-ry - rz);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const float dU = ((k == 1) ? e1 : e0) * Ui[k];
+              st.wsq[p][j * 3 + k] = fmaf(dU, dU, st.wsq[p][j * 3 + k]);
+              cnt += (dU > c.overlap_thr) ? 1 : 0;
+            }
+          }
+          // Crespo-Hernandez with overlap gating [A.3-8]
+          const float dxp = (dx > 0.1f) ? dx : dx + 1.0f;
+          const float ti = ch_pref * fexp2(c.ch_down * flog2(dxp * c.invD));
+          const float tia = (dx <= c.fifteenD) ? ti * ((float)cnt * (1.0f / 9.0f)) : 0.0f;
+          const float cand = fsqrt(fmaf(tia, tia, c.amb2));
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const bool m = fabsf(dy + c.off[j]) < c.twoD;
+            st.TI[p][j] = m ? fmaxf(st.TI[p][j], cand) : st.TI[p][j];
+          }
+        }
+      }
+    }  // li
+
+    // rotate the slots so that the next block of sources sits in slot 0
+    if (S > 1) {
+      const double x0 = st.x[0];
+      const float y0 = st.y[0], w0 = st.yaw[0];
+      float a0[9], b0[9], c0[9], t0[3];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { a0[q] = st.wsq[0][q]; b0[q] = st.V[0][q]; c0[q] = st.W[0][q]; }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) t0[j] = st.TI[0][j];
+#pragma unroll
+      for (int p = 0; p + 1 < S; ++p) {
+        st.x[p] = st.x[p + 1]; st.y[p] = st.y[p + 1]; st.yaw[p] = st.yaw[p + 1];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          st.wsq[p][q] = st.wsq[p + 1][q]; st.V[p][q] = st.V[p + 1][q]; st.W[p][q] = st.W[p + 1][q];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) st.TI[p][j] = st.TI[p + 1][j];
+      }
+      st.x[S - 1] = x0; st.y[S - 1] = y0; st.yaw[S - 1] = w0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { st.wsq[S - 1][q] = a0[q]; st.V[S - 1][q] = b0[q]; st.W[S - 1][q] = c0[q]; }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) st.TI[S - 1][j] = t0[j];
+    }
+  }  // blk
+
+  // ---- outputs [A.4]: slot p now holds block (p + nblk) % S ----------------------------------
+#pragma unroll
+  for (int p = 0; p < S; ++p) {
+    const int t = ((p + nblk) % S) * G + sub;
+    if (t < N && env_ok) {
+      const int o = gidx[gofs + t];
+      float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        U[q] = Ui[q % 3] - fsqrt(st.wsq[p][q]);
+        m3 = fmaf(U[q] * U[q], U[q], m3);
+        mu += U[q]; mv += st.V[p][q]; mw += st.W[p][q];
+        adir += atan2f(st.V[p][q], U[q]);
+      }
+      mu *= (1.0f / 9.0f); mv *= (1.0f / 9.0f); mw *= (1.0f / 9.0f);
+      float su = 0.0f, sv = 0.0f, sw = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const float du = U[q] - mu, dv = st.V[p][q] - mv, dw = st.W[p][q] - mw;
+        su = fmaf(du, du, su); sv = fmaf(dv, dv, sv); sw = fmaf(dw, dw, sw);
+      }
+      const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
+      const float cy = cosf(st.yaw[p] * kDeg2Rad);
+      const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cy));
+      const size_t oo = yofs + o;
+      o_power[oo] = c.rho * table_pw(c, T, veff);
+      o_ws[oo] = wsp;
+      o_wd[oo] = wd - adir * (kRad2Deg / 9.0f);
+      float4 l;
+      l.x = (st.TI[p][0] + st.TI[p][1] + st.TI[p][2]) * (1.0f / 3.0f);
+      l.y = fsqrt(su * (1.0f / 9.0f));
+      l.z = fsqrt(sv * (1.0f / 9.0f));
+      l.w = fsqrt(sw * (1.0f / 9.0f));
+      reinterpret_cast<float4*>(o_load)[oo] = l;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch table
+// ---------------------------------------------------------------------------------------------
+struct WfVariant {
+  int G, S;
+  const void* fn;
+};
+
+#define WF_VARIANT(G_, S_) {G_, S_, (const void*)&wf_step_kernel<G_, S_>}
+static const WfVariant kVariants[] = {
+    WF_VARIANT(4, 1),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(8, 3),  WF_VARIANT(8, 4),
+    WF_VARIANT(16, 3), WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(16, 6), WF_VARIANT(32, 3),
+    WF_VARIANT(32, 4), WF_VARIANT(64, 3), WF_VARIANT(64, 4),
+};
+
+extern "C" int wfk_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
+extern "C" void wfk_variant(int i, int* G, int* S, const void** fn) {
+  *G = kVariants[i].G;
+  *S = kVariants[i].S;
+  *fn = kVariants[i].fn;
+}
+
+extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
+                                          const double* wd, double* gx, float* gy, int* gidx, hipStream_t s) {
+  const int threads = ((N + 63) / 64) * 64;
+  hipLaunchKernelGGL(wf_geometry_kernel, dim3(n_env), dim3(threads), 0, s, N, lx, ly, xc, yc, wd, gx, gy, gidx);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
+                                      const float* gy, const int* gidx, int geom_stride, const double* ws,
+                                      const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
+                                      float* o_wd, float* load, int B, hipStream_t s, int* grid_out) {
+  const WfVariant& v = kVariants[variant];
+  const int envs_per_block = 4 * (64 / v.G);
+  const int grid = (B + envs_per_block - 1) / envs_per_block;
+  if (grid_out) *grid_out = grid;
+  WfConsts cc = *c;
+  void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B};
+  return hipLaunchKernel(v.fn, dim3(grid), dim3(256), args, 0, s);
+}
