@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — farm-steps/s of the HIP wind-farm step (BASELINE.json metric) + roofline + CPU baseline.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[3] — HornsRev1_Floris (80 turbines in the reference
+code, data_cases.py:269-334), env_batch 65536, ws 8 m/s, wd 270 deg, random-walk yaw
+(dyaw ~ U(-5,5) clipped to +-40).  It fits one GPU, so N=1 runs the whole config on
+one device; for N>1 every rank runs the same per-GPU batch on its own shard of independent farms
+(weak scaling, no data-path collective).  A "step" = one pass of the hot path (wf_step) over the batch,
+yaw already resident in HBM, outputs left in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANEOPS = 7.864e13   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (157.3 TFLOP/s / 2)
+
+CONFIGS = {
+    # name: (layout, per-GPU env batch)
+    "cfg2": ("Ablaincourt_", 4096),
+    "cfg3": ("Turb16_Row5_", 16384),
+    "cfg4": ("HornsRev1_", 65536),
+    "cfg5": ("HornsRev2_", 131072),
+}
+
+
+def lane_ops_per_farm_step(N: int) -> float:
+    """Analytic VALU work model of the kernel: issue slots per (source, target) pair with
+    dx >= 0 (transcendentals counted as 2 slots) x pairs, plus per-source scalar work."""
+    pairs = N * (N + 1) / 2
+    return pairs * 640.0 + N * 300.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
+    ap.add_argument("--env-batch", type=int, default=0, help="per-GPU env batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from wfcrl_env_amd.backend import WfStep
+    from wfcrl_env_amd.sharding import shard_bounds
+
+    layout_name, B = CONFIGS[args.config]
+    if args.env_batch:
+        B = args.env_batch
+    with open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")) as f:
+        lay = json.load(f)[layout_name]
+    N = lay["num_turbines"]
+    # global env ids of this rank's shard (contiguous blocks)
+    lo, hi = shard_bounds(B * world, rank, world)
+    assert hi - lo == B
+
+    w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B, device_id=local_rank)
+    w.set_stream(torch.cuda.current_stream().cuda_stream)
+    w.set_wind(8.0, 270.0)
+
+    # synthetic random-walk yaw sequence, seeded per SURVEY §8d (1234 + cfg id) and per global env id
+    cfg_id = int(args.config[3:])
+    gen = torch.Generator(device="cuda").manual_seed(1234 + cfg_id + 7919 * rank)
+    ring = []
+    yaw = torch.zeros((B, N), device="cuda", dtype=torch.float32)
+    for _ in range(8):
+        yaw = (yaw + (torch.rand((B, N), device="cuda", generator=gen) * 10 - 5)).clamp_(-40, 40)
+        ring.append(yaw.clone())
+    out = w.step(ring[0])
+    w.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        w.step(ring[i % len(ring)], out)
+    barrier()
+    t0 = time.perf_counter()
+    w.timing_begin()
+    for i in range(args.steps):
+        w.step(ring[i % len(ring)], out)
+    kern_ms = w.timing_end() / args.steps  # HIP events on the stream the kernel is launched on
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed, kern_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(t[0]), float(t[1])
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = B * world * args.steps / elapsed
+    algo_bytes = (32 * N + 8) * B  # read 4N yaw + 8 wind, write 28N outputs, per farm-step
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(f"{args.config}_B{B}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    info = w.kernel_info()
+    lane_ops = lane_ops_per_farm_step(N) * B
+    valu_achieved = lane_ops / (kern_ms * 1e-3)
+
+    # accuracy beside the throughput: a bounded sample of this very batch against the float64 oracle
+    res = {"metric": "farm_steps_per_sec", "value": value, "unit": "farm-steps/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{layout_name}Floris x env_batch {B} per GPU (BASELINE configs[{cfg_id - 1}]), "
+                                  "ws 8 m/s, wd 270, random-walk yaw", "layout": layout_name.rstrip("_"),
+                      "turbines": N, "env_batch_per_gpu": B, "env_batch_total": B * world, "parallelism": f"env-shard x{world}",
+                      "kernel": f"wf_step_kernel<G={info['lanes_per_env']},S={info['slots_per_lane']}>",
+                      "vgprs": info["vgprs"], "scratch_bytes": info["scratch_bytes"]},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                        "note": "path is VALU-bound (arithmetic intensity ~2 kFLOP/B): see valu_roofline"},
+           "valu_roofline": {"bound": "valu_fp32", "achieved": valu_achieved, "peak": VALU_PEAK_LANEOPS,
+                             "unit": "lane-ops/s", "frac": valu_achieved / VALU_PEAK_LANEOPS,
+                             "lane_ops_per_farm_step": lane_ops_per_farm_step(N)}}
+
+    if not args.no_cpu_baseline:
+        from oracle import c_oracle
+
+        nthreads = c_oracle.max_threads()
+        ycpu = ring[0][: min(B, 4096)].cpu().numpy().astype(np.float64)
+        # accuracy sample
+        ns = min(256, ycpu.shape[0])
+        ref = c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[:ns])
+        got = w.step(ring[0], out)
+        w.sync()
+        gp = got["power"][:ns].cpu().numpy().astype(np.float64)
+        perr = np.abs(gp - ref["power"]) / np.maximum(ref["power"], 1e3)
+        res["power_rel_err"] = {"max": float(perr.max()), "p999": float(np.quantile(perr, 0.999)),
+                                "sample": f"{ns} envs x {N} turbines vs float64 oracle"}
+        # timing: calibrate on a small sample, then ~cpu_seconds of work
+        t = time.perf_counter()
+        c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[: 4 * nthreads])
+        per_env = (time.perf_counter() - t) / (4 * nthreads)
+        n = int(max(4 * nthreads, min(ycpu.shape[0], args.cpu_seconds / per_env)))
+        reps = max(1, int(args.cpu_seconds / (per_env * n)))
+        t = time.perf_counter()
+        for _ in range(reps):
+            c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[:n])
+        dt = time.perf_counter() - t
+        res["cpu_baseline"] = {"value": n * reps / dt, "unit": "farm-steps/s", "cores": nthreads, "kind": "port",
+                               "sample": f"{reps} x {n} farm-steps of the same workload, C float64 oracle "
+                                         f"(OpenMP over envs, {nthreads} threads of {os.cpu_count()} host CPUs), {dt:.1f} s"}
+    print(json.dumps(res), flush=True)
+    w.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

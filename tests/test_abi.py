@@ -1,0 +1,67 @@
+"""CPU: libwfstep.so builds, loads, and exports every symbol include/wfstep.h declares.
+No compute calls here (no GPU); with no device wf_create must fail loudly, not fall back."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, gpu_available
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "wfstep.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wf_[a-z_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_surface():
+    syms = declared_symbols()
+    for s in ("wf_create", "wf_destroy", "wf_set_layout", "wf_set_model", "wf_set_batch", "wf_set_wind", "wf_step",
+              "wf_sync", "wf_last_error", "wf_version"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from wfcrl_env_amd import _lib
+
+    lib = _lib.load()
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"libwfstep.so does not export {s}"
+        assert s in _lib.ABI, f"ctypes binding table lacks {s}"
+    assert set(_lib.ABI) == set(declared_symbols())
+    assert lib.wf_version() == 1
+
+
+def test_default_model_matches_oracle_defaults():
+    """The product's constants and the oracle's are two independent statements of case.yaml + nrel_5MW."""
+    from oracle.floris_gch_numpy import ModelParams
+    from wfcrl_env_amd.backend import default_model
+
+    d, o = default_model(), ModelParams()
+    ren = {"rotor_diameter": "D", "hub_height": "HH", "tsr": "TSR"}
+    for k, v in d.items():
+        if k.startswith("table_"):
+            assert list(v) == list(getattr(o, k))
+        else:
+            assert v == getattr(o, ren.get(k, k)), k
+
+
+def test_no_cpu_fallback_without_device():
+    if gpu_available():
+        pytest.skip("a GPU is present")
+    from wfcrl_env_amd import _lib
+    from wfcrl_env_amd.backend import WfStep
+
+    with pytest.raises(_lib.WfError, match="WF_E_NODEVICE"):
+        WfStep([0.0, 500.0], [0.0, 0.0])
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "wfcrl-env_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "libwforacle" not in src, f

@@ -1,0 +1,101 @@
+"""CPU: the oracles against the reference's known-answer vector and against each other.
+
+KAT-1 (tests/golden/kat1_demo_notebook.json) is the ONLY vector pinned by the reference itself
+(reference examples/demo.ipynb:137-139).  Everything else here is oracle-pinned.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import floris_gch_numpy as onp
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "oracle_goldens.npz")
+
+
+def test_numpy_oracle_reproduces_reference_kat(kat1):
+    r = onp.farm_step(kat1["xcoords"], kat1["ycoords"], kat1["wind_speed_free"], kat1["wind_direction_free"],
+                      np.array(kat1["yaw"]))
+    # the notebook prints 8 decimals: half a unit in the last place is 5e-9
+    assert np.abs(r["wind_speed"] - np.array(kat1["wind_speed"])).max() <= 1e-8
+    assert np.abs(r["wind_direction"] - np.array(kat1["wind_direction"])).max() <= 1.2e-8
+    assert np.abs(r["wind_speed"] / np.array(kat1["wind_speed"]) - 1).max() <= 1e-8
+
+
+def test_c_oracle_reproduces_reference_kat(kat1):
+    r = c_oracle.farm_step_batch(kat1["xcoords"], kat1["ycoords"], kat1["wind_speed_free"],
+                                 kat1["wind_direction_free"], np.array([kat1["yaw"]]))
+    assert np.abs(r["wind_speed"][0] / np.array(kat1["wind_speed"]) - 1).max() <= 1e-8
+    assert np.abs(r["wind_direction"][0] - np.array(kat1["wind_direction"])).max() <= 1.2e-8
+
+
+def test_kat_oracle_derived_intermediates(kat1):
+    """SURVEY Appendix B (oracle-derived, not reference-pinned): powers, load proxies, reward."""
+    r = onp.farm_step(kat1["xcoords"], kat1["ycoords"], kat1["wind_speed_free"], kat1["wind_direction_free"],
+                      np.zeros(7))
+    p = np.array([897109.26, 289160.86, 896636.25, 793482.19, 788737.41, 752001.51, 626876.67])
+    assert np.allclose(r["power"], p, rtol=0, atol=0.006)
+    assert np.allclose(r["load"][:, 0], [0.0602306076, 0.1204899426, 0.0604958592, 0.0908289244, 0.0918397491,
+                                         0.0918914198, 0.1202582964], rtol=0, atol=1e-10)
+    assert np.allclose(r["load"][:, 1], [0.23158, 1.15882, 0.23153, 0.36036, 0.36488, 0.43621, 0.70063], atol=6e-6)
+    reward = np.mean(r["power"] / 1e6 * 1e3 / kat1["wind_speed_free"] ** 3) - 0.1 * np.mean(np.abs(r["load"]))
+    assert abs(reward - 2.61847) < 6e-6
+
+
+def test_unwaked_cubic_mean_factor():
+    """A single turbine sees 0.99670412*ws (shear over the 3x3 grid, SURVEY A.2 check)."""
+    r = onp.farm_step([0.0], [0.0], 8.0, 270.0, np.zeros(1))
+    assert abs(r["wind_speed"][0] / 8.0 - 0.99670412) < 1e-8
+    assert abs(r["load"][0, 0] - (0.06 + 2 * 0.0)) < 2e-3  # ambient + tiny self-induced mixing
+
+
+@pytest.mark.parametrize("yaw,total", [([0, 0, 0], 2.377), ([20, 0, 0], 2.570), ([-20, 0, 0], 2.530),
+                                        ([25, 15, 0], 2.798), ([40, 40, 40], 2.309)])
+def test_three_turbine_row_steering_sanity(yaw, total):
+    """SURVEY Appendix D physical sanity (4D spacing, 8 m/s, 270 deg): GCH asymmetry of +/- yaw."""
+    r = onp.farm_step([0, 504, 1008], [0, 0, 0], 8.0, 270.0, np.array(yaw, float))
+    assert abs(r["power"].sum() / 1e6 - total) < 6e-4
+
+
+def test_c_oracle_matches_numpy_oracle_on_goldens(layouts):
+    g = np.load(GOLD)
+    for key in sorted({k.split("__")[0] for k in g.files}):
+        l = layouts[key + "_"]
+        r = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], g[f"{key}__ws"], g[f"{key}__wd"], g[f"{key}__yaw"])
+        for name in ("power", "wind_speed", "wind_direction", "load"):
+            ref = g[f"{key}__{name}"]
+            assert np.abs(r[name] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), (key, name)
+
+
+def test_numpy_oracle_still_matches_goldens(layouts):
+    g = np.load(GOLD)
+    for key in ("Turb3_Row1", "Turb6_Row2", "Ablaincourt"):
+        l = layouts[key + "_"]
+        r = onp.farm_step_batch(l["xcoords"], l["ycoords"], g[f"{key}__ws"], g[f"{key}__wd"], g[f"{key}__yaw"])
+        for name in ("power", "wind_speed", "wind_direction", "load"):
+            assert np.array_equal(r[name], g[f"{key}__{name}"]), (key, name)
+
+
+def test_oracle_edge_cases_finite(layouts):
+    l = layouts["Turb6_Row2_"]
+    rng = np.random.default_rng(3)
+    for ws, wd in [(3.0, 270.0), (28.0, 0.0), (25.0, 180.0), (12.0, -90.0), (8.0, 630.0), (8.0, 359.999)]:
+        r = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], ws, wd, rng.uniform(-40, 40, (3, 6)))
+        for v in r.values():
+            assert np.isfinite(v).all()
+    # wd and wd+360 are the same wind (reference interface.py:664)
+    y = rng.uniform(-40, 40, (2, 6))
+    a = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], 9.0, -90.0, y)
+    b = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], 9.0, 270.0, y)
+    assert np.allclose(a["power"], b["power"], rtol=1e-12)
+    # above cut-out the power table returns 0
+    r = c_oracle.farm_step_batch([0.0], [0.0], 28.0, 270.0, np.zeros((1, 1)))
+    assert r["power"][0, 0] == 0.0
+
+
+def test_layout_counts(layouts):
+    """Checksum of SURVEY Appendix C1 (counts in the reference CODE, not its README)."""
+    want = {"Turb3_Row1_": 3, "Turb6_Row2_": 6, "Turb16_Row5_": 16, "Turb32_Row5_": 32, "Turb_TCRWP_": 32,
+            "Ablaincourt_": 7, "HornsRev1_": 80, "Ormonde_": 30, "HornsRev2_": 91, "WMR_": 35}
+    assert {k: v["num_turbines"] for k, v in layouts.items()} == want
