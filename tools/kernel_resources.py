@@ -3,7 +3,7 @@
 import re, subprocess, sys
 from pathlib import Path
 src = Path(__file__).resolve().parents[1] / "wfcrl-env_amd" / "csrc"
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-fast-math", "-ffp-contract=off", "-fno-slp-vectorize",
        "-c", "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", str(src / "wf_kernels.hip")] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None

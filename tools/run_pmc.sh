@@ -1,0 +1,13 @@
+#!/bin/bash
+# GPU box: PMC counters for the step kernel, one counter group per rocprofv3 pass (never combined with
+# --sys-trace etc.).  Usage: tools/run_pmc.sh <tag> [bench args]
+tag=$1; shift
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_$tag
+mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$name -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline $BENCH_ARGS > $O/$name.json 2> $O/$name.err; }
+BENCH_ARGS="$*"
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY
+run sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
+find $O -name "*counter_collection.csv" | head

@@ -172,16 +172,20 @@ int build_consts(wf_handle* h) {
     c.decay_a[k] = (float)(4.0 * nu / uinf / eps2);
   }
   c.exp_c = (float)(1.4426950408889634 / eps2);
+  const double m_eps = m.num_eps;
+  const double q = D / 4.0;
+  for (int m = -3; m <= 3; ++m) {
+    const double zc = m * q + m_eps, zm = 2.0 * HH + m * q + m_eps;
+    c.zc[m + 3] = (float)zc; c.zc2[m + 3] = (float)(zc * zc); c.ez[m + 3] = (float)std::exp(-zc * zc / eps2);
+    c.zm[m + 3] = (float)zm; c.zm2[m + 3] = (float)(zm * zm); c.ezm[m + 3] = (float)std::exp(-zm * zm / eps2);
+  }
   const double hs[3] = {HH + R, HH - R, HH};
   double ks[3] = {0, 0, 0};
   for (int v = 0; v < 3; ++v)
     for (int k = 0; k < 3; ++k) {
-      const double z = HH + off[k];
-      const double zc = z - hs[v] + m.num_eps, zm = z + hs[v] + m.num_eps;
-      c.zc[v][k] = (float)zc; c.zc2[v][k] = (float)(zc * zc); c.ez[v][k] = (float)std::exp(-zc * zc / eps2);
-      c.zm[v][k] = (float)zm; c.zm2[v][k] = (float)(zm * zm); c.ezm[v][k] = (float)std::exp(-zm * zm / eps2);
+      const double zc = HH + off[k] - hs[v] + m_eps;
       for (int j = 0; j < 3; ++j) {  // secondary-steering means on the source's own grid [A.3-2]
-        const double yL = off[j] + m.num_eps;
+        const double yL = off[j] + m_eps;
         const double r = yL * yL + zc * zc;
         ks[v] += zc / r * (1.0 - std::exp(-r / eps2)) / 9.0;
       }

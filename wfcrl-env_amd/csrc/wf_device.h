@@ -17,10 +17,13 @@ struct WfConsts {
   float uinf_f;      // mean shearf    : Uinf    = ws*uinf_f
   float decay_a[3];  // 4 nu_k / (Uinf eps^2) : decay_k = 1/(decay_a[k]*dx + 1)   [A.3-4]
   float exp_c;       // log2(e)/eps^2  : exp(-r/eps^2) = exp2(-r*exp_c)
-  // the six vortices of the transverse-velocity model, per (vortex v, grid row k)     [A.3-4]
-  // v = 0 top (h = HH+R), 1 bottom (h = HH-R), 2 wake rotation (h = HH); m = ground mirror
-  float zc[3][3], zc2[3][3], ez[3][3];   // zc = z_k - h + eps ; ez = exp(-zc^2/eps^2)
-  float zm[3][3], zm2[3][3], ezm[3][3];  // zm = z_k + h + eps
+  // the six vortices of the transverse-velocity model [A.3-4]: v = top (h = HH+R), bottom (HH-R), wake
+  // rotation (HH), each with a ground mirror.  On the 3x3 grid (rows z_k = HH + k'q, q = D/4, k' = -1,0,1)
+  // the 9 real offsets z_k - h + eps take only 7 distinct values m*q + eps, m = -3..3, and the 9 mirror
+  // offsets z_k + h + eps the 7 values 2HH + m*q + eps: class index = m + 3.
+  //   real:   top m = k'-2, bottom m = k'+2, rotation m = k'      mirror: top k'+2, bottom k'-2, rotation k'
+  float zc[7], zc2[7], ez[7];    // zc = m q + eps       ; ez  = exp(-zc^2/eps^2)
+  float zm[7], zm2[7], ezm[7];   // zm = 2HH + m q + eps ; ezm = exp(-zm^2/eps^2)
   float gam_top, gam_bot;  // (1/2pi)(pi/8) D vel_{top,bot} uinf_f : Gamma/(2pi) = gam*ws*ct
   float gam_wr;            // (1/2pi) 0.25*2pi*D/TSR               : Gamma_wr/(2pi) = gam_wr*(a-a^2)*ubar
   // secondary steering: mean_9( z/(r) * core ) on the source's own grid (dx = 0, dy = 0)   [A.3-2]

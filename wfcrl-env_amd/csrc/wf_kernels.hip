@@ -71,15 +71,58 @@ __device__ __forceinline__ float table_pw(const WfConsts& c, const TableLds& T, 
   return r;
 }
 
+// Register-resident per-turbine state of one lane: S target slots x (9 + 9 + 9 + 3) floats.
 template <int S>
 struct Slots {
-  double x[S];   // sorted x' (float64: the sign of dx decides every upstream/downstream mask)
-  float y[S];    // sorted y' - yc
-  float yaw[S];  // commanded yaw, degrees
   float wsq[S][9];  // SOSFS: sum of (deficit*Uinit)^2                 [A.3-7]
   float V[S][9], W[S][9];
   float TI[S][3];   // per grid column j (independent of k)            [A.3-8]
 };
+
+// Per-wave sorted geometry + commanded yaw, staged in LDS once (lane-private reads for targets,
+// group-broadcast reads for the source).
+template <int EPW, int NP>
+struct GeoLds {
+  double x[EPW][NP];  // sorted x' (float64: the sign of dx decides every upstream/downstream mask)
+  float y[EPW][NP];   // sorted y' - yc
+  float yaw[EPW][NP]; // commanded yaw in sorted order, degrees
+};
+
+// Source-side constants of the deflection + deficit models for one grid column j [A.3-3, A.3-6]
+struct ColConsts {
+  float x0d, kyd, d0, pj;   // deflection: near-wake length, expansion rate, delta0, far-wake log prefactor
+  float x0v, ix0v, kyv;     // deficit:    near-wake length, its reciprocal, expansion rate
+};
+struct SrcConsts {
+  float sy0d, sz0d, inv_s0d, lnA, lnB, sM, tan_th0;  // deflection
+  float sy0v, snw, kdef;                             // deficit
+};
+
+// deflection + deficit of one target column: returns (e1, e0) = deficit at k = 1 and at k = 0, 2
+__device__ __forceinline__ void column_deficit(const WfConsts& c, const SrcConsts& sc, const ColConsts& cc, float dx,
+                                               float ylat, float lin, float amp_on, float& e1, float& e0) {
+  // deflection (TI before mixing) [A.3-3]
+  const float xs = fmaxf(dx - cc.x0d, 0.0f);
+  const float syd = fmaf(cc.kyd, xs, sc.sy0d), szd = fmaf(cc.kyd, xs, sc.sz0d);
+  const float s = fsqrt(syd * szd * sc.inv_s0d);
+  const float arg = sc.lnA * fmaf(1.6f, s, -sc.sM) * frcp(sc.lnB * fmaf(1.6f, s, sc.sM));
+  const float d_far = fmaf(cc.pj, flog2(arg), cc.d0);
+  const float delta = ((dx > cc.x0d) ? d_far : dx * sc.tan_th0) + lin;
+  // deficit (TI after mixing) [A.3-6]
+  const bool far = dx >= cc.x0v;
+  const float up = dx * cc.ix0v;
+  const float xf = dx - cc.x0v;
+  const float sy = far ? fmaf(cc.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
+  const float sz = far ? fmaf(cc.kyv, xf, c.sz0v) : fmaf(up, c.sz0v - sc.snw, sc.snw);
+  const float isy = frcp(sy), isz = frcp(sz);
+  const float xarg = sc.kdef * isy * isz;
+  const float C = (xarg >= 1.0f) ? 1.0f : xarg * frcp(1.0f + fsqrt(fmaxf(1.0f - xarg, 0.0f)));
+  const float yy = (ylat - delta) * isy;
+  const float zz = c.off[2] * isz;
+  const float amp = amp_on * C;
+  e1 = amp * fexp2(-0.5f * kLog2e * yy * yy);
+  e0 = e1 * fexp2(-0.5f * kLog2e * zz * zz);
+}
 
 }  // namespace
 
@@ -131,7 +174,9 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
     int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power, float* __restrict__ o_ws,
     float* __restrict__ o_wd, float* __restrict__ o_load, int B) {
   constexpr int EPW = 64 / G;  // envs per wave
+  constexpr int NP = G * S;    // turbine capacity of this variant
   __shared__ TableLds T;
+  __shared__ GeoLds<EPW, NP> geo[4];
   for (int k = threadIdx.x; k < WF_TABLE_PAD; k += blockDim.x) {
     T.knot[k] = tab->knot[k];
     T.ct[k] = tab->ct[k];
@@ -140,13 +185,13 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
     T.pws[k] = tab->pw_slope[k];
   }
   for (int k = threadIdx.x; k < WF_BUCKETS; k += blockDim.x) T.bucket[k] = tab->bucket[k];
-  __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
-  const int env_raw = (blockIdx.x * (blockDim.x >> 6) + wave) * EPW + lane / G;
+  const int eiw = lane / G;  // env index inside the wave
+  const int env_raw = (blockIdx.x * (blockDim.x >> 6) + wave) * EPW + eiw;
   const bool env_ok = env_raw < B;
   const int env = env_ok ? env_raw : (B - 1);
   const int N = c.N;
@@ -158,16 +203,21 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
 
   const size_t gofs = (size_t)env * geom_stride;
   const size_t yofs = (size_t)env * N;
-
-  Slots<S> st;
+  GeoLds<EPW, NP>& L = geo[wave];
 #pragma unroll
   for (int p = 0; p < S; ++p) {
     const int t = p * G + sub;
     const bool ok = t < N;
     const int tt = ok ? t : 0;
-    st.x[p] = ok ? gx[gofs + tt] : -1.0e300;  // never downstream of anything
-    st.y[p] = gy[gofs + tt];
-    st.yaw[p] = yaw_in[yofs + gidx[gofs + tt]];
+    L.x[eiw][t] = ok ? gx[gofs + tt] : -1.0e300;  // padding is never downstream of anything
+    L.y[eiw][t] = gy[gofs + tt];
+    L.yaw[eiw][t] = yaw_in[yofs + gidx[gofs + tt]];
+  }
+  __syncthreads();
+
+  Slots<S> st;
+#pragma unroll
+  for (int p = 0; p < S; ++p) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       st.wsq[p][q] = 0.0f;
@@ -179,10 +229,12 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
   }
 
   const int nblk = (N + G - 1) / G;
+  int rot = 0;  // register slot p currently holds turbine block (p + rot) % S
   for (int blk = 0; blk < nblk; ++blk) {
     const int nsrc = min(G, N - blk * G);
     for (int li = 0; li < nsrc; ++li) {
       const int src = gbase + li;
+      const int i = blk * G + li;
       // ---- A. the source's state (slot 0 of lane `li` of the group) ------------------------
       float m3 = 0.0f, vsum = 0.0f;
 #pragma unroll
@@ -193,12 +245,12 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       }
       m3 = __shfl(m3, src);
       const float Vmean = __shfl(vsum, src) * (1.0f / 9.0f);
-      const double x_i = __shfl(st.x[0], src);
-      const float y_i = __shfl(st.y[0], src);
-      const float yaw_i = __shfl(st.yaw[0], src);
       float TIs[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) TIs[j] = __shfl(st.TI[0][j], src);
+      const double x_i = L.x[eiw][i];
+      const float y_i = L.y[eiw][i];
+      const float yaw_i = L.yaw[eiw][i];
 
       // ---- B. source constants, part 1 [A.3-1 .. A.3-4] ------------------------------------
       const float ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
@@ -217,34 +269,40 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       const float s_cc = fsqrt(1.0f - ct * cgd), s_c = fsqrt(1.0f - ct);
       const float om_scc = ct * cgd * frcp(1.0f + s_cc);  // 1 - s_cc
       const float om_sc = ct * frcp(1.0f + s_c);          // 1 - s_c  (== C0)
-      const float sM = fsqrt(ct);                         // sqrt(M0), M0 = C0(2-C0) = ct
+      SrcConsts sc;
+      sc.sM = fsqrt(ct);  // sqrt(M0), M0 = C0(2-C0) = ct
       const float E0 = fmaf(om_sc, om_sc, fmaf(-c.e0c1, om_sc, c.e0c2));
-      const float sz0d = 0.5f * c.D * fsqrt((1.0f + s_cc) * frcp(2.0f * (1.0f + s_c)));
-      const float sy0d = sz0d * cgd;
+      sc.sz0d = 0.5f * c.D * fsqrt((1.0f + s_cc) * frcp(2.0f * (1.0f + s_c)));
+      sc.sy0d = sc.sz0d * cgd;
       const float th0 = c.dm03 * gd * frcp(cgd) * om_scc;
-      const float tan_th0 = tanf(th0);
-      const float inv_s0d = frcp(sy0d * sz0d);
-      const float pfac = th0 * E0 * (1.0f / 5.2f) * fsqrt(sy0d * sz0d * frcp(ct)) * kLn2;  // * log2(arg)/ky
-      const float lnA = 1.6f + sM, lnB = 1.6f - sM;
-      float x0d[3], kyd[3], d0[3], pj[3];
+      sc.tan_th0 = tanf(th0);
+      sc.inv_s0d = frcp(sc.sy0d * sc.sz0d);
+      const float pfac = th0 * E0 * (1.0f / 5.2f) * fsqrt(sc.sy0d * sc.sz0d * frcp(ct)) * kLn2;  // * log2(arg)/ky
+      sc.lnA = 1.6f + sc.sM;
+      sc.lnB = 1.6f - sc.sM;
+      const float x0num_d = c.D * cgd * (1.0f + s_cc) * (1.0f / 1.41421356237f);
+      ColConsts cc[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        x0d[j] = c.D * cgd * (1.0f + s_cc) * frcp(1.41421356237f * fmaf(c.alpha4, TIs[j], c.beta2 * om_sc));
-        kyd[j] = fmaf(c.ka, TIs[j], c.kb);
-        d0[j] = tan_th0 * x0d[j];
-        pj[j] = pfac * frcp(kyd[j]);
+        cc[j].x0d = x0num_d * frcp(fmaf(c.alpha4, TIs[j], c.beta2 * om_sc));
+        cc[j].kyd = fmaf(c.ka, TIs[j], c.kb);
+        cc[j].d0 = sc.tan_th0 * cc[j].x0d;
+        cc[j].pj = pfac * frcp(cc[j].kyd);
       }
       // transverse circulations / (2 pi), commanded yaw
       const float scg = sg * cg;
-      const float Gv[3] = {scg * gt, -scg * gb, Gwr};
+      const float Gt = scg * gt, Gb = -scg * gb;
 
       // ---- C. pass 1: transverse velocities on every target at or downstream of the source --
       float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
 #pragma unroll
       for (int p = 0; p < S; ++p) {
-        const float dx = (float)(st.x[p] - x_i);
+        int b = p + rot;
+        b = (b >= S) ? b - S : b;
+        const int t = b * G + sub;
+        const float dx = (float)(L.x[eiw][t] - x_i);
         if (dx >= 0.0f) {
-          const float dy = st.y[p] - y_i;
+          const float dy = L.y[eiw][t] - y_i;
           float dec[3];
 #pragma unroll
           for (int k = 0; k < 3; ++k) dec[k] = frcp(fmaf(c.decay_a[k], dx, 1.0f));
@@ -253,20 +311,23 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
             const float yL = dy + c.yoff[j];
             const float yL2 = yL * yL;
             const float Ey = fexp2(-yL2 * c.exp_c);
+            // core/r of the 7 distinct real and 7 distinct mirror vortex offsets
+            float Tr[7], Tm[7], Pr[7], Pm[7];
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+              Tr[m] = fmaf(-Ey, c.ez[m], 1.0f) * frcp(yL2 + c.zc2[m]);
+              Tm[m] = fmaf(-Ey, c.ezm[m], 1.0f) * frcp(yL2 + c.zm2[m]);
+              Pr[m] = c.zc[m] * Tr[m];
+              Pm[m] = c.zm[m] * Tm[m];
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-              float A = 0.0f, Bw = 0.0f;
-#pragma unroll
-              for (int v = 0; v < 3; ++v) {
-                const float tr = fmaf(-Ey, c.ez[v][k], 1.0f) * frcp(yL2 + c.zc2[v][k]);
-                const float tm = fmaf(-Ey, c.ezm[v][k], 1.0f) * frcp(yL2 + c.zm2[v][k]);
-                A = fmaf(Gv[v], fmaf(c.zc[v][k], tr, -c.zm[v][k] * tm), A);
-                Bw = fmaf(Gv[v], tr - tm, Bw);
-              }
-              const float vw = A * dec[k];
-              const float ww = fmaxf(-yL * Bw * dec[k], 0.0f);  // W[W<0] = 0, quirk (5)
-              st.V[p][j * 3 + k] += vw;
-              st.W[p][j * 3 + k] += ww;
+              // class index m+3 with k' = k-1: real top k'-2, bottom k'+2, rot k'; mirror top k'+2, bottom k'-2, rot k'
+              const int rt = k, rb = k + 4, rc = k + 2;
+              const float A = fmaf(Gt, Pr[rt] - Pm[rb], fmaf(Gb, Pr[rb] - Pm[rt], Gwr * (Pr[rc] - Pm[rc])));
+              const float Bw = fmaf(Gt, Tr[rt] - Tm[rb], fmaf(Gb, Tr[rb] - Tm[rt], Gwr * (Tr[rc] - Tm[rc])));
+              st.V[p][j * 3 + k] = fmaf(A, dec[k], st.V[p][j * 3 + k]);
+              st.W[p][j * 3 + k] += fmaxf(-yL * Bw * dec[k], 0.0f);  // W[W<0] = 0, quirk (5)
             }
           }
         }
@@ -293,57 +354,71 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
 #pragma unroll
         for (int j = 0; j < 3; ++j) st.TI[0][j] += dTI;
       }
-      const float sy0v = c.sz0v * cg;
-      const float snw = c.near_c * fsqrt(0.5f * ct);
-      const float kdef = ct * cg * c.kdef;
+      sc.sy0v = c.sz0v * cg;
+      sc.snw = c.near_c * fsqrt(0.5f * ct);
+      sc.kdef = ct * cg * c.kdef;
       const float ch_pref = c.ch_c * fexp2(c.ch_ai * flog2(a));
-      float x0v[3], ix0v[3], kyv[3];
+      const float x0num_v = c.D * cg * (1.0f + s_c) * (1.0f / 1.41421356237f);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const float ti = TIs[j] + dTI;
-        x0v[j] = c.D * cg * (1.0f + s_c) * frcp(1.41421356237f * fmaf(c.alpha4, ti, c.beta2 * om_sc));
-        ix0v[j] = frcp(x0v[j]);
-        kyv[j] = fmaf(c.ka, ti, c.kb);
+        cc[j].x0v = x0num_v * frcp(fmaf(c.alpha4, ti, c.beta2 * om_sc));
+        cc[j].ix0v = frcp(cc[j].x0v);
+        cc[j].kyv = fmaf(c.ka, ti, c.kb);
       }
+      // The three grid columns of a source almost always carry the same TI (they differ only when the
+      // |dy| < 2D gate of A.3-8 split a rotor): then sigma, C and the far-wake deflection are evaluated
+      // once per target instead of once per column.  Wave-uniform choice, identical results.
+      const bool uni = __all((TIs[0] == TIs[1]) && (TIs[1] == TIs[2]));
 
       // ---- E. pass 2: deflection, deficit, SOSFS, wake-added turbulence ----------------------
 #pragma unroll
       for (int p = 0; p < S; ++p) {
-        const float dx = (float)(st.x[p] - x_i);
+        int b = p + rot;
+        b = (b >= S) ? b - S : b;
+        const int t = b * G + sub;
+        const float dx = (float)(L.x[eiw][t] - x_i);
         if (dx > 0.0f) {
-          const float dy = st.y[p] - y_i;
+          const float dy = L.y[eiw][t] - y_i;
           const float lin = fmaf(c.bd, dx, c.ad);
-          const bool wake_on = dx > 0.1f;
+          const float amp_on = (dx > 0.1f) ? 1.0f : 0.0f;
+          float e1[3], e0[3];
+          if (uni) {
+            // column-independent part once
+            const ColConsts& k0 = cc[0];
+            const float xs = fmaxf(dx - k0.x0d, 0.0f);
+            const float syd = fmaf(k0.kyd, xs, sc.sy0d), szd = fmaf(k0.kyd, xs, sc.sz0d);
+            const float s = fsqrt(syd * szd * sc.inv_s0d);
+            const float arg = sc.lnA * fmaf(1.6f, s, -sc.sM) * frcp(sc.lnB * fmaf(1.6f, s, sc.sM));
+            const float d_far = fmaf(k0.pj, flog2(arg), k0.d0);
+            const float delta = ((dx > k0.x0d) ? d_far : dx * sc.tan_th0) + lin;
+            const bool far = dx >= k0.x0v;
+            const float up = dx * k0.ix0v;
+            const float xf = dx - k0.x0v;
+            const float sy = far ? fmaf(k0.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
+            const float sz = far ? fmaf(k0.kyv, xf, c.sz0v) : fmaf(up, c.sz0v - sc.snw, sc.snw);
+            const float isy = frcp(sy), isz = frcp(sz);
+            const float xarg = sc.kdef * isy * isz;
+            const float C = (xarg >= 1.0f) ? 1.0f : xarg * frcp(1.0f + fsqrt(fmaxf(1.0f - xarg, 0.0f)));
+            const float zz = c.off[2] * isz;
+            const float ez = fexp2(-0.5f * kLog2e * zz * zz);
+            const float amp = amp_on * C;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const float yy = (dy + c.off[j] - delta) * isy;
+              e1[j] = amp * fexp2(-0.5f * kLog2e * yy * yy);
+              e0[j] = e1[j] * ez;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) column_deficit(c, sc, cc[j], dx, dy + c.off[j], lin, amp_on, e1[j], e0[j]);
+          }
           int cnt = 0;
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-            // deflection (TI before mixing) [A.3-3]
-            const float xs = fmaxf(dx - x0d[j], 0.0f);
-            const float syd = fmaf(kyd[j], xs, sy0d), szd = fmaf(kyd[j], xs, sz0d);
-            const float s = fsqrt(syd * szd * inv_s0d);
-            const float arg = lnA * fmaf(1.6f, s, -sM) * frcp(lnB * fmaf(1.6f, s, sM));
-            const float d_far = fmaf(pj[j], flog2(arg), d0[j]);
-            const float d_near = dx * tan_th0;  // (dx/x0d)*d0
-            const float delta = ((dx > x0d[j]) ? d_far : d_near) + lin;
-            // deficit (TI after mixing) [A.3-6]
-            const bool far = dx >= x0v[j];
-            const float up = dx * ix0v[j];
-            const float xf = dx - x0v[j];
-            const float sy = far ? fmaf(kyv[j], xf, sy0v) : fmaf(up, sy0v - snw, snw);
-            const float sz = far ? fmaf(kyv[j], xf, c.sz0v) : fmaf(up, c.sz0v - snw, snw);
-            const float isy = frcp(sy), isz = frcp(sz);
-            const float xarg = kdef * isy * isz;
-            const float C = (xarg >= 1.0f) ? 1.0f : xarg * frcp(1.0f + fsqrt(fmaxf(1.0f - xarg, 0.0f)));
-            const float yy = (dy + c.off[j] - delta) * isy;
-            const float zz = c.off[2] * isz;
-            const float ry = 0.5f * kLog2e * yy * yy;
-            const float rz = 0.5f * kLog2e * zz * zz;
-            const float amp = wake_on ? C : 0.0f;
-            const float e1 = amp * fexp2(-ry);
-            const float e0 = amp * fexp2(-ry - rz);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-              const float dU = ((k == 1) ? e1 : e0) * Ui[k];
+              const float dU = ((k == 1) ? e1[j] : e0[j]) * Ui[k];
               st.wsq[p][j * 3 + k] = fmaf(dU, dU, st.wsq[p][j * 3 + k]);
               cnt += (dU > c.overlap_thr) ? 1 : 0;
             }
@@ -362,10 +437,8 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       }
     }  // li
 
-    // rotate the slots so that the next block of sources sits in slot 0
+    // rotate the register slots so that the next block of sources sits in slot 0
     if (S > 1) {
-      const double x0 = st.x[0];
-      const float y0 = st.y[0], w0 = st.yaw[0];
       float a0[9], b0[9], c0[9], t0[3];
 #pragma unroll
       for (int q = 0; q < 9; ++q) { a0[q] = st.wsq[0][q]; b0[q] = st.V[0][q]; c0[q] = st.W[0][q]; }
@@ -373,7 +446,6 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       for (int j = 0; j < 3; ++j) t0[j] = st.TI[0][j];
 #pragma unroll
       for (int p = 0; p + 1 < S; ++p) {
-        st.x[p] = st.x[p + 1]; st.y[p] = st.y[p + 1]; st.yaw[p] = st.yaw[p + 1];
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
           st.wsq[p][q] = st.wsq[p + 1][q]; st.V[p][q] = st.V[p + 1][q]; st.W[p][q] = st.W[p + 1][q];
@@ -381,18 +453,20 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
 #pragma unroll
         for (int j = 0; j < 3; ++j) st.TI[p][j] = st.TI[p + 1][j];
       }
-      st.x[S - 1] = x0; st.y[S - 1] = y0; st.yaw[S - 1] = w0;
 #pragma unroll
       for (int q = 0; q < 9; ++q) { st.wsq[S - 1][q] = a0[q]; st.V[S - 1][q] = b0[q]; st.W[S - 1][q] = c0[q]; }
 #pragma unroll
       for (int j = 0; j < 3; ++j) st.TI[S - 1][j] = t0[j];
+      rot = (rot + 1 == S) ? 0 : rot + 1;
     }
   }  // blk
 
-  // ---- outputs [A.4]: slot p now holds block (p + nblk) % S ----------------------------------
+  // ---- outputs [A.4]: slot p holds block (p + rot) % S ----------------------------------------
 #pragma unroll
   for (int p = 0; p < S; ++p) {
-    const int t = ((p + nblk) % S) * G + sub;
+    int b = p + rot;
+    b = (b >= S) ? b - S : b;
+    const int t = b * G + sub;
     if (t < N && env_ok) {
       const int o = gidx[gofs + t];
       float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
@@ -411,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         su = fmaf(du, du, su); sv = fmaf(dv, dv, sv); sw = fmaf(dw, dw, sw);
       }
       const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
-      const float cy = cosf(st.yaw[p] * kDeg2Rad);
+      const float cy = cosf(L.yaw[eiw][t] * kDeg2Rad);
       const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cy));
       const size_t oo = yofs + o;
       o_power[oo] = c.rho * table_pw(c, T, veff);
