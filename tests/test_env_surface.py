@@ -1,0 +1,220 @@
+"""CPU: the host-side mirror of the reference's env surface on an
+oracle-backed interface.  Fixtures from the reference's notebook are in tests/golden/surface_fixtures.json."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from helpers import OracleFlorisInterface
+
+
+@pytest.fixture()
+def patched(monkeypatch):
+    from wfcrl_env_amd.environments import registration
+
+    monkeypatch.setattr(registration, "HipFlorisInterface", OracleFlorisInterface)
+    return registration
+
+
+@pytest.fixture(scope="module")
+def fixtures():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "surface_fixtures.json")))
+
+
+def test_registry_names(patched):
+    names = patched.list_envs()
+    assert len(names) == 88  # 2 control types x 22 layouts x 2 simulators
+    for n in ("Ablaincourt_Floris", "Dec_Ablaincourt_Floris", "HornsRev1_Floris", "Turb3_Row1_Floris",
+              "Turb12_Row1_Floris", "Turb_TCRWP_Floris", "Turb16_Row5_Floris", "Dec_Turb6_Row2_Fastfarm"):
+        assert n in names
+    assert "Turb16_TCRWP_Floris" not in names  # not a reference name (Appendix C2) ...
+    with pytest.raises(ValueError, match="not a registered"):
+        patched.make("Turb16_Nope_Floris")
+    with pytest.raises(NotImplementedError):
+        patched.make("Ablaincourt_Fastfarm")
+    env = patched.make("Turb16_TCRWP_Floris")  # ... but available as a build-defined alias
+    assert env.num_turbines == 16
+
+
+def test_spaces_match_notebook_reprs(patched, fixtures):
+    env = patched.make("Ablaincourt_Floris", max_num_steps=70)
+    assert env.num_turbines == 7
+    assert repr(env.action_space) == fixtures["action_space_repr"]["value"]
+    assert repr(env.observation_space) == fixtures["observation_space_repr"]["value"]
+    assert list(env.observation_space.keys()) == ["yaw", "freewind_measurements", "wind_speed", "wind_direction"]
+
+
+def test_reset_reproduces_reference_kat_observation(patched, kat1):
+    """demo.ipynb cell 10: the first observation after reset at the notebook's sampled wind."""
+    env = patched.make("Ablaincourt_Floris", max_num_steps=70)
+    obs = env.reset(options={"wind_speed": kat1["wind_speed_free"], "wind_direction": kat1["wind_direction_free"]})
+    assert list(obs.keys()) == ["yaw", "freewind_measurements", "wind_speed", "wind_direction"]
+    assert np.array_equal(obs["yaw"], np.zeros(7))
+    assert np.allclose(obs["freewind_measurements"], [6.48958384, 266.363907], rtol=0, atol=1e-9)
+    assert np.abs(obs["wind_speed"] / np.array(kat1["wind_speed"]) - 1).max() < 1e-6  # float32 backend surface
+    assert np.abs(obs["wind_direction"] - np.array(kat1["wind_direction"])).max() < 1e-4
+
+
+def test_seeded_reset_draw_order(patched):
+    """rng = default_rng(seed): weibull first, then normal (mdp.py:235-253)."""
+    env = patched.make("Turb3_Row1_Floris")
+    obs = env.reset(seed=123)
+    rng = np.random.default_rng(123)
+    ws = np.clip(8 * rng.weibull(8), 3, 28)
+    wd = np.clip(rng.normal(270, 20) % 360, 0, 360)
+    assert np.allclose(obs["freewind_measurements"], [ws, wd])
+    obs2 = env.reset(seed=123)
+    for k in obs:
+        assert np.array_equal(obs[k], obs2[k])
+
+
+def test_episode_length_and_truncation(patched, fixtures):
+    """max_num_steps=70 -> 69 agent steps before `truncated` (one solve is consumed by reset, C8)."""
+    env = patched.make("Ablaincourt_Floris", max_num_steps=70)
+    env.reset(seed=0)
+    n, done = 0, False
+    while not done:
+        obs, reward, terminated, truncated, info = env.step({"yaw": np.zeros(7)})
+        n += 1
+        done = terminated or truncated
+        assert terminated is False
+    assert n == fixtures["max_num_steps_70_history_len"]["value"]
+    assert len(env.history["reward"]) == 69 and len(env.history["power"]) == 69
+
+
+def test_step_semantics_reward_and_constraint(patched):
+    from oracle import c_oracle
+
+    env = patched.make("Turb3_Row1_Floris", max_num_steps=50, load_coef=0.1)
+    obs = env.reset(options={"wind_speed": 8.0, "wind_direction": 270.0})
+    a = {"yaw": np.array([7.0, -3.0, 2.0])}  # 7 is clipped to the +-5 step
+    obs, reward, term, trunc, info = env.step(a)
+    assert np.allclose(obs["yaw"], [5.0, -3.0, 2.0]) and obs["yaw"].dtype == np.float32
+    assert reward.shape == (1,) and info["power"].shape == (3,) and info["load"].shape == (3, 4)
+    ref = c_oracle.farm_step_batch([0, 504, 1008], [0, 0, 0], 8.0, 270.0, np.array([[5.0, -3.0, 2.0]]))
+    assert np.allclose(info["power"], ref["power"][0] / 1e6, rtol=1e-6)  # MW
+    assert np.allclose(info["load"], ref["load"][0], rtol=1e-5, atol=1e-7)
+    r = np.mean(ref["power"][0] / 1e6 * 1e3 / 8.0**3) - 0.1 * np.mean(np.abs(ref["load"][0]))
+    assert abs(reward[0] - r) < 1e-5
+    # actuation budget: mean |dyaw| per step <= 0.1 * dt * 0.3 = 1.8 deg; the caller's array is zeroed IN PLACE
+    act = {"yaw": np.array([5.0, 0.5, 0.0])}
+    env.step(act)  # turbine 0 accumulated 5 deg in 1 move -> 5/0.3/2/60 = 0.139 >= 0.1 -> blocked
+    assert act["yaw"][0] == 0.0 and act["yaw"][1] == 0.5
+    # observations after the first state are not clipped and are float64 (C9)
+    assert obs["wind_speed"].dtype == np.float64
+
+
+def test_reward_shapers():
+    from wfcrl_env_amd.rewards import DoNothingReward, ReferencePercentage, StepPercentage
+
+    assert DoNothingReward()(3.5) == 3.5
+    assert ReferencePercentage(2.0)(3.0) == 0.5
+    s = StepPercentage()
+    assert s(2.0) == 0.0 and s(3.0) == 0.5 and s(3.0) == 0.0
+    s.reset()
+    assert s(4.0) == 0.0
+
+
+def test_custom_controls_and_errors(patched, fixtures):
+    with pytest.raises(ValueError, match="only allows"):
+        patched.make("Dec_Ablaincourt_Floris", controls={"yaw": (-20, 20, 15), "pitch": (0, 45, 1)})
+    with pytest.raises(ValueError, match="lower_bound < upper_bound"):
+        patched.make("Ablaincourt_Floris", controls={"yaw": (20, -20, 1)})
+    with pytest.raises(TypeError, match="Wrong bounds"):
+        patched.make("Ablaincourt_Floris", controls={"yaw": (20,)})
+    with pytest.warns(UserWarning, match="Step size will default to 1"):
+        env = patched.make("Ablaincourt_Floris", controls={"yaw": (-20, 20)})
+    assert repr(env.action_space) == "Dict('yaw': Box(-1.0, 1.0, (7,), float32))"
+    env = patched.make("Ablaincourt_Floris", controls={"yaw": (-20, 20, 15)}, continuous_control=False)
+    assert repr(env.action_space["yaw"]).startswith("MultiDiscrete")
+    obs = env.reset(seed=1)
+    obs, *_ = env.step({"yaw": np.array([2, 1, 0, 1, 1, 1, 1])})  # up / hold / down
+    assert np.allclose(obs["yaw"], [15, 0, -15, 0, 0, 0, 0])
+
+
+def test_aec_env_cycle(patched, fixtures):
+    from wfcrl_env_amd.rewards import StepPercentage
+
+    env = patched.make("Dec_Ablaincourt_Floris", max_num_steps=6, reward_shaper=StepPercentage(), load_coef=1)
+    assert env.possible_agents == fixtures["agents"]["value"]
+    assert repr(env.action_space("turbine_1")) == "{'yaw': Box(-5.0, 5.0, (1,), float32)}"
+    assert list(env.observation_space("turbine_3")) == ["yaw", "wind_speed", "wind_direction"]
+    env.reset(seed=5)
+    totals = {a: 0.0 for a in env.possible_agents}
+    solves0 = env.mdp.interface.fi.calls
+    steps = {a: 0 for a in env.possible_agents}
+    for agent in env.agent_iter():
+        obs, reward, termination, truncation, info = env.last()
+        totals[agent] += reward
+        if termination or truncation:
+            action = None
+        else:
+            action = {"yaw": np.array([1.0 if agent == "turbine_1" else 0.0])}
+            steps[agent] += 1
+            assert set(obs) == {"yaw", "wind_speed", "wind_direction"}
+        env.step(action)
+    assert set(steps.values()) == {5}  # max_num_steps - 1 joint steps
+    assert env.mdp.interface.fi.calls - solves0 == 5  # ONE solve per N agent calls
+    assert len({float(np.ravel(v)[0]) for v in totals.values()}) == 1  # cooperative reward
+    assert len(env.history["turbine_2"]["power"]) > 0
+
+
+def test_interface_duck_type_and_wind_modes(tmp_path):
+    from wfcrl_env_amd.environments.data_cases import named_cases_dictionary
+
+    case = named_cases_dictionary["Turb3_Row1_"][1].clone()
+    case.max_iter = 4
+    it = OracleFlorisInterface.from_case(case)
+    assert it.CONTROL_SET == ["yaw"] and it.num_turbines == 3 and it.dt == 60
+    assert (it.wind_speed, it.wind_dir) == (8.0, 270.0)
+    assert np.isnan(it.current_measures).all()
+    assert it.get_measure("nope") is None
+    assert it.update_command(np.array([10.0, 0, 0])) is False
+    assert np.allclose(it.get_measure("yaw"), [10, 0, 0])
+    assert it.get_measure("load").shape == (3, 4) and it.get_measure("load").max() > 1e5  # stored x1e7
+    p = it.avg_powers()
+    assert p.shape == (3,) and 1e5 < p.min() and abs(it.avg_farm_power() - p.sum()) < 1e-6
+    it.update_command(); it.update_command()
+    assert it.update_command() is True  # _num_iter == max_iter
+    # wd % 360 and TypeError on a missing direction, as the reference (interface.py:664)
+    it.init(9.0, 630.0)
+    assert it.wind_dir == 270.0
+    with pytest.raises(TypeError):
+        it.update_wind(8.0, None)
+    # geometry is redone only when the wind actually changes
+    n = it.fi.wind_sets
+    it.update_command(); it.update_command()
+    assert it.fi.wind_sets - n == 1
+    # time series: CSV with a header line, finite generator, requested wind ignored with a warning
+    csv = tmp_path / "wind.csv"
+    csv.write_text("ws,wd\n7.0,260.0\n8.0,270.0\n9.0,280.0\n")
+    case.wind_time_series = str(csv)
+    it = OracleFlorisInterface.from_case(case, seed=0)
+    with pytest.warns(UserWarning, match="wind_time_series"):
+        it.init(5.0, 200.0)
+    seen = [(it.wind_speed, it.wind_dir)]
+    it.update_command(); seen.append((it.wind_speed, it.wind_dir))
+    it.update_command(); seen.append((it.wind_speed, it.wind_dir))
+    assert sorted(seen) == [(7.0, 260.0), (8.0, 270.0), (9.0, 280.0)]
+    with pytest.raises(StopIteration):
+        it.update_command()
+    it2 = OracleFlorisInterface(3, case.xcoords, case.ycoords, wind_time_series=np.array([[7.0, 260.0], [8.0, 270.0]]), seed=1)
+    assert it2.wind_speed in (7.0, 8.0)
+
+
+def test_case_is_not_mutated_and_yaml_dump(patched, tmp_path):
+    from wfcrl_env_amd.environments.data_cases import named_cases_dictionary
+    from wfcrl_env_amd.simul_utils import dump_case_yaml
+
+    before = copy.deepcopy(named_cases_dictionary["Ablaincourt_"][1].max_iter)
+    patched.make("Ablaincourt_Floris", max_num_steps=33)
+    assert named_cases_dictionary["Ablaincourt_"][1].max_iter == before  # C7
+    path = dump_case_yaml(named_cases_dictionary["Ablaincourt_"][1].dict(), tmp_path / "case")
+    import yaml
+
+    cfg = yaml.safe_load(open(path))
+    assert cfg["wake"]["model_strings"]["velocity_model"] == "gauss" and len(cfg["farm"]["layout_x"]) == 7
+    assert cfg["flow_field"]["wind_speeds"] == [8] and cfg["solver"]["turbine_grid_points"] == 3

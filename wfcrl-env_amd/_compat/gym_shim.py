@@ -187,6 +187,18 @@ class Wrapper(Env):
             raise AttributeError(name)
         return getattr(self.env, name)
 
+    @property
+    def action_space(self):
+        return self.env.action_space
+
+    @property
+    def observation_space(self):
+        return self.env.observation_space
+
+    @property
+    def metadata(self):
+        return self.env.metadata
+
     def reset(self, seed=None, options=None):
         return self.env.reset(seed=seed, options=options)
 

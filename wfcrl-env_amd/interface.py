@@ -81,7 +81,7 @@ class HipFlorisInterface(BaseInterface):
         if len(xcoords) != num_turbines or len(ycoords) != num_turbines:
             raise ValueError("xcoords and ycoords layout coordinates must have num_turbines entries")
         self.num_turbines = num_turbines
-        self.fi = WfStep(xcoords, ycoords, env_batch=1, device_id=device_id, model=model)
+        self.fi = self._make_backend(xcoords, ycoords, device_id, model)
         self.measure_map = self.DEFAULT_MEASURE_MAP
         self._num_measures = sum(len(v) if isinstance(v, list) else 1 for v in self.measure_map.values()) - 1
         self.dt = 60
@@ -101,6 +101,11 @@ class HipFlorisInterface(BaseInterface):
             self._logging = True
 
     # -- construction -----------------------------------------------------------------------------
+    def _make_backend(self, xcoords, ycoords, device_id, model):
+        """The device handle.  Always the HIP library: there is no CPU fallback in the product (the CPU
+        test-suite substitutes an oracle-backed stand-in by overriding this hook in a tests/ subclass)."""
+        return WfStep(xcoords, ycoords, env_batch=1, device_id=device_id, model=model)
+
     @classmethod
     def from_case(cls, case, log_file: str = None, output_dir: str = None, **kw):
         """interface.py:526-547.  No case.yaml is written on this path; pass
