@@ -83,7 +83,7 @@ def main():
     assert hi - lo == B
 
     w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B, device_id=local_rank)
-    w.set_stream(torch.cuda.current_stream().cuda_stream)
+    w.set_stream(torch.cuda.current_stream().cuda_stream, True)
     w.set_wind(8.0, 270.0)
 
     # synthetic random-walk yaw sequence, seeded per SURVEY §8d (1234 + cfg id) and per global env id

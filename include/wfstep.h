@@ -73,8 +73,9 @@ int wf_default_model(wf_model_params* p);
 int wf_create(int device_id, wf_handle** out);
 int wf_destroy(wf_handle* h);
 
-/* Adopt an external hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
-int wf_set_stream(wf_handle* h, void* hip_stream);
+/* external != 0: adopt the caller's hipStream_t (e.g. torch's current stream; NULL = the HIP null stream);
+ * external == 0: back to the handle's own non-blocking stream.  Drains the previous stream first. */
+int wf_set_stream(wf_handle* h, void* hip_stream, int external);
 void* wf_get_stream(wf_handle* h);
 
 /* Replaces the model section of case.yaml (simul_utils.py:34-48 writes it, interface.py:479 reads it). */
@@ -106,6 +107,33 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wind_speed, flo
             int on_device);
 
 int wf_sync(wf_handle* h);
+
+/* ---- Fused env step (not in the reference, which does this in Python per farm) ----
+ * Device-resident env state per farm instance: absolute yaw [B*N], actuation accumulator [B*N], move
+ * counter [B].  One wf_env_step launch performs, per farm,
+ *   the actuation-budget gate         (reference wfcrl/simple_env.py:64-72),
+ *   the clipped yaw transition        (reference wfcrl/mdp.py:291-319),
+ *   the farm solve + measurements     (wf_step),
+ *   the reward  mean_j(P_j[MW]*1e3/ws^3) - load_coef*mean|loads|   (reference wfcrl/simple_env.py:78-84)
+ * with the reference's float32 arithmetic for the MDP part. */
+typedef struct wf_env_params {
+  float yaw_lo, yaw_hi, yaw_step; /* controls["yaw"] = (lo, hi, step): data_cases.py:19-23 default (-40, 40, 5) */
+  float actuator_rate;            /* WindFarmMDP.ACTUATORS_RATE["yaw"] = 0.3 deg/s (mdp.py:52) */
+  float dt;                       /* FarmCase.dt, 60 s for FLORIS cases */
+  float budget;                   /* 0.1: an actuator may move at most 10 % of the time */
+  float load_coef;                /* env kwarg load_coef, default 0.1 */
+  int discrete;                   /* 0: action = dyaw clipped to +-step; 1: action in {0,1,2} = down/hold/up */
+} wf_env_params;
+
+int wf_env_config(wf_handle* h, const wf_env_params* p);
+
+/* Zero yaw, accumulators and move counters (WindFarmMDP.reset, mdp.py:267-270). Wind: wf_set_wind. */
+int wf_env_reset(wf_handle* h);
+
+/* action [B*N] (NULL: no transition, solve at the current yaw — the warm-up solve of reset, mdp.py:261-262).
+ * Outputs (each may be NULL = not written): reward [B]; yaw [B*N] new absolute yaw; then as wf_step. */
+int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, float* power, float* wind_speed,
+                float* wind_dir, float* load, int on_device);
 
 /* HIP-event timing of the step kernel on the handle's stream (used by bench.py for the roofline
  * object): wf_timing_begin records an event, wf_timing_end records another, synchronises, and

@@ -37,6 +37,13 @@ class ModelParams(C.Structure):
     ]
 
 
+class EnvParams(C.Structure):
+    """Mirror of `struct wf_env_params`."""
+
+    _fields_ = [(n, C.c_float) for n in ("yaw_lo", "yaw_hi", "yaw_step", "actuator_rate", "dt", "budget", "load_coef")] + [
+        ("discrete", C.c_int)]
+
+
 class KernelInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "lanes_per_env", "slots_per_lane", "envs_per_block", "threads_per_block", "grid_blocks",
@@ -50,7 +57,7 @@ ABI = {
     "wf_default_model": (C.c_int, [C.POINTER(ModelParams)]),
     "wf_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "wf_destroy": (C.c_int, [_P]),
-    "wf_set_stream": (C.c_int, [_P, _P]),
+    "wf_set_stream": (C.c_int, [_P, _P, C.c_int]),
     "wf_get_stream": (_P, [_P]),
     "wf_set_model": (C.c_int, [_P, C.POINTER(ModelParams)]),
     "wf_set_layout": (C.c_int, [_P, C.c_int, _P, _P]),
@@ -58,6 +65,9 @@ ABI = {
     "wf_set_wind": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "wf_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int]),
     "wf_sync": (C.c_int, [_P]),
+    "wf_env_config": (C.c_int, [_P, C.POINTER(EnvParams)]),
+    "wf_env_reset": (C.c_int, [_P]),
+    "wf_env_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int]),
     "wf_timing_begin": (C.c_int, [_P]),
     "wf_timing_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "wf_get_kernel_info": (C.c_int, [_P, C.POINTER(KernelInfo)]),

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import KernelInfo, ModelParams, check
+from ._lib import EnvParams, KernelInfo, ModelParams, check
 
 
 def _is_torch(a) -> bool:
@@ -71,14 +71,27 @@ class WfStep:
         check(self._lib.wf_set_batch(self._h, int(env_batch)), self._h)
         self.env_batch = int(env_batch)
 
-    def set_stream(self, hip_stream: int | None):
-        check(self._lib.wf_set_stream(self._h, C.c_void_p(hip_stream or 0)), self._h)
+    def set_stream(self, hip_stream: int | None, external: bool = True):
+        """Adopt an external HIP stream (int handle; 0/None = the null stream) or, with external=False,
+        return to the handle's own stream."""
+        check(self._lib.wf_set_stream(self._h, C.c_void_p(hip_stream or 0), int(external)), self._h)
+        self._stream_key = (int(hip_stream or 0), bool(external))
+
+    def _follow_torch_stream(self):
+        """Device tensors are produced/consumed on torch's current stream: run there too, so that no
+        cross-stream synchronisation is needed around our kernels."""
+        import torch
+
+        s = torch.cuda.current_stream(self.device_id).cuda_stream
+        if getattr(self, "_stream_key", None) != (int(s), True):
+            self.set_stream(s, True)
 
     def set_wind(self, wind_speed, wind_direction):
         """Scalar (shared by the batch) or one value per env; NumPy/float or torch float64 CUDA tensors."""
         if _is_torch(wind_speed):
             ws, wd = wind_speed.contiguous(), wind_direction.contiguous()
             assert ws.dtype == wd.dtype and str(ws.dtype) == "torch.float64" and ws.is_cuda
+            self._follow_torch_stream()
             check(self._lib.wf_set_wind(self._h, ws.data_ptr(), wd.data_ptr(), ws.numel(), 1), self._h)
             return
         ws = np.ascontiguousarray(np.atleast_1d(wind_speed), dtype=np.float64)
@@ -96,6 +109,7 @@ class WfStep:
 
             assert yaw.is_cuda and yaw.dtype == torch.float32 and yaw.numel() == B * N
             yaw = yaw.contiguous()
+            self._follow_torch_stream()
             if out is None:
                 out = {
                     "power": torch.empty((B, N), device=yaw.device, dtype=torch.float32),
@@ -117,6 +131,48 @@ class WfStep:
         check(self._lib.wf_step(self._h, yaw.ctypes.data, out["power"].ctypes.data, out["wind_speed"].ctypes.data,
                                 out["wind_direction"].ctypes.data, out["load"].ctypes.data, 0), self._h)
         return out
+
+    # -- fused env step ---------------------------------------------------------------
+    def env_config(self, yaw_lo=-40.0, yaw_hi=40.0, yaw_step=5.0, actuator_rate=0.3, dt=60.0, budget=0.1,
+                   load_coef=0.1, discrete=False):
+        p = EnvParams(yaw_lo, yaw_hi, yaw_step, actuator_rate, dt, budget, load_coef, int(bool(discrete)))
+        check(self._lib.wf_env_config(self._h, C.byref(p)), self._h)
+
+    def env_reset(self):
+        check(self._lib.wf_env_reset(self._h), self._h)
+
+    def env_step(self, action=None, want=("reward", "yaw", "power", "wind_speed", "wind_direction", "load"), out=None):
+        """One fused env step.  `action` (B, N) torch CUDA float32 tensor or NumPy array, or None for a solve
+        at the current yaw (reset warm-up).  `want` selects which outputs are produced at all."""
+        B, N = self.env_batch, self.num_turbines
+        shapes = {"reward": (B,), "yaw": (B, N), "power": (B, N), "wind_speed": (B, N), "wind_direction": (B, N),
+                  "load": (B, N, 4)}
+        order = ("reward", "yaw", "power", "wind_speed", "wind_direction", "load")
+        use_torch = _is_torch(action) or (action is None and out is not None and any(_is_torch(v) for v in out.values()))
+        if use_torch:
+            import torch
+
+            dev = action.device if action is not None else next(iter(out.values())).device
+            self._follow_torch_stream()
+            if action is not None:
+                assert action.is_cuda and action.dtype == torch.float32 and action.numel() == B * N
+                action = action.contiguous()
+            out = dict(out or {})
+            for k in want:
+                if k not in out:
+                    out[k] = torch.empty(shapes[k], device=dev, dtype=torch.float32)
+            ptrs = [out[k].data_ptr() if k in want else None for k in order]
+            check(self._lib.wf_env_step(self._h, action.data_ptr() if action is not None else None, *ptrs, 1), self._h)
+            return {k: out[k] for k in want}
+        if action is not None:
+            action = np.ascontiguousarray(action, dtype=np.float32).reshape(B, N)
+        out = dict(out or {})
+        for k in want:
+            if k not in out:
+                out[k] = np.empty(shapes[k], np.float32)
+        ptrs = [out[k].ctypes.data if k in want else None for k in order]
+        check(self._lib.wf_env_step(self._h, action.ctypes.data if action is not None else None, *ptrs, 0), self._h)
+        return {k: out[k] for k in want}
 
     def sync(self):
         check(self._lib.wf_sync(self._h), self._h)

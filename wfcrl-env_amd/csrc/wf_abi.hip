@@ -24,7 +24,8 @@ extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, co
 extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
                                       const float* gy, const int* gidx, int geom_stride, const double* ws,
                                       const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
-                                      float* o_wd, float* load, int B, hipStream_t s, int* grid_out);
+                                      float* o_wd, float* load, int B, const WfEnvArgs* env, hipStream_t s,
+                                      int* grid_out);
 
 namespace {
 
@@ -88,6 +89,11 @@ struct wf_handle {
   float *d_yaw = nullptr, *d_out = nullptr;  // staging for host callers: yaw [B*N], out [B*N*7]
   float *h_yaw = nullptr, *h_out = nullptr;  // pinned
   size_t cap_env = 0, cap_bn = 0;
+  // fused env state
+  wf_env_params env{-40.f, 40.f, 5.f, 0.3f, 60.f, 0.1f, 0.1f, 0};
+  float *d_env_yaw = nullptr, *d_env_acc = nullptr, *d_env_act = nullptr, *d_env_out = nullptr;  // out: reward[B] + yaw[BN]
+  int* d_env_moves = nullptr;
+  float *h_env_act = nullptr, *h_env_out = nullptr;
 };
 
 namespace {
@@ -105,6 +111,11 @@ int fail(wf_handle* h, int code, const std::string& msg) {
 void free_batch(wf_handle* h) {
   hipFree(h->d_ws); hipFree(h->d_wd); hipFree(h->d_gx); hipFree(h->d_gy); hipFree(h->d_gidx);
   hipFree(h->d_yaw); hipFree(h->d_out);
+  hipFree(h->d_env_yaw); hipFree(h->d_env_acc); hipFree(h->d_env_act); hipFree(h->d_env_out); hipFree(h->d_env_moves);
+  if (h->h_env_act) hipHostFree(h->h_env_act);
+  if (h->h_env_out) hipHostFree(h->h_env_out);
+  h->d_env_yaw = h->d_env_acc = h->d_env_act = h->d_env_out = h->h_env_act = h->h_env_out = nullptr;
+  h->d_env_moves = nullptr;
   if (h->h_yaw) hipHostFree(h->h_yaw);
   if (h->h_out) hipHostFree(h->h_out);
   h->d_ws = h->d_wd = h->d_gx = nullptr; h->d_gy = nullptr; h->d_gidx = nullptr;
@@ -309,10 +320,14 @@ int wf_destroy(wf_handle* h) {
   return WF_OK;
 }
 
-int wf_set_stream(wf_handle* h, void* s) {
+int wf_set_stream(wf_handle* h, void* s, int external) {
   if (!h) return WF_E_INVALID;
-  hipStreamSynchronize(h->stream);
-  h->stream = s ? (hipStream_t)s : h->own_stream;
+  WF_HIP(h, hipSetDevice(h->device));
+  hipStream_t next = external ? (hipStream_t)s : h->own_stream;
+  if (next != h->stream) {
+    WF_HIP(h, hipStreamSynchronize(h->stream));
+    h->stream = next;
+  }
   return WF_OK;
 }
 void* wf_get_stream(wf_handle* h) { return h ? (void*)h->stream : nullptr; }
@@ -403,14 +418,8 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
   const int gstride = (h->wind_count == 1) ? 0 : h->N;
   const int wstride = (h->wind_count == 1) ? 0 : 1;
   if (on_device) {
-    float* scratch = nullptr;
-    if (!power || !wspd || !wdir || !load) {  // kernel always writes all outputs: park skipped ones in staging
-      if (!h->d_out) WF_HIP(h, hipMalloc(&h->d_out, sizeof(float) * bn * 7));
-      scratch = h->d_out;
-    }
     WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
-                              wstride, yaw, power ? power : scratch, wspd ? wspd : scratch + bn,
-                              wdir ? wdir : scratch + 2 * bn, load ? load : scratch + 3 * bn, h->B, h->stream, &h->grid));
+                              wstride, yaw, power, wspd, wdir, load, h->B, nullptr, h->stream, &h->grid));
     return WF_OK;
   }
   if (!h->d_yaw) {
@@ -423,9 +432,100 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
   WF_HIP(h, hipMemcpyAsync(h->d_yaw, h->h_yaw, sizeof(float) * bn, hipMemcpyHostToDevice, h->stream));
   WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                             wstride, h->d_yaw, h->d_out, h->d_out + bn, h->d_out + 2 * bn, h->d_out + 3 * bn, h->B,
-                            h->stream, &h->grid));
+                            nullptr, h->stream, &h->grid));
   WF_HIP(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(float) * bn * 7, hipMemcpyDeviceToHost, h->stream));
   WF_HIP(h, hipStreamSynchronize(h->stream));
+  if (power) std::memcpy(power, h->h_out, sizeof(float) * bn);
+  if (wspd) std::memcpy(wspd, h->h_out + bn, sizeof(float) * bn);
+  if (wdir) std::memcpy(wdir, h->h_out + 2 * bn, sizeof(float) * bn);
+  if (load) std::memcpy(load, h->h_out + 3 * bn, sizeof(float) * bn * 4);
+  return WF_OK;
+}
+
+int wf_env_config(wf_handle* h, const wf_env_params* p) {
+  if (!h || !p) return WF_E_INVALID;
+  if (!(p->yaw_lo < p->yaw_hi) || !(p->yaw_step > 0) || !(p->actuator_rate > 0) || !(p->dt > 0))
+    return fail(h, WF_E_INVALID, "need yaw_lo < yaw_hi, yaw_step > 0, actuator_rate > 0, dt > 0");
+  h->env = *p;
+  return WF_OK;
+}
+
+static int env_alloc(wf_handle* h) {
+  if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called first");
+  if (h->d_env_yaw) return WF_OK;
+  const size_t bn = (size_t)h->B * h->N;
+  WF_HIP(h, hipMalloc(&h->d_env_yaw, sizeof(float) * bn));
+  WF_HIP(h, hipMalloc(&h->d_env_acc, sizeof(float) * bn));
+  WF_HIP(h, hipMalloc(&h->d_env_moves, sizeof(int) * h->B));
+  WF_HIP(h, hipMemsetAsync(h->d_env_yaw, 0, sizeof(float) * bn, h->stream));
+  WF_HIP(h, hipMemsetAsync(h->d_env_acc, 0, sizeof(float) * bn, h->stream));
+  WF_HIP(h, hipMemsetAsync(h->d_env_moves, 0, sizeof(int) * h->B, h->stream));
+  return WF_OK;
+}
+
+int wf_env_reset(wf_handle* h) {
+  if (!h) return WF_E_INVALID;
+  WF_HIP(h, hipSetDevice(h->device));
+  const bool fresh = h->d_env_yaw == nullptr;
+  int rc = env_alloc(h);
+  if (rc != WF_OK) return rc;
+  if (!fresh) {
+    const size_t bn = (size_t)h->B * h->N;
+    WF_HIP(h, hipMemsetAsync(h->d_env_yaw, 0, sizeof(float) * bn, h->stream));
+    WF_HIP(h, hipMemsetAsync(h->d_env_acc, 0, sizeof(float) * bn, h->stream));
+    WF_HIP(h, hipMemsetAsync(h->d_env_moves, 0, sizeof(int) * h->B, h->stream));
+  }
+  return WF_OK;
+}
+
+int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, float* power, float* wspd, float* wdir,
+                float* load, int on_device) {
+  if (!h) return WF_E_INVALID;
+  if (h->wind_count == 0) return fail(h, WF_E_INVALID, "wf_set_wind must be called before wf_env_step");
+  WF_HIP(h, hipSetDevice(h->device));
+  int rc = env_alloc(h);
+  if (rc != WF_OK) return rc;
+  if (h->model_dirty && (rc = build_consts(h)) != WF_OK) return rc;
+  const size_t bn = (size_t)h->B * h->N, B = (size_t)h->B;
+  const int gstride = (h->wind_count == 1) ? 0 : h->N;
+  const int wstride = (h->wind_count == 1) ? 0 : 1;
+  WfEnvArgs ea{};
+  ea.yaw_state = h->d_env_yaw; ea.acc = h->d_env_acc; ea.moves = h->d_env_moves;
+  ea.yaw_step = h->env.yaw_step; ea.yaw_lo = h->env.yaw_lo; ea.yaw_hi = h->env.yaw_hi;
+  ea.rate = h->env.actuator_rate; ea.dt = h->env.dt; ea.budget = h->env.budget;
+  ea.load_coef = h->env.load_coef; ea.discrete = h->env.discrete;
+  if (on_device) {
+    ea.action = action; ea.reward = reward;
+    WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
+                              wstride, nullptr, power, wspd, wdir, load, h->B, &ea, h->stream, &h->grid));
+    if (yaw) WF_HIP(h, hipMemcpyAsync(yaw, h->d_env_yaw, sizeof(float) * bn, hipMemcpyDeviceToDevice, h->stream));
+    return WF_OK;
+  }
+  if (!h->d_env_act) {
+    WF_HIP(h, hipMalloc(&h->d_env_act, sizeof(float) * bn));
+    WF_HIP(h, hipMalloc(&h->d_env_out, sizeof(float) * B));
+    WF_HIP(h, hipHostMalloc(&h->h_env_act, sizeof(float) * bn, hipHostMallocDefault));
+    WF_HIP(h, hipHostMalloc(&h->h_env_out, sizeof(float) * (B + bn), hipHostMallocDefault));
+  }
+  if (!h->d_out) WF_HIP(h, hipMalloc(&h->d_out, sizeof(float) * bn * 7));
+  if (!h->h_out) WF_HIP(h, hipHostMalloc(&h->h_out, sizeof(float) * bn * 7, hipHostMallocDefault));
+  if (action) {
+    std::memcpy(h->h_env_act, action, sizeof(float) * bn);
+    WF_HIP(h, hipMemcpyAsync(h->d_env_act, h->h_env_act, sizeof(float) * bn, hipMemcpyHostToDevice, h->stream));
+    ea.action = h->d_env_act;
+  }
+  ea.reward = reward ? h->d_env_out : nullptr;
+  WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
+                            wstride, nullptr, power ? h->d_out : nullptr, wspd ? h->d_out + bn : nullptr,
+                            wdir ? h->d_out + 2 * bn : nullptr, load ? h->d_out + 3 * bn : nullptr, h->B, &ea, h->stream,
+                            &h->grid));
+  if (reward) WF_HIP(h, hipMemcpyAsync(h->h_env_out, h->d_env_out, sizeof(float) * B, hipMemcpyDeviceToHost, h->stream));
+  if (yaw) WF_HIP(h, hipMemcpyAsync(h->h_env_out + B, h->d_env_yaw, sizeof(float) * bn, hipMemcpyDeviceToHost, h->stream));
+  if (power || wspd || wdir || load)
+    WF_HIP(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(float) * bn * 7, hipMemcpyDeviceToHost, h->stream));
+  WF_HIP(h, hipStreamSynchronize(h->stream));
+  if (reward) std::memcpy(reward, h->h_env_out, sizeof(float) * B);
+  if (yaw) std::memcpy(yaw, h->h_env_out + B, sizeof(float) * bn);
   if (power) std::memcpy(power, h->h_out, sizeof(float) * bn);
   if (wspd) std::memcpy(wspd, h->h_out + bn, sizeof(float) * bn);
   if (wdir) std::memcpy(wdir, h->h_out + 2 * bn, sizeof(float) * bn);

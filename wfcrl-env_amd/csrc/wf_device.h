@@ -54,3 +54,19 @@ struct WfTables {
   float pw_slope[WF_TABLE_PAD];
   unsigned char bucket[WF_BUCKETS];  // index of the last knot <= bucket start
 };
+
+// Device-resident env state + fused MDP transition / reward.  All pointers may be null:
+// then the kernel is the plain farm step on `yaw_in`.
+//   reference semantics: simple_env.py:64-72 (actuation budget), mdp.py:291-319 (transition),
+//   simple_env.py:78-85 (reward); float32 arithmetic exactly as NumPy performs it there.
+struct WfEnvArgs {
+  float* yaw_state;     // [B][N] absolute yaw, in/out (caller's turbine order)
+  float* acc;           // [B][N] accumulated |dyaw|, in/out
+  int* moves;           // [B] number of env steps taken, in/out
+  const float* action;  // [B][N] dyaw (continuous) or {0,1,2} (discrete); null = no transition
+  float* reward;        // [B] out (null = skip)
+  float yaw_step, yaw_lo, yaw_hi;  // controls["yaw"] = (lo, hi, step)
+  float rate, dt, budget;          // ACTUATORS_RATE["yaw"] = 0.3 deg/s, case.dt, 0.1
+  float load_coef;
+  int discrete;
+};

@@ -19,6 +19,8 @@
 //     indices, no scratch).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "wf_device.h"
 
 namespace {
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const float* __restrict__ gy,
     const int* __restrict__ gidx, int geom_stride, const double* __restrict__ ws_in, const double* __restrict__ wd_in,
     int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power, float* __restrict__ o_ws,
-    float* __restrict__ o_wd, float* __restrict__ o_load, int B) {
+    float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea) {
   constexpr int EPW = 64 / G;  // envs per wave
   constexpr int NP = G * S;    // turbine capacity of this variant
   __shared__ TableLds T;
@@ -204,6 +206,12 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
   const size_t gofs = (size_t)env * geom_stride;
   const size_t yofs = (size_t)env * N;
   GeoLds<EPW, NP>& L = geo[wave];
+  // fused MDP transition: budget gate -> clip increment -> clip setpoint -> accumulate
+  const bool env_mode = ea.yaw_state != nullptr;
+  int moves_new = 0;
+  if (env_mode && ea.action) {
+    moves_new = ea.moves[env] + 1;
+  }
 #pragma unroll
   for (int p = 0; p < S; ++p) {
     const int t = p * G + sub;
@@ -211,8 +219,33 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
     const int tt = ok ? t : 0;
     L.x[eiw][t] = ok ? gx[gofs + tt] : -1.0e300;  // padding is never downstream of anything
     L.y[eiw][t] = gy[gofs + tt];
-    L.yaw[eiw][t] = yaw_in[yofs + gidx[gofs + tt]];
+    const size_t oi = yofs + gidx[gofs + tt];
+    float yw;
+    if (env_mode) {
+      yw = ea.yaw_state[oi];
+      if (ea.action) {
+        float a = ea.action[oi];
+        float acc = ea.acc[oi];
+        // actuating_frac = acc / rate / num_moves / dt >= budget  -> action zeroed   (simple_env.py:64-72)
+        const float frac = __fdiv_rn(__fdiv_rn(__fdiv_rn(acc, ea.rate), (float)moves_new), ea.dt);
+        // the gate zeroes the RAW action (simple_env.py:72) — in the discrete encoding 0 means "down",
+        // a quirk of the reference that is kept for parity
+        if (frac >= ea.budget) a = 0.0f;
+        if (ea.discrete) a = (a - 1.0f) * ea.yaw_step;       // 0/1/2 = down/hold/up   (mdp.py:305-309)
+        if (!ea.discrete) a = fminf(fmaxf(a, -ea.yaw_step), ea.yaw_step);
+        yw = fminf(fmaxf(yw + a, ea.yaw_lo), ea.yaw_hi);
+        acc += fabsf(a);
+        if (ok && env_ok) {
+          ea.yaw_state[oi] = yw;
+          ea.acc[oi] = acc;
+        }
+      }
+    } else {
+      yw = yaw_in[oi];
+    }
+    L.yaw[eiw][t] = yw;
   }
+  if (env_mode && ea.action && sub == 0 && env_ok) ea.moves[env] = moves_new;
   __syncthreads();
 
   Slots<S> st;
@@ -462,12 +495,13 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
   }  // blk
 
   // ---- outputs [A.4]: slot p holds block (p + rot) % S ----------------------------------------
+  float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
 #pragma unroll
   for (int p = 0; p < S; ++p) {
     int b = p + rot;
     b = (b >= S) ? b - S : b;
     const int t = b * G + sub;
-    if (t < N && env_ok) {
+    if (t < N) {
       const int o = gidx[gofs + t];
       float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
 #pragma unroll
@@ -475,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         U[q] = Ui[q % 3] - fsqrt(st.wsq[p][q]);
         m3 = fmaf(U[q] * U[q], U[q], m3);
         mu += U[q]; mv += st.V[p][q]; mw += st.W[p][q];
-        adir += atan2f(st.V[p][q], U[q]);
+        if (o_wd) adir += atan2f(st.V[p][q], U[q]);
       }
       mu *= (1.0f / 9.0f); mv *= (1.0f / 9.0f); mw *= (1.0f / 9.0f);
       float su = 0.0f, sv = 0.0f, sw = 0.0f;
@@ -487,16 +521,34 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
       const float cy = cosf(L.yaw[eiw][t] * kDeg2Rad);
       const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cy));
-      const size_t oo = yofs + o;
-      o_power[oo] = c.rho * table_pw(c, T, veff);
-      o_ws[oo] = wsp;
-      o_wd[oo] = wd - adir * (kRad2Deg / 9.0f);
+      const float pwr = c.rho * table_pw(c, T, veff);
       float4 l;
       l.x = (st.TI[p][0] + st.TI[p][1] + st.TI[p][2]) * (1.0f / 3.0f);
       l.y = fsqrt(su * (1.0f / 9.0f));
       l.z = fsqrt(sv * (1.0f / 9.0f));
       l.w = fsqrt(sw * (1.0f / 9.0f));
-      reinterpret_cast<float4*>(o_load)[oo] = l;
+      psum += pwr;
+      lsum += (l.x + l.y) + (l.z + l.w);  // loads are non-negative: |.| is the identity
+      if (env_ok) {
+        const size_t oo = yofs + o;
+        if (o_power) o_power[oo] = pwr;
+        if (o_ws) o_ws[oo] = wsp;
+        if (o_wd) o_wd[oo] = wd - adir * (kRad2Deg / 9.0f);
+        if (o_load) reinterpret_cast<float4*>(o_load)[oo] = l;
+      }
+    }
+  }
+  if (ea.reward) {
+    // r = mean_j(P_j[MW] * 1e3 / ws^3) - load_coef * mean|loads|      (simple_env.py:78-84)
+#pragma unroll
+    for (int w = G / 2; w >= 1; w >>= 1) {
+      psum += __shfl_xor(psum, w);
+      lsum += __shfl_xor(lsum, w);
+    }
+    if (sub == 0 && env_ok) {
+      const float invN = __fdiv_rn(1.0f, (float)N);
+      const float r = psum * invN * 1.0e-3f * frcp(ws * ws * ws) - ea.load_coef * lsum * invN * 0.25f;
+      ea.reward[env] = r;
     }
   }
 }
@@ -533,12 +585,15 @@ extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, co
 extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
                                       const float* gy, const int* gidx, int geom_stride, const double* ws,
                                       const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
-                                      float* o_wd, float* load, int B, hipStream_t s, int* grid_out) {
+                                      float* o_wd, float* load, int B, const WfEnvArgs* env, hipStream_t s,
+                                      int* grid_out) {
   const WfVariant& v = kVariants[variant];
   const int envs_per_block = 4 * (64 / v.G);
   const int grid = (B + envs_per_block - 1) / envs_per_block;
   if (grid_out) *grid_out = grid;
   WfConsts cc = *c;
-  void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B};
+  WfEnvArgs ea;
+  if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
+  void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea};
   return hipLaunchKernel(v.fn, dim3(grid), dim3(256), args, 0, s);
 }

@@ -67,7 +67,7 @@ class MAWindFarmEnv(AECEnv):
         joint = {c: np.zeros(self.num_turbines, dtype=np.float32) for c in self.mdp.controls}
         for j, action in enumerate(agent_actions.values()):
             for control in action:
-                joint[control][j] = action[control][:]
+                joint[control][j] = np.asarray(action[control]).reshape(-1)[0]
         return joint
 
     # -- episode ------------------------------------------------------------------------------------

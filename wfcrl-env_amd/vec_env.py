@@ -1,0 +1,203 @@
+"""`VecWindFarmEnv` — B independent wind-farm envs stepped by ONE fused kernel launch.
+
+Batched restatement of the reference's centralised env: reset wind sampling (wfcrl/mdp.py:233-271),
+actuation budget (simple_env.py:64-72), yaw transition (mdp.py:291-319), reward (simple_env.py:78-85),
+truncation bookkeeping (interface.py:578-586, mdp.py:261-262).  Env state (yaw, actuation accumulators,
+move counters) lives on the device; actions and observations are torch CUDA tensors (NumPy accepted).
+All B envs share the horizon, so they truncate together and are reset together.
+
+Differences from running B reference envs, by construction of a batch: `reset` draws all winds from ONE
+`default_rng(seed)` (vectorised weibull then normal draws; for B = 1 this is exactly the reference's
+stream), and constrained actions are not zeroed in the caller's array (the gate is applied on the device).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+from ._compat import spaces
+from .backend import WfStep
+from .mdp import WD_MEAN, WD_STD, WEIBULL_SCALE, WEIBULL_SHAPE, WindFarmMDP
+from .rewards import DoNothingReward, ReferencePercentage, StepPercentage
+
+_OBS_KEYS = ("yaw", "freewind_measurements", "wind_speed", "wind_direction")
+
+
+class VecWindFarmEnv:
+    metadata = {"name": "vectorized-centralized-windfarm"}
+
+    def __init__(self, farm_case, controls: dict = None, env_batch: int = 1, continuous_control: bool = True,
+                 reward_shaper=None, start_iter: int = 0, max_num_steps: int = 500, load_coef: float = 0.1,
+                 device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None):
+        controls = {"yaw": (-40, 40, 5)} if controls is None else dict(controls)
+        if list(controls) != ["yaw"]:
+            raise ValueError(f"Cannot control {list(controls)}. Interface HipFlorisInterface only allows for the "
+                             "following: ['yaw']")
+        spec = controls["yaw"]
+        if not (len(spec) in (2, 3) and spec[0] < spec[1]):
+            raise ValueError("Wrong bounds for actuator yaw: ensure that lower_bound < upper_bound")
+        if len(spec) == 2:
+            spec = tuple(spec) + (1,)
+        self.controls = {"yaw": tuple(spec)}
+        self.farm_case = farm_case.clone() if hasattr(farm_case, "clone") else farm_case
+        self.num_envs = int(env_batch)
+        self.num_turbines = self.farm_case.num_turbines
+        self.continuous_control = continuous_control
+        self.max_num_steps = max_num_steps
+        self.start_iter = start_iter
+        self.load_coef = load_coef
+        self.dt = self.farm_case.dt
+        self.reward_shaper = DoNothingReward() if reward_shaper is None else reward_shaper
+        self.return_torch = return_torch
+        self.farm_case.max_iter = start_iter + max_num_steps
+        p = self.farm_case.simul_params
+        self.fi = backend if backend is not None else WfStep(p["xcoords"], p["ycoords"], env_batch=self.num_envs,
+                                                              device_id=device_id, model=model)
+        self.fi.env_config(yaw_lo=spec[0], yaw_hi=spec[1], yaw_step=spec[2],
+                           actuator_rate=WindFarmMDP.ACTUATORS_RATE["yaw"], dt=self.dt, budget=0.1,
+                           load_coef=load_coef, discrete=not continuous_control)
+        n = self.num_turbines
+        # per-env spaces, identical to the reference's (mdp.py:108-153)
+        if continuous_control:
+            self.single_action_space = spaces.Dict({"yaw": spaces.Box(-spec[2], spec[2], shape=(n,))})
+        else:
+            self.single_action_space = spaces.Dict({"yaw": spaces.MultiDiscrete([3] * n)})
+        ones = np.ones(n, dtype=np.float32)
+        b = WindFarmMDP.DEFAULT_BOUNDS
+        self.single_observation_space = spaces.Dict(OrderedDict([
+            ("yaw", spaces.Box(ones * spec[0], ones * spec[1], shape=(n,))),
+            ("freewind_measurements", spaces.Box(np.array([b["wind_speed"][0], b["wind_direction"][0]], np.float32),
+                                                 np.array([b["wind_speed"][1], b["wind_direction"][1]], np.float32),
+                                                 shape=(2,))),
+            ("wind_speed", spaces.Box(ones * b["wind_speed"][0], ones * b["wind_speed"][1], shape=(n,))),
+            ("wind_direction", spaces.Box(ones * b["wind_direction"][0], ones * b["wind_direction"][1], shape=(n,))),
+        ]))
+        self.action_space = self.single_action_space
+        self.observation_space = self.single_observation_space
+        self._num_iter = 0
+        self._freewind = None
+        self._shaper_ref = None
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _sample_wind(self, seed, options):
+        rng = np.random.default_rng(seed)
+        B = self.num_envs
+        lo, hi = self.single_observation_space["freewind_measurements"].low, \
+            self.single_observation_space["freewind_measurements"].high
+        if options is not None and "wind_speed" in options:
+            ws = np.broadcast_to(np.asarray(options["wind_speed"], np.float64), (B,)).copy()
+        elif self.farm_case.set_wind_speed:
+            ws = np.full(B, float(self.farm_case.simul_params["speed"]))
+        else:
+            ws = np.clip(WEIBULL_SCALE * rng.weibull(WEIBULL_SHAPE, B), lo[0], hi[0])
+        if options is not None and "wind_direction" in options:
+            wd = np.broadcast_to(np.asarray(options["wind_direction"], np.float64), (B,)).copy()
+        elif self.farm_case.set_wind_direction:
+            wd = np.full(B, float(self.farm_case.simul_params["direction"]))
+        else:
+            wd = np.clip(rng.normal(WD_MEAN, WD_STD, B) % 360, lo[1], hi[1])
+        return ws, wd % 360
+
+    def _obs(self, out):
+        obs = OrderedDict()
+        obs["yaw"] = out["yaw"]
+        obs["freewind_measurements"] = self._freewind
+        obs["wind_speed"] = out["wind_speed"]
+        obs["wind_direction"] = out["wind_direction"]
+        return obs
+
+    def _to_device(self, a):
+        if not self.return_torch:
+            return np.ascontiguousarray(a, dtype=np.float32)
+        import torch
+
+        if isinstance(a, torch.Tensor):
+            return a.to(device=f"cuda:{self.fi.device_id}", dtype=torch.float32)
+        return torch.as_tensor(np.asarray(a, dtype=np.float32), device=f"cuda:{self.fi.device_id}")
+
+    def _shape(self, r):
+        s = self.reward_shaper
+        if isinstance(s, DoNothingReward):
+            return r
+        if isinstance(s, ReferencePercentage):
+            return (r - s.reference) / s.reference
+        if isinstance(s, StepPercentage):
+            ref = self._shaper_ref
+            shaped = r * 0 if ref is None else (r - ref) / ref
+            self._shaper_ref = r.clone() if hasattr(r, "clone") else r.copy()
+            return shaped
+        return s(r)
+
+    # -- episode ------------------------------------------------------------------------------------
+    def reset(self, seed=None, options=None):
+        """Samples one wind per env, zeroes the env state, runs the warm-up solve(s) at yaw = 0 and returns
+        the start observation (clipped to the observation space like the reference's, mdp.py:263-266)."""
+        ws, wd = self._sample_wind(seed, options)
+        self.fi.set_wind(ws, wd)
+        self.fi.env_reset()
+        self.reward_shaper.reset()
+        self._shaper_ref = None
+        if self.return_torch:
+            import torch
+
+            self._freewind = torch.as_tensor(np.stack([ws, wd], axis=1), device=f"cuda:{self.fi.device_id}")
+            seed_out = {"yaw": torch.empty((self.num_envs, self.num_turbines), device=self._freewind.device)}
+        else:
+            self._freewind = np.stack([ws, wd], axis=1)
+            seed_out = None
+        self._num_iter = 0
+        out = None
+        for _ in range(self.start_iter + 1):
+            out = self.fi.env_step(None, want=("yaw", "wind_speed", "wind_direction"), out=seed_out)
+            self._num_iter += 1
+        obs = self._obs(out)
+        sp = self.single_observation_space
+        for k in ("wind_speed", "wind_direction"):
+            lo, hi = float(sp[k].low[0]), float(sp[k].high[0])
+            obs[k] = obs[k].clamp(lo, hi) if self.return_torch else np.clip(obs[k], lo, hi)
+        return obs
+
+    def step(self, actions):
+        """actions: {"yaw": (B, N)} or the (B, N) array itself.  Returns (obs, reward[B], terminated[B],
+        truncated[B], info) with info["power"] in MW and info["load"] (B, N, 4) — units of the reference."""
+        a = actions["yaw"] if isinstance(actions, dict) else actions
+        out = self.fi.env_step(self._to_device(a))
+        self._num_iter += 1
+        truncated = self._num_iter == self.farm_case.max_iter
+        reward = self._shape(out["reward"])
+        info = {"power": out["power"] * 1e-6, "load": out["load"]}
+        if self.return_torch:
+            import torch
+
+            trunc = torch.full((self.num_envs,), bool(truncated), device=out["reward"].device)
+            term = torch.zeros_like(trunc)
+        else:
+            trunc = np.full(self.num_envs, bool(truncated))
+            term = np.zeros(self.num_envs, bool)
+        return self._obs(out), reward, term, trunc, info
+
+    def step_light(self, actions):
+        """Learner-facing variant: only reward + local wind observations leave the kernel (no power/load
+        arrays are written: 2N+1 instead of 7N floats per env)."""
+        a = actions["yaw"] if isinstance(actions, dict) else actions
+        out = self.fi.env_step(self._to_device(a), want=("reward", "yaw", "wind_speed", "wind_direction"))
+        self._num_iter += 1
+        return self._obs(out), self._shape(out["reward"]), self._num_iter == self.farm_case.max_iter
+
+    def close(self):
+        self.fi.close()
+
+
+def make_vec(env_id: str, env_batch: int, controls=("yaw",), **kw):
+    """`make(env_id, env_batch=B)` shortcut."""
+    from .environments import make
+
+    return make(env_id, controls=list(controls) if not isinstance(controls, dict) else controls, env_batch=env_batch,
+                **kw)
+
+
+def episode_steps(max_num_steps: int, start_iter: int = 0) -> int:
+    """Agent steps per episode = max_num_steps - 1: reset consumes one solve."""
+    return max(0, start_iter + max_num_steps - (start_iter + 1))
