@@ -34,6 +34,24 @@ CONFIGS = {
 }
 
 
+def effective_cpus() -> int:
+    """CPUs this process may actually use: affinity mask, capped by a cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def lane_ops_per_farm_step(N: int) -> float:
     """Analytic VALU work model of the kernel: issue slots per (source, target) pair with
     dx >= 0 (transcendentals counted as 2 slots) x pairs, plus per-source scalar work."""
@@ -156,7 +174,7 @@ def main():
     if not args.no_cpu_baseline:
         from oracle import c_oracle
 
-        nthreads = c_oracle.max_threads()
+        nthreads = min(c_oracle.max_threads(), effective_cpus())
         ycpu = ring[0][: min(B, 4096)].cpu().numpy().astype(np.float64)
         # accuracy sample
         ns = min(256, ycpu.shape[0])
@@ -169,17 +187,18 @@ def main():
                                 "sample": f"{ns} envs x {N} turbines vs float64 oracle"}
         # timing: calibrate on a small sample, then ~cpu_seconds of work
         t = time.perf_counter()
-        c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[: 4 * nthreads])
+        c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[: 4 * nthreads], nthreads=nthreads)
         per_env = (time.perf_counter() - t) / (4 * nthreads)
         n = int(max(4 * nthreads, min(ycpu.shape[0], args.cpu_seconds / per_env)))
         reps = max(1, int(args.cpu_seconds / (per_env * n)))
         t = time.perf_counter()
         for _ in range(reps):
-            c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[:n])
+            c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[:n], nthreads=nthreads)
         dt = time.perf_counter() - t
         res["cpu_baseline"] = {"value": n * reps / dt, "unit": "farm-steps/s", "cores": nthreads, "kind": "port",
                                "sample": f"{reps} x {n} farm-steps of the same workload, C float64 oracle "
-                                         f"(OpenMP over envs, {nthreads} threads of {os.cpu_count()} host CPUs), {dt:.1f} s"}
+                                         f"(OpenMP over envs, {nthreads} threads; os.cpu_count()={os.cpu_count()}, "
+                                         f"usable={effective_cpus()}), {dt:.1f} s"}
     print(json.dumps(res), flush=True)
     w.close()
     if dist is not None:

@@ -135,6 +135,26 @@ int wf_env_reset(wf_handle* h);
 int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, float* power, float* wind_speed,
                 float* wind_dir, float* load, int on_device);
 
+/* ---- On-device wind process ------------------------------------------------------
+ * wf_wind_sample: per-farm reset sampling with the reference's distributions (wfcrl/mdp.py:237-258):
+ *   ws = clip(ws_scale * Weibull(ws_shape), ws_lo, ws_hi);  wd = clip(Normal(wd_mean, wd_std) mod 360, wd_lo, wd_hi)
+ * from a counter-based generator keyed by (seed, farm index); dist == NULL uses 8, 8, 3, 28, 270, 20, 0, 360.
+ * Then the geometry (rotation + sort) of every farm is rebuilt, as wf_set_wind does. */
+typedef struct wf_wind_dist {
+  double ws_scale, ws_shape, ws_lo, ws_hi, wd_mean, wd_std, wd_lo, wd_hi;
+} wf_wind_dist;
+int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* dist);
+
+/* Time-series mode (wfcrl/interface.py:512-524): a shared series of T (ws, wd) rows; farm b plays it from
+ * start[b] (host array of env_batch ints, or NULL: drawn uniformly in [0, T) from `seed`).  The call positions
+ * every farm on its first row; each wf_wind_series_step advances all farms by one row.  Like the reference's
+ * finite generator, stepping past T rows fails (WF_E_INVALID, "wind series exhausted"). */
+int wf_wind_series(wf_handle* h, int T, const double* ws, const double* wd, const int* start, unsigned long long seed);
+int wf_wind_series_step(wf_handle* h);
+
+/* Current free-stream wind of every farm (env_batch entries each; shared wind is broadcast). */
+int wf_get_wind(wf_handle* h, double* ws, double* wd, int on_device);
+
 /* HIP-event timing of the step kernel on the handle's stream (used by bench.py for the roofline
  * object): wf_timing_begin records an event, wf_timing_end records another, synchronises, and
  * returns the elapsed milliseconds between them. */

@@ -218,3 +218,42 @@ def test_case_is_not_mutated_and_yaml_dump(patched, tmp_path):
     cfg = yaml.safe_load(open(path))
     assert cfg["wake"]["model_strings"]["velocity_model"] == "gauss" and len(cfg["farm"]["layout_x"]) == 7
     assert cfg["flow_field"]["wind_speeds"] == [8] and cfg["solver"]["turbine_grid_points"] == 3
+
+
+def test_case_yaml_round_trip_and_rejections(tmp_path):
+    """a FLORIS case.yaml is ingested into the ABI's model struct; unsupported options fail loudly."""
+    import yaml
+
+    from wfcrl_env_amd.backend import default_model
+    from wfcrl_env_amd.environments.data_cases import named_cases_dictionary
+    from wfcrl_env_amd.simul_utils import UnsupportedCaseError, case_config, dump_case_yaml, load_case_yaml
+
+    case = named_cases_dictionary["Ablaincourt_"][1]
+    path = dump_case_yaml(case.dict(), tmp_path / "c")
+    c = load_case_yaml(path)
+    assert c["xcoords"] == case.xcoords and (c["speed"], c["direction"]) == (8.0, 270.0)
+    d = default_model()
+    for k, v in c["model"].items():
+        assert d[k] == v, k
+    cfg = case_config(case.dict())
+    cfg["farm"]["turbine_type"] = [{"turbine_type": "custom", "rotor_diameter": 120.0, "hub_height": 85.0, "TSR": 7.5,
+                                    "pP": 1.9, "pT": 1.9, "generator_efficiency": 0.95, "ref_density_cp_ct": 1.225,
+                                    "ref_tilt_cp_ct": 5.0,
+                                    "power_thrust_table": {"wind_speed": [0.0, 3.0, 12.0, 25.0], "thrust": [0.0, 0.9, 0.6, 0.1],
+                                                           "power": [0.0, 0.3, 0.45, 0.1]}}] * 7
+    cfg["flow_field"]["turbulence_intensity"] = 0.08
+    m = load_case_yaml(cfg)["model"]
+    assert (m["rotor_diameter"], m["hub_height"], m["tsr"], m["gen_eff"], m["ambient_ti"]) == (120.0, 85.0, 7.5, 0.95, 0.08)
+    assert m["table_ws"] == [0.0, 3.0, 12.0, 25.0]
+    for mutate, msg in [
+        (lambda c: c["wake"]["model_strings"].__setitem__("velocity_model", "jensen"), "velocity_model"),
+        (lambda c: c["wake"].__setitem__("enable_secondary_steering", False), "enable_secondary_steering"),
+        (lambda c: c["solver"].__setitem__("turbine_grid_points", 5), "turbine_grid_points"),
+        (lambda c: c["flow_field"].__setitem__("wind_veer", 2.0), "veer"),
+        (lambda c: c["farm"].__setitem__("turbine_type", ["iea_10MW"]), "nrel_5MW"),
+        (lambda c: c["wake"]["wake_velocity_parameters"]["gauss"].__setitem__("ka", 0.5), "differ"),
+    ]:
+        bad = yaml.safe_load(yaml.safe_dump(case_config(case.dict())))
+        mutate(bad)
+        with pytest.raises(UnsupportedCaseError, match=msg):
+            load_case_yaml(bad)

@@ -125,3 +125,108 @@ def test_vec_env_light_step_and_numpy_mode(layouts):
     o2, r2, term, tr, info = venv.step(a)
     assert np.allclose(o2["yaw"], 4.0) and info["power"].shape == (5, 3) and info["power"].max() < 6.0  # MW
     venv.close()
+
+
+def test_device_wind_sampling_distribution_and_determinism(layouts):
+    """f2: on-device reset sampling has the reference's distributions (mdp.py:237-258) and is a pure function
+    of (seed, farm index)."""
+    from scipy import stats
+
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["Turb3_Row1_"]
+    B = 200000
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w.sample_wind(1234)
+    ws, wd = w.get_wind()
+    w.sample_wind(1234)
+    ws2, wd2 = w.get_wind()
+    assert np.array_equal(ws, ws2) and np.array_equal(wd, wd2)
+    w.sample_wind(1235)
+    ws3, _ = w.get_wind()
+    assert not np.array_equal(ws, ws3)
+    assert ws.min() >= 3.0 and ws.max() <= 28.0 and wd.min() >= 0.0 and wd.max() <= 360.0
+    # Weibull(8) scaled by 8, clipped at 3 (P[<3] = 1 - exp(-(3/8)^8) = 3.9e-4: negligible for the KS test)
+    ks = stats.kstest(ws[ws > 3.0] / 8.0, stats.weibull_min(c=8).cdf)
+    assert ks.pvalue > 1e-3, ks
+    ks = stats.kstest((wd - 270.0) / 20.0, "norm")
+    assert ks.pvalue > 1e-3, ks
+    # a custom distribution goes through the same kernel
+    w.sample_wind(7, dict(ws_scale=10.0, ws_shape=2.0, ws_lo=4.0, ws_hi=20.0, wd_mean=10.0, wd_std=30.0))
+    ws, wd = w.get_wind()
+    assert ws.min() >= 4.0 and ws.max() <= 20.0 and ((wd > 300) | (wd < 100)).mean() > 0.95  # wraps through 0/360
+    # and the farms are solvable at the sampled winds
+    out = w.step(np.zeros((B, 3), np.float32))
+    assert np.isfinite(out["power"]).all()
+    w.close()
+
+
+def test_vec_env_device_sampling_and_series_mode(layouts, tmp_path):
+    from oracle import c_oracle
+    from wfcrl_env_amd import environments as envs
+
+    venv = envs.make("Turb6_Row2_Floris", env_batch=64, max_num_steps=5, wind_sampling="device")
+    o1 = venv.reset(seed=3)
+    fw = o1["freewind_measurements"].cpu().numpy()
+    assert fw[:, 0].std() > 0.1 and fw[:, 1].std() > 5  # one wind per farm
+    l = layouts["Turb6_Row2_"]
+    ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], fw[:, 0], fw[:, 1], np.zeros((64, 6)))
+    assert np.abs(o1["wind_speed"].cpu().numpy() - np.clip(ref["wind_speed"], 3, 28)).max() < 1e-4
+    venv.close()
+
+    # time series: T rows shared by the farms, per-farm random start, one row per solve, previous-state wind in the reward
+    T, B = 9, 5
+    rng = np.random.default_rng(0)
+    series = np.stack([rng.uniform(6, 10, T), rng.uniform(255, 285, T)], axis=1)
+    csv = tmp_path / "wind.csv"
+    csv.write_text("ws,wd\n" + "\n".join(f"{float(a)!r},{float(b)!r}" for a, b in series))
+    venv = envs.make("Turb6_Row2_Floris", env_batch=B, max_num_steps=50, wind_time_series=str(csv), load_coef=0.1)
+    obs = venv.reset(seed=11)
+    fw0 = obs["freewind_measurements"].cpu().numpy()
+    # after reset two rows are consumed (init + warm-up solve): row index = start + 1
+    idx = [int(np.argmin(np.abs(series[:, 0] - fw0[b, 0]))) for b in range(B)]
+    assert all(np.allclose(series[i], fw0[b]) for b, i in enumerate(idx))
+    yaw = np.zeros((B, 6))
+    prev = fw0
+    for step in range(T - 2):  # T rows in total: 2 consumed by reset
+        a = rng.uniform(-5, 5, (B, 6)).astype(np.float32)
+        obs, rew, term, trunc, info = venv.step({"yaw": a})
+        yaw = obs["yaw"].cpu().numpy().astype(np.float64)  # transition + budget gate are covered by the test above
+        fw = obs["freewind_measurements"].cpu().numpy()
+        for b in range(B):
+            assert np.allclose(fw[b], series[(idx[b] + step + 1) % T])
+        ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], fw[:, 0], fw[:, 1], yaw)
+        r = (ref["power"] / 1e6 * 1e3 / prev[:, :1] ** 3).mean(axis=1) - 0.1 * np.abs(ref["load"]).reshape(B, -1).mean(axis=1)
+        assert np.abs(rew.cpu().numpy() - r).max() < 5e-5 * np.abs(r).max()
+        prev = fw
+    with pytest.raises(ValueError, match="exhausted"):
+        venv.step({"yaw": np.zeros((B, 6), np.float32)})
+    venv.close()
+
+
+def test_parallel_adaptor_and_ring_logger(layouts):
+    import torch
+
+    from wfcrl_env_amd import environments as envs
+    from wfcrl_env_amd.vec_adapters import VecLogWrapper, VecParallelWindFarmEnv
+
+    B = 8
+    venv = VecLogWrapper(envs.make("Ablaincourt_Floris", env_batch=B, max_num_steps=7), capacity=4)
+    penv = VecParallelWindFarmEnv(venv)
+    assert penv.possible_agents[0] == "turbine_1" and len(penv.possible_agents) == 7
+    assert repr(penv.action_space("turbine_2")) == "{'yaw': Box(-5.0, 5.0, (1,), float32)}"
+    obs = penv.reset(seed=0)
+    assert set(obs["turbine_3"]) == {"yaw", "wind_speed", "wind_direction"} and obs["turbine_3"]["yaw"].shape == (B,)
+    n = 0
+    while penv.agents:
+        acts = {a: {"yaw": torch.full((B,), 1.0 if a == "turbine_1" else 0.0, device="cuda")} for a in penv.possible_agents}
+        obs, rew, term, trunc, info = penv.step(acts)
+        n += 1
+        assert torch.equal(rew["turbine_1"], rew["turbine_7"]) and info["turbine_2"]["power"].shape == (B,)
+    assert n == 6 and float(obs["turbine_1"]["yaw"][0]) == 6.0 and float(obs["turbine_2"]["yaw"][0]) == 0.0
+    with pytest.raises(ValueError, match="incomplete"):
+        penv.step({"turbine_1": {"yaw": torch.zeros(B, device="cuda")}})
+    h = venv.history
+    assert h["reward"].shape == (4, B) and h["observation/yaw"].shape == (4, B, 7) and h["load"].shape == (4, B, 7, 4)
+    assert float(h["observation/yaw"][-1, 0, 0]) == 6.0 and float(h["observation/yaw"][0, 0, 0]) == 3.0  # last 4 of 6 steps
+    penv.close()

@@ -44,6 +44,12 @@ class EnvParams(C.Structure):
         ("discrete", C.c_int)]
 
 
+class WindDist(C.Structure):
+    """Mirror of `struct wf_wind_dist`."""
+
+    _fields_ = [(n, C.c_double) for n in ("ws_scale", "ws_shape", "ws_lo", "ws_hi", "wd_mean", "wd_std", "wd_lo", "wd_hi")]
+
+
 class KernelInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "lanes_per_env", "slots_per_lane", "envs_per_block", "threads_per_block", "grid_blocks",
@@ -65,6 +71,10 @@ ABI = {
     "wf_set_wind": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "wf_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int]),
     "wf_sync": (C.c_int, [_P]),
+    "wf_wind_sample": (C.c_int, [_P, C.c_ulonglong, C.POINTER(WindDist)]),
+    "wf_wind_series": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_ulonglong]),
+    "wf_wind_series_step": (C.c_int, [_P]),
+    "wf_get_wind": (C.c_int, [_P, _P, _P, C.c_int]),
     "wf_env_config": (C.c_int, [_P, C.POINTER(EnvParams)]),
     "wf_env_reset": (C.c_int, [_P]),
     "wf_env_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int]),

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import EnvParams, KernelInfo, ModelParams, check
+from ._lib import EnvParams, KernelInfo, ModelParams, WindDist, check
 
 
 def _is_torch(a) -> bool:
@@ -99,6 +99,45 @@ class WfStep:
         if ws.shape != wd.shape:
             raise ValueError("wind_speed and wind_direction must have the same shape")
         check(self._lib.wf_set_wind(self._h, ws.ctypes.data, wd.ctypes.data, ws.size, 0), self._h)
+
+    def sample_wind(self, seed: int, dist: dict | None = None):
+        """On-device per-farm reset sampling (reference distributions by default, mdp.py:237-258)."""
+        d = None
+        if dist is not None:
+            base = dict(ws_scale=8.0, ws_shape=8.0, ws_lo=3.0, ws_hi=28.0, wd_mean=270.0, wd_std=20.0, wd_lo=0.0, wd_hi=360.0)
+            base.update(dist)
+            d = C.byref(WindDist(**base))
+        check(self._lib.wf_wind_sample(self._h, C.c_ulonglong(int(seed) & (2**64 - 1)), d), self._h)
+
+    def set_wind_series(self, series, start=None, seed: int = 0):
+        """series: (T, 2) [speed, direction]; start: (B,) ints or None (random per farm from `seed`)."""
+        ts = np.ascontiguousarray(series, dtype=np.float64)
+        if ts.ndim != 2 or ts.shape[1] < 2:
+            raise ValueError("wind series must have shape (T, 2): speed, direction")
+        ws, wd = np.ascontiguousarray(ts[:, 0]), np.ascontiguousarray(ts[:, 1])
+        st = None if start is None else np.ascontiguousarray(start, dtype=np.int32)
+        if st is not None and st.shape != (self.env_batch,):
+            raise ValueError("start must have one entry per farm")
+        check(self._lib.wf_wind_series(self._h, ts.shape[0], ws.ctypes.data, wd.ctypes.data,
+                                       None if st is None else st.ctypes.data, C.c_ulonglong(int(seed) & (2**64 - 1))), self._h)
+
+    def wind_series_step(self):
+        check(self._lib.wf_wind_series_step(self._h), self._h)
+
+    def get_wind(self, as_torch: bool = False):
+        """Current (ws, wd) of every farm: two float64 arrays of length B."""
+        B = self.env_batch
+        if as_torch:
+            import torch
+
+            self._follow_torch_stream()
+            ws = torch.empty(B, dtype=torch.float64, device=f"cuda:{self.device_id}")
+            wd = torch.empty_like(ws)
+            check(self._lib.wf_get_wind(self._h, ws.data_ptr(), wd.data_ptr(), 1), self._h)
+            return ws, wd
+        ws, wd = np.empty(B), np.empty(B)
+        check(self._lib.wf_get_wind(self._h, ws.ctypes.data, wd.ctypes.data, 0), self._h)
+        return ws, wd
 
     # -- the step ----------------------------------------------------------------------------------
     def step(self, yaw, out: dict | None = None):

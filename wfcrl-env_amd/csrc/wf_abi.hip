@@ -27,6 +27,12 @@ extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTa
                                       float* o_wd, float* load, int B, const WfEnvArgs* env, hipStream_t s,
                                       int* grid_out);
 
+extern "C" hipError_t wfk_launch_wind_sample(int B, unsigned long long seed, const double* dist, double* ws, double* wd,
+                                             hipStream_t s);
+extern "C" hipError_t wfk_launch_series_start(int B, int T, unsigned long long seed, int* start, hipStream_t s);
+extern "C" hipError_t wfk_launch_series_gather(int B, int T, int t, const int* start, const double* s_ws,
+                                               const double* s_wd, double* ws, double* wd, hipStream_t s);
+
 namespace {
 
 // ---- nrel_5MW power/thrust table (DATA, replaceable via wf_set_model) ----
@@ -94,6 +100,11 @@ struct wf_handle {
   float *d_env_yaw = nullptr, *d_env_acc = nullptr, *d_env_act = nullptr, *d_env_out = nullptr;  // out: reward[B] + yaw[BN]
   int* d_env_moves = nullptr;
   float *h_env_act = nullptr, *h_env_out = nullptr;
+  // wind series
+  int series_T = 0, series_t = 0;
+  double *d_series_ws = nullptr, *d_series_wd = nullptr;
+  int* d_series_start = nullptr;
+  double* d_ws_prev = nullptr;
 };
 
 namespace {
@@ -116,6 +127,8 @@ void free_batch(wf_handle* h) {
   if (h->h_env_out) hipHostFree(h->h_env_out);
   h->d_env_yaw = h->d_env_acc = h->d_env_act = h->d_env_out = h->h_env_act = h->h_env_out = nullptr;
   h->d_env_moves = nullptr;
+  hipFree(h->d_series_ws); hipFree(h->d_series_wd); hipFree(h->d_series_start); hipFree(h->d_ws_prev);
+  h->d_series_ws = h->d_series_wd = h->d_ws_prev = nullptr; h->d_series_start = nullptr; h->series_T = 0;
   if (h->h_yaw) hipHostFree(h->h_yaw);
   if (h->h_out) hipHostFree(h->h_out);
   h->d_ws = h->d_wd = h->d_gx = nullptr; h->d_gy = nullptr; h->d_gidx = nullptr;
@@ -403,6 +416,7 @@ int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int
   WF_HIP(h, wfk_launch_geometry(count, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
   if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));  // caller's host arrays may go away
   h->wind_count = count;
+  h->series_T = 0;
   return WF_OK;
 }
 
@@ -439,6 +453,88 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
   if (wspd) std::memcpy(wspd, h->h_out + bn, sizeof(float) * bn);
   if (wdir) std::memcpy(wdir, h->h_out + 2 * bn, sizeof(float) * bn);
   if (load) std::memcpy(load, h->h_out + 3 * bn, sizeof(float) * bn * 4);
+  return WF_OK;
+}
+
+int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* dist) {
+  if (!h) return WF_E_INVALID;
+  if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called before wf_wind_sample");
+  WF_HIP(h, hipSetDevice(h->device));
+  const wf_wind_dist def{8.0, 8.0, 3.0, 28.0, 270.0, 20.0, 0.0, 360.0};
+  const wf_wind_dist d = dist ? *dist : def;
+  if (!(d.ws_scale > 0) || !(d.ws_shape > 0) || !(d.ws_lo > 0) || !(d.ws_lo <= d.ws_hi) || !(d.wd_std >= 0))
+    return fail(h, WF_E_INVALID, "invalid wind distribution parameters");
+  const double dv[8] = {d.ws_scale, d.ws_shape, d.ws_lo, d.ws_hi, d.wd_mean, d.wd_std, d.wd_lo, d.wd_hi};
+  WF_HIP(h, wfk_launch_wind_sample(h->B, seed, dv, h->d_ws, h->d_wd, h->stream));
+  WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+  h->wind_count = h->B;
+  h->series_T = 0;
+  return WF_OK;
+}
+
+int wf_wind_series(wf_handle* h, int T, const double* ws, const double* wd, const int* start, unsigned long long seed) {
+  if (!h || !ws || !wd) return WF_E_INVALID;
+  if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called before wf_wind_series");
+  if (T < 1) return fail(h, WF_E_INVALID, "the wind series needs at least one row");
+  for (int i = 0; i < T; ++i)
+    if (!(ws[i] > 0.0) || !std::isfinite(wd[i])) return fail(h, WF_E_INVALID, "wind speed must be > 0 and direction finite");
+  WF_HIP(h, hipSetDevice(h->device));
+  WF_HIP(h, hipStreamSynchronize(h->stream));
+  hipFree(h->d_series_ws); hipFree(h->d_series_wd); hipFree(h->d_series_start);
+  h->d_series_ws = h->d_series_wd = nullptr; h->d_series_start = nullptr;
+  WF_HIP(h, hipMalloc(&h->d_series_ws, sizeof(double) * T));
+  WF_HIP(h, hipMalloc(&h->d_series_wd, sizeof(double) * T));
+  WF_HIP(h, hipMalloc(&h->d_series_start, sizeof(int) * h->B));
+  WF_HIP(h, hipMemcpy(h->d_series_ws, ws, sizeof(double) * T, hipMemcpyHostToDevice));
+  WF_HIP(h, hipMemcpy(h->d_series_wd, wd, sizeof(double) * T, hipMemcpyHostToDevice));
+  if (start) {
+    for (int b = 0; b < h->B; ++b)
+      if (start[b] < 0 || start[b] >= T) return fail(h, WF_E_INVALID, "series start out of range");
+    WF_HIP(h, hipMemcpy(h->d_series_start, start, sizeof(int) * h->B, hipMemcpyHostToDevice));
+  } else {
+    WF_HIP(h, wfk_launch_series_start(h->B, T, seed, h->d_series_start, h->stream));
+  }
+  h->series_T = T;
+  h->series_t = -1;
+  return wf_wind_series_step(h);
+}
+
+int wf_wind_series_step(wf_handle* h) {
+  if (!h) return WF_E_INVALID;
+  if (h->series_T <= 0) return fail(h, WF_E_INVALID, "wf_wind_series must be called first");
+  if (h->series_t + 1 >= h->series_T) return fail(h, WF_E_INVALID, "wind series exhausted");
+  WF_HIP(h, hipSetDevice(h->device));
+  h->series_t += 1;
+  if (h->series_t >= 1) {  // keep the wind of the state before this tick for the reward normalisation
+    if (!h->d_ws_prev) WF_HIP(h, hipMalloc(&h->d_ws_prev, sizeof(double) * h->B));
+    WF_HIP(h, hipMemcpyAsync(h->d_ws_prev, h->d_ws, sizeof(double) * h->B, hipMemcpyDeviceToDevice, h->stream));
+  }
+  WF_HIP(h, wfk_launch_series_gather(h->B, h->series_T, h->series_t, h->d_series_start, h->d_series_ws, h->d_series_wd,
+                                     h->d_ws, h->d_wd, h->stream));
+  WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+  h->wind_count = h->B;
+  return WF_OK;
+}
+
+int wf_get_wind(wf_handle* h, double* ws, double* wd, int on_device) {
+  if (!h || !ws || !wd) return WF_E_INVALID;
+  if (h->wind_count == 0) return fail(h, WF_E_INVALID, "no wind has been set");
+  WF_HIP(h, hipSetDevice(h->device));
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (h->wind_count == h->B) {
+    WF_HIP(h, hipMemcpyAsync(ws, h->d_ws, sizeof(double) * h->B, kind, h->stream));
+    WF_HIP(h, hipMemcpyAsync(wd, h->d_wd, sizeof(double) * h->B, kind, h->stream));
+    if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));
+    return WF_OK;
+  }
+  double v[2];
+  WF_HIP(h, hipMemcpyAsync(&v[0], h->d_ws, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  WF_HIP(h, hipMemcpyAsync(&v[1], h->d_wd, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  WF_HIP(h, hipStreamSynchronize(h->stream));
+  std::vector<double> a(h->B, v[0]), b(h->B, v[1]);
+  const hipMemcpyKind k2 = on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost;
+  WF_HIP(h, hipMemcpy(ws, a.data(), sizeof(double) * h->B, k2));
+  WF_HIP(h, hipMemcpy(wd, b.data(), sizeof(double) * h->B, k2));
   return WF_OK;
 }
 
@@ -494,6 +590,7 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
   ea.yaw_step = h->env.yaw_step; ea.yaw_lo = h->env.yaw_lo; ea.yaw_hi = h->env.yaw_hi;
   ea.rate = h->env.actuator_rate; ea.dt = h->env.dt; ea.budget = h->env.budget;
   ea.load_coef = h->env.load_coef; ea.discrete = h->env.discrete;
+  ea.ws_prev = (h->series_T > 0 && h->series_t >= 1) ? h->d_ws_prev : nullptr;
   if (on_device) {
     ea.action = action; ea.reward = reward;
     WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,

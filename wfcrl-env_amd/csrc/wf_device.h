@@ -65,6 +65,7 @@ struct WfEnvArgs {
   int* moves;           // [B] number of env steps taken, in/out
   const float* action;  // [B][N] dyaw (continuous) or {0,1,2} (discrete); null = no transition
   float* reward;        // [B] out (null = skip)
+  const double* ws_prev; // [B] free-stream speed of the state BEFORE the step (null: the current one)
   float yaw_step, yaw_lo, yaw_hi;  // controls["yaw"] = (lo, hi, step)
   float rate, dt, budget;          // ACTUATORS_RATE["yaw"] = 0.3 deg/s, case.dt, 0.1
   float load_coef;

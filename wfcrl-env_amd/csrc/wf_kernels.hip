@@ -167,6 +167,95 @@ __global__ void wf_geometry_kernel(int N, const double* __restrict__ lx, const d
 }
 
 // ---------------------------------------------------------------------------------------------
+// On-device wind process
+//   reset sampling  ws = clip(scale * Weibull(shape), lo, hi), wd = clip(Normal(mean, std) mod 360, lo, hi)
+//                   (reference wfcrl/mdp.py:237-258; NumPy draws there, a counter-based Philox4x32-10 here:
+//                   same distributions, different stream)
+//   series playback per-farm position in a shared (ws, wd) series, rolled to a per-farm start
+//                   (reference wfcrl/interface.py:512-524)
+// ---------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0,
+                                             unsigned k1) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+  const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+  const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned long long ctr, unsigned stream,
+                                              unsigned out[4]) {
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = stream, c3 = 0;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double u01(unsigned hi, unsigned lo) {  // (0, 1), 53 bits
+  const unsigned long long v = (((unsigned long long)hi << 32) | lo) >> 11;
+  return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+}  // namespace
+
+__global__ void wf_wind_sample_kernel(int B, unsigned long long seed, double ws_scale, double ws_shape, double ws_lo,
+                                      double ws_hi, double wd_mean, double wd_std, double wd_lo, double wd_hi,
+                                      double* __restrict__ ws, double* __restrict__ wd) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  unsigned r0[4], r1[4];
+  philox4x32_10(seed, (unsigned long long)b, 0u, r0);
+  philox4x32_10(seed, (unsigned long long)b, 1u, r1);
+  const double e = -log(u01(r0[0], r0[1]));                 // standard exponential
+  double s = ws_scale * pow(e, 1.0 / ws_shape);               // Weibull(shape) = E^(1/shape)
+  s = fmin(fmax(s, ws_lo), ws_hi);
+  const double rad = sqrt(-2.0 * log(u01(r0[2], r0[3])));    // Box-Muller
+  double d = wd_mean + wd_std * rad * cos(2.0 * M_PI * u01(r1[0], r1[1]));
+  d = fmod(d, 360.0);
+  if (d < 0.0) d += 360.0;
+  d = fmin(fmax(d, wd_lo), wd_hi);
+  ws[b] = s;
+  wd[b] = d;
+}
+
+__global__ void wf_series_start_kernel(int B, int T, unsigned long long seed, int* __restrict__ start) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  unsigned r[4];
+  philox4x32_10(seed, (unsigned long long)b, 2u, r);
+  start[b] = (int)(((unsigned long long)r[0] * (unsigned long long)T) >> 32);  // uniform in [0, T)
+}
+
+__global__ void wf_series_gather_kernel(int B, int T, int t, const int* __restrict__ start,
+                                        const double* __restrict__ s_ws, const double* __restrict__ s_wd,
+                                        double* __restrict__ ws, double* __restrict__ wd) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int k = (start[b] + t) % T;
+  ws[b] = s_ws[k];
+  wd[b] = s_wd[k];
+}
+
+extern "C" hipError_t wfk_launch_wind_sample(int B, unsigned long long seed, const double* dist, double* ws, double* wd,
+                                             hipStream_t s) {
+  hipLaunchKernelGGL(wf_wind_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, seed, dist[0], dist[1], dist[2],
+                     dist[3], dist[4], dist[5], dist[6], dist[7], ws, wd);
+  return hipGetLastError();
+}
+extern "C" hipError_t wfk_launch_series_start(int B, int T, unsigned long long seed, int* start, hipStream_t s) {
+  hipLaunchKernelGGL(wf_series_start_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, T, seed, start);
+  return hipGetLastError();
+}
+extern "C" hipError_t wfk_launch_series_gather(int B, int T, int t, const int* start, const double* s_ws,
+                                               const double* s_wd, double* ws, double* wd, hipStream_t s) {
+  hipLaunchKernelGGL(wf_series_gather_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, T, t, start, s_ws, s_wd, ws, wd);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // The farm step
 // ---------------------------------------------------------------------------------------------
 template <int G, int S>
@@ -334,7 +423,12 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         b = (b >= S) ? b - S : b;
         const int t = b * G + sub;
         const float dx = (float)(L.x[eiw][t] - x_i);
+#if defined(WF_ABLATE) && (WF_ABLATE & 1)
+        if (dx >= 0.0f) { st.V[p][0] += Gt * dx; st.W[p][0] += Gb + Gwr; }
+        if (false) {
+#else
         if (dx >= 0.0f) {
+#endif
           const float dy = L.y[eiw][t] - y_i;
           float dec[3];
 #pragma unroll
@@ -411,7 +505,12 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         b = (b >= S) ? b - S : b;
         const int t = b * G + sub;
         const float dx = (float)(L.x[eiw][t] - x_i);
+#if defined(WF_ABLATE) && (WF_ABLATE & 2)
+        if (dx > 0.0f) { st.wsq[p][0] += sc.sy0v * cc[0].x0v * cc[1].kyv * cc[2].pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * cc[2].d0 * sc.snw * sc.kdef; }
+        if (false) {
+#else
         if (dx > 0.0f) {
+#endif
           const float dy = L.y[eiw][t] - y_i;
           const float lin = fmaf(c.bd, dx, c.ad);
           const float amp_on = (dx > 0.1f) ? 1.0f : 0.0f;
@@ -547,7 +646,8 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
     }
     if (sub == 0 && env_ok) {
       const float invN = __fdiv_rn(1.0f, (float)N);
-      const float r = psum * invN * 1.0e-3f * frcp(ws * ws * ws) - ea.load_coef * lsum * invN * 0.25f;
+      const float wr = ea.ws_prev ? (float)ea.ws_prev[env] : ws;  // normalised by the PREVIOUS state's free wind
+      const float r = psum * invN * 1.0e-3f * frcp(wr * wr * wr) - ea.load_coef * lsum * invN * 0.25f;
       ea.reward[env] = r;
     }
   }

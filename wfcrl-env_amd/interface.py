@@ -119,6 +119,17 @@ class HipFlorisInterface(BaseInterface):
                    max_iter=case.max_iter, log_file=log_file, wind_speed=float(p["speed"]),
                    wind_direction=float(p["direction"]), wind_time_series=p["wind_time_series"], **kw)
 
+    @classmethod
+    def from_yaml(cls, simul_file, max_iter: int = int(1e4), log_file: str = None, wind_time_series=None, **kw):
+        """The reference's constructor path `FlorisInterface(num_turbines, simul_file, ...)` (interface.py:462-479):
+        layout, wind and model constants are read from a FLORIS v3 case.yaml (simul_utils.load_case_yaml)."""
+        from .simul_utils import load_case_yaml
+
+        c = load_case_yaml(simul_file)
+        return cls(num_turbines=len(c["xcoords"]), xcoords=c["xcoords"], ycoords=c["ycoords"], max_iter=max_iter,
+                   log_file=log_file, wind_speed=c["speed"], wind_direction=c["direction"],
+                   wind_time_series=wind_time_series, model=c["model"], **kw)
+
     def _make_wind_generator(self, wind_speed=None, wind_direction=None, time_series=None):
         """Constant infinite generator, or a finite playback of the series rolled to a random start
         (interface.py:503-524: global np.random there; seedable here via `seed=`)."""

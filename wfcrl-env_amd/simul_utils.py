@@ -45,3 +45,90 @@ def dump_case_yaml(case: dict, output_dir) -> str:
     with open(path, "w") as fp:
         yaml.safe_dump(case_config(case), fp)
     return str(path)
+
+
+# ---------------------------------------------------------------------------------------------------
+# FLORIS-YAML ingestion: read a (possibly user-modified) case.yaml into what the C ABI takes.
+# ---------------------------------------------------------------------------------------------------
+_SUPPORTED_MODELS = {"combination_model": "sosfs", "deflection_model": "gauss", "turbulence_model": "crespo_hernandez",
+                     "velocity_model": "gauss"}
+
+
+class UnsupportedCaseError(ValueError):
+    """The case selects a FLORIS option the HIP kernels do not implement."""
+
+
+def _turbine_fields(t) -> dict:
+    if isinstance(t, str):
+        if t != "nrel_5MW":
+            raise UnsupportedCaseError(f"turbine library entry {t!r}: only 'nrel_5MW' is built in; pass the turbine "
+                                       "as an inline dict (FLORIS turbine yaml content) instead")
+        return {}
+    out = {}
+    ren = {"rotor_diameter": "rotor_diameter", "hub_height": "hub_height", "TSR": "tsr", "pP": "pP", "pT": "pT",
+           "generator_efficiency": "gen_eff", "ref_density_cp_ct": "ref_density"}
+    for k, v in ren.items():
+        if k in t:
+            out[v] = float(t[k])
+    if "ref_tilt_cp_ct" in t and "tilt_angle" in t and float(t["ref_tilt_cp_ct"]) != float(t.get("tilt_angle", t["ref_tilt_cp_ct"])):
+        raise UnsupportedCaseError("tilt_angle != ref_tilt_cp_ct (tilt corrections) is not implemented")
+    tab = t.get("power_thrust_table")
+    if tab is not None:
+        out["table_ws"] = [float(v) for v in tab["wind_speed"]]
+        out["table_ct"] = [float(v) for v in tab["thrust"]]
+        out["table_cp"] = [float(v) for v in tab["power"]]
+    return out
+
+
+def load_case_yaml(path_or_dict) -> dict:
+    """Parse a FLORIS v3 input (file path or already-loaded dict) into
+    {"xcoords", "ycoords", "speed", "direction", "model": {...wf_model_params fields...}}.
+    Raises UnsupportedCaseError for anything outside the reference template's model family
+    (reference wfcrl/simulators/floris/inputs/template/case.yaml:14-89)."""
+    if isinstance(path_or_dict, dict):
+        cfg = path_or_dict
+    else:
+        import yaml
+
+        with open(path_or_dict) as fp:
+            cfg = yaml.safe_load(fp)
+    solver = cfg.get("solver", {})
+    if solver.get("type", "turbine_grid") != "turbine_grid" or int(solver.get("turbine_grid_points", 3)) != 3:
+        raise UnsupportedCaseError("only solver.type = turbine_grid with turbine_grid_points = 3 is implemented")
+    farm, flow, wake = cfg["farm"], cfg["flow_field"], cfg["wake"]
+    for key, want in _SUPPORTED_MODELS.items():
+        got = wake["model_strings"].get(key)
+        if got != want:
+            raise UnsupportedCaseError(f"wake.model_strings.{key} = {got!r} is not implemented (only {want!r})")
+    for flag in ("enable_secondary_steering", "enable_yaw_added_recovery", "enable_transverse_velocities"):
+        if not wake.get(flag, False):
+            raise UnsupportedCaseError(f"wake.{flag} = false is not implemented (the reference template enables it)")
+    if len(flow.get("wind_speeds", [0])) != 1 or len(flow.get("wind_directions", [0])) != 1:
+        raise UnsupportedCaseError("exactly one wind speed and one wind direction per case (as the reference uses)")
+    if float(flow.get("wind_veer", 0.0)) != 0.0:
+        raise UnsupportedCaseError("wind_veer != 0 is not implemented")
+    if flow.get("heterogenous_inflow_config") or flow.get("heterogeneous_inflow_config"):
+        raise UnsupportedCaseError("heterogeneous inflow is not implemented")
+    ttypes = farm.get("turbine_type", ["nrel_5MW"])
+    if any(t != ttypes[0] for t in ttypes):
+        raise UnsupportedCaseError("mixed turbine types are not implemented")
+    model = _turbine_fields(ttypes[0])
+    ref_h = float(flow.get("reference_wind_height", -1))
+    hub = model.get("hub_height", 90.0)
+    if ref_h != -1 and ref_h != hub:
+        raise UnsupportedCaseError("reference_wind_height must be -1 (hub height) or equal to the hub height")
+    model.update(air_density=float(flow["air_density"]), ambient_ti=float(flow["turbulence_intensity"]),
+                 shear=float(flow["wind_shear"]), veer=0.0)
+    gd = wake["wake_deflection_parameters"]["gauss"]
+    gv = wake["wake_velocity_parameters"]["gauss"]
+    for k in ("alpha", "beta", "ka", "kb"):
+        if float(gd[k]) != float(gv[k]):
+            raise UnsupportedCaseError(f"gauss deflection and velocity parameter {k!r} differ ({gd[k]} vs {gv[k]}): "
+                                       "one shared set is implemented, as in the reference template")
+        model[k] = float(gv[k])
+    model.update(ad=float(gd.get("ad", 0.0)), bd=float(gd.get("bd", 0.0)), dm=float(gd.get("dm", 1.0)))
+    ch = wake["wake_turbulence_parameters"]["crespo_hernandez"]
+    model.update(ch_initial=float(ch["initial"]), ch_constant=float(ch["constant"]), ch_ai=float(ch["ai"]),
+                 ch_downstream=float(ch["downstream"]))
+    return {"xcoords": [float(v) for v in farm["layout_x"]], "ycoords": [float(v) for v in farm["layout_y"]],
+            "speed": float(flow["wind_speeds"][0]), "direction": float(flow["wind_directions"][0]), "model": model}

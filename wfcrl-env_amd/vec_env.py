@@ -30,7 +30,8 @@ class VecWindFarmEnv:
 
     def __init__(self, farm_case, controls: dict = None, env_batch: int = 1, continuous_control: bool = True,
                  reward_shaper=None, start_iter: int = 0, max_num_steps: int = 500, load_coef: float = 0.1,
-                 device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None):
+                 device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None,
+                 wind_sampling: str = "host"):
         controls = {"yaw": (-40, 40, 5)} if controls is None else dict(controls)
         if list(controls) != ["yaw"]:
             raise ValueError(f"Cannot control {list(controls)}. Interface HipFlorisInterface only allows for the "
@@ -76,6 +77,17 @@ class VecWindFarmEnv:
         ]))
         self.action_space = self.single_action_space
         self.observation_space = self.single_observation_space
+        if wind_sampling not in ("host", "device"):
+            raise ValueError("wind_sampling must be 'host' (NumPy stream of the reference) or 'device' (Philox on the GPU)")
+        self.wind_sampling = wind_sampling
+        ts = self.farm_case.wind_time_series
+        has_series = ts is not None and (ts.size > 0 if isinstance(ts, np.ndarray) else bool(ts))
+        if has_series:
+            from .interface import _load_time_series
+
+            self._series = np.ascontiguousarray(_load_time_series(ts)[:, :2], dtype=np.float64)
+        else:
+            self._series = None
         self._num_iter = 0
         self._freewind = None
         self._shaper_ref = None
@@ -99,6 +111,16 @@ class VecWindFarmEnv:
         else:
             wd = np.clip(rng.normal(WD_MEAN, WD_STD, B) % 360, lo[1], hi[1])
         return ws, wd % 360
+
+    def _refresh_freewind(self):
+        if self.return_torch:
+            import torch
+
+            ws, wd = self.fi.get_wind(as_torch=True)
+            self._freewind = torch.stack([ws, wd], dim=1)
+        else:
+            ws, wd = self.fi.get_wind()
+            self._freewind = np.stack([ws, wd], axis=1)
 
     def _obs(self, out):
         obs = OrderedDict()
@@ -134,24 +156,34 @@ class VecWindFarmEnv:
     def reset(self, seed=None, options=None):
         """Samples one wind per env, zeroes the env state, runs the warm-up solve(s) at yaw = 0 and returns
         the start observation (clipped to the observation space like the reference's, mdp.py:263-266)."""
-        ws, wd = self._sample_wind(seed, options)
-        self.fi.set_wind(ws, wd)
+        if self._series is not None:
+            # time-series mode: requested / sampled wind is ignored (interface.py:588-600); every farm starts at a
+            # random row (interface.py:516-518), then each solve consumes one row
+            s = seed if seed is not None else int(np.random.randint(0, 2**31 - 1))
+            self.fi.set_wind_series(self._series, start=None, seed=s)
+        elif self.wind_sampling == "device" and not (options and ("wind_speed" in options or "wind_direction" in options)) \
+                and not (self.farm_case.set_wind_speed or self.farm_case.set_wind_direction):
+            s = seed if seed is not None else int(np.random.randint(0, 2**31 - 1))
+            self.fi.sample_wind(s)
+        else:
+            ws, wd = self._sample_wind(seed, options)
+            self.fi.set_wind(ws, wd)
         self.fi.env_reset()
         self.reward_shaper.reset()
         self._shaper_ref = None
+        seed_out = None
         if self.return_torch:
             import torch
 
-            self._freewind = torch.as_tensor(np.stack([ws, wd], axis=1), device=f"cuda:{self.fi.device_id}")
-            seed_out = {"yaw": torch.empty((self.num_envs, self.num_turbines), device=self._freewind.device)}
-        else:
-            self._freewind = np.stack([ws, wd], axis=1)
-            seed_out = None
+            seed_out = {"yaw": torch.empty((self.num_envs, self.num_turbines), device=f"cuda:{self.fi.device_id}")}
         self._num_iter = 0
         out = None
         for _ in range(self.start_iter + 1):
+            if self._series is not None:
+                self.fi.wind_series_step()
             out = self.fi.env_step(None, want=("yaw", "wind_speed", "wind_direction"), out=seed_out)
             self._num_iter += 1
+        self._refresh_freewind()
         obs = self._obs(out)
         sp = self.single_observation_space
         for k in ("wind_speed", "wind_direction"):
@@ -163,6 +195,9 @@ class VecWindFarmEnv:
         """actions: {"yaw": (B, N)} or the (B, N) array itself.  Returns (obs, reward[B], terminated[B],
         truncated[B], info) with info["power"] in MW and info["load"] (B, N, 4) — units of the reference."""
         a = actions["yaw"] if isinstance(actions, dict) else actions
+        if self._series is not None:
+            self.fi.wind_series_step()  # ValueError("wind series exhausted") ~ the reference's StopIteration
+            self._refresh_freewind()
         out = self.fi.env_step(self._to_device(a))
         self._num_iter += 1
         truncated = self._num_iter == self.farm_case.max_iter
@@ -182,6 +217,9 @@ class VecWindFarmEnv:
         """Learner-facing variant: only reward + local wind observations leave the kernel (no power/load
         arrays are written: 2N+1 instead of 7N floats per env)."""
         a = actions["yaw"] if isinstance(actions, dict) else actions
+        if self._series is not None:
+            self.fi.wind_series_step()
+            self._refresh_freewind()
         out = self.fi.env_step(self._to_device(a), want=("reward", "yaw", "wind_speed", "wind_direction"))
         self._num_iter += 1
         return self._obs(out), self._shape(out["reward"]), self._num_iter == self.farm_case.max_iter
