@@ -150,7 +150,7 @@ int pick_variant(int N) {
     }
   }
   static const int pref[][3] = {  // {max N, G, S}
-      {4, 4, 1}, {8, 8, 1}, {16, 8, 2}, {24, 8, 3}, {32, 8, 4}, {48, 16, 3}, {64, 16, 4},
+      {4, 4, 1}, {8, 4, 2}, {12, 4, 3}, {16, 4, 4}, {24, 8, 3}, {32, 8, 4}, {48, 16, 3}, {64, 16, 4},
       {80, 16, 5}, {96, 16, 6}, {128, 32, 4}, {192, 64, 3}, {256, 64, 4}};
   for (auto& r : pref) {
     if (N <= r[0]) {
@@ -203,6 +203,10 @@ int build_consts(wf_handle* h) {
     c.zc[m + 3] = (float)zc; c.zc2[m + 3] = (float)(zc * zc); c.ez[m + 3] = (float)std::exp(-zc * zc / eps2);
     c.zm[m + 3] = (float)zm; c.zm2[m + 3] = (float)(zm * zm); c.ezm[m + 3] = (float)std::exp(-zm * zm / eps2);
   }
+  // 1 - Ey*ezm with Ey <= 1 rounds to exactly 1.0f once ezm < 2^-25: those classes skip the core factor
+  c.mirror_core_n = 0;
+  for (int m = 0; m < 7; ++m)
+    if (c.ezm[m] >= 2.9e-8f) c.mirror_core_n = m + 1;
   const double hs[3] = {HH + R, HH - R, HH};
   double ks[3] = {0, 0, 0};
   for (int v = 0; v < 3; ++v)

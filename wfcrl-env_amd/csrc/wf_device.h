@@ -6,7 +6,7 @@
 #pragma once
 
 #define WF_TABLE_PAD 64
-#define WF_BUCKETS 256
+#define WF_BUCKETS 2048
 
 struct WfConsts {
   int N;             // turbines
@@ -24,6 +24,7 @@ struct WfConsts {
   //   real:   top m = k'-2, bottom m = k'+2, rotation m = k'      mirror: top k'+2, bottom k'-2, rotation k'
   float zc[7], zc2[7], ez[7];    // zc = m q + eps       ; ez  = exp(-zc^2/eps^2)
   float zm[7], zm2[7], ezm[7];   // zm = 2HH + m q + eps ; ezm = exp(-zm^2/eps^2)
+  int mirror_core_n;             // mirror classes [0, n) need the core factor; for the others 1 - Ey*ezm == 1.0f exactly
   float gam_top, gam_bot;  // (1/2pi)(pi/8) D vel_{top,bot} uinf_f : Gamma/(2pi) = gam*ws*ct
   float gam_wr;            // (1/2pi) 0.25*2pi*D/TSR               : Gamma_wr/(2pi) = gam_wr*(a-a^2)*ubar
   // secondary steering: mean_9( z/(r) * core ) on the source's own grid (dx = 0, dy = 0)   [A.3-2]
@@ -52,7 +53,7 @@ struct WfTables {
   float ct_slope[WF_TABLE_PAD];  // (ct[j+1]-ct[j])/(knot[j+1]-knot[j])
   float pw[WF_TABLE_PAD];        // 1/2 A Cp eta ws^3 at knot
   float pw_slope[WF_TABLE_PAD];
-  unsigned char bucket[WF_BUCKETS];  // index of the last knot <= bucket start
+  unsigned char bucket[WF_BUCKETS];  // index of the last knot <= start of the previous bucket
 };
 
 // Device-resident env state + fused MDP transition / reward.  All pointers may be null:

@@ -53,8 +53,11 @@ __device__ __forceinline__ int table_segment(const WfConsts& c, const TableLds& 
   int b = (int)((v - c.bucket_x0) * c.bucket_h_inv);
   b = min(max(b, 0), WF_BUCKETS - 1);
   int j = T.bucket[b];
-  for (int p = 0; p < c.max_probe; ++p)
-    if (T.knot[j + 1] <= v) ++j;
+  for (int p = 0; p < c.max_probe; ++p) {  // usually 0-1 rounds: leave as soon as no lane moves
+    const bool mv = T.knot[j + 1] <= v;
+    if (!__any(mv)) break;
+    j += mv ? 1 : 0;
+  }
   return min(j, c.n_table - 2);
 }
 
@@ -88,6 +91,7 @@ struct GeoLds {
   double x[EPW][NP];  // sorted x' (float64: the sign of dx decides every upstream/downstream mask)
   float y[EPW][NP];   // sorted y' - yc
   float yaw[EPW][NP]; // commanded yaw in sorted order, degrees
+  float cg[EPW][NP], sg[EPW][NP];  // cos / sin of the commanded yaw (evaluated once per turbine)
 };
 
 // Source-side constants of the deflection + deficit models for one grid column j [A.3-3, A.3-6]
@@ -333,6 +337,10 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       yw = yaw_in[oi];
     }
     L.yaw[eiw][t] = yw;
+    float sy_, cy_;
+    sincosf(yw * kDeg2Rad, &sy_, &cy_);
+    L.cg[eiw][t] = cy_;
+    L.sg[eiw][t] = sy_;
   }
   if (env_mode && ea.action && sub == 0 && env_ok) ea.moves[env] = moves_new;
   __syncthreads();
@@ -376,8 +384,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
 
       // ---- B. source constants, part 1 [A.3-1 .. A.3-4] ------------------------------------
       const float ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
-      float sg, cg;
-      sincosf(yaw_i * kDeg2Rad, &sg, &cg);
+      const float cg = L.cg[eiw][i], sg = L.sg[eiw][i];
       const float ct = table_ct(c, T, ubar) * cg;
       const float sq1 = fsqrt(1.0f - ct * cg);
       const float a = 0.5f * ct * frcp(1.0f + sq1);  // == 0.5/cg*(1 - sqrt(1 - ct*cg))
@@ -387,7 +394,11 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       float val = 2.0f * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
       val = fminf(fmaxf(val, -1.0f), 1.0f);
       const float gd = -(yaw_i * kDeg2Rad + 0.5f * asinf(val));  // radians, deflection sign convention
-      const float cgd = cosf(gd);
+      // cos(gd) = cos(yaw + h), h = asin(val)/2: half-angle identities instead of a second libm call
+      const float c2h = fsqrt(fmaxf(fmaf(-val, val, 1.0f), 0.0f));  // cos(2h) >= 0
+      const float ch = fsqrt(0.5f * (1.0f + c2h));                   // cos h >= 0.707
+      const float sh = 0.5f * val * frcp(ch);                        // sin h = sin(2h) / (2 cos h)
+      const float cgd = fmaf(cg, ch, -sg * sh);
       const float s_cc = fsqrt(1.0f - ct * cgd), s_c = fsqrt(1.0f - ct);
       const float om_scc = ct * cgd * frcp(1.0f + s_cc);  // 1 - s_cc
       const float om_sc = ct * frcp(1.0f + s_c);          // 1 - s_c  (== C0)
@@ -397,7 +408,13 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       sc.sz0d = 0.5f * c.D * fsqrt((1.0f + s_cc) * frcp(2.0f * (1.0f + s_c)));
       sc.sy0d = sc.sz0d * cgd;
       const float th0 = c.dm03 * gd * frcp(cgd) * om_scc;
-      sc.tan_th0 = tanf(th0);
+      {
+        // |th0| < 0.3 for every admissible yaw: odd polynomial (rel. err < 1e-8 there), libm beyond 0.35
+        const float t2 = th0 * th0;
+        const float poly = th0 * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 0.0088632355f, 0.0218694885f), 0.0539682540f),
+                                                          0.1333333333f), 0.3333333333f), 1.0f);
+        sc.tan_th0 = __any(fabsf(th0) > 0.35f) ? tanf(th0) : poly;
+      }
       sc.inv_s0d = frcp(sc.sy0d * sc.sz0d);
       const float pfac = th0 * E0 * (1.0f / 5.2f) * fsqrt(sc.sy0d * sc.sz0d * frcp(ct)) * kLn2;  // * log2(arg)/ky
       sc.lnA = 1.6f + sc.sM;
@@ -443,10 +460,18 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
               Tr[m] = fmaf(-Ey, c.ez[m], 1.0f) * frcp(yL2 + c.zc2[m]);
-              Tm[m] = fmaf(-Ey, c.ezm[m], 1.0f) * frcp(yL2 + c.zm2[m]);
               Pr[m] = c.zc[m] * Tr[m];
-              Pm[m] = c.zm[m] * Tm[m];
             }
+            if (c.mirror_core_n <= 1) {  // wave-uniform: only the lowest mirror offset has a core factor != 1.0f
+              Tm[0] = fmaf(-Ey, c.ezm[0], 1.0f) * frcp(yL2 + c.zm2[0]);
+#pragma unroll
+              for (int m = 1; m < 7; ++m) Tm[m] = frcp(yL2 + c.zm2[m]);
+            } else {
+#pragma unroll
+              for (int m = 0; m < 7; ++m) Tm[m] = fmaf(-Ey, c.ezm[m], 1.0f) * frcp(yL2 + c.zm2[m]);
+            }
+#pragma unroll
+            for (int m = 0; m < 7; ++m) Pm[m] = c.zm[m] * Tm[m];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
               // class index m+3 with k' = k-1: real top k'-2, bottom k'+2, rot k'; mirror top k'+2, bottom k'-2, rot k'
@@ -618,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         su = fmaf(du, du, su); sv = fmaf(dv, dv, sv); sw = fmaf(dw, dw, sw);
       }
       const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
-      const float cy = cosf(L.yaw[eiw][t] * kDeg2Rad);
+      const float cy = L.cg[eiw][t];
       const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cy));
       const float pwr = c.rho * table_pw(c, T, veff);
       float4 l;
@@ -663,7 +688,7 @@ struct WfVariant {
 
 #define WF_VARIANT(G_, S_) {G_, S_, (const void*)&wf_step_kernel<G_, S_>}
 static const WfVariant kVariants[] = {
-    WF_VARIANT(4, 1),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(8, 3),  WF_VARIANT(8, 4),
+    WF_VARIANT(4, 1),  WF_VARIANT(4, 2),  WF_VARIANT(4, 3),  WF_VARIANT(4, 4),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(8, 3),  WF_VARIANT(8, 4),
     WF_VARIANT(16, 3), WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(16, 6), WF_VARIANT(32, 3),
     WF_VARIANT(32, 4), WF_VARIANT(64, 3), WF_VARIANT(64, 4),
 };
