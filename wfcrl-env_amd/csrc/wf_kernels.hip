@@ -262,7 +262,9 @@ extern "C" hipError_t wfk_launch_series_gather(int B, int T, int t, const int* s
 // ---------------------------------------------------------------------------------------------
 // The farm step
 // ---------------------------------------------------------------------------------------------
-template <int G, int S>
+// MC1: only the lowest mirror vortex offset needs its core factor (WfConsts::mirror_core_n <= 1, the case for
+// every physical turbine: for the other mirror offsets 1 - Ey*ezm == 1.0f exactly in float32).
+template <int G, int S, bool MC1>
 __global__ __launch_bounds__(256, 2) void wf_step_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const float* __restrict__ gy,
     const int* __restrict__ gidx, int geom_stride, const double* __restrict__ ws_in, const double* __restrict__ wd_in,
@@ -390,6 +392,77 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       const float a = 0.5f * ct * frcp(1.0f + sq1);  // == 0.5/cg*(1 - sqrt(1 - ct*cg))
       const float Gwr = c.gam_wr * (a - a * a) * ubar;
       const float gt = c.gam_top * ws * ct, gb = c.gam_bot * ws * ct;
+      // transverse circulations / (2 pi), commanded yaw
+      const float scg = sg * cg;
+      const float Gt = scg * gt, Gb = -scg * gb;
+
+      // ---- C. pass 1: transverse velocities on every target at or downstream of the source --
+      float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
+#pragma unroll
+      for (int p = 0; p < S; ++p) {
+        int b = p + rot;
+        b = (b >= S) ? b - S : b;
+        const int t = b * G + sub;
+        const float dx = (float)(L.x[eiw][t] - x_i);
+#if defined(WF_ABLATE) && (WF_ABLATE & 1)
+        if (dx >= 0.0f) { st.V[p][0] += Gt * dx; st.W[p][0] += Gb + Gwr; }
+        if (false) {
+#else
+        if (dx >= 0.0f) {
+#endif
+          const float dy = L.y[eiw][t] - y_i;
+          float dec[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dec[k] = frcp(fmaf(c.decay_a[k], dx, 1.0f));
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float yL = dy + c.yoff[j];
+            const float yL2 = yL * yL;
+            const float Ey = fexp2(-yL2 * c.exp_c);
+            // core/r of the 7 distinct real and 7 distinct mirror vortex offsets, accumulated on the fly into
+            // the row sums  A_k = sum Gamma z core/r  (-> V)  and  B_k = sum Gamma core/r  (-> W):
+            //   class index mi = m + 3;  real:   top k = mi (mi<=2), bottom k = mi-4 (mi>=4), rotation k = mi-2
+            //                            mirror: top k = mi-4 (mi>=4), bottom k = mi (mi<=2), rotation k = mi-2
+            float A[3] = {0.0f, 0.0f, 0.0f}, Bw[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int mi = 0; mi < 7; ++mi) {
+              const float tr = fmaf(-Ey, c.ez[mi], 1.0f) * frcp(yL2 + c.zc2[mi]);
+              const float pr = c.zc[mi] * tr;
+              float tm = frcp(yL2 + c.zm2[mi]);
+              if (mi == 0 || !MC1) tm *= fmaf(-Ey, c.ezm[mi], 1.0f);  // compile-time: see mirror_core_n
+              const float pm = c.zm[mi] * tm;
+              if (mi <= 2) {
+                A[mi] = fmaf(Gt, pr, A[mi]);   Bw[mi] = fmaf(Gt, tr, Bw[mi]);      // real top
+                A[mi] = fmaf(-Gb, pm, A[mi]);  Bw[mi] = fmaf(-Gb, tm, Bw[mi]);     // mirror bottom
+              }
+              if (mi >= 4) {
+                A[mi - 4] = fmaf(Gb, pr, A[mi - 4]);   Bw[mi - 4] = fmaf(Gb, tr, Bw[mi - 4]);   // real bottom
+                A[mi - 4] = fmaf(-Gt, pm, A[mi - 4]);  Bw[mi - 4] = fmaf(-Gt, tm, Bw[mi - 4]);  // mirror top
+              }
+              if (mi >= 2 && mi <= 4) {
+                A[mi - 2] = fmaf(Gwr, pr - pm, A[mi - 2]);  // rotation, real - mirror
+                Bw[mi - 2] = fmaf(Gwr, tr - tm, Bw[mi - 2]);
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              st.V[p][j * 3 + k] = fmaf(A[k], dec[k], st.V[p][j * 3 + k]);
+              st.W[p][j * 3 + k] += fmaxf(-yL * Bw[k] * dec[k], 0.0f);  // W[W<0] = 0, quirk (5)
+            }
+          }
+        }
+        if (p == 0) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            vbar += st.V[0][q];
+            wbar += st.W[0][q];
+          }
+        }
+      }
+      vbar = __shfl(vbar, src) * (1.0f / 9.0f);
+      wbar = __shfl(wbar, src) * (1.0f / 9.0f);
+
+      // ---- B2. steering + deflection constants [A.3-2, A.3-3] (kept out of pass 1's live range) ----
       // secondary steering
       float val = 2.0f * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
       val = fminf(fmaxf(val, -1.0f), 1.0f);
@@ -428,72 +501,6 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         cc[j].d0 = sc.tan_th0 * cc[j].x0d;
         cc[j].pj = pfac * frcp(cc[j].kyd);
       }
-      // transverse circulations / (2 pi), commanded yaw
-      const float scg = sg * cg;
-      const float Gt = scg * gt, Gb = -scg * gb;
-
-      // ---- C. pass 1: transverse velocities on every target at or downstream of the source --
-      float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
-#pragma unroll
-      for (int p = 0; p < S; ++p) {
-        int b = p + rot;
-        b = (b >= S) ? b - S : b;
-        const int t = b * G + sub;
-        const float dx = (float)(L.x[eiw][t] - x_i);
-#if defined(WF_ABLATE) && (WF_ABLATE & 1)
-        if (dx >= 0.0f) { st.V[p][0] += Gt * dx; st.W[p][0] += Gb + Gwr; }
-        if (false) {
-#else
-        if (dx >= 0.0f) {
-#endif
-          const float dy = L.y[eiw][t] - y_i;
-          float dec[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) dec[k] = frcp(fmaf(c.decay_a[k], dx, 1.0f));
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const float yL = dy + c.yoff[j];
-            const float yL2 = yL * yL;
-            const float Ey = fexp2(-yL2 * c.exp_c);
-            // core/r of the 7 distinct real and 7 distinct mirror vortex offsets
-            float Tr[7], Tm[7], Pr[7], Pm[7];
-#pragma unroll
-            for (int m = 0; m < 7; ++m) {
-              Tr[m] = fmaf(-Ey, c.ez[m], 1.0f) * frcp(yL2 + c.zc2[m]);
-              Pr[m] = c.zc[m] * Tr[m];
-            }
-            if (c.mirror_core_n <= 1) {  // wave-uniform: only the lowest mirror offset has a core factor != 1.0f
-              Tm[0] = fmaf(-Ey, c.ezm[0], 1.0f) * frcp(yL2 + c.zm2[0]);
-#pragma unroll
-              for (int m = 1; m < 7; ++m) Tm[m] = frcp(yL2 + c.zm2[m]);
-            } else {
-#pragma unroll
-              for (int m = 0; m < 7; ++m) Tm[m] = fmaf(-Ey, c.ezm[m], 1.0f) * frcp(yL2 + c.zm2[m]);
-            }
-#pragma unroll
-            for (int m = 0; m < 7; ++m) Pm[m] = c.zm[m] * Tm[m];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              // class index m+3 with k' = k-1: real top k'-2, bottom k'+2, rot k'; mirror top k'+2, bottom k'-2, rot k'
-              const int rt = k, rb = k + 4, rc = k + 2;
-              const float A = fmaf(Gt, Pr[rt] - Pm[rb], fmaf(Gb, Pr[rb] - Pm[rt], Gwr * (Pr[rc] - Pm[rc])));
-              const float Bw = fmaf(Gt, Tr[rt] - Tm[rb], fmaf(Gb, Tr[rb] - Tm[rt], Gwr * (Tr[rc] - Tm[rc])));
-              st.V[p][j * 3 + k] = fmaf(A, dec[k], st.V[p][j * 3 + k]);
-              st.W[p][j * 3 + k] += fmaxf(-yL * Bw * dec[k], 0.0f);  // W[W<0] = 0, quirk (5)
-            }
-          }
-        }
-        if (p == 0) {
-#pragma unroll
-          for (int q = 0; q < 9; ++q) {
-            vbar += st.V[0][q];
-            wbar += st.W[0][q];
-          }
-        }
-      }
-      vbar = __shfl(vbar, src) * (1.0f / 9.0f);
-      wbar = __shfl(wbar, src) * (1.0f / 9.0f);
-
       // ---- D. yaw-added recovery [A.3-5] and deficit constants [A.3-6] -----------------------
       const float I0 = TIs[0];
       const float uI = ubar * I0;
@@ -683,10 +690,11 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
 // ---------------------------------------------------------------------------------------------
 struct WfVariant {
   int G, S;
-  const void* fn;
+  const void* fn;      // MC1 = true
+  const void* fn_all;  // MC1 = false (general mirror cores)
 };
 
-#define WF_VARIANT(G_, S_) {G_, S_, (const void*)&wf_step_kernel<G_, S_>}
+#define WF_VARIANT(G_, S_) {G_, S_, (const void*)&wf_step_kernel<G_, S_, true>, (const void*)&wf_step_kernel<G_, S_, false>}
 static const WfVariant kVariants[] = {
     WF_VARIANT(4, 1),  WF_VARIANT(4, 2),  WF_VARIANT(4, 3),  WF_VARIANT(4, 4),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(8, 3),  WF_VARIANT(8, 4),
     WF_VARIANT(16, 3), WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(16, 6), WF_VARIANT(32, 3),
@@ -720,5 +728,5 @@ extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTa
   WfEnvArgs ea;
   if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
   void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea};
-  return hipLaunchKernel(v.fn, dim3(grid), dim3(256), args, 0, s);
+  return hipLaunchKernel(cc.mirror_core_n <= 1 ? v.fn : v.fn_all, dim3(grid), dim3(256), args, 0, s);
 }
