@@ -482,24 +482,34 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       sc.sy0d = sc.sz0d * cgd;
       const float th0 = c.dm03 * gd * frcp(cgd) * om_scc;
       {
-        // |th0| < 0.3 for every admissible yaw: odd polynomial (rel. err < 1e-8 there), libm beyond 0.35
+        // |th0| < 0.3 for every admissible yaw: odd polynomial (rel. err < 1e-8 there).  Beyond 0.35 rad (not
+        // reachable with |yaw| <= 45 deg) the hardware sin/cos ratio takes over: no libm range reduction inline.
         const float t2 = th0 * th0;
         const float poly = th0 * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 0.0088632355f, 0.0218694885f), 0.0539682540f),
                                                           0.1333333333f), 0.3333333333f), 1.0f);
-        sc.tan_th0 = __any(fabsf(th0) > 0.35f) ? tanf(th0) : poly;
+        const float rev = th0 * 0.15915494309189535f;  // v_sin/v_cos take revolutions
+        const float hw = __builtin_amdgcn_sinf(rev) * frcp(__builtin_amdgcn_cosf(rev));
+        sc.tan_th0 = (fabsf(th0) > 0.35f) ? hw : poly;
       }
       sc.inv_s0d = frcp(sc.sy0d * sc.sz0d);
       const float pfac = th0 * E0 * (1.0f / 5.2f) * fsqrt(sc.sy0d * sc.sz0d * frcp(ct)) * kLn2;  // * log2(arg)/ky
       sc.lnA = 1.6f + sc.sM;
       sc.lnB = 1.6f - sc.sM;
       const float x0num_d = c.D * cgd * (1.0f + s_cc) * (1.0f / 1.41421356237f);
+      // The three grid columns of a source almost always carry the same TI (they differ only when the
+      // |dy| < 2D gate of A.3-8 split a rotor): then sigma, C and the far-wake deflection are evaluated
+      // once per target instead of once per column, from column 0's constants.  Wave-uniform choice,
+      // identical results.
+      const bool uni = __all((TIs[0] == TIs[1]) && (TIs[1] == TIs[2]));
       ColConsts cc[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        cc[j].x0d = x0num_d * frcp(fmaf(c.alpha4, TIs[j], c.beta2 * om_sc));
-        cc[j].kyd = fmaf(c.ka, TIs[j], c.kb);
-        cc[j].d0 = sc.tan_th0 * cc[j].x0d;
-        cc[j].pj = pfac * frcp(cc[j].kyd);
+        if (j == 0 || !uni) {  // static indices (a runtime-indexed cc[] would live in scratch)
+          cc[j].x0d = x0num_d * frcp(fmaf(c.alpha4, TIs[j], c.beta2 * om_sc));
+          cc[j].kyd = fmaf(c.ka, TIs[j], c.kb);
+          cc[j].d0 = sc.tan_th0 * cc[j].x0d;
+          cc[j].pj = pfac * frcp(cc[j].kyd);
+        }
       }
       // ---- D. yaw-added recovery [A.3-5] and deficit constants [A.3-6] -----------------------
       const float I0 = TIs[0];
@@ -520,15 +530,13 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       const float x0num_v = c.D * cg * (1.0f + s_c) * (1.0f / 1.41421356237f);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const float ti = TIs[j] + dTI;
-        cc[j].x0v = x0num_v * frcp(fmaf(c.alpha4, ti, c.beta2 * om_sc));
-        cc[j].ix0v = frcp(cc[j].x0v);
-        cc[j].kyv = fmaf(c.ka, ti, c.kb);
+        if (j == 0 || !uni) {
+          const float ti = TIs[j] + dTI;
+          cc[j].x0v = x0num_v * frcp(fmaf(c.alpha4, ti, c.beta2 * om_sc));
+          cc[j].ix0v = frcp(cc[j].x0v);
+          cc[j].kyv = fmaf(c.ka, ti, c.kb);
+        }
       }
-      // The three grid columns of a source almost always carry the same TI (they differ only when the
-      // |dy| < 2D gate of A.3-8 split a rotor): then sigma, C and the far-wake deflection are evaluated
-      // once per target instead of once per column.  Wave-uniform choice, identical results.
-      const bool uni = __all((TIs[0] == TIs[1]) && (TIs[1] == TIs[2]));
 
       // ---- E. pass 2: deflection, deficit, SOSFS, wake-added turbulence ----------------------
 #pragma unroll
