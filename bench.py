@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--env-batch", type=int, default=0, help="per-GPU env batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-env-leg", action="store_true", help="skip the fused-env-step leg (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -135,6 +136,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
 
+    # the same farms through the fused env step (transition + budget gate + reward in the launch,
+    # only reward + local wind observations written): reported beside the headline, not as `value`
+    venv_ms = None
+    try:
+        if args.no_env_leg:
+            raise RuntimeError("skipped")
+        w.env_config(load_coef=0.1)
+        w.env_reset()
+        act = [(r - ring[i - 1]) if i else r for i, r in enumerate(ring)]
+        eout = w.env_step(act[0], want=("reward", "yaw", "wind_speed", "wind_direction"))
+        w.sync()
+        w.timing_begin()
+        for i in range(args.steps):
+            w.env_step(act[i % len(act)], want=("reward", "yaw", "wind_speed", "wind_direction"), out=eout)
+        venv_ms = w.timing_end() / args.steps
+    except Exception as e:  # pragma: no cover
+        if not args.no_env_leg:
+            print(f"bench.py: fused env step leg failed: {e}", file=sys.stderr)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -171,6 +191,9 @@ def main():
                              "unit": "lane-ops/s", "frac": valu_achieved / VALU_PEAK_LANEOPS,
                              "lane_ops_per_farm_step": lane_ops_per_farm_step(N)}}
 
+    if venv_ms is not None:
+        res["fused_env_step"] = {"ms_per_step": venv_ms, "env_steps_per_sec_per_gpu": B / (venv_ms * 1e-3),
+                                 "outputs": "reward[B], yaw/wind_speed/wind_direction[B,N]"}
     if not args.no_cpu_baseline:
         from oracle import c_oracle
 

@@ -4,7 +4,7 @@
 tag=$1; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_$tag
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$name -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline $BENCH_ARGS > $O/$name.json 2> $O/$name.err; }
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$name -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-env-leg $BENCH_ARGS > $O/$name.json 2> $O/$name.err; }
 BENCH_ARGS="$*"
 run fetch FETCH_SIZE
 run write WRITE_SIZE
