@@ -6,7 +6,6 @@ Same duck type, names, units and error behaviour; the FLORIS object (`self.fi`) 
 """
 from __future__ import annotations
 
-import time
 import warnings
 from abc import ABC
 from typing import List, Union

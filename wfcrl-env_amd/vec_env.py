@@ -12,7 +12,6 @@ stream), and constrained actions are not zeroed in the caller's array (the gate 
 """
 from __future__ import annotations
 
-import math
 from collections import OrderedDict
 
 import numpy as np
@@ -234,8 +233,3 @@ def make_vec(env_id: str, env_batch: int, controls=("yaw",), **kw):
 
     return make(env_id, controls=list(controls) if not isinstance(controls, dict) else controls, env_batch=env_batch,
                 **kw)
-
-
-def episode_steps(max_num_steps: int, start_iter: int = 0) -> int:
-    """Agent steps per episode = max_num_steps - 1: reset consumes one solve."""
-    return max(0, start_iter + max_num_steps - (start_iter + 1))
