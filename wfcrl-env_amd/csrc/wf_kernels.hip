@@ -36,11 +36,15 @@ __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
 
-// cube root of a positive number: exp2(log2(x)/3) polished by one Newton step (rel. err ~1e-7)
+// cube root, sign-aware like np.cbrt (unphysically tight layouts can drive grid velocities negative, and the
+// reference keeps computing): exp2(log2|x|/3) polished by one Newton step (rel. err ~1e-7); cbrt(0) = 0
 __device__ __forceinline__ float fcbrt_pos(float x) {
-  float y = fexp2(flog2(x) * (1.0f / 3.0f));
-  float y2 = y * y;
-  return y - (y2 * y - x) * frcp(3.0f * y2);
+  const float ax = fabsf(x);
+  float y = fexp2(flog2(ax) * (1.0f / 3.0f));
+  const float y2 = y * y;
+  y = y - (y2 * y - ax) * frcp(3.0f * y2);
+  y = (ax > 1.0e-30f) ? y : 0.0f;
+  return copysignf(y, x);
 }
 
 struct TableLds {
