@@ -222,6 +222,16 @@ def main():
                                "sample": f"{reps} x {n} farm-steps of the same workload, C float64 oracle "
                                          f"(OpenMP over envs, {nthreads} threads; os.cpu_count()={os.cpu_count()}, "
                                          f"usable={effective_cpus()}), {dt:.1f} s"}
+        # the same algorithm in FLORIS' own execution style (NumPy, one process, one core)
+        from oracle import floris_gch_numpy as onp
+
+        t = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t < 3.0:
+            onp.farm_step(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[k % ycpu.shape[0]])
+            k += 1
+        res["cpu_baseline_numpy"] = {"value": k / (time.perf_counter() - t), "unit": "farm-steps/s", "cores": 1,
+                                     "kind": "port", "sample": f"{k} farm-steps, NumPy float64 oracle, single process"}
     print(json.dumps(res), flush=True)
     w.close()
     if dist is not None:

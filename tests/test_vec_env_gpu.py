@@ -230,3 +230,29 @@ def test_parallel_adaptor_and_ring_logger(layouts):
     assert h["reward"].shape == (4, B) and h["observation/yaw"].shape == (4, B, 7) and h["load"].shape == (4, B, 7, 4)
     assert float(h["observation/yaw"][-1, 0, 0]) == 6.0 and float(h["observation/yaw"][0, 0, 0]) == 3.0  # last 4 of 6 steps
     penv.close()
+
+
+def test_multi_device_wrapper_on_one_gpu(layouts):
+    """Single-process sharding: two handles on device 0 reproduce the one-handle result exactly."""
+    from wfcrl_env_amd.backend import WfStep
+    from wfcrl_env_amd.sharding import MultiDeviceWfStep
+
+    l = layouts["Turb16_Row5_"]
+    rng = np.random.default_rng(8)
+    B = 37  # ragged split 19 + 18
+    yaw = rng.uniform(-40, 40, (B, 16)).astype(np.float32)
+    ws = np.clip(8 * rng.weibull(8, B), 3, 28)
+    wd = rng.normal(270, 20, B) % 360
+    one = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    one.set_wind(ws, wd)
+    ref = one.step(yaw)
+    m = MultiDeviceWfStep(l["xcoords"], l["ycoords"], env_batch=B, device_ids=[0, 0])
+    assert m.bounds == [(0, 19), (19, 37)]
+    m.set_wind(ws, wd)
+    got = m.step(yaw)
+    for k in ref:
+        assert np.array_equal(ref[k], got[k]), k
+    m.set_wind(8.0, 270.0)
+    one.set_wind(8.0, 270.0)
+    assert np.array_equal(one.step(yaw)["power"], m.step(yaw)["power"])
+    one.close(); m.close()
