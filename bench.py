@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--env-batch", type=int, default=0, help="per-GPU env batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-leg", action="store_true", help="skip the fused-env-step leg (profiling runs)")
+    ap.add_argument("--per-env-wind", action="store_true",
+                    help="cfg5 variant: wd_b(t) = wd(t) + U(-10,10) per farm (per-farm rotation + sort on the device)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -103,16 +105,35 @@ def main():
 
     w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B, device_id=local_rank)
     w.set_stream(torch.cuda.current_stream().cuda_stream, True)
-    w.set_wind(8.0, 270.0)
-
-    # synthetic random-walk yaw sequence, seeded per SURVEY §8d (1234 + cfg id) and per global env id
+    # synthetic inputs, seeded per SURVEY §8d (1234 + cfg id) and per rank:
+    #   cfg2: absolute yaw ~ U(-40,40), fixed wind;  cfg3/cfg4: random-walk yaw (dyaw ~ U(-5,5), clipped to +-40),
+    #   fixed wind;  cfg5: random-walk yaw + wd(t) = 270 + 30 sin(2 pi t/200), shared by the farms (or per farm
+    #   with --per-env-wind), re-set every step on the device (rotation + sort kernel, no host sync)
     cfg_id = int(args.config[3:])
     gen = torch.Generator(device="cuda").manual_seed(1234 + cfg_id + 7919 * rank)
     ring = []
     yaw = torch.zeros((B, N), device="cuda", dtype=torch.float32)
     for _ in range(8):
-        yaw = (yaw + (torch.rand((B, N), device="cuda", generator=gen) * 10 - 5)).clamp_(-40, 40)
+        if cfg_id == 2:
+            yaw = torch.rand((B, N), device="cuda", generator=gen) * 80 - 40
+        else:
+            yaw = (yaw + (torch.rand((B, N), device="cuda", generator=gen) * 10 - 5)).clamp_(-40, 40)
         ring.append(yaw.clone())
+    sweep = cfg_id == 5
+    if sweep:
+        t_all = torch.arange(args.warmup + args.steps + 1, device="cuda", dtype=torch.float64)
+        wd_t = 270.0 + 30.0 * torch.sin(2 * torch.pi * t_all / 200.0)
+        nw = B if args.per_env_wind else 1
+        jitter = (torch.rand(nw, device="cuda", generator=gen, dtype=torch.float64) * 20 - 10) if args.per_env_wind \
+            else torch.zeros(1, device="cuda", dtype=torch.float64)
+        ws_dev = torch.full((nw,), 8.0, device="cuda", dtype=torch.float64)
+
+        def set_wind_at(t):
+            w.set_wind(ws_dev, wd_t[t] + jitter)
+    else:
+        def set_wind_at(t):
+            return None
+    w.set_wind(8.0, 270.0)
     out = w.step(ring[0])
     w.sync()
 
@@ -122,15 +143,25 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
+        set_wind_at(i)
         w.step(ring[i % len(ring)], out)
     barrier()
     t0 = time.perf_counter()
     w.timing_begin()
     for i in range(args.steps):
+        set_wind_at(args.warmup + i)
         w.step(ring[i % len(ring)], out)
     kern_ms = w.timing_end() / args.steps  # HIP events on the stream the kernel is launched on
     barrier()
     elapsed = time.perf_counter() - t0
+    # host-synchronised per step (what a Python RL loop that reads every observation sees)
+    t1 = time.perf_counter()
+    nsync = min(args.steps, 20)
+    for i in range(nsync):
+        set_wind_at(args.warmup + i)
+        w.step(ring[i % len(ring)], out)
+        w.sync()
+    sync_ms = (time.perf_counter() - t1) / nsync * 1e3
     if dist is not None:
         t = torch.tensor([elapsed, kern_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -177,9 +208,12 @@ def main():
     # accuracy beside the throughput: a bounded sample of this very batch against the float64 oracle
     res = {"metric": "farm_steps_per_sec", "value": value, "unit": "farm-steps/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "ms_per_step_host_synced": sync_ms,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{layout_name}Floris x env_batch {B} per GPU (BASELINE configs[{cfg_id - 1}]), "
-                                  "ws 8 m/s, wd 270, random-walk yaw", "layout": layout_name.rstrip("_"),
+                                  + ("ws 8 m/s, wd(t) = 270 + 30 sin(2 pi t/200)" + (" + U(-10,10) per farm" if args.per_env_wind else " shared")
+                                     if sweep else "ws 8 m/s, wd 270") + (", yaw ~ U(-40,40)" if cfg_id == 2 else ", random-walk yaw"),
+                      "layout": layout_name.rstrip("_"),
                       "turbines": N, "env_batch_per_gpu": B, "env_batch_total": B * world, "parallelism": f"env-shard x{world}",
                       "kernel": f"wf_step_kernel<G={info['lanes_per_env']},S={info['slots_per_lane']}>",
                       "vgprs": info["vgprs"], "scratch_bytes": info["scratch_bytes"]},
@@ -199,15 +233,21 @@ def main():
 
         nthreads = min(c_oracle.max_threads(), effective_cpus())
         ycpu = ring[0][: min(B, 4096)].cpu().numpy().astype(np.float64)
-        # accuracy sample
+        # accuracy sample: this very batch (fixed wind 8 m/s / 270 deg) against the float64 oracle
         ns = min(256, ycpu.shape[0])
         ref = c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[:ns])
+        w.set_wind(8.0, 270.0)
         got = w.step(ring[0], out)
         w.sync()
-        gp = got["power"][:ns].cpu().numpy().astype(np.float64)
-        perr = np.abs(gp - ref["power"]) / np.maximum(ref["power"], 1e3)
+        g = {k: v[:ns].cpu().numpy().astype(np.float64) for k, v in got.items()}
+        perr = np.abs(g["power"] - ref["power"]) / np.maximum(ref["power"], 1e3)
         res["power_rel_err"] = {"max": float(perr.max()), "p999": float(np.quantile(perr, 0.999)),
-                                "sample": f"{ns} envs x {N} turbines vs float64 oracle"}
+                                "frac_gt_1e-4": float((perr > 1e-4).mean()),
+                                "wind_speed_rel_max": float((np.abs(g["wind_speed"] - ref["wind_speed"]) / ref["wind_speed"]).max()),
+                                "wind_direction_abs_max_deg": float(np.abs(g["wind_direction"] - ref["wind_direction"]).max()),
+                                "ti_abs_max": float(np.abs(g["load"][..., 0] - ref["load"][..., 0]).max()),
+                                "sample": f"{ns} envs x {N} turbines vs float64 oracle (oracle-pinned; the reference "
+                                          "pins only its yaw = 0 notebook vector, tests/golden/kat1_demo_notebook.json)"}
         # timing: calibrate on a small sample, then ~cpu_seconds of work
         t = time.perf_counter()
         c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[: 4 * nthreads], nthreads=nthreads)
