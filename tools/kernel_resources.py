@@ -13,8 +13,8 @@ for line in out.splitlines():
     t = m.group(1)
     if t.startswith("Function Name:"):
         name = t.split(":", 1)[1].strip()
-        g = re.search(r"wf_step_kernelILi(\d+)ELi(\d+)ELb(\d)E", name)
-        cur = {"kernel": f"step<{g.group(1)},{g.group(2)},{g.group(3)}>" if g else name[:30]}
+        g = re.search(r"wf_step_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)E", name)
+        cur = {"kernel": f"step<{g.group(1)},{g.group(2)},mc1={g.group(3)},tab={g.group(4)}>" if g else name[:30]}
         rows.append(cur)
     elif cur is not None and ":" in t:
         k, v = t.split(":", 1); cur[k.strip()] = v.strip()

@@ -19,13 +19,16 @@
 
 extern "C" int wfk_num_variants();
 extern "C" void wfk_variant(int i, int* G, int* S, const void** fn);
+extern "C" int wfk_variant_has_table(int i);
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
                                           const double* wd, double* gx, float* gy, int* gidx, hipStream_t s);
 extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
                                       const float* gy, const int* gidx, int geom_stride, const double* ws,
                                       const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
-                                      float* o_wd, float* load, int B, const WfEnvArgs* env, hipStream_t s,
-                                      int* grid_out);
+                                      float* o_wd, float* load, int B, const WfEnvArgs* env, const float* pair_tab,
+                                      hipStream_t s, int* grid_out);
+extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double* gx, const float* gy, float* tab,
+                                            hipStream_t s);
 
 extern "C" hipError_t wfk_launch_wind_sample(int B, unsigned long long seed, const double* dist, double* ws, double* wd,
                                              hipStream_t s);
@@ -105,6 +108,9 @@ struct wf_handle {
   double *d_series_ws = nullptr, *d_series_wd = nullptr;
   int* d_series_start = nullptr;
   double* d_ws_prev = nullptr;
+  // shared-wind pair-coefficient table
+  float* d_pair_tab = nullptr;
+  bool pair_dirty = true;
 };
 
 namespace {
@@ -128,6 +134,7 @@ void free_batch(wf_handle* h) {
   h->d_env_yaw = h->d_env_acc = h->d_env_act = h->d_env_out = h->h_env_act = h->h_env_out = nullptr;
   h->d_env_moves = nullptr;
   hipFree(h->d_series_ws); hipFree(h->d_series_wd); hipFree(h->d_series_start); hipFree(h->d_ws_prev);
+  hipFree(h->d_pair_tab); h->d_pair_tab = nullptr; h->pair_dirty = true;
   h->d_series_ws = h->d_series_wd = h->d_ws_prev = nullptr; h->d_series_start = nullptr; h->series_T = 0;
   if (h->h_yaw) hipHostFree(h->h_yaw);
   if (h->h_out) hipHostFree(h->h_out);
@@ -275,6 +282,39 @@ int build_consts(wf_handle* h) {
   return WF_OK;
 }
 
+// Shared wind: (re)build the geometry-only pair table after the geometry kernel (same stream).  Returns the table
+// pointer to hand to the step kernel, or nullptr when the on-the-fly path applies (per-farm wind, N too large,
+// or WF_NO_PAIR_TABLE set for A/B runs).
+int pair_table(wf_handle* h, const float** out) {
+  *out = nullptr;
+  if (h->wind_count != 1 || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || getenv("WF_NO_PAIR_TABLE"))
+    return WF_OK;
+  if (!h->d_pair_tab) {
+    WF_HIP(h, hipMalloc(&h->d_pair_tab, sizeof(float) * (size_t)h->N * WF_PAIR_ROW_FLOATS(h->N)));
+    h->pair_dirty = true;
+  }
+  if (h->pair_dirty) {
+    const wf_model_params& m = h->model;
+    WfPairConsts pc{};
+    const double D = m.rotor_diameter, HH = m.hub_height, eps = m.eps_gain * D;
+    pc.N = h->N; pc.D = D; pc.HH = HH; pc.eps2 = eps * eps; pc.num_eps = m.num_eps; pc.ch_down = m.ch_downstream;
+    const double off[3] = {-D / 4, 0.0, D / 4};
+    double uinf = 0;
+    for (int k = 0; k < 3; ++k) uinf += std::pow((HH + off[k]) / HH, m.shear) / 3.0;
+    for (int k = 0; k < 3; ++k) {
+      pc.off[k] = off[k];
+      const double z = HH + off[k];
+      const double dudz = m.shear * std::pow(1.0 / HH, m.shear) * std::pow(z, m.shear - 1.0);
+      const double lm = m.kappa * z / (1.0 + m.kappa * z / (D / 8.0));
+      pc.decay_a[k] = 4.0 * lm * lm * std::fabs(dudz) / uinf / pc.eps2;
+    }
+    WF_HIP(h, wfk_launch_pair_table(&pc, h->d_gx, h->d_gy, h->d_pair_tab, h->stream));
+    h->pair_dirty = false;
+  }
+  *out = h->d_pair_tab;
+  return WF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -360,6 +400,7 @@ int wf_set_model(wf_handle* h, const wf_model_params* p) {
   h->tcp.assign(p->table_cp, p->table_cp + p->n_table);
   h->model.table_ws = h->model.table_ct = h->model.table_cp = nullptr;
   h->model_dirty = true;
+  h->pair_dirty = true;
   return WF_OK;
 }
 
@@ -421,6 +462,7 @@ int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int
   if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));  // caller's host arrays may go away
   h->wind_count = count;
   h->series_T = 0;
+  h->pair_dirty = true;
   return WF_OK;
 }
 
@@ -435,9 +477,14 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
   const size_t bn = (size_t)h->B * h->N;
   const int gstride = (h->wind_count == 1) ? 0 : h->N;
   const int wstride = (h->wind_count == 1) ? 0 : 1;
+  const float* ptab = nullptr;
+  {
+    int rc = pair_table(h, &ptab);
+    if (rc != WF_OK) return rc;
+  }
   if (on_device) {
     WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
-                              wstride, yaw, power, wspd, wdir, load, h->B, nullptr, h->stream, &h->grid));
+                              wstride, yaw, power, wspd, wdir, load, h->B, nullptr, ptab, h->stream, &h->grid));
     return WF_OK;
   }
   if (!h->d_yaw) {
@@ -450,7 +497,7 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
   WF_HIP(h, hipMemcpyAsync(h->d_yaw, h->h_yaw, sizeof(float) * bn, hipMemcpyHostToDevice, h->stream));
   WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                             wstride, h->d_yaw, h->d_out, h->d_out + bn, h->d_out + 2 * bn, h->d_out + 3 * bn, h->B,
-                            nullptr, h->stream, &h->grid));
+                            nullptr, ptab, h->stream, &h->grid));
   WF_HIP(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(float) * bn * 7, hipMemcpyDeviceToHost, h->stream));
   WF_HIP(h, hipStreamSynchronize(h->stream));
   if (power) std::memcpy(power, h->h_out, sizeof(float) * bn);
@@ -595,10 +642,12 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
   ea.rate = h->env.actuator_rate; ea.dt = h->env.dt; ea.budget = h->env.budget;
   ea.load_coef = h->env.load_coef; ea.discrete = h->env.discrete;
   ea.ws_prev = (h->series_T > 0 && h->series_t >= 1) ? h->d_ws_prev : nullptr;
+  const float* ptab = nullptr;
+  if ((rc = pair_table(h, &ptab)) != WF_OK) return rc;
   if (on_device) {
     ea.action = action; ea.reward = reward;
     WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
-                              wstride, nullptr, power, wspd, wdir, load, h->B, &ea, h->stream, &h->grid));
+                              wstride, nullptr, power, wspd, wdir, load, h->B, &ea, ptab, h->stream, &h->grid));
     if (yaw) WF_HIP(h, hipMemcpyAsync(yaw, h->d_env_yaw, sizeof(float) * bn, hipMemcpyDeviceToDevice, h->stream));
     return WF_OK;
   }
@@ -618,8 +667,8 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
   ea.reward = reward ? h->d_env_out : nullptr;
   WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                             wstride, nullptr, power ? h->d_out : nullptr, wspd ? h->d_out + bn : nullptr,
-                            wdir ? h->d_out + 2 * bn : nullptr, load ? h->d_out + 3 * bn : nullptr, h->B, &ea, h->stream,
-                            &h->grid));
+                            wdir ? h->d_out + 2 * bn : nullptr, load ? h->d_out + 3 * bn : nullptr, h->B, &ea, ptab,
+                            h->stream, &h->grid));
   if (reward) WF_HIP(h, hipMemcpyAsync(h->h_env_out, h->d_env_out, sizeof(float) * B, hipMemcpyDeviceToHost, h->stream));
   if (yaw) WF_HIP(h, hipMemcpyAsync(h->h_env_out + B, h->d_env_yaw, sizeof(float) * bn, hipMemcpyDeviceToHost, h->stream));
   if (power || wspd || wdir || load)

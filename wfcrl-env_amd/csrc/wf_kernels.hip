@@ -264,20 +264,82 @@ extern "C" hipError_t wfk_launch_series_gather(int B, int T, int t, const int* s
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pair-coefficient table for a wind condition shared by the whole batch: everything in the transverse-velocity
+// pass [A.3-4] that does not depend on the farm's state.  One thread per (source i, target t); float64.
+// ---------------------------------------------------------------------------------------------
+__global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __restrict__ gx, const float* __restrict__ gy,
+                                     float* __restrict__ tab) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  if (t >= pc.N) return;
+  float* o = tab + (size_t)i * WF_PAIR_ROW_FLOATS(pc.N) + (size_t)t * WF_PAIR_STRIDE;
+  const double dx = gx[t] - gx[i];
+  if (dx < 0.0) {
+    for (int q = 0; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
+    return;
+  }
+  const double dy = (double)gy[t] - (double)gy[i];
+  const double R = pc.D / 2.0;
+  const double hs[3] = {pc.HH + R, pc.HH - R, pc.HH};
+  for (int j = 0; j < 3; ++j) {
+    const double yL = dy + pc.off[j] + pc.num_eps;
+    for (int k = 0; k < 3; ++k) {
+      const double z = pc.HH + pc.off[k];
+      const double dec = 1.0 / (pc.decay_a[k] * dx + 1.0);
+      for (int v = 0; v < 3; ++v) {
+        const double zc = z - hs[v] + pc.num_eps, zm = z + hs[v] + pc.num_eps;
+        const double r = yL * yL + zc * zc, rm = yL * yL + zm * zm;
+        const double T = (1.0 - exp(-r / pc.eps2)) / r, Tm = (1.0 - exp(-rm / pc.eps2)) / rm;
+        o[(j * 3 + k) * 6 + v] = (float)(dec * (zc * T - zm * Tm));
+        o[(j * 3 + k) * 6 + 3 + v] = (float)(-yL * dec * (T - Tm));
+      }
+    }
+  }
+  const double dxp = (dx > 0.1) ? dx : dx + 1.0;  // Crespo-Hernandez distance with FLORIS' masks [A.3-8]
+  o[54] = (float)pow(dxp / pc.D, pc.ch_down);
+  for (int q = 55; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
+}
+
+extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double* gx, const float* gy, float* tab,
+                                            hipStream_t s) {
+  const int threads = ((pc->N + 63) / 64) * 64;
+  hipLaunchKernelGGL(wf_pair_table_kernel, dim3(pc->N), dim3(threads), 0, s, *pc, gx, gy, tab);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // The farm step
 // ---------------------------------------------------------------------------------------------
 // MC1: only the lowest mirror vortex offset needs its core factor (WfConsts::mirror_core_n <= 1, the case for
 // every physical turbine: for the other mirror offsets 1 - Ey*ezm == 1.0f exactly in float32).
-template <int G, int S, bool MC1>
+// TAB: the transverse-velocity pass reads the shared-wind pair-coefficient table instead of evaluating the
+// vortex system per farm (MC1 is then irrelevant).
+template <int G, int S, bool MC1, bool TAB>
 __global__ __launch_bounds__(256, 2) void wf_step_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const float* __restrict__ gy,
     const int* __restrict__ gidx, int geom_stride, const double* __restrict__ ws_in, const double* __restrict__ wd_in,
     int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power, float* __restrict__ o_ws,
-    float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea) {
+    float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea,
+    const float* __restrict__ pair_tab) {
   constexpr int EPW = 64 / G;  // envs per wave
   constexpr int NP = G * S;    // turbine capacity of this variant
   __shared__ TableLds T;
   __shared__ GeoLds<EPW, NP> geo[4];
+  // shared-wind pair table: the current and the next source's row, filled by LDS-DMA (no VGPR staging)
+  constexpr int ROWF = TAB ? WF_PAIR_ROW_FLOATS(NP) : 4;
+  __shared__ __attribute__((aligned(16))) float prow[2][ROWF];
+  const int row_chunks = TAB ? (WF_PAIR_ROW_FLOATS(c.N) / 256) : 0;  // 1-KiB pieces per row
+  auto stage_row = [&](int src_i) {
+    if constexpr (TAB) {
+      const char* g0 = reinterpret_cast<const char*>(pair_tab + (size_t)src_i * WF_PAIR_ROW_FLOATS(c.N));
+      char* l0 = reinterpret_cast<char*>(&prow[src_i & 1][0]);
+      for (int ch = (int)(threadIdx.x >> 6); ch < row_chunks; ch += 4) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(g0 + ch * 1024 + (threadIdx.x & 63) * 16),
+            (__attribute__((address_space(3))) void*)(l0 + ch * 1024), 16, 0, 0);
+      }
+    }
+  };
+  stage_row(0);
   for (int k = threadIdx.x; k < WF_TABLE_PAD; k += blockDim.x) {
     T.knot[k] = tab->knot[k];
     T.ct[k] = tab->ct[k];
@@ -371,6 +433,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
     for (int li = 0; li < nsrc; ++li) {
       const int src = gbase + li;
       const int i = blk * G + li;
+      if (TAB && i + 1 < N) stage_row(i + 1);  // lands in the other buffer while this source is processed
       // ---- A. the source's state (slot 0 of lane `li` of the group) ------------------------
       float m3 = 0.0f, vsum = 0.0f;
 #pragma unroll
@@ -414,6 +477,19 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
 #else
         if (dx >= 0.0f) {
 #endif
+         if constexpr (TAB) {
+          // geometry-only coefficients of this (source, target) pair from the staged row: 6 floats per grid point
+          const float* pr = &prow[i & 1][t * WF_PAIR_STRIDE];
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            const float2 c0 = *reinterpret_cast<const float2*>(pr + q * 6);
+            const float2 c1 = *reinterpret_cast<const float2*>(pr + q * 6 + 2);
+            const float2 c2 = *reinterpret_cast<const float2*>(pr + q * 6 + 4);
+            st.V[p][q] = fmaf(Gwr, c1.x, fmaf(Gb, c0.y, fmaf(Gt, c0.x, st.V[p][q])));
+            const float ww = fmaf(Gwr, c2.y, fmaf(Gb, c2.x, Gt * c1.y));
+            st.W[p][q] += fmaxf(ww, 0.0f);  // W[W<0] = 0, quirk (5)
+          }
+         } else {
           const float dy = L.y[eiw][t] - y_i;
           float dec[3];
 #pragma unroll
@@ -454,6 +530,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
               st.W[p][j * 3 + k] += fmaxf(-yL * Bw[k] * dec[k], 0.0f);  // W[W<0] = 0, quirk (5)
             }
           }
+         }
         }
         if (p == 0) {
 #pragma unroll
@@ -600,8 +677,14 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
             }
           }
           // Crespo-Hernandez with overlap gating [A.3-8]
-          const float dxp = (dx > 0.1f) ? dx : dx + 1.0f;
-          const float ti = ch_pref * fexp2(c.ch_down * flog2(dxp * c.invD));
+          float tipow;
+          if constexpr (TAB) {
+            tipow = prow[i & 1][t * WF_PAIR_STRIDE + 54];
+          } else {
+            const float dxp = (dx > 0.1f) ? dx : dx + 1.0f;
+            tipow = fexp2(c.ch_down * flog2(dxp * c.invD));
+          }
+          const float ti = ch_pref * tipow;
           const float tia = (dx <= c.fifteenD) ? ti * ((float)cnt * (1.0f / 9.0f)) : 0.0f;
           const float cand = fsqrt(fmaf(tia, tia, c.amb2));
 #pragma unroll
@@ -611,6 +694,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
           }
         }
       }
+      if constexpr (TAB) __syncthreads();  // next row has landed; everyone is done with the current one
     }  // li
 
     // rotate the register slots so that the next block of sources sits in slot 0
@@ -704,9 +788,23 @@ struct WfVariant {
   int G, S;
   const void* fn;      // MC1 = true
   const void* fn_all;  // MC1 = false (general mirror cores)
+  const void* fn_tab;  // shared-wind pair table
 };
 
-#define WF_VARIANT(G_, S_) {G_, S_, (const void*)&wf_step_kernel<G_, S_, true>, (const void*)&wf_step_kernel<G_, S_, false>}
+// The table path is instantiated only where two blocks per CU still fit in the 160 KiB LDS and N <= WF_PAIR_MAX_N.
+template <int G, int S>
+constexpr bool tab_fits() {
+  return G * S <= WF_PAIR_MAX_N &&
+         2 * (sizeof(TableLds) + 4 * sizeof(GeoLds<64 / G, G * S>) + 2 * 4 * WF_PAIR_ROW_FLOATS(G * S)) <= 160 * 1024;
+}
+template <int G, int S>
+const void* tab_kernel() {
+  if constexpr (tab_fits<G, S>()) return (const void*)&wf_step_kernel<G, S, true, true>;
+  else return nullptr;
+}
+#define WF_VARIANT(G_, S_)                                                                              \
+  {G_, S_, (const void*)&wf_step_kernel<G_, S_, true, false>, (const void*)&wf_step_kernel<G_, S_, false, false>, \
+   tab_kernel<G_, S_>()}
 static const WfVariant kVariants[] = {
     WF_VARIANT(4, 1),  WF_VARIANT(4, 2),  WF_VARIANT(4, 3),  WF_VARIANT(4, 4),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(8, 3),  WF_VARIANT(8, 4),
     WF_VARIANT(16, 3), WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(16, 6), WF_VARIANT(32, 3),
@@ -719,6 +817,7 @@ extern "C" void wfk_variant(int i, int* G, int* S, const void** fn) {
   *S = kVariants[i].S;
   *fn = kVariants[i].fn;
 }
+extern "C" int wfk_variant_has_table(int i) { return kVariants[i].fn_tab != nullptr; }
 
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
                                           const double* wd, double* gx, float* gy, int* gidx, hipStream_t s) {
@@ -730,8 +829,8 @@ extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, co
 extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
                                       const float* gy, const int* gidx, int geom_stride, const double* ws,
                                       const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
-                                      float* o_wd, float* load, int B, const WfEnvArgs* env, hipStream_t s,
-                                      int* grid_out) {
+                                      float* o_wd, float* load, int B, const WfEnvArgs* env, const float* pair_tab,
+                                      hipStream_t s, int* grid_out) {
   const WfVariant& v = kVariants[variant];
   const int envs_per_block = 4 * (64 / v.G);
   const int grid = (B + envs_per_block - 1) / envs_per_block;
@@ -739,6 +838,8 @@ extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTa
   WfConsts cc = *c;
   WfEnvArgs ea;
   if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
-  void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea};
-  return hipLaunchKernel(cc.mirror_core_n <= 1 ? v.fn : v.fn_all, dim3(grid), dim3(256), args, 0, s);
+  void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &pair_tab};
+  const void* fn = (pair_tab && v.fn_tab) ? v.fn_tab : (cc.mirror_core_n <= 1 ? v.fn : v.fn_all);
+  if (fn != v.fn_tab) pair_tab = nullptr;
+  return hipLaunchKernel(fn, dim3(grid), dim3(256), args, 0, s);
 }
