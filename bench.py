@@ -215,7 +215,8 @@ def main():
                                      if sweep else "ws 8 m/s, wd 270") + (", yaw ~ U(-40,40)" if cfg_id == 2 else ", random-walk yaw"),
                       "layout": layout_name.rstrip("_"),
                       "turbines": N, "env_batch_per_gpu": B, "env_batch_total": B * world, "parallelism": f"env-shard x{world}",
-                      "kernel": f"wf_step_kernel<G={info['lanes_per_env']},S={info['slots_per_lane']}>",
+                      "kernel": f"wf_step_kernel<G={info['lanes_per_env']},S={info['slots_per_lane']}>"
+                                + (" + shared-wind pair table" if info.get("pair_table") else ""),
                       "vgprs": info["vgprs"], "scratch_bytes": info["scratch_bytes"]},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -166,6 +166,7 @@ int wf_timing_end(wf_handle* h, float* elapsed_ms);
 typedef struct wf_kernel_info {
   int lanes_per_env, slots_per_lane, envs_per_block, threads_per_block, grid_blocks;
   int vgprs, sgprs, lds_bytes, scratch_bytes;
+  int pair_table; /* 1: shared-wind pair-coefficient table path, 0: per-farm on-the-fly path */
 } wf_kernel_info;
 int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info);
 

@@ -53,7 +53,7 @@ class WindDist(C.Structure):
 class KernelInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "lanes_per_env", "slots_per_lane", "envs_per_block", "threads_per_block", "grid_blocks",
-        "vgprs", "sgprs", "lds_bytes", "scratch_bytes")]
+        "vgprs", "sgprs", "lds_bytes", "scratch_bytes", "pair_table")]
 
 
 # every symbol include/wfstep.h declares: name -> (restype, argtypes)

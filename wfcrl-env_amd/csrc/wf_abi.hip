@@ -20,6 +20,7 @@
 extern "C" int wfk_num_variants();
 extern "C" void wfk_variant(int i, int* G, int* S, const void** fn);
 extern "C" int wfk_variant_has_table(int i);
+extern "C" const void* wfk_variant_fn(int i, int kind);
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
                                           const double* wd, double* gx, float* gy, int* gidx, hipStream_t s);
 extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
@@ -289,15 +290,18 @@ int pair_table(wf_handle* h, const float** out) {
   *out = nullptr;
   if (h->wind_count != 1 || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || getenv("WF_NO_PAIR_TABLE"))
     return WF_OK;
+  int vG, vS; const void* vfn;
+  wfk_variant(h->variant, &vG, &vS, &vfn);
+  const int NP = vG * vS;
   if (!h->d_pair_tab) {
-    WF_HIP(h, hipMalloc(&h->d_pair_tab, sizeof(float) * (size_t)h->N * WF_PAIR_ROW_FLOATS(h->N)));
+    WF_HIP(h, hipMalloc(&h->d_pair_tab, sizeof(float) * (size_t)h->N * WF_PAIR_ROW_FLOATS(NP)));
     h->pair_dirty = true;
   }
   if (h->pair_dirty) {
     const wf_model_params& m = h->model;
     WfPairConsts pc{};
     const double D = m.rotor_diameter, HH = m.hub_height, eps = m.eps_gain * D;
-    pc.N = h->N; pc.D = D; pc.HH = HH; pc.eps2 = eps * eps; pc.num_eps = m.num_eps; pc.ch_down = m.ch_downstream;
+    pc.N = h->N; pc.NP = NP; pc.D = D; pc.HH = HH; pc.eps2 = eps * eps; pc.num_eps = m.num_eps; pc.ch_down = m.ch_downstream;
     const double off[3] = {-D / 4, 0.0, D / 4};
     double uinf = 0;
     for (int k = 0; k < 3; ++k) uinf += std::pow((HH + off[k]) / HH, m.shear) / 3.0;
@@ -711,6 +715,11 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   if (h->variant < 0) return fail(h, WF_E_INVALID, "wf_set_layout must be called first");
   int G, S; const void* fn;
   wfk_variant(h->variant, &G, &S, &fn);
+  // the instantiation the next step would launch: pair table (shared wind), general mirror cores, or default
+  if (h->model_dirty && h->N > 0) { int rc = build_consts(h); if (rc != WF_OK) return rc; }
+  const bool tab = h->wind_count == 1 && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && !getenv("WF_NO_PAIR_TABLE");
+  fn = wfk_variant_fn(h->variant, tab ? 2 : (h->consts.mirror_core_n <= 1 ? 0 : 1));
+  info->pair_table = tab ? 1 : 0;
   hipFuncAttributes a;
   WF_HIP(h, hipSetDevice(h->device));
   WF_HIP(h, hipFuncGetAttributes(&a, fn));

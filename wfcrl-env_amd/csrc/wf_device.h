@@ -78,15 +78,16 @@ struct WfEnvArgs {
 //   V_wake(j,k) =        Gt*cv[0] + Gb*cv[1] + Gwr*cv[2]        W_wake(j,k) = max(0, Gt*cw[0] + Gb*cw[1] + Gwr*cw[2])
 // with coefficients that depend on geometry and model constants only (decay, vortex cores, mirrors folded in).
 // Layout per pair (WF_PAIR_STRIDE floats; 60 = conflict-free stride for the 16 lanes of a group): for each grid
-// point q = j*3+k six floats {cv[0..2], cw[0..2]} (54 floats), then (dx'/D)^ch_downstream of the Crespo-Hernandez
-// term [A.3-8], then padding.  A source's row (all targets) is padded to a multiple of 1 KiB: the step kernel
+// point q = j*3+k six floats {cv[0..2], cw[0..2]} (54 floats), [54] (dx'/D)^ch_downstream of the Crespo-Hernandez
+// term [A.3-8], [56] dx = x'_t - x'_i (float64 difference, rounded once), [57] dy, rest padding.  A source's row (all targets) is padded to a multiple of 1 KiB: the step kernel
 // stages it into LDS with 1-KiB global_load_lds wave-instructions.
 #define WF_PAIR_STRIDE 60
 #define WF_PAIR_MAX_N 128
 #define WF_PAIR_ROW_FLOATS(n) ((((n) * WF_PAIR_STRIDE * 4 + 1023) / 1024) * 256)
 
 struct WfPairConsts {
-  int N;
+  int N;   // turbines
+  int NP;  // targets per row = capacity G*S of the step-kernel variant (entries t >= N carry dx = -1: never active)
   double D, HH, eps2, num_eps;
   double off[3];
   double decay_a[3];

@@ -90,10 +90,10 @@ struct Slots {
 
 // Per-wave sorted geometry + commanded yaw, staged in LDS once (lane-private reads for targets,
 // group-broadcast reads for the source).
-template <int EPW, int NP>
+template <int EPW, int NP, bool WITH_XY>
 struct GeoLds {
-  double x[EPW][NP];  // sorted x' (float64: the sign of dx decides every upstream/downstream mask)
-  float y[EPW][NP];   // sorted y' - yc
+  double x[WITH_XY ? EPW : 1][WITH_XY ? NP : 1];  // sorted x' (float64: the sign of dx decides every mask)
+  float y[WITH_XY ? EPW : 1][WITH_XY ? NP : 1];   // sorted y' - yc    (table mode takes dx, dy from the pair table)
   float yaw[EPW][NP]; // commanded yaw in sorted order, degrees
   float cg[EPW][NP], sg[EPW][NP];  // cos / sin of the commanded yaw (evaluated once per turbine)
 };
@@ -270,14 +270,21 @@ extern "C" hipError_t wfk_launch_series_gather(int B, int T, int t, const int* s
 __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __restrict__ gx, const float* __restrict__ gy,
                                      float* __restrict__ tab) {
   const int i = blockIdx.x, t = threadIdx.x;
-  if (t >= pc.N) return;
-  float* o = tab + (size_t)i * WF_PAIR_ROW_FLOATS(pc.N) + (size_t)t * WF_PAIR_STRIDE;
-  const double dx = gx[t] - gx[i];
-  if (dx < 0.0) {
+  if (t >= pc.NP) return;
+  float* o = tab + (size_t)i * WF_PAIR_ROW_FLOATS(pc.NP) + (size_t)t * WF_PAIR_STRIDE;
+  if (t >= pc.N) {  // padding target of the kernel variant: permanently "upstream"
     for (int q = 0; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
+    o[56] = -1.0f;
     return;
   }
+  const double dx = gx[t] - gx[i];
   const double dy = (double)gy[t] - (double)gy[i];
+  if (dx < 0.0) {  // upstream target: nothing reaches it; only the sign of dx is ever looked at
+    for (int q = 0; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
+    o[56] = (float)dx;
+    o[57] = (float)dy;
+    return;
+  }
   const double R = pc.D / 2.0;
   const double hs[3] = {pc.HH + R, pc.HH - R, pc.HH};
   for (int j = 0; j < 3; ++j) {
@@ -297,11 +304,13 @@ __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __rest
   const double dxp = (dx > 0.1) ? dx : dx + 1.0;  // Crespo-Hernandez distance with FLORIS' masks [A.3-8]
   o[54] = (float)pow(dxp / pc.D, pc.ch_down);
   for (int q = 55; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
+  o[56] = (float)dx;
+  o[57] = (float)dy;
 }
 
 extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double* gx, const float* gy, float* tab,
                                             hipStream_t s) {
-  const int threads = ((pc->N + 63) / 64) * 64;
+  const int threads = ((pc->NP + 63) / 64) * 64;
   hipLaunchKernelGGL(wf_pair_table_kernel, dim3(pc->N), dim3(threads), 0, s, *pc, gx, gy, tab);
   return hipGetLastError();
 }
@@ -323,14 +332,14 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
   constexpr int EPW = 64 / G;  // envs per wave
   constexpr int NP = G * S;    // turbine capacity of this variant
   __shared__ TableLds T;
-  __shared__ GeoLds<EPW, NP> geo[4];
+  __shared__ GeoLds<EPW, NP, !TAB> geo[4];
   // shared-wind pair table: the current and the next source's row, filled by LDS-DMA (no VGPR staging)
   constexpr int ROWF = TAB ? WF_PAIR_ROW_FLOATS(NP) : 4;
   __shared__ __attribute__((aligned(16))) float prow[2][ROWF];
-  const int row_chunks = TAB ? (WF_PAIR_ROW_FLOATS(c.N) / 256) : 0;  // 1-KiB pieces per row
+  constexpr int row_chunks = TAB ? (WF_PAIR_ROW_FLOATS(NP) / 256) : 0;  // 1-KiB pieces per row
   auto stage_row = [&](int src_i) {
     if constexpr (TAB) {
-      const char* g0 = reinterpret_cast<const char*>(pair_tab + (size_t)src_i * WF_PAIR_ROW_FLOATS(c.N));
+      const char* g0 = reinterpret_cast<const char*>(pair_tab + (size_t)src_i * WF_PAIR_ROW_FLOATS(NP));
       char* l0 = reinterpret_cast<char*>(&prow[src_i & 1][0]);
       for (int ch = (int)(threadIdx.x >> 6); ch < row_chunks; ch += 4) {
         __builtin_amdgcn_global_load_lds(
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
 
   const size_t gofs = (size_t)env * geom_stride;
   const size_t yofs = (size_t)env * N;
-  GeoLds<EPW, NP>& L = geo[wave];
+  GeoLds<EPW, NP, !TAB>& L = geo[wave];
   // fused MDP transition: budget gate -> clip increment -> clip setpoint -> accumulate
   const bool env_mode = ea.yaw_state != nullptr;
   int moves_new = 0;
@@ -378,8 +387,10 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
     const int t = p * G + sub;
     const bool ok = t < N;
     const int tt = ok ? t : 0;
-    L.x[eiw][t] = ok ? gx[gofs + tt] : -1.0e300;  // padding is never downstream of anything
-    L.y[eiw][t] = gy[gofs + tt];
+    if constexpr (!TAB) {
+      L.x[eiw][t] = ok ? gx[gofs + tt] : -1.0e300;  // padding is never downstream of anything
+      L.y[eiw][t] = gy[gofs + tt];
+    }
     const size_t oi = yofs + gidx[gofs + tt];
     float yw;
     if (env_mode) {
@@ -447,8 +458,12 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       float TIs[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) TIs[j] = __shfl(st.TI[0][j], src);
-      const double x_i = L.x[eiw][i];
-      const float y_i = L.y[eiw][i];
+      double x_i = 0.0;
+      float y_i = 0.0f;
+      if constexpr (!TAB) {
+        x_i = L.x[eiw][i];
+        y_i = L.y[eiw][i];
+      }
       const float yaw_i = L.yaw[eiw][i];
 
       // ---- B. source constants, part 1 [A.3-1 .. A.3-4] ------------------------------------
@@ -470,7 +485,9 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         int b = p + rot;
         b = (b >= S) ? b - S : b;
         const int t = b * G + sub;
-        const float dx = (float)(L.x[eiw][t] - x_i);
+        float dx;
+        if constexpr (TAB) dx = prow[i & 1][t * WF_PAIR_STRIDE + 56];
+        else dx = (float)(L.x[eiw][t] - x_i);
 #if defined(WF_ABLATE) && (WF_ABLATE & 1)
         if (dx >= 0.0f) { st.V[p][0] += Gt * dx; st.W[p][0] += Gb + Gwr; }
         if (false) {
@@ -625,14 +642,18 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         int b = p + rot;
         b = (b >= S) ? b - S : b;
         const int t = b * G + sub;
-        const float dx = (float)(L.x[eiw][t] - x_i);
+        float dx;
+        if constexpr (TAB) dx = prow[i & 1][t * WF_PAIR_STRIDE + 56];
+        else dx = (float)(L.x[eiw][t] - x_i);
 #if defined(WF_ABLATE) && (WF_ABLATE & 2)
         if (dx > 0.0f) { st.wsq[p][0] += sc.sy0v * cc[0].x0v * cc[1].kyv * cc[2].pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * cc[2].d0 * sc.snw * sc.kdef; }
         if (false) {
 #else
         if (dx > 0.0f) {
 #endif
-          const float dy = L.y[eiw][t] - y_i;
+          float dy;
+          if constexpr (TAB) dy = prow[i & 1][t * WF_PAIR_STRIDE + 57];
+          else dy = L.y[eiw][t] - y_i;
           const float lin = fmaf(c.bd, dx, c.ad);
           const float amp_on = (dx > 0.1f) ? 1.0f : 0.0f;
           float e1[3], e0[3];
@@ -795,7 +816,7 @@ struct WfVariant {
 template <int G, int S>
 constexpr bool tab_fits() {
   return G * S <= WF_PAIR_MAX_N &&
-         2 * (sizeof(TableLds) + 4 * sizeof(GeoLds<64 / G, G * S>) + 2 * 4 * WF_PAIR_ROW_FLOATS(G * S)) <= 160 * 1024;
+         2 * (sizeof(TableLds) + 4 * sizeof(GeoLds<64 / G, G * S, false>) + 2 * 4 * WF_PAIR_ROW_FLOATS(G * S)) <= 160 * 1024;
 }
 template <int G, int S>
 const void* tab_kernel() {
@@ -818,6 +839,10 @@ extern "C" void wfk_variant(int i, int* G, int* S, const void** fn) {
   *fn = kVariants[i].fn;
 }
 extern "C" int wfk_variant_has_table(int i) { return kVariants[i].fn_tab != nullptr; }
+// kind 0: MC1 on-the-fly, 1: general mirror cores, 2: shared-wind pair table
+extern "C" const void* wfk_variant_fn(int i, int kind) {
+  return kind == 2 ? kVariants[i].fn_tab : (kind == 1 ? kVariants[i].fn_all : kVariants[i].fn);
+}
 
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
                                           const double* wd, double* gx, float* gy, int* gidx, hipStream_t s) {
