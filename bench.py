@@ -52,11 +52,12 @@ def effective_cpus() -> int:
     return max(1, n)
 
 
-def lane_ops_per_farm_step(N: int) -> float:
-    """Analytic VALU work model of the kernel: issue slots per (source, target) pair with
-    dx >= 0 (transcendentals counted as 2 slots) x pairs, plus per-source scalar work."""
+def lane_ops_per_farm_step(N: int, pair_table: bool) -> float:
+    """Analytic VALU work model of the kernel, in plain-fp32-issue-slot equivalents (a transcendental
+    = 2.5 slots, its measured issue cost): per (source, target) pair with dx >= 0 — transverse pass 421 on the fly or
+    85 with the shared-wind pair table, deflection/deficit/SOSFS/TI pass 169 — plus 460 per source."""
     pairs = N * (N + 1) / 2
-    return pairs * 640.0 + N * 300.0
+    return pairs * ((85.0 if pair_table else 421.0) + 169.0) + N * 460.0
 
 
 def main():
@@ -202,7 +203,8 @@ def main():
         except Exception:
             traffic = None
     info = w.kernel_info()
-    lane_ops = lane_ops_per_farm_step(N) * B
+    lops = lane_ops_per_farm_step(N, bool(info.get("pair_table")))
+    lane_ops = lops * B
     valu_achieved = lane_ops / (kern_ms * 1e-3)
 
     # accuracy beside the throughput: a bounded sample of this very batch against the float64 oracle
@@ -224,7 +226,7 @@ def main():
                         "note": "path is VALU-bound (arithmetic intensity ~2 kFLOP/B): see valu_roofline"},
            "valu_roofline": {"bound": "valu_fp32", "achieved": valu_achieved, "peak": VALU_PEAK_LANEOPS,
                              "unit": "lane-ops/s", "frac": valu_achieved / VALU_PEAK_LANEOPS,
-                             "lane_ops_per_farm_step": lane_ops_per_farm_step(N)}}
+                             "lane_ops_per_farm_step": lops}}
 
     if venv_ms is not None:
         res["fused_env_step"] = {"ms_per_step": venv_ms, "env_steps_per_sec_per_gpu": B / (venv_ms * 1e-3),

@@ -1,10 +1,10 @@
 """Per-basic-block instruction statistics of one step-kernel variant (after `make -C wfcrl-env_amd/csrc asm`).
 usage: python tools/isa_blocks.py 16x5 [min_instrs]"""
 import collections, re, sys
-g, s_ = sys.argv[1].split("x")
+g, s_ = sys.argv[1].split("x")[:2]; TAB = 1 if sys.argv[1].endswith("t") else 0; s_ = s_.rstrip("t")
 minn = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 lines = open("wfcrl-env_amd/csrc/wf_kernels.s").read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith(f"_Z14wf_step_kernelILi{g}ELi{s_}ELb1E") and l.rstrip().split(";")[0].strip().endswith(":"))
+start = next(i for i, l in enumerate(lines) if l.startswith(f"_Z14wf_step_kernelILi{g}ELi{s_}ELb1ELb{TAB}E") and l.rstrip().split(";")[0].strip().endswith(":"))
 end = next(j for j in range(start, len(lines)) if "s_endpgm" in lines[j])
 blocks, cur = [], ("entry", [])
 for l in lines[start:end]:
