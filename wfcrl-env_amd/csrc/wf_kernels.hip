@@ -47,6 +47,19 @@ __device__ __forceinline__ float fcbrt_pos(float x) {
   return copysignf(y, x);
 }
 
+// atan(r) and asin(x) for the small arguments this model produces (|V/U| ~ 1e-2, |val| ~ 3e-2): 7-term odd series,
+// abs. err < 1e-10 for |r| <= 0.25 resp. |x| <= 0.3; callers fall back to libm (wave-uniform) beyond that.
+__device__ __forceinline__ float atan_small(float r) {
+  const float r2 = r * r;
+  return r * fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 0.0769230769f, -0.0909090909f), 0.1111111111f),
+                                              -0.1428571429f), 0.2f), -0.3333333333f), 1.0f);
+}
+__device__ __forceinline__ float asin_small(float x) {
+  const float x2 = x * x;
+  return x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.0173527644f, 0.0223721591f), 0.0303819444f),
+                                              0.0446428571f), 0.075f), 0.1666666667f), 1.0f);
+}
+
 struct TableLds {
   float knot[WF_TABLE_PAD], ct[WF_TABLE_PAD], cts[WF_TABLE_PAD], pw[WF_TABLE_PAD], pws[WF_TABLE_PAD];
   unsigned char bucket[WF_BUCKETS];
@@ -564,7 +577,8 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       // secondary steering
       float val = 2.0f * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
       val = fminf(fmaxf(val, -1.0f), 1.0f);
-      const float gd = -(yaw_i * kDeg2Rad + 0.5f * asinf(val));  // radians, deflection sign convention
+      const float asv = __any(fabsf(val) > 0.3f) ? asinf(val) : asin_small(val);
+      const float gd = -(yaw_i * kDeg2Rad + 0.5f * asv);  // radians, deflection sign convention
       // cos(gd) = cos(yaw + h), h = asin(val)/2: half-angle identities instead of a second libm call
       const float c2h = fsqrt(fmaxf(fmaf(-val, val, 1.0f), 0.0f));  // cos(2h) >= 0
       const float ch = fsqrt(0.5f * (1.0f + c2h));                   // cos h >= 0.707
@@ -757,7 +771,23 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         U[q] = Ui[q % 3] - fsqrt(st.wsq[p][q]);
         m3 = fmaf(U[q] * U[q], U[q], m3);
         mu += U[q]; mv += st.V[p][q]; mw += st.W[p][q];
-        if (o_wd) adir += atan2f(st.V[p][q], U[q]);
+      }
+      if (o_wd) {
+        // mean of atan2(V, U) over the rotor grid: U > 0 and |V| << U except in unphysical layouts
+        bool small = true;
+        float rr[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          rr[q] = st.V[p][q] * frcp(U[q]);
+          small = small && (U[q] > 0.0f) && (fabsf(rr[q]) <= 0.25f);
+        }
+        if (__all(small)) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) adir += atan_small(rr[q]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) adir += atan2f(st.V[p][q], U[q]);
+        }
       }
       mu *= (1.0f / 9.0f); mv *= (1.0f / 9.0f); mw *= (1.0f / 9.0f);
       float su = 0.0f, sv = 0.0f, sw = 0.0f;
