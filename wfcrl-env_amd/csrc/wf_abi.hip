@@ -20,6 +20,7 @@
 extern "C" int wfk_num_variants();
 extern "C" void wfk_variant(int i, int* G, int* S, const void** fn);
 extern "C" int wfk_variant_has_table(int i);
+extern "C" int wfk_tab_waves();
 extern "C" const void* wfk_variant_fn(int i, int kind);
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
                                           const double* wd, double* gx, float* gy, int* gidx, hipStream_t s);
@@ -27,9 +28,9 @@ extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTa
                                       const float* gy, const int* gidx, int geom_stride, const double* ws,
                                       const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
                                       float* o_wd, float* load, int B, const WfEnvArgs* env, const float* pair_tab,
-                                      hipStream_t s, int* grid_out);
+                                      const int* pair_first, hipStream_t s, int* grid_out);
 extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double* gx, const float* gy, float* tab,
-                                            hipStream_t s);
+                                            int* first_active, hipStream_t s);
 
 extern "C" hipError_t wfk_launch_wind_sample(int B, unsigned long long seed, const double* dist, double* ws, double* wd,
                                              hipStream_t s);
@@ -111,6 +112,7 @@ struct wf_handle {
   double* d_ws_prev = nullptr;
   // shared-wind pair-coefficient table
   float* d_pair_tab = nullptr;
+  int* d_pair_first = nullptr;  // per source: first sorted target index with dx >= 0
   bool pair_dirty = true;
 };
 
@@ -135,7 +137,7 @@ void free_batch(wf_handle* h) {
   h->d_env_yaw = h->d_env_acc = h->d_env_act = h->d_env_out = h->h_env_act = h->h_env_out = nullptr;
   h->d_env_moves = nullptr;
   hipFree(h->d_series_ws); hipFree(h->d_series_wd); hipFree(h->d_series_start); hipFree(h->d_ws_prev);
-  hipFree(h->d_pair_tab); h->d_pair_tab = nullptr; h->pair_dirty = true;
+  hipFree(h->d_pair_tab); hipFree(h->d_pair_first); h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_dirty = true;
   h->d_series_ws = h->d_series_wd = h->d_ws_prev = nullptr; h->d_series_start = nullptr; h->series_T = 0;
   if (h->h_yaw) hipHostFree(h->h_yaw);
   if (h->h_out) hipHostFree(h->h_out);
@@ -295,6 +297,7 @@ int pair_table(wf_handle* h, const float** out) {
   const int NP = vG * vS;
   if (!h->d_pair_tab) {
     WF_HIP(h, hipMalloc(&h->d_pair_tab, sizeof(float) * (size_t)h->N * WF_PAIR_ROW_FLOATS(NP)));
+    WF_HIP(h, hipMalloc(&h->d_pair_first, sizeof(int) * h->N));
     h->pair_dirty = true;
   }
   if (h->pair_dirty) {
@@ -312,7 +315,7 @@ int pair_table(wf_handle* h, const float** out) {
       const double lm = m.kappa * z / (1.0 + m.kappa * z / (D / 8.0));
       pc.decay_a[k] = 4.0 * lm * lm * std::fabs(dudz) / uinf / pc.eps2;
     }
-    WF_HIP(h, wfk_launch_pair_table(&pc, h->d_gx, h->d_gy, h->d_pair_tab, h->stream));
+    WF_HIP(h, wfk_launch_pair_table(&pc, h->d_gx, h->d_gy, h->d_pair_tab, h->d_pair_first, h->stream));
     h->pair_dirty = false;
   }
   *out = h->d_pair_tab;
@@ -488,7 +491,7 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
   }
   if (on_device) {
     WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
-                              wstride, yaw, power, wspd, wdir, load, h->B, nullptr, ptab, h->stream, &h->grid));
+                              wstride, yaw, power, wspd, wdir, load, h->B, nullptr, ptab, h->d_pair_first, h->stream, &h->grid));
     return WF_OK;
   }
   if (!h->d_yaw) {
@@ -501,7 +504,7 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
   WF_HIP(h, hipMemcpyAsync(h->d_yaw, h->h_yaw, sizeof(float) * bn, hipMemcpyHostToDevice, h->stream));
   WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                             wstride, h->d_yaw, h->d_out, h->d_out + bn, h->d_out + 2 * bn, h->d_out + 3 * bn, h->B,
-                            nullptr, ptab, h->stream, &h->grid));
+                            nullptr, ptab, h->d_pair_first, h->stream, &h->grid));
   WF_HIP(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(float) * bn * 7, hipMemcpyDeviceToHost, h->stream));
   WF_HIP(h, hipStreamSynchronize(h->stream));
   if (power) std::memcpy(power, h->h_out, sizeof(float) * bn);
@@ -651,7 +654,7 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
   if (on_device) {
     ea.action = action; ea.reward = reward;
     WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
-                              wstride, nullptr, power, wspd, wdir, load, h->B, &ea, ptab, h->stream, &h->grid));
+                              wstride, nullptr, power, wspd, wdir, load, h->B, &ea, ptab, h->d_pair_first, h->stream, &h->grid));
     if (yaw) WF_HIP(h, hipMemcpyAsync(yaw, h->d_env_yaw, sizeof(float) * bn, hipMemcpyDeviceToDevice, h->stream));
     return WF_OK;
   }
@@ -672,7 +675,7 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
   WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                             wstride, nullptr, power ? h->d_out : nullptr, wspd ? h->d_out + bn : nullptr,
                             wdir ? h->d_out + 2 * bn : nullptr, load ? h->d_out + 3 * bn : nullptr, h->B, &ea, ptab,
-                            h->stream, &h->grid));
+                            h->d_pair_first, h->stream, &h->grid));
   if (reward) WF_HIP(h, hipMemcpyAsync(h->h_env_out, h->d_env_out, sizeof(float) * B, hipMemcpyDeviceToHost, h->stream));
   if (yaw) WF_HIP(h, hipMemcpyAsync(h->h_env_out + B, h->d_env_yaw, sizeof(float) * bn, hipMemcpyDeviceToHost, h->stream));
   if (power || wspd || wdir || load)
@@ -724,7 +727,8 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   WF_HIP(h, hipSetDevice(h->device));
   WF_HIP(h, hipFuncGetAttributes(&a, fn));
   info->lanes_per_env = G; info->slots_per_lane = S;
-  info->envs_per_block = 4 * (64 / G); info->threads_per_block = 256;
+  const int wpb = tab ? wfk_tab_waves() : 4;
+  info->envs_per_block = wpb * (64 / G); info->threads_per_block = 64 * wpb;
   info->grid_blocks = h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0;
   info->vgprs = a.numRegs; info->sgprs = 0;
   info->lds_bytes = (int)a.sharedSizeBytes; info->scratch_bytes = (int)a.localSizeBytes;

@@ -23,6 +23,10 @@
 
 #include "wf_device.h"
 
+#ifndef WF_TAB_WAVES
+#define WF_TAB_WAVES 4
+#endif
+
 namespace {
 
 constexpr float kPi = 3.14159265358979323846f;
@@ -281,7 +285,7 @@ extern "C" hipError_t wfk_launch_series_gather(int B, int T, int t, const int* s
 // pass [A.3-4] that does not depend on the farm's state.  One thread per (source i, target t); float64.
 // ---------------------------------------------------------------------------------------------
 __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __restrict__ gx, const float* __restrict__ gy,
-                                     float* __restrict__ tab) {
+                                     float* __restrict__ tab, int* __restrict__ first_active) {
   const int i = blockIdx.x, t = threadIdx.x;
   if (t >= pc.NP) return;
   float* o = tab + (size_t)i * WF_PAIR_ROW_FLOATS(pc.NP) + (size_t)t * WF_PAIR_STRIDE;
@@ -292,6 +296,7 @@ __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __rest
   }
   const double dx = gx[t] - gx[i];
   const double dy = (double)gy[t] - (double)gy[i];
+  if (dx >= 0.0) atomicMin(&first_active[i], t);  // lowest sorted index the source reaches (ties included)
   if (dx < 0.0) {  // upstream target: nothing reaches it; only the sign of dx is ever looked at
     for (int q = 0; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
     o[56] = (float)dx;
@@ -322,9 +327,11 @@ __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __rest
 }
 
 extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double* gx, const float* gy, float* tab,
-                                            hipStream_t s) {
+                                            int* first_active, hipStream_t s) {
   const int threads = ((pc->NP + 63) / 64) * 64;
-  hipLaunchKernelGGL(wf_pair_table_kernel, dim3(pc->N), dim3(threads), 0, s, *pc, gx, gy, tab);
+  hipError_t e = hipMemsetAsync(first_active, 0x7f, sizeof(int) * pc->N, s);  // "infinity" for atomicMin
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(wf_pair_table_kernel, dim3(pc->N), dim3(threads), 0, s, *pc, gx, gy, tab, first_active);
   return hipGetLastError();
 }
 
@@ -335,26 +342,34 @@ extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double
 // every physical turbine: for the other mirror offsets 1 - Ey*ezm == 1.0f exactly in float32).
 // TAB: the transverse-velocity pass reads the shared-wind pair-coefficient table instead of evaluating the
 // vortex system per farm (MC1 is then irrelevant).
-template <int G, int S, bool MC1, bool TAB>
-__global__ __launch_bounds__(256, 2) void wf_step_kernel(
+// WPB: waves per block (4; 8 for the table path so that one staged row serves twice as many farms).
+template <int G, int S, bool MC1, bool TAB, int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const float* __restrict__ gy,
     const int* __restrict__ gidx, int geom_stride, const double* __restrict__ ws_in, const double* __restrict__ wd_in,
     int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power, float* __restrict__ o_ws,
     float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea,
-    const float* __restrict__ pair_tab) {
+    const float* __restrict__ pair_tab, const int* __restrict__ pair_first) {
   constexpr int EPW = 64 / G;  // envs per wave
   constexpr int NP = G * S;    // turbine capacity of this variant
   __shared__ TableLds T;
-  __shared__ GeoLds<EPW, NP, !TAB> geo[4];
+  __shared__ GeoLds<EPW, NP, !TAB> geo[WPB];
   // shared-wind pair table: the current and the next source's row, filled by LDS-DMA (no VGPR staging)
   constexpr int ROWF = TAB ? WF_PAIR_ROW_FLOATS(NP) : 4;
   __shared__ __attribute__((aligned(16))) float prow[2][ROWF];
+  __shared__ int pfirst[TAB ? NP : 1];  // per source: first sorted target index it reaches (dx >= 0, ties included)
+  if constexpr (TAB) {
+    for (int k = threadIdx.x; k < NP; k += blockDim.x) pfirst[k] = (k < c.N) ? pair_first[k] : 0;
+    __syncthreads();
+  }
   constexpr int row_chunks = TAB ? (WF_PAIR_ROW_FLOATS(NP) / 256) : 0;  // 1-KiB pieces per row
   auto stage_row = [&](int src_i) {
     if constexpr (TAB) {
       const char* g0 = reinterpret_cast<const char*>(pair_tab + (size_t)src_i * WF_PAIR_ROW_FLOATS(NP));
       char* l0 = reinterpret_cast<char*>(&prow[src_i & 1][0]);
-      for (int ch = (int)(threadIdx.x >> 6); ch < row_chunks; ch += 4) {
+      // targets upstream of the source are never read: start at the 1-KiB piece holding its first active target
+      const int ch0 = __builtin_amdgcn_readfirstlane(pfirst[src_i]) * (WF_PAIR_STRIDE * 4) / 1024;
+      for (int ch = ch0 + (int)(threadIdx.x >> 6); ch < row_chunks; ch += WPB) {
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(g0 + ch * 1024 + (threadIdx.x & 63) * 16),
             (__attribute__((address_space(3))) void*)(l0 + ch * 1024), 16, 0, 0);
@@ -457,7 +472,9 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
     for (int li = 0; li < nsrc; ++li) {
       const int src = gbase + li;
       const int i = blk * G + li;
+#if !defined(WF_DIAG_NODMA)
       if (TAB && i + 1 < N) stage_row(i + 1);  // lands in the other buffer while this source is processed
+#endif
       // ---- A. the source's state (slot 0 of lane `li` of the group) ------------------------
       float m3 = 0.0f, vsum = 0.0f;
 #pragma unroll
@@ -473,6 +490,8 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
       for (int j = 0; j < 3; ++j) TIs[j] = __shfl(st.TI[0][j], src);
       double x_i = 0.0;
       float y_i = 0.0f;
+      int first_i = 0;
+      if constexpr (TAB) first_i = __builtin_amdgcn_readfirstlane(pfirst[i]);
       if constexpr (!TAB) {
         x_i = L.x[eiw][i];
         y_i = L.y[eiw][i];
@@ -499,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         b = (b >= S) ? b - S : b;
         const int t = b * G + sub;
         float dx;
-        if constexpr (TAB) dx = prow[i & 1][t * WF_PAIR_STRIDE + 56];
+        if constexpr (TAB) dx = (t >= first_i) ? prow[i & 1][t * WF_PAIR_STRIDE + 56] : -1.0f;  // un-staged pieces hold stale rows
         else dx = (float)(L.x[eiw][t] - x_i);
 #if defined(WF_ABLATE) && (WF_ABLATE & 1)
         if (dx >= 0.0f) { st.V[p][0] += Gt * dx; st.W[p][0] += Gb + Gwr; }
@@ -657,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
         b = (b >= S) ? b - S : b;
         const int t = b * G + sub;
         float dx;
-        if constexpr (TAB) dx = prow[i & 1][t * WF_PAIR_STRIDE + 56];
+        if constexpr (TAB) dx = (t >= first_i) ? prow[i & 1][t * WF_PAIR_STRIDE + 56] : -1.0f;  // un-staged pieces hold stale rows
         else dx = (float)(L.x[eiw][t] - x_i);
 #if defined(WF_ABLATE) && (WF_ABLATE & 2)
         if (dx > 0.0f) { st.wsq[p][0] += sc.sy0v * cc[0].x0v * cc[1].kyv * cc[2].pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * cc[2].d0 * sc.snw * sc.kdef; }
@@ -729,7 +748,9 @@ __global__ __launch_bounds__(256, 2) void wf_step_kernel(
           }
         }
       }
+#if !defined(WF_DIAG_NOBARRIER)
       if constexpr (TAB) __syncthreads();  // next row has landed; everyone is done with the current one
+#endif
     }  // li
 
     // rotate the register slots so that the next block of sources sits in slot 0
@@ -843,18 +864,20 @@ struct WfVariant {
 };
 
 // The table path is instantiated only where two blocks per CU still fit in the 160 KiB LDS and N <= WF_PAIR_MAX_N.
+constexpr int kTabWaves = WF_TAB_WAVES;  // waves per block on the table path
 template <int G, int S>
 constexpr bool tab_fits() {
   return G * S <= WF_PAIR_MAX_N &&
-         2 * (sizeof(TableLds) + 4 * sizeof(GeoLds<64 / G, G * S, false>) + 2 * 4 * WF_PAIR_ROW_FLOATS(G * S)) <= 160 * 1024;
+         (8 / kTabWaves) * (sizeof(TableLds) + kTabWaves * sizeof(GeoLds<64 / G, G * S, false>) +
+                            2 * 4 * WF_PAIR_ROW_FLOATS(G * S) + 4 * G * S) <= 160 * 1024;
 }
 template <int G, int S>
 const void* tab_kernel() {
-  if constexpr (tab_fits<G, S>()) return (const void*)&wf_step_kernel<G, S, true, true>;
+  if constexpr (tab_fits<G, S>()) return (const void*)&wf_step_kernel<G, S, true, true, kTabWaves>;
   else return nullptr;
 }
 #define WF_VARIANT(G_, S_)                                                                              \
-  {G_, S_, (const void*)&wf_step_kernel<G_, S_, true, false>, (const void*)&wf_step_kernel<G_, S_, false, false>, \
+  {G_, S_, (const void*)&wf_step_kernel<G_, S_, true, false, 4>, (const void*)&wf_step_kernel<G_, S_, false, false, 4>, \
    tab_kernel<G_, S_>()}
 static const WfVariant kVariants[] = {
     WF_VARIANT(4, 1),  WF_VARIANT(4, 2),  WF_VARIANT(4, 3),  WF_VARIANT(4, 4),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(8, 3),  WF_VARIANT(8, 4),
@@ -869,6 +892,7 @@ extern "C" void wfk_variant(int i, int* G, int* S, const void** fn) {
   *fn = kVariants[i].fn;
 }
 extern "C" int wfk_variant_has_table(int i) { return kVariants[i].fn_tab != nullptr; }
+extern "C" int wfk_tab_waves() { return kTabWaves; }
 // kind 0: MC1 on-the-fly, 1: general mirror cores, 2: shared-wind pair table
 extern "C" const void* wfk_variant_fn(int i, int kind) {
   return kind == 2 ? kVariants[i].fn_tab : (kind == 1 ? kVariants[i].fn_all : kVariants[i].fn);
@@ -885,16 +909,18 @@ extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTa
                                       const float* gy, const int* gidx, int geom_stride, const double* ws,
                                       const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
                                       float* o_wd, float* load, int B, const WfEnvArgs* env, const float* pair_tab,
-                                      hipStream_t s, int* grid_out) {
+                                      const int* pair_first, hipStream_t s, int* grid_out) {
   const WfVariant& v = kVariants[variant];
-  const int envs_per_block = 4 * (64 / v.G);
+  const bool use_tab = pair_tab && v.fn_tab;
+  const int wpb = use_tab ? kTabWaves : 4;
+  const int envs_per_block = wpb * (64 / v.G);
   const int grid = (B + envs_per_block - 1) / envs_per_block;
   if (grid_out) *grid_out = grid;
   WfConsts cc = *c;
   WfEnvArgs ea;
   if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
-  void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &pair_tab};
+  void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &pair_tab, &pair_first};
   const void* fn = (pair_tab && v.fn_tab) ? v.fn_tab : (cc.mirror_core_n <= 1 ? v.fn : v.fn_all);
   if (fn != v.fn_tab) pair_tab = nullptr;
-  return hipLaunchKernel(fn, dim3(grid), dim3(256), args, 0, s);
+  return hipLaunchKernel(fn, dim3(grid), dim3(64 * wpb), args, 0, s);
 }
