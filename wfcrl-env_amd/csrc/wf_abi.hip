@@ -146,32 +146,44 @@ void free_batch(wf_handle* h) {
   h->cap_env = h->cap_bn = 0;
 }
 
-// Kernel variant for N turbines: G lanes per env, S target slots per lane, G*S >= N.
-// Smaller G wastes fewer lanes on the triangular (upstream->downstream) structure; S is bounded by
+// Kernel variant for N turbines and B farms: G lanes per farm, S target slots per lane, G*S >= N.
+// Throughput regime (the grid fills the chip): smaller G wastes fewer lanes on the triangular
+// (upstream->downstream) structure and amortises the per-source work over more farms per wave; S is bounded by
 // the 256-VGPR budget that keeps two waves per SIMD resident.
-int pick_variant(int N) {
+// Latency regime (few farms, e.g. the reference's single-farm env): the chip is not full anyway, so G is widened
+// as long as all waves still fit in one residency round — fewer slot passes per source step.
+int find_variant(int G, int S) {
+  for (int i = 0; i < wfk_num_variants(); ++i) {
+    int g, s; const void* fn;
+    wfk_variant(i, &g, &s, &fn);
+    if (g == G && s == S) return i;
+  }
+  return -1;
+}
+
+int pick_variant(int N, int B) {
   const char* ov = getenv("WF_KERNEL_GS");  // tuning override, e.g. "16x5"
   int og = 0, os = 0;
-  if (ov && sscanf(ov, "%dx%d", &og, &os) == 2) {
-    for (int i = 0; i < wfk_num_variants(); ++i) {
-      int G, S; const void* fn;
-      wfk_variant(i, &G, &S, &fn);
-      if (G == og && S == os && G * S >= N) return i;
-    }
+  if (ov && sscanf(ov, "%dx%d", &og, &os) == 2 && og * os >= N) {
+    const int v = find_variant(og, os);
+    if (v >= 0) return v;
   }
   static const int pref[][3] = {  // {max N, G, S}
       {4, 4, 1}, {8, 4, 2}, {12, 4, 3}, {16, 4, 4}, {24, 8, 3}, {32, 8, 4}, {48, 16, 3}, {64, 16, 4},
       {80, 16, 5}, {96, 16, 6}, {128, 32, 4}, {192, 64, 3}, {256, 64, 4}};
-  for (auto& r : pref) {
-    if (N <= r[0]) {
-      for (int i = 0; i < wfk_num_variants(); ++i) {
-        int G, S; const void* fn;
-        wfk_variant(i, &G, &S, &fn);
-        if (G == r[1] && S == r[2]) return i;
-      }
+  int G = 0, S = 0;
+  for (auto& r : pref)
+    if (N <= r[0]) { G = r[1]; S = r[2]; break; }
+  if (!G) return -1;
+  if (B > 0) {
+    const long resident = 256L * 4 * 2;  // waves the chip holds at two per SIMD
+    while (G < 64) {
+      const int g2 = G * 2, s2 = (N + g2 - 1) / g2;
+      if ((long)B * g2 / 64 > resident / 2 || find_variant(g2, s2) < 0) break;
+      G = g2; S = s2;
     }
   }
-  return -1;
+  return find_variant(G, S);
 }
 
 int build_consts(wf_handle* h) {
@@ -415,7 +427,7 @@ int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
   if (!h || !x || !y) return WF_E_INVALID;
   if (n < 1 || n > WF_MAX_TURBINES) return fail(h, WF_E_INVALID, "n_turbines must be in 1..256");
   WF_HIP(h, hipSetDevice(h->device));
-  const int v = pick_variant(n);
+  const int v = pick_variant(n, h->B);
   if (v < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
   h->lx.assign(x, x + n); h->ly.assign(y, y + n);
   double xmin = x[0], xmax = x[0], ymin = y[0], ymax = y[0];
@@ -440,6 +452,15 @@ int wf_set_batch(wf_handle* h, int B) {
   if (B < 1) return fail(h, WF_E_INVALID, "env_batch must be >= 1");
   WF_HIP(h, hipSetDevice(h->device));
   WF_HIP(h, hipStreamSynchronize(h->stream));
+  {
+    const int v = pick_variant(h->N, B);
+    if (v < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
+    if (v != h->variant) {  // the pair table is laid out for the variant's capacity
+      hipFree(h->d_pair_tab); hipFree(h->d_pair_first);
+      h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_dirty = true;
+      h->variant = v;
+    }
+  }
   if ((size_t)B != h->cap_env) {
     free_batch(h);
     const size_t bn = (size_t)B * h->N;

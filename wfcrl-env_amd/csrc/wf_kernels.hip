@@ -882,7 +882,8 @@ const void* tab_kernel() {
 static const WfVariant kVariants[] = {
     WF_VARIANT(4, 1),  WF_VARIANT(4, 2),  WF_VARIANT(4, 3),  WF_VARIANT(4, 4),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(8, 3),  WF_VARIANT(8, 4),
     WF_VARIANT(16, 3), WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(16, 6), WF_VARIANT(32, 3),
-    WF_VARIANT(32, 4), WF_VARIANT(64, 3), WF_VARIANT(64, 4),
+    WF_VARIANT(32, 4), WF_VARIANT(64, 3), WF_VARIANT(64, 4), WF_VARIANT(16, 1), WF_VARIANT(16, 2), WF_VARIANT(32, 1),
+    WF_VARIANT(32, 2), WF_VARIANT(64, 1), WF_VARIANT(64, 2),
 };
 
 extern "C" int wfk_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
