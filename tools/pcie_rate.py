@@ -1,0 +1,21 @@
+"""GPU box: farm-steps/s when the boundary hands over HOST buffers (wf_step on_device=0: pinned staging, H2D yaw,
+kernel, D2H of the 7 outputs, synchronous) — the PCIe-inclusive rate DESIGN.md quotes beside the HBM-resident one."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wfcrl_env_amd.backend import WfStep
+L = json.load(open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")))["HornsRev1_"]
+B, N = 65536, 80
+w = WfStep(L["xcoords"], L["ycoords"], env_batch=B); w.set_wind(8.0, 270.0)
+yaw = np.random.default_rng(0).uniform(-40, 40, (B, N)).astype(np.float32)
+out = w.step(yaw)
+for want_all in (True, False):
+    t = time.perf_counter()
+    for _ in range(10):
+        if want_all:
+            w.step(yaw, out)
+        else:
+            w.env_step(None, want=("reward",))  # nothing but a [B] vector crosses PCIe back
+    dt = (time.perf_counter() - t) / 10
+    print(("all 7 outputs to host" if want_all else "reward only to host  "), f"{dt*1e3:.2f} ms/step  {B/dt:.3e} farm-steps/s")
