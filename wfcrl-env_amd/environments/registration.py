@@ -1,11 +1,16 @@
-"""Env registry and factory: `make("<Layout>_Floris" | "Dec_<Layout>_Floris", ...)`
-(reference wfcrl/environments/registration.py:17-117).  The `_Floris` suffix is served by the HIP
-backend; `_Fastfarm` names are listed (same registry as the reference) but raise on make()."""
+"""Env registry and factory.
+
+`make("<Layout>_Floris")` builds the centralised Gymnasium env, `make("Dec_<Layout>_Floris")` the per-turbine
+PettingZoo AEC env; `<Layout>` is one of the named farms (layouts.json) or a procedural single row `Turb<N>_Row1_`
+with N = 1..12.  Same name grammar, defaults and 88 registered names as reference
+wfcrl/environments/registration.py:17-117; the `_Floris` suffix is served by the HIP backend, `_Fastfarm` names are
+listed for compatibility but raise (that simulator is out of scope).  Extra keyword of this build: `env_batch=B`
+returns the batched, device-resident `VecWindFarmEnv`.
+"""
 from __future__ import annotations
 
 import math
 import re
-from itertools import product
 from typing import Union
 
 from ..interface import FastFarmInterface, HipFlorisInterface
@@ -14,70 +19,76 @@ from ..simple_env import WindFarmEnv
 from ..wrappers import AECLogWrapper, LogWrapper
 from .data_cases import ALIASES, DefaultControl, FarmRowFastfarm, FarmRowFloris, named_cases_dictionary
 
+# "<Dec_>?<layout>_<simulator>"  and  "Turb<N>_Row<R>"
 env_pattern = r"(Dec_)*(\w+\d*_)(\w+)"
 layout_pattern = r"Turb(\d+)_Row(\d+)"
 
 registered_simulators = ["Fastfarm", "Floris"]
-registered_layouts = list(named_cases_dictionary.keys()) + [f"Turb{n}_Row1_" for n in range(1, 13)]
 control_types = ["", "Dec_"]
-registered_envs = ["".join(p) for p in product(control_types, registered_layouts, registered_simulators)]
+registered_layouts = [*named_cases_dictionary, *(f"Turb{n}_Row1_" for n in range(1, 13))]
+
+
+def _enumerate(prefixes, layouts, simulators):
+    return [p + layout + sim for p in prefixes for layout in layouts for sim in simulators]
+
+
+registered_envs = _enumerate(control_types, registered_layouts, registered_simulators)
 # build-defined aliases, kept apart from the reference's 88 names
-alias_envs = ["".join(p) for p in product(control_types, ALIASES.keys(), ["Floris"])]
+alias_envs = _enumerate(control_types, list(ALIASES), ["Floris"])
 
 
-def get_default_control(controls):
-    d = DefaultControl()
-    return {name: getattr(d, name) for name in ("yaw", "pitch", "torque") if name in controls}
+def get_default_control(controls) -> dict:
+    defaults = DefaultControl()
+    return {name: getattr(defaults, name) for name in ("yaw", "pitch", "torque") if name in controls}
 
 
 def get_case(name: str, simulator: str):
-    k = registered_simulators.index(simulator)
-    if name in named_cases_dictionary:
-        return named_cases_dictionary[name][k]
-    if name in ALIASES:
-        return ALIASES[name][k]
-    m = re.match(layout_pattern, name)
-    n_turbines, n_rows = int(m.group(1)), int(m.group(2))
+    column = registered_simulators.index(simulator)  # [FAST.Farm case, FLORIS case]
+    for table in (named_cases_dictionary, ALIASES):
+        if name in table:
+            return table[name][column]
+    n_turbines, n_rows = (int(g) for g in re.match(layout_pattern, name).groups())
     assert n_rows == 1  # only single rows are generated procedurally
-    return (FarmRowFastfarm if k == 0 else FarmRowFloris).build(n_turbines)
+    return (FarmRowFloris if simulator == "Floris" else FarmRowFastfarm).build(n_turbines)
 
 
-def validate_case(env_id, case):
-    try:
-        assert len(case.xcoords) == len(case.ycoords), \
-            "xcoords and ycoords layout coordinates must have the same length"
-    except Exception as e:
-        raise ValueError(f"Invalid configuration for case {env_id}: {e}")
+def validate_case(env_id, case) -> None:
+    if len(case.xcoords) != len(case.ycoords):
+        raise ValueError(f"Invalid configuration for case {env_id}: "
+                         "xcoords and ycoords layout coordinates must have the same length")
+
+
+def _parse(env_id: str):
+    if env_id not in registered_envs and env_id not in alias_envs:
+        raise ValueError(f"{env_id} is not a registered WFCRL benchmark environment.")
+    prefix, layout, simulator = re.match(env_pattern, env_id).groups()
+    return prefix == "Dec_", layout, simulator
 
 
 def make(env_id: str, controls: Union[dict, list] = ["yaw"], log=True, **env_kwargs):
-    """Return a wind-farm benchmark environment.  Extra kwarg of this build: `env_batch=B` (B > 1)
-    returns the batched, device-resident `VecWindFarmEnv` instead of the single-farm env."""
-    if env_id not in registered_envs and env_id not in alias_envs:
-        raise ValueError(f"{env_id} is not a registered WFCRL benchmark environment.")
-    dec, name, simulator = re.match(env_pattern, env_id).groups()
-    case = get_case(name, simulator).clone()
+    """Return a wind-farm benchmark environment (see the module docstring)."""
+    decentralised, layout, simulator = _parse(env_id)
+    case = get_case(layout, simulator).clone()
     validate_case(env_id, case)
-    if "wind_time_series" in env_kwargs:
-        case.wind_time_series = env_kwargs.pop("wind_time_series")
-    if "path_to_simulator" in env_kwargs:
-        case.path_to_simulator = env_kwargs.pop("path_to_simulator")
-    if not isinstance(controls, dict):
-        controls = get_default_control(controls)
-    start_iter = math.ceil(case.t_init / case.dt)
+    for key in ("wind_time_series", "path_to_simulator"):  # case-level options passed as env kwargs
+        if key in env_kwargs:
+            setattr(case, key, env_kwargs.pop(key))
     if simulator == "Fastfarm":
         FastFarmInterface.from_case(case)  # raises NotImplementedError: out of scope
-    env_batch = env_kwargs.pop("env_batch", None)
-    if env_batch is not None:
+    if not isinstance(controls, dict):
+        controls = get_default_control(controls)
+    first_control_iter = math.ceil(case.t_init / case.dt)
+
+    batch = env_kwargs.pop("env_batch", None)
+    if batch is not None:
         from ..vec_env import VecWindFarmEnv
 
-        return VecWindFarmEnv(case, controls, env_batch=env_batch, start_iter=start_iter, **env_kwargs)
-    env_class = MAWindFarmEnv if dec == "Dec_" else WindFarmEnv
-    env = env_class(interface=HipFlorisInterface, farm_case=case, controls=controls, start_iter=start_iter,
-                    **env_kwargs)
-    if log:
-        env = (AECLogWrapper if dec == "Dec_" else LogWrapper)(env)
-    return env
+        return VecWindFarmEnv(case, controls, env_batch=batch, start_iter=first_control_iter, **env_kwargs)
+
+    flavour, logger = (MAWindFarmEnv, AECLogWrapper) if decentralised else (WindFarmEnv, LogWrapper)
+    env = flavour(interface=HipFlorisInterface, farm_case=case, controls=controls, start_iter=first_control_iter,
+                  **env_kwargs)
+    return logger(env) if log else env
 
 
 def list_envs():

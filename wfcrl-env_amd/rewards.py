@@ -1,20 +1,37 @@
-"""Reward shapers — post-processing of the scalar farm reward (reference wfcrl/rewards.py:4-46).
+"""Reward expression and shapers.
 
-The power reward itself is the inline expression of reference simple_env.py:78-85 (there is no
-`PowerReward` class in the reference); `power_reward` below states it once for
-both env flavours and for the batched env.
+The farm reward is the inline expression of reference wfcrl/simple_env.py:78-85 and multiagent_env.py:220-227
+(there is no `PowerReward` class in the reference); `power_reward` states it once for the
+single-farm envs and for batches.  The shapers post-process that scalar exactly like reference
+wfcrl/rewards.py:4-46 (same class names, constructor arguments and call results).
 """
 from __future__ import annotations
 
-from abc import ABC, abstractmethod
+import abc
 
 import numpy as np
 
 
-class RewardShaper(ABC):
-    @abstractmethod
+def power_reward(powers_mw, freewind_speed_prev, loads=None, load_coef: float = 0.1):
+    """mean_j(P_j [MW] * 1e3 / ws_prev^3) - load_coef * mean |loads|.
+
+    `powers_mw` (N,) with scalar `freewind_speed_prev`, or (B, N) with (B,); `loads` (N, 4) / (B, N, 4) or None."""
+    p = np.asarray(powers_mw)
+    batched = p.ndim == 2
+    ws_cubed = np.asarray(freewind_speed_prev) ** 3
+    production = (p * 1e3 / (ws_cubed[:, None] if batched else ws_cubed)).mean(axis=-1)
+    if loads is None:
+        return production
+    fatigue = np.abs(loads).reshape(p.shape[0], -1).mean(axis=1) if batched else np.mean(np.abs(loads))
+    return production - load_coef * fatigue
+
+
+class RewardShaper(abc.ABC):
+    """Maps the raw farm reward to what the learner sees; `reset` is called at every env reset."""
+
+    @abc.abstractmethod
     def __call__(self, reward):
-        ...
+        raise NotImplementedError
 
     def update(self):
         return None
@@ -24,50 +41,34 @@ class RewardShaper(ABC):
 
 
 class DoNothingReward(RewardShaper):
-    """Identity."""
-
     def __call__(self, reward):
-        return reward
+        return reward  # identity
 
 
 class ReferencePercentage(RewardShaper):
-    """(r - ref) / ref against a fixed reference."""
+    """Relative gain over a fixed baseline reward."""
 
     def __init__(self, reference: float):
         self.reference = reference
 
     def __call__(self, reward):
-        return (reward - self.reference) / self.reference
+        baseline = self.reference
+        return (reward - baseline) / baseline
 
 
 class StepPercentage(RewardShaper):
-    """Relative change with respect to the previous reward; 0 on the first call after reset."""
+    """Relative change from one step to the next; the first step after a reset yields 0."""
 
     def __init__(self, reference: float = 0.0):
         self.reference = reference
 
     def __call__(self, reward):
-        shaped = 0.0 if self.reference == 0 else (reward - self.reference) / self.reference
-        self.reference = reward
-        return shaped
+        previous, self.reference = self.reference, reward
+        return 0.0 if previous == 0 else (reward - previous) / previous
 
     def reset(self, reference: float = 0.0):
         self.reference = reference
 
 
-def power_reward(powers_mw, freewind_speed_prev, loads=None, load_coef: float = 0.1):
-    """mean_j(P_j[MW] * 1e3 / ws_prev^3) - load_coef * mean|loads|   (simple_env.py:78-84,
-    multiagent_env.py:220-226).  Works on (N,) arrays and on (B, N) batches (ws_prev (B,))."""
-    powers_mw = np.asarray(powers_mw)
-    ws3 = np.asarray(freewind_speed_prev) ** 3
-    if powers_mw.ndim == 2:
-        r = (powers_mw * 1e3 / ws3[:, None]).mean(axis=1)
-        pen = 0 if loads is None else np.abs(loads).reshape(powers_mw.shape[0], -1).mean(axis=1)
-    else:
-        r = (powers_mw * 1e3 / ws3).mean()
-        pen = 0 if loads is None else np.mean(np.abs(loads))
-    return r - load_coef * pen
-
-
-# Alias for BASELINE.json's wording; NOT a class of the reference (SURVEY Appendix C3).
+# BASELINE.json's wording; NOT a class of the reference (SURVEY Appendix C3)
 PowerReward = power_reward
