@@ -29,6 +29,7 @@ CONFIGS = {
     # name: (layout, per-GPU env batch)
     "cfg2": ("Ablaincourt_", 4096),
     "cfg3": ("Turb16_Row5_", 16384),
+    "cfg3b": ("Turb16_TCRWP_", 16384),  # build-defined alias: first 16 TCRWP turbines
     "cfg4": ("HornsRev1_", 65536),
     "cfg5": ("HornsRev2_", 131072),
 }
@@ -98,7 +99,12 @@ def main():
     if args.env_batch:
         B = args.env_batch
     with open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")) as f:
-        lay = json.load(f)[layout_name]
+        all_layouts = json.load(f)
+    if layout_name == "Turb16_TCRWP_":
+        t = all_layouts["Turb_TCRWP_"]
+        lay = {"num_turbines": 16, "xcoords": t["xcoords"][:16], "ycoords": t["ycoords"][:16]}
+    else:
+        lay = all_layouts[layout_name]
     N = lay["num_turbines"]
     # global env ids of this rank's shard (contiguous blocks)
     lo, hi = shard_bounds(B * world, rank, world)
@@ -110,7 +116,7 @@ def main():
     #   cfg2: absolute yaw ~ U(-40,40), fixed wind;  cfg3/cfg4: random-walk yaw (dyaw ~ U(-5,5), clipped to +-40),
     #   fixed wind;  cfg5: random-walk yaw + wd(t) = 270 + 30 sin(2 pi t/200), shared by the farms (or per farm
     #   with --per-env-wind), re-set every step on the device (rotation + sort kernel, no host sync)
-    cfg_id = int(args.config[3:])
+    cfg_id = int(args.config[3])
     gen = torch.Generator(device="cuda").manual_seed(1234 + cfg_id + 7919 * rank)
     ring = []
     yaw = torch.zeros((B, N), device="cuda", dtype=torch.float32)

@@ -257,3 +257,23 @@ def test_case_yaml_round_trip_and_rejections(tmp_path):
         mutate(bad)
         with pytest.raises(UnsupportedCaseError, match=msg):
             load_case_yaml(bad)
+
+
+def test_baseline_config1_plumbing_100_random_yaw_steps(patched):
+    """BASELINE.json configs[0] / SURVEY §8d cfg1: Turb3_Row1_Floris, single env, ws 8, wd 270, 100 steps of
+    dyaw ~ U(-5,5)^3 through the full env surface (actuation budget active), seeded rng(1234 + 1)."""
+    env = patched.make("Turb3_Row1_Floris", max_num_steps=101)
+    obs = env.reset(options={"wind_speed": 8.0, "wind_direction": 270.0})
+    rng = np.random.default_rng(1234 + 1)
+    total, blocked = 0.0, 0
+    for t in range(100):
+        a = {"yaw": rng.uniform(-5, 5, 3)}
+        before = a["yaw"].copy()
+        obs, reward, terminated, truncated, info = env.step(a)
+        blocked += int((a["yaw"] != before).sum())
+        total += float(reward[0])
+        assert np.all(np.abs(obs["yaw"]) <= 40) and np.isfinite(reward).all() and info["power"].shape == (3,)
+        assert truncated == (t == 99) and terminated is False
+    assert blocked > 50  # mean |dyaw| = 2.5 deg/step exceeds the 1.8 deg/step budget: the gate must act often
+    assert 100 * 1.2 < total < 100 * 2.0  # ~ mean(1.69, 0.36, 0.32 MW) * 1e3 / 8^3 = 1.54 per step, minus loads
+    assert len(env.history["reward"]) == 100

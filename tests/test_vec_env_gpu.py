@@ -256,3 +256,23 @@ def test_multi_device_wrapper_on_one_gpu(layouts):
     one.set_wind(8.0, 270.0)
     assert np.array_equal(one.step(yaw)["power"], m.step(yaw)["power"])
     one.close(); m.close()
+
+
+def test_baseline_config1_hip_env_matches_oracle_env(layouts):
+    """cfg1 on the GPU: the single-farm HIP env and the oracle-backed env agree step by step over 100 steps."""
+    from wfcrl_env_amd import environments as envs
+
+    env = envs.make("Turb3_Row1_Floris", max_num_steps=101)
+    ref = _host_env("Turb3_Row1_", layouts, max_num_steps=101)
+    opts = {"wind_speed": 8.0, "wind_direction": 270.0}
+    env.reset(options=opts)
+    ref.reset(options=opts)
+    rng = np.random.default_rng(1234 + 1)
+    for _ in range(100):
+        a = rng.uniform(-5, 5, 3)
+        o1, r1, _, tr1, i1 = env.step({"yaw": a.copy()})
+        o2, r2, _, tr2, i2 = ref.step({"yaw": a.copy()})
+        assert np.array_equal(o1["yaw"], o2["yaw"]) and tr1 == tr2
+        assert abs(r1[0] - r2[0]) <= 2e-5 * abs(r2[0])
+        assert np.abs(i1["power"] / i2["power"] - 1).max() < 1e-4
+    assert tr1 is True
