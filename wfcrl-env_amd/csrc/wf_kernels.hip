@@ -7,16 +7,27 @@
 //   reference wfcrl/interface.py:663-671  update_wind -> fi.reinitialize (rotation + sort)
 // following SURVEY.md Appendix A ([A.x] tags below).
 //
-// Mapping: this is a VALU-bound pairwise recurrence, not a contraction — no MFMA.
-//   * one farm instance (env) is owned by a GROUP of G lanes of a 64-wide wavefront (64/G envs per
-//     wave); lane `sub` of the group owns the S target turbines  t = p*G + sub  (p = slot);
-//   * the per-turbine state (SOSFS wake^2, V, W on the 3x3 rotor grid, TI per grid column) lives in
-//     VGPRs for the whole solve; HBM is touched once for yaw in and once for the 7 outputs;
-//   * the upstream->downstream recurrence runs over sources i = 0..N-1; the source's scalars are
-//     broadcast inside the group with ds_bpermute (__shfl) and every lane evaluates the source's
-//     influence on its own targets; slots with no target downstream of the source are skipped by a
-//     wave-uniform branch; slots rotate so the source always sits in slot 0 (static register
-//     indices, no scratch).
+// Mapping: a VALU-bound pairwise recurrence with an N-stage sequential dependency, not a
+// contraction — no MFMA.
+//   * one farm instance is owned by a GROUP of G lanes of a 64-wide wavefront (64/G farms per wave); lane `sub`
+//     of the group owns the S target turbines  t = p*G + sub  (p = register slot);
+//   * the per-turbine state (SOSFS wake^2, V, W on the 3x3 rotor grid, TI per grid column = 30 floats) lives in
+//     VGPRs for the whole solve; HBM is touched once for yaw in and once for the 7 outputs; yaw (with its sin/cos)
+//     and the sorted geometry are staged per wave in LDS;
+//   * the upstream->downstream recurrence runs over sources i = 0..N-1: the owner lane's rotor means are broadcast
+//     in the group with ds_bpermute (__shfl), every lane derives the source's constants and applies the source to
+//     its own targets in two passes (transverse velocities; then deflection + deficit + SOSFS + wake-added TI);
+//     slots whose turbines are all upstream of the source are skipped by a wave-uniform execz branch; the register
+//     slots rotate after each block of G sources so the source always sits in slot 0 (static indices, no scratch);
+//   * template parameters: <G, S> lane group / slots per lane (chosen by the host from N and the batch size);
+//     MC1  compile-time skip of ground-mirror vortex cores that are exactly 1.0f in float32;
+//     TAB  shared-wind path: the geometry-only coefficients of the transverse pass come from a float64
+//          pair-coefficient table (wf_pair_table_kernel) whose rows are staged into a double-buffered LDS slab with
+//          global_load_lds_dwordx4 (LDS-DMA) one source ahead, one __syncthreads() per source;
+//     WPB  waves per block.
+//   * optional fused env step (WfEnvArgs): actuation-budget gate, clipped yaw transition and reward in the launch.
+// Diagnostic-only preprocessor hooks (never defined in the product build): WF_ABLATE (skip a pass body, keeping its
+// inputs alive — the ablation timings of profiles/), WF_DIAG_NOBARRIER / WF_DIAG_NODMA (staging experiments).
 #include <hip/hip_runtime.h>
 
 #include <cstring>
