@@ -99,3 +99,18 @@ def test_layout_counts(layouts):
     want = {"Turb3_Row1_": 3, "Turb6_Row2_": 6, "Turb16_Row5_": 16, "Turb32_Row5_": 32, "Turb_TCRWP_": 32,
             "Ablaincourt_": 7, "HornsRev1_": 80, "Ormonde_": 30, "HornsRev2_": 91, "WMR_": 35}
     assert {k: v["num_turbines"] for k, v in layouts.items()} == want
+
+
+def test_turbine_table_corroboration_point():
+    """a row recollected from FLORIS v3's gauss regression baseline for the unwaked NREL 5MW
+    turbine — rotor-averaged speed 7.9803783 m/s -> Ct 0.7634300, power 1 695 368.8 W, axial induction 0.2568077.
+    NOT a fixture of the reference repository (hence only a corroboration of the table of Appendix A.5, which the
+    reference's own KAT pins at 4.5-6.5 m/s only)."""
+    p = onp.ModelParams()
+    v = 7.9803783
+    ct = float(onp._interp_fill(v, p.table_ws, p.table_ct, 0.0001, 0.9999))
+    power = p.ref_density * float(onp._interp_fill(v, p.table_ws, p.power_table(), 0.0, 0.0))
+    a = 0.5 * (1.0 - np.sqrt(1.0 - ct))
+    assert abs(ct - 0.7634300) < 5e-8
+    assert abs(power - 1695368.8) < 0.5
+    assert abs(a - 0.2568077) < 5e-8
