@@ -173,6 +173,14 @@ def main():
         t = torch.tensor([elapsed, kern_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
+        # the collective part of the job is over: every rank leaves the group now, so that rank 0's CPU-baseline
+        # leg (tens of seconds) runs with no peer waiting on it
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+    if rank != 0:
+        w.close()
+        return
 
     # the same farms through the fused env step (transition + budget gate + reward in the launch,
     # only reward + local wind observations written): reported beside the headline, not as `value`
@@ -192,11 +200,6 @@ def main():
     except Exception as e:  # pragma: no cover
         if not args.no_env_leg:
             print(f"bench.py: fused env step leg failed: {e}", file=sys.stderr)
-
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
 
     value = B * world * args.steps / elapsed
     algo_bytes = (32 * N + 8) * B  # read 4N yaw + 8 wind, write 28N outputs, per farm-step
@@ -283,8 +286,6 @@ def main():
                                      "kind": "port", "sample": f"{k} farm-steps, NumPy float64 oracle, single process"}
     print(json.dumps(res), flush=True)
     w.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
