@@ -226,6 +226,13 @@ def test_error_behaviour(layouts):
         w.set_wind(-1.0, 270.0)
     with pytest.raises(ValueError, match="veer"):
         w.set_model({"veer": 3.0})
+    for bad, msg in [({"num_eps": 0.0}, "num_eps"), ({"ambient_ti": -0.1}, "turbulence_intensity"), ({"tsr": float("nan")}, "TSR"),
+                     ({"hub_height": 60.0}, "hub_height"), ({"table_ws": [0.0, 5.0, 4.0], "table_ct": [0, 0.8, 0.5], "table_cp": [0, 0.4, 0.3]}, "ascending"),
+                     ({"table_ws": [0.0, 5.0, 9.0], "table_ct": [0, -0.8, 0.5], "table_cp": [0, 0.4, 0.3]}, "non-negative")]:
+        with pytest.raises(ValueError, match=msg):
+            w.set_model(bad)
+    w.set_wind(8.0, 270.0)
+    assert np.isfinite(w.step(np.zeros((4, 3), np.float32))["power"]).all()  # the handle is still usable after rejected models
     w.close()
 
 

@@ -413,6 +413,31 @@ int wf_set_model(wf_handle* h, const wf_model_params* p) {
   if (p->n_table < 2 || p->n_table > WF_MAX_TABLE - 1 || !p->table_ws || !p->table_ct || !p->table_cp)
     return fail(h, WF_E_INVALID, "power_thrust_table needs 2..63 entries");
   if (p->veer != 0.0) return fail(h, WF_E_UNSUPPORTED, "wind_veer != 0 is not implemented");
+  {
+    const struct { double v; const char* name; } positive[] = {
+        {p->air_density, "air_density"}, {p->ambient_ti, "turbulence_intensity"}, {p->rotor_diameter, "rotor_diameter"},
+        {p->hub_height, "hub_height"}, {p->tsr, "TSR"}, {p->pP, "pP"}, {p->gen_eff, "generator_efficiency"},
+        {p->ref_density, "ref_density_cp_ct"}, {p->ka * p->ambient_ti + p->kb, "ka*TI + kb"},
+        {p->alpha, "alpha"}, {p->eps_gain, "eps_gain"}, {p->num_eps, "num_eps"}, {p->kappa, "kappa"},
+        {p->ch_constant, "crespo_hernandez.constant"}};
+    for (const auto& q : positive)
+      if (!(q.v > 0.0) || !std::isfinite(q.v))
+        return fail(h, WF_E_INVALID, std::string("model parameter must be finite and > 0: ") + q.name);
+    const double finite[] = {p->shear, p->beta, p->ad, p->bd, p->dm, p->ch_initial, p->ch_ai, p->ch_downstream, p->gch_gain,
+                             p->overlap_thresh, p->near_wake_c, p->pT};
+    for (double v : finite)
+      if (!std::isfinite(v)) return fail(h, WF_E_INVALID, "model parameters must be finite");
+    if (!(p->hub_height > 0.75 * p->rotor_diameter))
+      return fail(h, WF_E_INVALID, "hub_height must exceed 0.75 rotor diameters (the lowest rotor-grid row and the "
+                                   "blade tip must stay above ground)");
+    for (int i = 0; i < p->n_table; ++i) {
+      if (!std::isfinite(p->table_ws[i]) || !std::isfinite(p->table_ct[i]) || !std::isfinite(p->table_cp[i]) ||
+          p->table_ct[i] < 0.0 || p->table_cp[i] < 0.0)
+        return fail(h, WF_E_INVALID, "power_thrust_table entries must be finite and non-negative");
+      if (i && !(p->table_ws[i] > p->table_ws[i - 1]))
+        return fail(h, WF_E_INVALID, "table wind speeds must be strictly ascending");
+    }
+  }
   h->model = *p;
   h->tws.assign(p->table_ws, p->table_ws + p->n_table);
   h->tct.assign(p->table_ct, p->table_ct + p->n_table);
