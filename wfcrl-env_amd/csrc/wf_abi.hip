@@ -427,9 +427,8 @@ int wf_set_model(wf_handle* h, const wf_model_params* p) {
                              p->overlap_thresh, p->near_wake_c, p->pT};
     for (double v : finite)
       if (!std::isfinite(v)) return fail(h, WF_E_INVALID, "model parameters must be finite");
-    if (!(p->hub_height > 0.75 * p->rotor_diameter))
-      return fail(h, WF_E_INVALID, "hub_height must exceed 0.75 rotor diameters (the lowest rotor-grid row and the "
-                                   "blade tip must stay above ground)");
+    if (!(p->hub_height > 0.5 * p->rotor_diameter))
+      return fail(h, WF_E_INVALID, "hub_height must exceed the rotor radius (blade tip above ground)");
     for (int i = 0; i < p->n_table; ++i) {
       if (!std::isfinite(p->table_ws[i]) || !std::isfinite(p->table_ct[i]) || !std::isfinite(p->table_cp[i]) ||
           p->table_ct[i] < 0.0 || p->table_cp[i] < 0.0)
