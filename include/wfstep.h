@@ -135,6 +135,10 @@ int wf_env_reset(wf_handle* h);
 int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, float* power, float* wind_speed,
                 float* wind_dir, float* load, int on_device);
 
+/* Checkpoint / resume of the device-resident env state: yaw [B*N], acc [B*N] (accumulated |dyaw|),
+ * moves [B].  set == 0 copies the state out, set != 0 overwrites it.  NULL pointers are skipped. */
+int wf_env_state(wf_handle* h, float* yaw, float* acc, int* moves, int set, int on_device);
+
 /* ---- On-device wind process ------------------------------------------------------
  * wf_wind_sample: per-farm reset sampling with the reference's distributions (wfcrl/mdp.py:237-258):
  *   ws = clip(ws_scale * Weibull(ws_shape), ws_lo, ws_hi);  wd = clip(Normal(wd_mean, wd_std) mod 360, wd_lo, wd_hi)

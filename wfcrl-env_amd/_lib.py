@@ -77,6 +77,7 @@ ABI = {
     "wf_get_wind": (C.c_int, [_P, _P, _P, C.c_int]),
     "wf_env_config": (C.c_int, [_P, C.POINTER(EnvParams)]),
     "wf_env_reset": (C.c_int, [_P]),
+    "wf_env_state": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),
     "wf_env_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int]),
     "wf_timing_begin": (C.c_int, [_P]),
     "wf_timing_end": (C.c_int, [_P, C.POINTER(C.c_float)]),

@@ -180,6 +180,20 @@ class WfStep:
     def env_reset(self):
         check(self._lib.wf_env_reset(self._h), self._h)
 
+    def env_get_state(self) -> dict:
+        """Host copy of the device-resident env state: yaw (B, N), acc (B, N), moves (B,)."""
+        B, N = self.env_batch, self.num_turbines
+        st = {"yaw": np.empty((B, N), np.float32), "acc": np.empty((B, N), np.float32), "moves": np.empty(B, np.int32)}
+        check(self._lib.wf_env_state(self._h, st["yaw"].ctypes.data, st["acc"].ctypes.data, st["moves"].ctypes.data, 0, 0), self._h)
+        return st
+
+    def env_set_state(self, state: dict):
+        B, N = self.env_batch, self.num_turbines
+        yaw = np.ascontiguousarray(state["yaw"], np.float32).reshape(B, N)
+        acc = np.ascontiguousarray(state["acc"], np.float32).reshape(B, N)
+        moves = np.ascontiguousarray(state["moves"], np.int32).reshape(B)
+        check(self._lib.wf_env_state(self._h, yaw.ctypes.data, acc.ctypes.data, moves.ctypes.data, 1, 0), self._h)
+
     def env_step(self, action=None, want=("reward", "yaw", "power", "wind_speed", "wind_direction", "load"), out=None):
         """One fused env step.  `action` (B, N) torch CUDA float32 tensor or NumPy array, or None for a solve
         at the current yaw (reset warm-up).  `want` selects which outputs are produced at all."""

@@ -677,6 +677,24 @@ int wf_env_reset(wf_handle* h) {
   return WF_OK;
 }
 
+int wf_env_state(wf_handle* h, float* yaw, float* acc, int* moves, int set, int on_device) {
+  if (!h) return WF_E_INVALID;
+  WF_HIP(h, hipSetDevice(h->device));
+  int rc = env_alloc(h);
+  if (rc != WF_OK) return rc;
+  const size_t bn = (size_t)h->B * h->N;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : (set ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
+  auto xfer = [&](void* user, void* dev, size_t bytes) -> hipError_t {
+    if (!user) return hipSuccess;
+    return set ? hipMemcpyAsync(dev, user, bytes, kind, h->stream) : hipMemcpyAsync(user, dev, bytes, kind, h->stream);
+  };
+  WF_HIP(h, xfer(yaw, h->d_env_yaw, sizeof(float) * bn));
+  WF_HIP(h, xfer(acc, h->d_env_acc, sizeof(float) * bn));
+  WF_HIP(h, xfer(moves, h->d_env_moves, sizeof(int) * h->B));
+  if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));
+  return WF_OK;
+}
+
 int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, float* power, float* wspd, float* wdir,
                 float* load, int on_device) {
   if (!h) return WF_E_INVALID;

@@ -223,6 +223,24 @@ class VecWindFarmEnv:
         self._num_iter += 1
         return self._obs(out), self._shape(out["reward"]), self._num_iter == self.farm_case.max_iter
 
+    # -- checkpoint / resume (the env state is tiny; FLORIS itself is stateless between steps) ------
+    def get_state(self) -> dict:
+        """Everything needed to resume the batch: device env state, the per-farm wind, the step counter."""
+        if self._series is not None:
+            raise NotImplementedError("checkpointing a time-series episode is not supported")
+        ws, wd = self.fi.get_wind()
+        return {**self.fi.env_get_state(), "wind_speed": ws, "wind_direction": wd, "num_iter": self._num_iter,
+                "shaper_ref": None if self._shaper_ref is None else np.asarray(
+                    self._shaper_ref.cpu() if hasattr(self._shaper_ref, "cpu") else self._shaper_ref).copy()}
+
+    def set_state(self, state: dict):
+        self.fi.set_wind(state["wind_speed"], state["wind_direction"])
+        self.fi.env_set_state(state)
+        self._num_iter = int(state["num_iter"])
+        ref = state.get("shaper_ref")
+        self._shaper_ref = None if ref is None else self._to_device(ref)
+        self._refresh_freewind()
+
     def close(self):
         self.fi.close()
 
