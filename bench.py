@@ -84,13 +84,20 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
+    # one rank per GPU (the driver's launch); BENCH_DIST_BACKEND=gloo + fewer GPUs than ranks is a test mode that
+    # exercises the multi-rank flow on a single-GPU box (ranks then share devices)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from wfcrl_env_amd.backend import WfStep
     from wfcrl_env_amd.sharding import shard_bounds
@@ -170,7 +177,7 @@ def main():
         w.sync()
     sync_ms = (time.perf_counter() - t1) / nsync * 1e3
     if dist is not None:
-        t = torch.tensor([elapsed, kern_ms], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, kern_ms], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
         # the collective part of the job is over: every rank leaves the group now, so that rank 0's CPU-baseline
