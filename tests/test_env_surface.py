@@ -277,3 +277,25 @@ def test_baseline_config1_plumbing_100_random_yaw_steps(patched):
     assert blocked > 50  # mean |dyaw| = 2.5 deg/step exceeds the 1.8 deg/step budget: the gate must act often
     assert 100 * 1.2 < total < 100 * 2.0  # ~ mean(1.69, 0.36, 0.32 MW) * 1e3 / 8^3 = 1.54 per step, minus loads
     assert len(env.history["reward"]) == 100
+
+
+def test_reference_import_names_resolve_to_this_build(tmp_path):
+    """Reference user code imports `wfcrl.*`; the alias package maps those names onto this build."""
+    import wfcrl
+    import wfcrl.environments as envs
+    import wfcrl_env_amd.environments
+    from wfcrl.environments import FarmCase, FlorisCase, list_envs, make  # noqa: F401
+    from wfcrl.interface import BaseInterface, FlorisInterface
+    from wfcrl.mdp import WindFarmMDP
+    from wfcrl.multiagent_env import MAWindFarmEnv  # noqa: F401
+    from wfcrl.rewards import DoNothingReward, ReferencePercentage, RewardShaper, StepPercentage  # noqa: F401
+    from wfcrl.simple_env import WindFarmEnv  # noqa: F401
+    from wfcrl.simul_utils import create_floris_case
+    from wfcrl.wrappers import AECLogWrapper, LogWrapper  # noqa: F401
+
+    assert len(envs.list_envs()) == 88 and issubclass(FlorisInterface, BaseInterface)
+    assert WindFarmMDP.ACTUATORS_RATE == {"yaw": 0.3, "pitch": 8}
+    assert os.path.samefile(wfcrl.__path__[0], wfcrl_env_amd.__path__[0])
+    case = envs.registration.get_case("Turb3_Row1_", "Floris")
+    path = create_floris_case(case.dict(), output_dir=tmp_path / "c")
+    assert os.path.basename(path) == "case.yaml" and os.path.exists(path)

@@ -47,6 +47,11 @@ def dump_case_yaml(case: dict, output_dir) -> str:
     return str(path)
 
 
+def create_floris_case(case: dict, output_dir=None) -> str:
+    """Name and signature of reference wfcrl/simul_utils.py:34-48: writes `<output_dir>/case.yaml`."""
+    return dump_case_yaml(case, "__simul__/floris/case" if output_dir is None else output_dir)
+
+
 # ---------------------------------------------------------------------------------------------------
 # FLORIS-YAML ingestion (SURVEY §8 f4): read a (possibly user-modified) case.yaml into what the C ABI takes.
 # ---------------------------------------------------------------------------------------------------
