@@ -77,11 +77,17 @@ struct WfEnvArgs {
 // transverse-velocity contribution is linear in the source's three circulations,
 //   V_wake(j,k) =        Gt*cv[0] + Gb*cv[1] + Gwr*cv[2]        W_wake(j,k) = max(0, Gt*cw[0] + Gb*cw[1] + Gwr*cw[2])
 // with coefficients that depend on geometry and model constants only (decay, vortex cores, mirrors folded in).
-// Layout per pair (WF_PAIR_STRIDE floats; 60 = conflict-free stride for the 16 lanes of a group): for each grid
-// point q = j*3+k six floats {cv[0..2], cw[0..2]} (54 floats), [54] (dx'/D)^ch_downstream of the Crespo-Hernandez
-// term [A.3-8], [56] dx = x'_t - x'_i (float64 difference, rounded once), [57] dy, rest padding.  A source's row (all targets) is padded to a multiple of 1 KiB: the step kernel
-// stages it into LDS with 1-KiB global_load_lds wave-instructions.
+// Layout per pair (WF_PAIR_STRIDE = 60 floats = 15 float4; 60 is also a conflict-free LDS stride for the 16 lanes
+// of a group): three 20-float blocks, one per grid column j.  Block j holds for k = 0..2 the six floats
+// {cv[0..2], cw[0..2]} of grid point (j,k) at [j*20 + k*6 .. +5] and two spare words [j*20+18], [j*20+19]:
+//   [18] dx = x'_t - x'_i (float64 difference, rounded once; < 0: target upstream, -1 for padding targets)
+//   [19] dy = y'_t - y'_i        [38] (dx'/D)^ch_downstream of the Crespo-Hernandez term [A.3-8]
+// A source's row (all targets) is padded to a multiple of 1 KiB: the step kernel stages it into LDS with 1-KiB
+// global_load_lds wave-instructions.
 #define WF_PAIR_STRIDE 60
+#define WF_PAIR_DX 18
+#define WF_PAIR_DY 19
+#define WF_PAIR_TIPOW 38
 #define WF_PAIR_MAX_N 128
 #define WF_PAIR_ROW_FLOATS(n) ((((n) * WF_PAIR_STRIDE * 4 + 1023) / 1024) * 256)
 

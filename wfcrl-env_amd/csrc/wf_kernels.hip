@@ -302,7 +302,7 @@ __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __rest
   float* o = tab + (size_t)i * WF_PAIR_ROW_FLOATS(pc.NP) + (size_t)t * WF_PAIR_STRIDE;
   if (t >= pc.N) {  // padding target of the kernel variant: permanently "upstream"
     for (int q = 0; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
-    o[56] = -1.0f;
+    o[WF_PAIR_DX] = -1.0f;
     return;
   }
   const double dx = gx[t] - gx[i];
@@ -310,8 +310,8 @@ __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __rest
   if (dx >= 0.0) atomicMin(&first_active[i], t);  // lowest sorted index the source reaches (ties included)
   if (dx < 0.0) {  // upstream target: nothing reaches it; only the sign of dx is ever looked at
     for (int q = 0; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
-    o[56] = (float)dx;
-    o[57] = (float)dy;
+    o[WF_PAIR_DX] = (float)dx;
+    o[WF_PAIR_DY] = (float)dy;
     return;
   }
   const double R = pc.D / 2.0;
@@ -325,16 +325,16 @@ __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __rest
         const double zc = z - hs[v] + pc.num_eps, zm = z + hs[v] + pc.num_eps;
         const double r = yL * yL + zc * zc, rm = yL * yL + zm * zm;
         const double T = (1.0 - exp(-r / pc.eps2)) / r, Tm = (1.0 - exp(-rm / pc.eps2)) / rm;
-        o[(j * 3 + k) * 6 + v] = (float)(dec * (zc * T - zm * Tm));
-        o[(j * 3 + k) * 6 + 3 + v] = (float)(-yL * dec * (T - Tm));
+        o[j * 20 + k * 6 + v] = (float)(dec * (zc * T - zm * Tm));
+        o[j * 20 + k * 6 + 3 + v] = (float)(-yL * dec * (T - Tm));
       }
     }
   }
   const double dxp = (dx > 0.1) ? dx : dx + 1.0;  // Crespo-Hernandez distance with FLORIS' masks [A.3-8]
-  o[54] = (float)pow(dxp / pc.D, pc.ch_down);
-  for (int q = 55; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
-  o[56] = (float)dx;
-  o[57] = (float)dy;
+  o[39] = o[58] = o[59] = 0.0f;
+  o[WF_PAIR_TIPOW] = (float)pow(dxp / pc.D, pc.ch_down);
+  o[WF_PAIR_DX] = (float)dx;
+  o[WF_PAIR_DY] = (float)dy;
 }
 
 extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double* gx, const float* gy, float* tab,
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
         b = (b >= S) ? b - S : b;
         const int t = b * G + sub;
         float dx;
-        if constexpr (TAB) dx = (t >= first_i) ? prow[i & 1][t * WF_PAIR_STRIDE + 56] : -1.0f;  // un-staged pieces hold stale rows
+        if constexpr (TAB) dx = (t >= first_i) ? prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DX] : -1.0f;  // un-staged pieces hold stale rows
         else dx = (float)(L.x[eiw][t] - x_i);
 #if defined(WF_ABLATE) && (WF_ABLATE & 1)
         if (dx >= 0.0f) { st.V[p][0] += Gt * dx; st.W[p][0] += Gb + Gwr; }
@@ -538,16 +538,21 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
         if (dx >= 0.0f) {
 #endif
          if constexpr (TAB) {
-          // geometry-only coefficients of this (source, target) pair from the staged row: 6 floats per grid point
-          const float* pr = &prow[i & 1][t * WF_PAIR_STRIDE];
+          // geometry-only coefficients of this (source, target) pair from the staged row: one grid column (five
+          // 16-byte reads, 20 floats) at a time — three LDS round trips per pair at a cost of 20 live registers
+          const float4* pr = reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]);
 #pragma unroll
-          for (int q = 0; q < 9; ++q) {
-            const float2 c0 = *reinterpret_cast<const float2*>(pr + q * 6);
-            const float2 c1 = *reinterpret_cast<const float2*>(pr + q * 6 + 2);
-            const float2 c2 = *reinterpret_cast<const float2*>(pr + q * 6 + 4);
-            st.V[p][q] = fmaf(Gwr, c1.x, fmaf(Gb, c0.y, fmaf(Gt, c0.x, st.V[p][q])));
-            const float ww = fmaf(Gwr, c2.y, fmaf(Gb, c2.x, Gt * c1.y));
-            st.W[p][q] += fmaxf(ww, 0.0f);  // W[W<0] = 0, quirk (5)
+          for (int j = 0; j < 3; ++j) {
+            const float4 c0 = pr[5 * j], c1 = pr[5 * j + 1], c2 = pr[5 * j + 2], c3 = pr[5 * j + 3], c4 = pr[5 * j + 4];
+            const float f[18] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x,
+                                 c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w, c4.x, c4.y};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const int q = j * 3 + k;
+              st.V[p][q] = fmaf(Gwr, f[k * 6 + 2], fmaf(Gb, f[k * 6 + 1], fmaf(Gt, f[k * 6], st.V[p][q])));
+              const float ww = fmaf(Gwr, f[k * 6 + 5], fmaf(Gb, f[k * 6 + 4], Gt * f[k * 6 + 3]));
+              st.W[p][q] += fmaxf(ww, 0.0f);  // W[W<0] = 0, quirk (5)
+            }
           }
          } else {
           const float dy = L.y[eiw][t] - y_i;
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
         b = (b >= S) ? b - S : b;
         const int t = b * G + sub;
         float dx;
-        if constexpr (TAB) dx = (t >= first_i) ? prow[i & 1][t * WF_PAIR_STRIDE + 56] : -1.0f;  // un-staged pieces hold stale rows
+        if constexpr (TAB) dx = (t >= first_i) ? prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DX] : -1.0f;  // un-staged pieces hold stale rows
         else dx = (float)(L.x[eiw][t] - x_i);
 #if defined(WF_ABLATE) && (WF_ABLATE & 2)
         if (dx > 0.0f) { st.wsq[p][0] += sc.sy0v * cc[0].x0v * cc[1].kyv * cc[2].pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * cc[2].d0 * sc.snw * sc.kdef; }
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
         if (dx > 0.0f) {
 #endif
           float dy;
-          if constexpr (TAB) dy = prow[i & 1][t * WF_PAIR_STRIDE + 57];
+          if constexpr (TAB) dy = prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DY];
           else dy = L.y[eiw][t] - y_i;
           const float lin = fmaf(c.bd, dx, c.ad);
           const float amp_on = (dx > 0.1f) ? 1.0f : 0.0f;
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
           // Crespo-Hernandez with overlap gating [A.3-8]
           float tipow;
           if constexpr (TAB) {
-            tipow = prow[i & 1][t * WF_PAIR_STRIDE + 54];
+            tipow = prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_TIPOW];
           } else {
             const float dxp = (dx > 0.1f) ? dx : dx + 1.0f;
             tipow = fexp2(c.ch_down * flog2(dxp * c.invD));
