@@ -166,7 +166,10 @@ class VecWindFarmEnv:
             self.fi.sample_wind(s)
         else:
             ws, wd = self._sample_wind(seed, options)
-            self.fi.set_wind(ws, wd)
+            if np.all(ws == ws[0]) and np.all(wd == wd[0]):
+                self.fi.set_wind(ws[0], wd[0])  # one wind for the whole batch: shared-wind (pair table) path
+            else:
+                self.fi.set_wind(ws, wd)
         self.fi.env_reset()
         self.reward_shaper.reset()
         self._shaper_ref = None
