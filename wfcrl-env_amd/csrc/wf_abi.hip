@@ -320,6 +320,8 @@ int pair_table(wf_handle* h, const float** out) {
     const double off[3] = {-D / 4, 0.0, D / 4};
     double uinf = 0;
     for (int k = 0; k < 3; ++k) uinf += std::pow((HH + off[k]) / HH, m.shear) / 3.0;
+    pc.gam_top = (1.0 / 16.0) * D * std::pow((HH + D / 2) / HH, m.shear) * uinf;  // (1/2pi)(pi/8) D vel_top uinf
+    pc.gam_bot = (1.0 / 16.0) * D * std::pow((HH - D / 2) / HH, m.shear) * uinf;
     for (int k = 0; k < 3; ++k) {
       pc.off[k] = off[k];
       const double z = HH + off[k];

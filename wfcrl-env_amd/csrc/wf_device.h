@@ -74,19 +74,21 @@ struct WfEnvArgs {
 };
 
 // Pair-coefficient table (shared wind only): for source i and target t (sorted indices) the
-// transverse-velocity contribution is linear in the source's three circulations,
-//   V_wake(j,k) =        Gt*cv[0] + Gb*cv[1] + Gwr*cv[2]        W_wake(j,k) = max(0, Gt*cw[0] + Gb*cw[1] + Gwr*cw[2])
-// with coefficients that depend on geometry and model constants only (decay, vortex cores, mirrors folded in).
-// Layout per pair (WF_PAIR_STRIDE = 60 floats = 15 float4; 60 is also a conflict-free LDS stride for the 16 lanes
-// of a group): three 20-float blocks, one per grid column j.  Block j holds for k = 0..2 the six floats
-// {cv[0..2], cw[0..2]} of grid point (j,k) at [j*20 + k*6 .. +5] and two spare words [j*20+18], [j*20+19]:
-//   [18] dx = x'_t - x'_i (float64 difference, rounded once; < 0: target upstream, -1 for padding targets)
-//   [19] dy = y'_t - y'_i        [38] (dx'/D)^ch_downstream of the Crespo-Hernandez term [A.3-8]
+// transverse-velocity contribution is linear in the source's circulations.  The tip vortices' circulations share
+// the farm-dependent factor Gy = sin(yaw) cos(yaw) Ct ws  (Gt = gam_top*Gy, Gb = -gam_bot*Gy), so they fold into ONE
+// coefficient; the wake-rotation circulation Gwr keeps its own:
+//   V_wake(j,k) = Gy*aV + Gwr*bV        W_wake(j,k) = max(0, Gy*aW + Gwr*bW)
+// with coefficients that depend on geometry and model constants only (decay, vortex cores, mirrors folded in),
+// evaluated in float64 and rounded once.
+// Layout per pair (WF_PAIR_STRIDE = 44 floats = 11 float4; 44 words is a conflict-free LDS stride for 16-byte reads
+// of consecutive lanes): grid point (j,k) is the float4 {aV, bV, aW, bW} at [(3j+k)*4 .. +3]; then
+//   [36] dx = x'_t - x'_i (float64 difference, rounded once; < 0: target upstream, -1 for padding targets)
+//   [37] dy = y'_t - y'_i        [38] (dx'/D)^ch_downstream of the Crespo-Hernandez term [A.3-8]      [39..43] 0
 // A source's row (all targets) is padded to a multiple of 1 KiB: the step kernel stages it into LDS with 1-KiB
 // global_load_lds wave-instructions.
-#define WF_PAIR_STRIDE 60
-#define WF_PAIR_DX 18
-#define WF_PAIR_DY 19
+#define WF_PAIR_STRIDE 44
+#define WF_PAIR_DX 36
+#define WF_PAIR_DY 37
 #define WF_PAIR_TIPOW 38
 #define WF_PAIR_MAX_N 128
 #define WF_PAIR_ROW_FLOATS(n) ((((n) * WF_PAIR_STRIDE * 4 + 1023) / 1024) * 256)
@@ -98,4 +100,5 @@ struct WfPairConsts {
   double off[3];
   double decay_a[3];
   double ch_down;
+  double gam_top, gam_bot;  // tip-vortex circulations per unit (sin cos Ct ws), over 2 pi  [A.3-1]
 };

@@ -45,6 +45,7 @@ constexpr float kDeg2Rad = kPi / 180.0f;
 constexpr float kRad2Deg = 180.0f / kPi;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kGs = 0.8493218002880191f;  // sqrt(log2(e) / 2)
 
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -108,10 +109,20 @@ __device__ __forceinline__ float table_pw(const WfConsts& c, const TableLds& T, 
   return r;
 }
 
+// 1.0f if e > thr else 0.0f, as one VALU instruction: fma with the clamp output modifier (thrB = thr * kBig; the
+// smallest positive e - thr is one ulp of thr ~ 2^-33, so the scaled difference is either <= 0 or >= 2^17)
+constexpr float kBig = 1125899906842624.0f;  // 2^50
+__device__ __forceinline__ float above(float e, float thrB) {
+  return __builtin_amdgcn_fmed3f(fmaf(e, kBig, -thrB), 0.0f, 1.0f);
+}
+
 // Register-resident per-turbine state of one lane: S target slots x (9 + 9 + 9 + 3) floats.
 template <int S>
 struct Slots {
-  float wsq[S][9];  // SOSFS: sum of (deficit*Uinit)^2                 [A.3-7]
+  // SOSFS [A.3-7]: FLORIS sums (deficit * Uinit(z))^2; Uinit(z_k) is the same for every source, so the sum of
+  // deficit^2 is kept instead, and the Gaussian deficit is even in z - HH: rows k = 0 and k = 2 always hold the
+  // same value.  esq[j*2] = rows 0 and 2 of column j, esq[j*2 + 1] = row 1:  u(j,k) = Uinit_k * (1 - sqrt(esq)).
+  float esq[S][6];
   float V[S][9], W[S][9];
   float TI[S][3];   // per grid column j (independent of k)            [A.3-8]
 };
@@ -315,23 +326,29 @@ __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __rest
     return;
   }
   const double R = pc.D / 2.0;
-  const double hs[3] = {pc.HH + R, pc.HH - R, pc.HH};
+  const double hs[3] = {pc.HH + R, pc.HH - R, pc.HH};  // top tip vortex, bottom tip vortex, wake rotation
   for (int j = 0; j < 3; ++j) {
     const double yL = dy + pc.off[j] + pc.num_eps;
     for (int k = 0; k < 3; ++k) {
       const double z = pc.HH + pc.off[k];
       const double dec = 1.0 / (pc.decay_a[k] * dx + 1.0);
+      double cv[3], cw[3];
       for (int v = 0; v < 3; ++v) {
         const double zc = z - hs[v] + pc.num_eps, zm = z + hs[v] + pc.num_eps;
         const double r = yL * yL + zc * zc, rm = yL * yL + zm * zm;
         const double T = (1.0 - exp(-r / pc.eps2)) / r, Tm = (1.0 - exp(-rm / pc.eps2)) / rm;
-        o[j * 20 + k * 6 + v] = (float)(dec * (zc * T - zm * Tm));
-        o[j * 20 + k * 6 + 3 + v] = (float)(-yL * dec * (T - Tm));
+        cv[v] = dec * (zc * T - zm * Tm);
+        cw[v] = -yL * dec * (T - Tm);
       }
+      float* q = o + (3 * j + k) * 4;  // {aV, bV, aW, bW}: Gt = gam_top*Gy and Gb = -gam_bot*Gy folded
+      q[0] = (float)(pc.gam_top * cv[0] - pc.gam_bot * cv[1]);
+      q[1] = (float)cv[2];
+      q[2] = (float)(pc.gam_top * cw[0] - pc.gam_bot * cw[1]);
+      q[3] = (float)cw[2];
     }
   }
   const double dxp = (dx > 0.1) ? dx : dx + 1.0;  // Crespo-Hernandez distance with FLORIS' masks [A.3-8]
-  o[39] = o[58] = o[59] = 0.0f;
+  for (int q = 39; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
   o[WF_PAIR_TIPOW] = (float)pow(dxp / pc.D, pc.ch_down);
   o[WF_PAIR_DX] = (float)dx;
   o[WF_PAIR_DY] = (float)dy;
@@ -411,6 +428,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
   const double wd_d = fmod(wd_in[(size_t)env * wind_stride], 360.0);
   const float wd = (float)(wd_d < 0.0 ? wd_d + 360.0 : wd_d);
   const float Ui[3] = {ws * c.shearf[0], ws * c.shearf[1], ws * c.shearf[2]};
+  const float offk = c.off[2] * kGs;
+  const float U02c = Ui[0] * Ui[0] * Ui[0] + Ui[2] * Ui[2] * Ui[2], U1c = Ui[1] * Ui[1] * Ui[1];
+  // overlap test "deficit * Uinit_k > threshold" [A.3-8] as a threshold on the deficit itself
+  const float thrB[3] = {__fdiv_rn(c.overlap_thr, Ui[0]) * kBig, __fdiv_rn(c.overlap_thr, Ui[1]) * kBig,
+                         __fdiv_rn(c.overlap_thr, Ui[2]) * kBig};
 
   const size_t gofs = (size_t)env * geom_stride;
   const size_t yofs = (size_t)env * N;
@@ -468,10 +490,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
   for (int p = 0; p < S; ++p) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      st.wsq[p][q] = 0.0f;
       st.V[p][q] = 0.0f;
       st.W[p][q] = 0.0f;
     }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) st.esq[p][q] = 0.0f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) st.TI[p][j] = c.amb;
   }
@@ -487,14 +510,16 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
       if (TAB && i + 1 < N) stage_row(i + 1);  // lands in the other buffer while this source is processed
 #endif
       // ---- A. the source's state (slot 0 of lane `li` of the group) ------------------------
-      float m3 = 0.0f, vsum = 0.0f;
+      float fe = 0.0f, fc = 0.0f, vsum = 0.0f;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const float u = Ui[q % 3] - fsqrt(st.wsq[0][q]);
-        m3 = fmaf(u * u, u, m3);
-        vsum += st.V[0][q];
+      for (int j = 0; j < 3; ++j) {
+        const float ue = 1.0f - fsqrt(st.esq[0][2 * j]), uc = 1.0f - fsqrt(st.esq[0][2 * j + 1]);
+        fe = fmaf(ue * ue, ue, fe);
+        fc = fmaf(uc * uc, uc, fc);
       }
-      m3 = __shfl(m3, src);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) vsum += st.V[0][q];
+      const float m3 = __shfl(fmaf(U02c, fe, U1c * fc), src);  // sum over the grid of u^3
       const float Vmean = __shfl(vsum, src) * (1.0f / 9.0f);
       float TIs[3];
 #pragma unroll
@@ -520,6 +545,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
       // transverse circulations / (2 pi), commanded yaw
       const float scg = sg * cg;
       const float Gt = scg * gt, Gb = -scg * gb;
+      const float Gy = scg * ct * ws;  // table path: Gt = gam_top*Gy, Gb = -gam_bot*Gy folded into the coefficients
 
       // ---- C. pass 1: transverse velocities on every target at or downstream of the source --
       float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
@@ -538,19 +564,17 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
         if (dx >= 0.0f) {
 #endif
          if constexpr (TAB) {
-          // geometry-only coefficients of this (source, target) pair from the staged row: one grid column (five
-          // 16-byte reads, 20 floats) at a time — three LDS round trips per pair at a cost of 20 live registers
+          // geometry-only coefficients of this (source, target) pair from the staged row: one float4
+          // {aV, bV, aW, bW} per grid point, a grid column (three 16-byte reads) at a time
           const float4* pr = reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]);
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-            const float4 c0 = pr[5 * j], c1 = pr[5 * j + 1], c2 = pr[5 * j + 2], c3 = pr[5 * j + 3], c4 = pr[5 * j + 4];
-            const float f[18] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x,
-                                 c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w, c4.x, c4.y};
+            const float4 cf[3] = {pr[3 * j], pr[3 * j + 1], pr[3 * j + 2]};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
               const int q = j * 3 + k;
-              st.V[p][q] = fmaf(Gwr, f[k * 6 + 2], fmaf(Gb, f[k * 6 + 1], fmaf(Gt, f[k * 6], st.V[p][q])));
-              const float ww = fmaf(Gwr, f[k * 6 + 5], fmaf(Gb, f[k * 6 + 4], Gt * f[k * 6 + 3]));
+              st.V[p][q] = fmaf(Gwr, cf[k].y, fmaf(Gy, cf[k].x, st.V[p][q]));
+              const float ww = fmaf(Gwr, cf[k].w, Gy * cf[k].z);
               st.W[p][q] += fmaxf(ww, 0.0f);  // W[W<0] = 0, quirk (5)
             }
           }
@@ -634,9 +658,12 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
         const float t2 = th0 * th0;
         const float poly = th0 * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 0.0088632355f, 0.0218694885f), 0.0539682540f),
                                                           0.1333333333f), 0.3333333333f), 1.0f);
-        const float rev = th0 * 0.15915494309189535f;  // v_sin/v_cos take revolutions
-        const float hw = __builtin_amdgcn_sinf(rev) * frcp(__builtin_amdgcn_cosf(rev));
-        sc.tan_th0 = (fabsf(th0) > 0.35f) ? hw : poly;
+        sc.tan_th0 = poly;
+        if (__any(fabsf(th0) > 0.35f)) {  // wave-uniform: never taken for admissible yaw
+          const float rev = th0 * 0.15915494309189535f;  // v_sin/v_cos take revolutions
+          const float hw = __builtin_amdgcn_sinf(rev) * frcp(__builtin_amdgcn_cosf(rev));
+          sc.tan_th0 = (fabsf(th0) > 0.35f) ? hw : poly;
+        }
       }
       sc.inv_s0d = frcp(sc.sy0d * sc.sz0d);
       const float pfac = th0 * E0 * (1.0f / 5.2f) * fsqrt(sc.sy0d * sc.sz0d * frcp(ct)) * kLn2;  // * log2(arg)/ky
@@ -692,16 +719,19 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
         b = (b >= S) ? b - S : b;
         const int t = b * G + sub;
         float dx;
-        if constexpr (TAB) dx = (t >= first_i) ? prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DX] : -1.0f;  // un-staged pieces hold stale rows
-        else dx = (float)(L.x[eiw][t] - x_i);
+        float4 ex = {0.0f, 0.0f, 0.0f, 0.0f};  // {dx, dy, tipow, -}
+        if constexpr (TAB) {
+          ex = *reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DX]);
+          dx = (t >= first_i) ? ex.x : -1.0f;  // un-staged pieces hold stale rows
+        } else dx = (float)(L.x[eiw][t] - x_i);
 #if defined(WF_ABLATE) && (WF_ABLATE & 2)
-        if (dx > 0.0f) { st.wsq[p][0] += sc.sy0v * cc[0].x0v * cc[1].kyv * cc[2].pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * cc[2].d0 * sc.snw * sc.kdef; }
+        if (dx > 0.0f) { st.esq[p][0] += sc.sy0v * cc[0].x0v * cc[1].kyv * cc[2].pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * cc[2].d0 * sc.snw * sc.kdef; }
         if (false) {
 #else
         if (dx > 0.0f) {
 #endif
           float dy;
-          if constexpr (TAB) dy = prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DY];
+          if constexpr (TAB) dy = ex.y;
           else dy = L.y[eiw][t] - y_i;
           const float lin = fmaf(c.bd, dx, c.ad);
           const float amp_on = (dx > 0.1f) ? 1.0f : 0.0f;
@@ -723,44 +753,44 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
             const float isy = frcp(sy), isz = frcp(sz);
             const float xarg = sc.kdef * isy * isz;
             const float C = (xarg >= 1.0f) ? 1.0f : xarg * frcp(1.0f + fsqrt(fmaxf(1.0f - xarg, 0.0f)));
-            const float zz = c.off[2] * isz;
-            const float ez = fexp2(-0.5f * kLog2e * zz * zz);
+            // exp(-t^2/2) = exp2(-(t*kGs)^2); the grid offsets are (-D/4, 0, +D/4) in y and in z
+            const float zz = offk * isz;
+            const float ez = fexp2(-(zz * zz));
             const float amp = amp_on * C;
+            const float y1 = (dy - delta) * isy * kGs, oy = offk * isy;
+            const float yy[3] = {y1 - oy, y1, y1 + oy};
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-              const float yy = (dy + c.off[j] - delta) * isy;
-              e1[j] = amp * fexp2(-0.5f * kLog2e * yy * yy);
+              e1[j] = amp * fexp2(-(yy[j] * yy[j]));
               e0[j] = e1[j] * ez;
             }
           } else {
 #pragma unroll
             for (int j = 0; j < 3; ++j) column_deficit(c, sc, cc[j], dx, dy + c.off[j], lin, amp_on, e1[j], e0[j]);
           }
-          int cnt = 0;
+          float cnt = 0.0f;  // grid points with deficit * Uinit_k > threshold
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const float dU = ((k == 1) ? e1[j] : e0[j]) * Ui[k];
-              st.wsq[p][j * 3 + k] = fmaf(dU, dU, st.wsq[p][j * 3 + k]);
-              cnt += (dU > c.overlap_thr) ? 1 : 0;
-            }
+            st.esq[p][2 * j] = fmaf(e0[j], e0[j], st.esq[p][2 * j]);
+            st.esq[p][2 * j + 1] = fmaf(e1[j], e1[j], st.esq[p][2 * j + 1]);
+            cnt += (above(e0[j], thrB[0]) + above(e1[j], thrB[1])) + above(e0[j], thrB[2]);
           }
           // Crespo-Hernandez with overlap gating [A.3-8]
           float tipow;
           if constexpr (TAB) {
-            tipow = prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_TIPOW];
+            tipow = ex.z;
           } else {
             const float dxp = (dx > 0.1f) ? dx : dx + 1.0f;
             tipow = fexp2(c.ch_down * flog2(dxp * c.invD));
           }
           const float ti = ch_pref * tipow;
-          const float tia = (dx <= c.fifteenD) ? ti * ((float)cnt * (1.0f / 9.0f)) : 0.0f;
+          const float tia = (dx <= c.fifteenD) ? ti * (cnt * (1.0f / 9.0f)) : 0.0f;
           const float cand = fsqrt(fmaf(tia, tia, c.amb2));
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-            const bool m = fabsf(dy + c.off[j]) < c.twoD;
-            st.TI[p][j] = m ? fmaxf(st.TI[p][j], cand) : st.TI[p][j];
+            // TI and cand are non-negative: the maximum is taken on the bit patterns (no NaN canonicalisation)
+            const float cm = (fabsf(dy + c.off[j]) < c.twoD) ? cand : 0.0f;
+            st.TI[p][j] = __uint_as_float(max(__float_as_uint(st.TI[p][j]), __float_as_uint(cm)));
           }
         }
       }
@@ -771,22 +801,26 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
 
     // rotate the register slots so that the next block of sources sits in slot 0
     if (S > 1) {
-      float a0[9], b0[9], c0[9], t0[3];
+      float a0[6], b0[9], c0[9], t0[3];
 #pragma unroll
-      for (int q = 0; q < 9; ++q) { a0[q] = st.wsq[0][q]; b0[q] = st.V[0][q]; c0[q] = st.W[0][q]; }
+      for (int q = 0; q < 9; ++q) { b0[q] = st.V[0][q]; c0[q] = st.W[0][q]; }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) a0[q] = st.esq[0][q];
 #pragma unroll
       for (int j = 0; j < 3; ++j) t0[j] = st.TI[0][j];
 #pragma unroll
       for (int p = 0; p + 1 < S; ++p) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          st.wsq[p][q] = st.wsq[p + 1][q]; st.V[p][q] = st.V[p + 1][q]; st.W[p][q] = st.W[p + 1][q];
-        }
+        for (int q = 0; q < 9; ++q) { st.V[p][q] = st.V[p + 1][q]; st.W[p][q] = st.W[p + 1][q]; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) st.esq[p][q] = st.esq[p + 1][q];
 #pragma unroll
         for (int j = 0; j < 3; ++j) st.TI[p][j] = st.TI[p + 1][j];
       }
 #pragma unroll
-      for (int q = 0; q < 9; ++q) { st.wsq[S - 1][q] = a0[q]; st.V[S - 1][q] = b0[q]; st.W[S - 1][q] = c0[q]; }
+      for (int q = 0; q < 9; ++q) { st.V[S - 1][q] = b0[q]; st.W[S - 1][q] = c0[q]; }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) st.esq[S - 1][q] = a0[q];
 #pragma unroll
       for (int j = 0; j < 3; ++j) st.TI[S - 1][j] = t0[j];
       rot = (rot + 1 == S) ? 0 : rot + 1;
@@ -804,8 +838,12 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
       const int o = gidx[gofs + t];
       float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
 #pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float ue = 1.0f - fsqrt(st.esq[p][2 * j]), uc = 1.0f - fsqrt(st.esq[p][2 * j + 1]);
+        U[3 * j] = Ui[0] * ue; U[3 * j + 1] = Ui[1] * uc; U[3 * j + 2] = Ui[2] * ue;
+      }
+#pragma unroll
       for (int q = 0; q < 9; ++q) {
-        U[q] = Ui[q % 3] - fsqrt(st.wsq[p][q]);
         m3 = fmaf(U[q] * U[q], U[q], m3);
         mu += U[q]; mv += st.V[p][q]; mw += st.W[p][q];
       }
