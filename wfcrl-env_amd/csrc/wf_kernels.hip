@@ -500,9 +500,12 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
   }
 
   const int nblk = (N + G - 1) / G;
-  int rot = 0;  // register slot p currently holds turbine block (p + rot) % S
+  float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
+  // Register slot p holds turbine block blk + p: once a block's own sources are done nothing downstream in the
+  // recurrence touches it again, so its outputs are written and the slots shift down by one (static indices).
   for (int blk = 0; blk < nblk; ++blk) {
     const int nsrc = min(G, N - blk * G);
+    const int live = S - blk;  // slots p >= live hold nothing any more
     for (int li = 0; li < nsrc; ++li) {
       const int src = gbase + li;
       const int i = blk * G + li;
@@ -551,9 +554,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
       float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
 #pragma unroll
       for (int p = 0; p < S; ++p) {
-        int b = p + rot;
-        b = (b >= S) ? b - S : b;
-        const int t = b * G + sub;
+        if (p > 0 && p >= live) break;
+        const int t = (blk + p) * G + sub;
         float dx;
         if constexpr (TAB) dx = (t >= first_i) ? prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DX] : -1.0f;  // un-staged pieces hold stale rows
         else dx = (float)(L.x[eiw][t] - x_i);
@@ -715,9 +717,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
       // ---- E. pass 2: deflection, deficit, SOSFS, wake-added turbulence ----------------------
 #pragma unroll
       for (int p = 0; p < S; ++p) {
-        int b = p + rot;
-        b = (b >= S) ? b - S : b;
-        const int t = b * G + sub;
+        if (p > 0 && p >= live) break;
+        const int t = (blk + p) * G + sub;
         float dx;
         float4 ex = {0.0f, 0.0f, 0.0f, 0.0f};  // {dx, dy, tipow, -}
         if constexpr (TAB) {
@@ -768,13 +769,17 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
 #pragma unroll
             for (int j = 0; j < 3; ++j) column_deficit(c, sc, cc[j], dx, dy + c.off[j], lin, amp_on, e1[j], e0[j]);
           }
-          float cnt = 0.0f;  // grid points with deficit * Uinit_k > threshold
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             st.esq[p][2 * j] = fmaf(e0[j], e0[j], st.esq[p][2 * j]);
             st.esq[p][2 * j + 1] = fmaf(e1[j], e1[j], st.esq[p][2 * j + 1]);
-            cnt += (above(e0[j], thrB[0]) + above(e1[j], thrB[1])) + above(e0[j], thrB[2]);
           }
+          // Wake-added TI reaches a target only within 15 D downstream and 2 D laterally [A.3-8]; elsewhere the
+          // candidate is the ambient value, which never exceeds the running maximum: skipped when no lane needs it.
+          if (!__any((dx <= c.fifteenD) && (fabsf(dy) < c.twoD + c.off[2]))) continue;
+          float cnt = 0.0f;  // grid points with deficit * Uinit_k > threshold
+#pragma unroll
+          for (int j = 0; j < 3; ++j) cnt += (above(e0[j], thrB[0]) + above(e1[j], thrB[1])) + above(e0[j], thrB[2]);
           // Crespo-Hernandez with overlap gating [A.3-8]
           float tipow;
           if constexpr (TAB) {
@@ -799,98 +804,78 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
 #endif
     }  // li
 
-    // rotate the register slots so that the next block of sources sits in slot 0
-    if (S > 1) {
-      float a0[6], b0[9], c0[9], t0[3];
+    // ---- outputs [A.4] of block blk (slot 0) ---------------------------------------------------
+    {
+      const int t = blk * G + sub;
+      if (t < N) {
+        const int o = gidx[gofs + t];
+        float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) { b0[q] = st.V[0][q]; c0[q] = st.W[0][q]; }
+        for (int j = 0; j < 3; ++j) {
+          const float ue = 1.0f - fsqrt(st.esq[0][2 * j]), uc = 1.0f - fsqrt(st.esq[0][2 * j + 1]);
+          U[3 * j] = Ui[0] * ue; U[3 * j + 1] = Ui[1] * uc; U[3 * j + 2] = Ui[2] * ue;
+        }
 #pragma unroll
-      for (int q = 0; q < 6; ++q) a0[q] = st.esq[0][q];
+        for (int q = 0; q < 9; ++q) {
+          m3 = fmaf(U[q] * U[q], U[q], m3);
+          mu += U[q]; mv += st.V[0][q]; mw += st.W[0][q];
+        }
+        if (o_wd) {
+          // mean of atan2(V, U) over the rotor grid: U > 0 and |V| << U except in unphysical layouts
+          bool small = true;
+          float rr[9];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) t0[j] = st.TI[0][j];
+          for (int q = 0; q < 9; ++q) {
+            rr[q] = st.V[0][q] * frcp(U[q]);
+            small = small && (U[q] > 0.0f) && (fabsf(rr[q]) <= 0.25f);
+          }
+          if (__all(small)) {
 #pragma unroll
-      for (int p = 0; p + 1 < S; ++p) {
+            for (int q = 0; q < 9; ++q) adir += atan_small(rr[q]);
+          } else {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { st.V[p][q] = st.V[p + 1][q]; st.W[p][q] = st.W[p + 1][q]; }
+            for (int q = 0; q < 9; ++q) adir += atan2f(st.V[0][q], U[q]);
+          }
+        }
+        mu *= (1.0f / 9.0f); mv *= (1.0f / 9.0f); mw *= (1.0f / 9.0f);
+        float su = 0.0f, sv = 0.0f, sw = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) st.esq[p][q] = st.esq[p + 1][q];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) st.TI[p][j] = st.TI[p + 1][j];
+        for (int q = 0; q < 9; ++q) {
+          const float du = U[q] - mu, dv = st.V[0][q] - mv, dw = st.W[0][q] - mw;
+          su = fmaf(du, du, su); sv = fmaf(dv, dv, sv); sw = fmaf(dw, dw, sw);
+        }
+        const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
+        const float cy = L.cg[eiw][t];
+        const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cy));
+        const float pwr = c.rho * table_pw(c, T, veff);
+        float4 l;
+        l.x = (st.TI[0][0] + st.TI[0][1] + st.TI[0][2]) * (1.0f / 3.0f);
+        l.y = fsqrt(su * (1.0f / 9.0f));
+        l.z = fsqrt(sv * (1.0f / 9.0f));
+        l.w = fsqrt(sw * (1.0f / 9.0f));
+        psum += pwr;
+        lsum += (l.x + l.y) + (l.z + l.w);  // loads are non-negative: |.| is the identity
+        if (env_ok) {
+          const size_t oo = yofs + o;
+          if (o_power) o_power[oo] = pwr;
+          if (o_ws) o_ws[oo] = wsp;
+          if (o_wd) o_wd[oo] = wd - adir * (kRad2Deg / 9.0f);
+          if (o_load) reinterpret_cast<float4*>(o_load)[oo] = l;
+        }
       }
+    }
+    // shift the register slots down: the next block of sources sits in slot 0
 #pragma unroll
-      for (int q = 0; q < 9; ++q) { st.V[S - 1][q] = b0[q]; st.W[S - 1][q] = c0[q]; }
+    for (int p = 0; p + 1 < S; ++p) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) st.esq[S - 1][q] = a0[q];
+      for (int q = 0; q < 9; ++q) { st.V[p][q] = st.V[p + 1][q]; st.W[p][q] = st.W[p + 1][q]; }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) st.TI[S - 1][j] = t0[j];
-      rot = (rot + 1 == S) ? 0 : rot + 1;
+      for (int q = 0; q < 6; ++q) st.esq[p][q] = st.esq[p + 1][q];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) st.TI[p][j] = st.TI[p + 1][j];
     }
   }  // blk
 
-  // ---- outputs [A.4]: slot p holds block (p + rot) % S ----------------------------------------
-  float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
-#pragma unroll
-  for (int p = 0; p < S; ++p) {
-    int b = p + rot;
-    b = (b >= S) ? b - S : b;
-    const int t = b * G + sub;
-    if (t < N) {
-      const int o = gidx[gofs + t];
-      float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float ue = 1.0f - fsqrt(st.esq[p][2 * j]), uc = 1.0f - fsqrt(st.esq[p][2 * j + 1]);
-        U[3 * j] = Ui[0] * ue; U[3 * j + 1] = Ui[1] * uc; U[3 * j + 2] = Ui[2] * ue;
-      }
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        m3 = fmaf(U[q] * U[q], U[q], m3);
-        mu += U[q]; mv += st.V[p][q]; mw += st.W[p][q];
-      }
-      if (o_wd) {
-        // mean of atan2(V, U) over the rotor grid: U > 0 and |V| << U except in unphysical layouts
-        bool small = true;
-        float rr[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          rr[q] = st.V[p][q] * frcp(U[q]);
-          small = small && (U[q] > 0.0f) && (fabsf(rr[q]) <= 0.25f);
-        }
-        if (__all(small)) {
-#pragma unroll
-          for (int q = 0; q < 9; ++q) adir += atan_small(rr[q]);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 9; ++q) adir += atan2f(st.V[p][q], U[q]);
-        }
-      }
-      mu *= (1.0f / 9.0f); mv *= (1.0f / 9.0f); mw *= (1.0f / 9.0f);
-      float su = 0.0f, sv = 0.0f, sw = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const float du = U[q] - mu, dv = st.V[p][q] - mv, dw = st.W[p][q] - mw;
-        su = fmaf(du, du, su); sv = fmaf(dv, dv, sv); sw = fmaf(dw, dw, sw);
-      }
-      const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
-      const float cy = L.cg[eiw][t];
-      const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cy));
-      const float pwr = c.rho * table_pw(c, T, veff);
-      float4 l;
-      l.x = (st.TI[p][0] + st.TI[p][1] + st.TI[p][2]) * (1.0f / 3.0f);
-      l.y = fsqrt(su * (1.0f / 9.0f));
-      l.z = fsqrt(sv * (1.0f / 9.0f));
-      l.w = fsqrt(sw * (1.0f / 9.0f));
-      psum += pwr;
-      lsum += (l.x + l.y) + (l.z + l.w);  // loads are non-negative: |.| is the identity
-      if (env_ok) {
-        const size_t oo = yofs + o;
-        if (o_power) o_power[oo] = pwr;
-        if (o_ws) o_ws[oo] = wsp;
-        if (o_wd) o_wd[oo] = wd - adir * (kRad2Deg / 9.0f);
-        if (o_load) reinterpret_cast<float4*>(o_load)[oo] = l;
-      }
-    }
-  }
   if (ea.reward) {
     // r = mean_j(P_j[MW] * 1e3 / ws^3) - load_coef * mean|loads|      (simple_env.py:78-84)
 #pragma unroll
