@@ -416,3 +416,39 @@ def test_shared_wind_pair_table_path_and_its_fallbacks(layouts, monkeypatch):
     w.close()
     _check(out, c_oracle.farm_step_batch(l16["xcoords"], l16["ycoords"], 7.5, 270.0, yaw.astype(np.float64), ModelParams(HH=70.0)))
     _check(out90, c_oracle.farm_step_batch(l16["xcoords"], l16["ycoords"], 7.5, 270.0, yaw.astype(np.float64)))
+
+
+_VARIANTS = [(g, s) for g, smax in ((4, 4), (8, 4), (16, 6), (32, 4), (64, 4)) for s in range(1, smax + 1)]
+
+
+@pytest.mark.parametrize("G,S", _VARIANTS)
+def test_every_kernel_variant_matches_the_oracle(G, S, monkeypatch):
+    """Every (lanes per farm, slots per lane) instantiation — including the ones only large batches pick and the
+    register-capped S <= 3 ones — on a ragged farm that does not fill the variant, on both transverse-pass paths."""
+    import zlib
+
+    from oracle import c_oracle
+    from wfcrl_env_amd.backend import WfStep
+
+    N = min(G * S, 256) - (1 if G * S > 1 else 0)
+    rng = np.random.default_rng(zlib.crc32(f"variant/{G}x{S}".encode()))
+    cols = 8
+    x = (np.arange(N) // cols) * 700.0 + rng.uniform(-60, 60, N)
+    y = (np.arange(N) % cols) * 560.0 + rng.uniform(-60, 60, N)
+    B = 6
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    monkeypatch.setenv("WF_KERNEL_GS", f"{G}x{S}")
+    w = WfStep(x, y, env_batch=B)
+    info = w.kernel_info()
+    assert (info["lanes_per_env"], info["slots_per_lane"]) == (G, S)
+    w.set_wind(9.5, 263.0)
+    shared = w.step(yaw)
+    tab = w.kernel_info()["pair_table"]
+    ws, wd = rng.uniform(6, 12, B), rng.uniform(250, 290, B)
+    w.set_wind(ws, wd)
+    assert w.kernel_info()["pair_table"] == 0
+    per_farm = w.step(yaw)
+    w.close()
+    assert tab in (0, 1)  # the table path exists where its LDS slab fits (wf_kernels.hip: tab_fits)
+    _check(shared, c_oracle.farm_step_batch(x, y, 9.5, 263.0, yaw.astype(np.float64)))
+    _check(per_farm, c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64)))

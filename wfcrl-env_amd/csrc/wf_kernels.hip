@@ -372,7 +372,7 @@ extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double
 // vortex system per farm (MC1 is then irrelevant).
 // WPB: waves per block (4; 8 for the table path so that one staged row serves twice as many farms).
 template <int G, int S, bool MC1, bool TAB, int WPB>
-__global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
+__global__ __launch_bounds__(64 * WPB, (S <= 3) ? 3 : 2) void wf_step_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const float* __restrict__ gy,
     const int* __restrict__ gidx, int geom_stride, const double* __restrict__ ws_in, const double* __restrict__ wd_in,
     int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power, float* __restrict__ o_ws,
@@ -486,6 +486,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
   __syncthreads();
 
   Slots<S> st;
+  // ambient TI exactly as the wake-added-TI candidate evaluates to with no added turbulence (sqrt(0 + amb^2) in
+  // device arithmetic): a no-op update then leaves the three grid columns bit-identical (uniform fast path)
+  const float amb0 = fsqrt(c.amb2);
 #pragma unroll
   for (int p = 0; p < S; ++p) {
 #pragma unroll
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void wf_step_kernel(
 #pragma unroll
     for (int q = 0; q < 6; ++q) st.esq[p][q] = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) st.TI[p][j] = c.amb;
+    for (int j = 0; j < 3; ++j) st.TI[p][j] = amb0;
   }
 
   const int nblk = (N + G - 1) / G;
