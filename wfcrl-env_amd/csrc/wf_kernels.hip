@@ -371,8 +371,18 @@ extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double
 // TAB: the transverse-velocity pass reads the shared-wind pair-coefficient table instead of evaluating the
 // vortex system per farm (MC1 is then irrelevant).
 // WPB: waves per block (4; 8 for the table path so that one staged row serves twice as many farms).
+// Blocks per CU the register allocator is asked to make room for (4-wave blocks: = waves per SIMD).  Instruction
+// throughput grows ~27 % from two to three waves per SIMD (measured); the <= 168-VGPR budget that needs is within
+// reach of the variants with at most three target slots (81 state registers), provided the LDS slab fits thrice.
+template <int G, int S, bool TAB, int WPB>
+constexpr int min_blocks_per_cu() {
+  constexpr size_t lds = sizeof(TableLds) + WPB * sizeof(GeoLds<64 / G, G * S, !TAB>) +
+                         (TAB ? 2 * 4 * WF_PAIR_ROW_FLOATS(G * S) + 4 * G * S : 16);
+  return (S <= 3 && WPB == 4 && 3 * lds <= 160 * 1024) ? 3 : 2;
+}
+
 template <int G, int S, bool MC1, bool TAB, int WPB>
-__global__ __launch_bounds__(64 * WPB, (S <= 3) ? 3 : 2) void wf_step_kernel(
+__global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) void wf_step_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const float* __restrict__ gy,
     const int* __restrict__ gidx, int geom_stride, const double* __restrict__ ws_in, const double* __restrict__ wd_in,
     int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power, float* __restrict__ o_ws,
@@ -559,14 +569,25 @@ __global__ __launch_bounds__(64 * WPB, (S <= 3) ? 3 : 2) void wf_step_kernel(
       for (int p = 0; p < S; ++p) {
         if (p > 0 && p >= live) break;
         const int t = (blk + p) * G + sub;
-        float dx;
-        if constexpr (TAB) dx = (t >= first_i) ? prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DX] : -1.0f;  // un-staged pieces hold stale rows
-        else dx = (float)(L.x[eiw][t] - x_i);
+        // Slot 0 holds the source's own block: its lanes sort out upstream / tied / downstream by the sign of dx.
+        // Slots p >= 1 hold later blocks of the ascending sort: every real turbine there is at or downstream of
+        // the source (dx >= 0), so only the padding beyond N is masked — no dependent read of dx in front of the
+        // branch.
+        float dx = 0.0f;
+        bool act;
+        if (p == 0) {
+          if constexpr (TAB) dx = (t >= first_i) ? prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DX] : -1.0f;  // un-staged pieces hold stale rows
+          else dx = (float)(L.x[eiw][t] - x_i);
+          act = dx >= 0.0f;
+        } else {
+          if constexpr (!TAB) dx = (float)(L.x[eiw][t] - x_i);
+          act = t < N;
+        }
 #if defined(WF_ABLATE) && (WF_ABLATE & 1)
-        if (dx >= 0.0f) { st.V[p][0] += Gt * dx; st.W[p][0] += Gb + Gwr; }
+        if (act) { st.V[p][0] += Gt * dx; st.W[p][0] += Gb + Gwr; }
         if (false) {
 #else
-        if (dx >= 0.0f) {
+        if (act) {
 #endif
          if constexpr (TAB) {
           // geometry-only coefficients of this (source, target) pair from the staged row: one float4
@@ -726,13 +747,16 @@ __global__ __launch_bounds__(64 * WPB, (S <= 3) ? 3 : 2) void wf_step_kernel(
         float4 ex = {0.0f, 0.0f, 0.0f, 0.0f};  // {dx, dy, tipow, -}
         if constexpr (TAB) {
           ex = *reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DX]);
-          dx = (t >= first_i) ? ex.x : -1.0f;  // un-staged pieces hold stale rows
+          dx = (p > 0 || t >= first_i) ? ex.x : -1.0f;  // un-staged pieces hold stale rows (slot 0 only)
         } else dx = (float)(L.x[eiw][t] - x_i);
+        // slots p >= 1: all real turbines have dx >= 0 (see pass 1), and at 0 <= dx <= 0.1 (ties) everything below is
+        // an exact no-op: amp_on = 0 zeroes the deficits and the TI candidate is the ambient value
+        const bool act = (p == 0) ? (dx > 0.0f) : (t < N);
 #if defined(WF_ABLATE) && (WF_ABLATE & 2)
-        if (dx > 0.0f) { st.esq[p][0] += sc.sy0v * cc[0].x0v * cc[1].kyv * cc[2].pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * cc[2].d0 * sc.snw * sc.kdef; }
+        if (act) { st.esq[p][0] += sc.sy0v * cc[0].x0v * cc[1].kyv * cc[2].pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * cc[2].d0 * sc.snw * sc.kdef; }
         if (false) {
 #else
-        if (dx > 0.0f) {
+        if (act) {
 #endif
           float dy;
           if constexpr (TAB) dy = ex.y;
