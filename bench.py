@@ -55,10 +55,12 @@ def effective_cpus() -> int:
 
 def lane_ops_per_farm_step(N: int, pair_table: bool) -> float:
     """Analytic VALU work model of the kernel, in plain-fp32-issue-slot equivalents (a transcendental
-    = 2.5 slots, its measured issue cost): per (source, target) pair with dx >= 0 — transverse pass 421 on the fly or
-    85 with the shared-wind pair table, deflection/deficit/SOSFS/TI pass 169 — plus 460 per source."""
+    = 2.5 slots, its measured issue cost), counted from the ISA of the final kernel: per (source, target) pair with
+    dx >= 0 — transverse pass 421 on the fly or 55 with the shared-wind pair table, deflection/deficit/SOSFS/TI pass
+    126 — plus 350 per source.  Useful work only: lanes idling on the triangle and the per-group redundancy of the
+    source phase are not credited."""
     pairs = N * (N + 1) / 2
-    return pairs * ((85.0 if pair_table else 421.0) + 169.0) + N * 460.0
+    return pairs * ((55.0 if pair_table else 421.0) + 126.0) + N * 350.0
 
 
 def main():

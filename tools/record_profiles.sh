@@ -1,0 +1,21 @@
+#!/bin/bash
+# GPU box: everything profiles/ cites for one kernel version.  Usage: tools/record_profiles.sh <tag>
+#   bench line (with cpu_baseline), the same command under rocprofv3 --kernel-trace --stats, PMC counters in
+#   separate passes (tools/run_pmc.sh), every BASELINE config, parity statistics (tools/gpu_check.py).
+tag=$1
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag
+mkdir -p $O
+cd $R
+python3 bench.py > $O/bench.json 2> $O/bench.err
+python3 tools/all_configs.py 40 > $O/all_configs.txt 2>&1
+python3 tools/gpu_check.py > $O/parity_stats.txt 2>&1
+bash tools/run_pmc.sh $tag > /dev/null 2>&1
+python3 tools/parse_pmc.py $tag > $O/pmc_cfg4.json
+rm -rf $R/gpurun_out/pmc_$tag
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
+cd $R
+f=$(find $O/rocprof -name "*kernel_stats.csv" | head -1)
+python3 tools/summarize_rocprof.py $f $O/kernel_stats_bench_cfg4.csv > /dev/null
+rm -rf $O/rocprof
+ls -la $O
