@@ -1,0 +1,25 @@
+import os, json, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+os.environ["WF_KERNEL_GS"] = sys.argv[1] if len(sys.argv) > 1 else "4x4"
+from wfcrl_env_amd.backend import WfStep
+from oracle import c_oracle
+L = json.load(open("wfcrl-env_amd/environments/layouts.json"))
+for name in ["Turb16_Row5_", "Turb6_Row2_"]:
+    l = L[name]; N = l["num_turbines"]
+    if name == "Turb6_Row2_": os.environ["WF_KERNEL_GS"] = "4x2"
+    rng = np.random.default_rng(5)
+    B = 32
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    for mode in ["shared", "perenv"]:
+        w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+        if mode == "shared": w.set_wind(8.0, 270.0)
+        else: w.set_wind(np.full(B, 8.0), np.full(B, 270.0))
+        out = w.step(yaw); info = w.kernel_info(); w.close()
+        out = {k: v.cpu().numpy() if hasattr(v, "cpu") else v for k, v in out.items()}
+        ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], 8.0, 270.0, yaw.astype(np.float64))
+        print(name, mode, info["lanes_per_env"], info["slots_per_lane"], info["pair_table"],
+              "power", np.abs(out["power"] / np.maximum(ref["power"], 1e3) - ref["power"] / np.maximum(ref["power"], 1e3)).max(),
+              "wd", np.abs(out["wind_direction"] - ref["wind_direction"]).max(),
+              "load", np.abs(out["load"] - ref["load"]).max(axis=(0, 1)))
+    print(sorted(zip(l["xcoords"], l["ycoords"]))[:8])

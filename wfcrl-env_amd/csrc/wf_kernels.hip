@@ -512,6 +512,81 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
     for (int j = 0; j < 3; ++j) st.TI[p][j] = amb0;
   }
 
+  // ---- transverse velocities of one source on the targets of register slot p [A.3-4] -------------------
+  // table path: geometry-only coefficients of the (source, target) pair, one float4 {aV, bV, aW, bW} per grid
+  // point, a grid column (three 16-byte reads) at a time
+  auto apply_tab = [&](int p, const float4* pr, float Gy, float Gwr) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float4 cf[3] = {pr[3 * j], pr[3 * j + 1], pr[3 * j + 2]};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int q = j * 3 + k;
+        st.V[p][q] = fmaf(Gwr, cf[k].y, fmaf(Gy, cf[k].x, st.V[p][q]));
+        const float ww = fmaf(Gwr, cf[k].w, Gy * cf[k].z);
+        st.W[p][q] += fmaxf(ww, 0.0f);  // W[W<0] = 0, quirk (5)
+      }
+    }
+  };
+  // on the fly (a wind condition per farm)
+  auto apply_fly = [&](int p, float dx, float dy, float Gt, float Gb, float Gwr) {
+    float dec[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dec[k] = frcp(fmaf(c.decay_a[k], dx, 1.0f));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float yL = dy + c.yoff[j];
+      const float yL2 = yL * yL;
+      const float Ey = fexp2(-yL2 * c.exp_c);
+      // core/r of the 7 distinct real and 7 distinct mirror vortex offsets, accumulated on the fly into
+      // the row sums  A_k = sum Gamma z core/r  (-> V)  and  B_k = sum Gamma core/r  (-> W):
+      //   class index mi = m + 3;  real:   top k = mi (mi<=2), bottom k = mi-4 (mi>=4), rotation k = mi-2
+      //                            mirror: top k = mi-4 (mi>=4), bottom k = mi (mi<=2), rotation k = mi-2
+      float A[3] = {0.0f, 0.0f, 0.0f}, Bw[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int mi = 0; mi < 7; ++mi) {
+        const float tr = fmaf(-Ey, c.ez[mi], 1.0f) * frcp(yL2 + c.zc2[mi]);
+        const float pr = c.zc[mi] * tr;
+        float tm = frcp(yL2 + c.zm2[mi]);
+        if (mi == 0 || !MC1) tm *= fmaf(-Ey, c.ezm[mi], 1.0f);  // compile-time: see mirror_core_n
+        const float pm = c.zm[mi] * tm;
+        if (mi <= 2) {
+          A[mi] = fmaf(Gt, pr, A[mi]);   Bw[mi] = fmaf(Gt, tr, Bw[mi]);      // real top
+          A[mi] = fmaf(-Gb, pm, A[mi]);  Bw[mi] = fmaf(-Gb, tm, Bw[mi]);     // mirror bottom
+        }
+        if (mi >= 4) {
+          A[mi - 4] = fmaf(Gb, pr, A[mi - 4]);   Bw[mi - 4] = fmaf(Gb, tr, Bw[mi - 4]);   // real bottom
+          A[mi - 4] = fmaf(-Gt, pm, A[mi - 4]);  Bw[mi - 4] = fmaf(-Gt, tm, Bw[mi - 4]);  // mirror top
+        }
+        if (mi >= 2 && mi <= 4) {
+          A[mi - 2] = fmaf(Gwr, pr - pm, A[mi - 2]);  // rotation, real - mirror
+          Bw[mi - 2] = fmaf(Gwr, tr - tm, Bw[mi - 2]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        st.V[p][j * 3 + k] = fmaf(A[k], dec[k], st.V[p][j * 3 + k]);
+        st.W[p][j * 3 + k] += fmaxf(-yL * Bw[k] * dec[k], 0.0f);  // W[W<0] = 0, quirk (5)
+      }
+    }
+  };
+  // circulations (over 2 pi) of source i from the sum over its rotor grid of u^3 [A.3-1, A.3-4]
+  auto circulations = [&](float m3, int i, float& Gt, float& Gb, float& Gwr, float& Gy, float& ubar, float& ct,
+                          float& a, float& gt, float& gb) {
+    ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
+    const float cg = L.cg[eiw][i], sg = L.sg[eiw][i];
+    ct = table_ct(c, T, ubar) * cg;
+    const float sq1 = fsqrt(1.0f - ct * cg);
+    a = 0.5f * ct * frcp(1.0f + sq1);  // == 0.5/cg*(1 - sqrt(1 - ct*cg))
+    Gwr = c.gam_wr * (a - a * a) * ubar;
+    gt = c.gam_top * ws * ct;
+    gb = c.gam_bot * ws * ct;
+    const float scg = sg * cg;  // commanded yaw
+    Gt = scg * gt;
+    Gb = -scg * gb;
+    Gy = scg * ct * ws;  // table path: Gt = gam_top*Gy, Gb = -gam_bot*Gy folded into the coefficients
+  };
+
   const int nblk = (N + G - 1) / G;
   float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
   // Register slot p holds turbine block blk + p: once a block's own sources are done nothing downstream in the
@@ -551,17 +626,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const float yaw_i = L.yaw[eiw][i];
 
       // ---- B. source constants, part 1 [A.3-1 .. A.3-4] ------------------------------------
-      const float ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
+      float ubar, ct, a, Gwr, gt, gb, Gt, Gb, Gy;
+      circulations(m3, i, Gt, Gb, Gwr, Gy, ubar, ct, a, gt, gb);
       const float cg = L.cg[eiw][i], sg = L.sg[eiw][i];
-      const float ct = table_ct(c, T, ubar) * cg;
-      const float sq1 = fsqrt(1.0f - ct * cg);
-      const float a = 0.5f * ct * frcp(1.0f + sq1);  // == 0.5/cg*(1 - sqrt(1 - ct*cg))
-      const float Gwr = c.gam_wr * (a - a * a) * ubar;
-      const float gt = c.gam_top * ws * ct, gb = c.gam_bot * ws * ct;
-      // transverse circulations / (2 pi), commanded yaw
-      const float scg = sg * cg;
-      const float Gt = scg * gt, Gb = -scg * gb;
-      const float Gy = scg * ct * ws;  // table path: Gt = gam_top*Gy, Gb = -gam_bot*Gy folded into the coefficients
 
       // ---- C. pass 1: transverse velocities on every target at or downstream of the source --
       float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
@@ -590,61 +657,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         if (act) {
 #endif
          if constexpr (TAB) {
-          // geometry-only coefficients of this (source, target) pair from the staged row: one float4
-          // {aV, bV, aW, bW} per grid point, a grid column (three 16-byte reads) at a time
-          const float4* pr = reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]);
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const float4 cf[3] = {pr[3 * j], pr[3 * j + 1], pr[3 * j + 2]};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const int q = j * 3 + k;
-              st.V[p][q] = fmaf(Gwr, cf[k].y, fmaf(Gy, cf[k].x, st.V[p][q]));
-              const float ww = fmaf(Gwr, cf[k].w, Gy * cf[k].z);
-              st.W[p][q] += fmaxf(ww, 0.0f);  // W[W<0] = 0, quirk (5)
-            }
-          }
+          apply_tab(p, reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]), Gy, Gwr);
          } else {
-          const float dy = L.y[eiw][t] - y_i;
-          float dec[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) dec[k] = frcp(fmaf(c.decay_a[k], dx, 1.0f));
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const float yL = dy + c.yoff[j];
-            const float yL2 = yL * yL;
-            const float Ey = fexp2(-yL2 * c.exp_c);
-            // core/r of the 7 distinct real and 7 distinct mirror vortex offsets, accumulated on the fly into
-            // the row sums  A_k = sum Gamma z core/r  (-> V)  and  B_k = sum Gamma core/r  (-> W):
-            //   class index mi = m + 3;  real:   top k = mi (mi<=2), bottom k = mi-4 (mi>=4), rotation k = mi-2
-            //                            mirror: top k = mi-4 (mi>=4), bottom k = mi (mi<=2), rotation k = mi-2
-            float A[3] = {0.0f, 0.0f, 0.0f}, Bw[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int mi = 0; mi < 7; ++mi) {
-              const float tr = fmaf(-Ey, c.ez[mi], 1.0f) * frcp(yL2 + c.zc2[mi]);
-              const float pr = c.zc[mi] * tr;
-              float tm = frcp(yL2 + c.zm2[mi]);
-              if (mi == 0 || !MC1) tm *= fmaf(-Ey, c.ezm[mi], 1.0f);  // compile-time: see mirror_core_n
-              const float pm = c.zm[mi] * tm;
-              if (mi <= 2) {
-                A[mi] = fmaf(Gt, pr, A[mi]);   Bw[mi] = fmaf(Gt, tr, Bw[mi]);      // real top
-                A[mi] = fmaf(-Gb, pm, A[mi]);  Bw[mi] = fmaf(-Gb, tm, Bw[mi]);     // mirror bottom
-              }
-              if (mi >= 4) {
-                A[mi - 4] = fmaf(Gb, pr, A[mi - 4]);   Bw[mi - 4] = fmaf(Gb, tr, Bw[mi - 4]);   // real bottom
-                A[mi - 4] = fmaf(-Gt, pm, A[mi - 4]);  Bw[mi - 4] = fmaf(-Gt, tm, Bw[mi - 4]);  // mirror top
-              }
-              if (mi >= 2 && mi <= 4) {
-                A[mi - 2] = fmaf(Gwr, pr - pm, A[mi - 2]);  // rotation, real - mirror
-                Bw[mi - 2] = fmaf(Gwr, tr - tm, Bw[mi - 2]);
-              }
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              st.V[p][j * 3 + k] = fmaf(A[k], dec[k], st.V[p][j * 3 + k]);
-              st.W[p][j * 3 + k] += fmaxf(-yL * Bw[k] * dec[k], 0.0f);  // W[W<0] = 0, quirk (5)
-            }
-          }
+          apply_fly(p, dx, L.y[eiw][t] - y_i, Gt, Gb, Gwr);
          }
         }
         if (p == 0) {
@@ -830,6 +845,54 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       if constexpr (TAB) __syncthreads();  // next row has landed; everyone is done with the current one
 #endif
     }  // li
+
+    // ---- x' ties across the block boundary ------------------------------------------------------
+    // dx = 0 counts as downstream in the transverse pass [A.3-4], in both directions of a tie.  Sources of later
+    // blocks that tie with turbines of this block therefore still owe them their transverse velocities (they change
+    // nothing but these turbines' wind-direction / std v / std w outputs: the turbines have acted already).  Such a
+    // source's circulations depend on its wake sum only, which is final (everything between the tied turbines is
+    // tied as well, and the deficit pass is a no-op at dx = 0), so they are evaluated ahead of the source's turn.
+    // Exact ties are what axis-aligned grid layouts have at wd = 270.
+    if (blk + 1 < nblk) {
+      const int t0 = blk * G + sub;
+      for (int k = 0; (blk + 1) * G + k < N; ++k) {
+        const int i2 = (blk + 1) * G + k;
+        const int p2 = 1 + k / G, l2 = k & (G - 1);  // register slot and lane (in the group) of that source
+        float dx0;
+        bool tied;
+        if constexpr (TAB) {
+          tied = __builtin_amdgcn_readfirstlane(pfirst[i2]) < (blk + 1) * G;
+          dx0 = 0.0f;
+        } else {
+          dx0 = (float)(L.x[eiw][t0] - L.x[eiw][i2]);  // <= 0 in the ascending sort; padding is -inf
+          tied = __any(dx0 >= 0.0f);
+        }
+        if (!tied) break;  // ties are contiguous in the sort
+        float fe = 0.0f, fc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float e0 = st.esq[S > 1 ? 1 : 0][2 * j], e1 = st.esq[S > 1 ? 1 : 0][2 * j + 1];
+#pragma unroll
+          for (int p = 2; p < S; ++p) {
+            e0 = (p2 == p) ? st.esq[p][2 * j] : e0;
+            e1 = (p2 == p) ? st.esq[p][2 * j + 1] : e1;
+          }
+          const float ue = 1.0f - fsqrt(e0), uc = 1.0f - fsqrt(e1);
+          fe = fmaf(ue * ue, ue, fe);
+          fc = fmaf(uc * uc, uc, fc);
+        }
+        const float m3 = __shfl(fmaf(U02c, fe, U1c * fc), gbase + l2);
+        float ubar, ct, a, Gwr, gt, gb, Gt, Gb, Gy;
+        circulations(m3, i2, Gt, Gb, Gwr, Gy, ubar, ct, a, gt, gb);
+        if constexpr (TAB) {
+          // the source's table row is not staged yet: its (source, target) record comes straight from L2
+          const float* rec = pair_tab + (size_t)i2 * WF_PAIR_ROW_FLOATS(NP) + (size_t)t0 * WF_PAIR_STRIDE;
+          if (rec[WF_PAIR_DX] >= 0.0f) apply_tab(0, reinterpret_cast<const float4*>(rec), Gy, Gwr);
+        } else {
+          if (dx0 >= 0.0f) apply_fly(0, dx0, L.y[eiw][t0] - L.y[eiw][i2], Gt, Gb, Gwr);
+        }
+      }
+    }
 
     // ---- outputs [A.4] of block blk (slot 0) ---------------------------------------------------
     {
