@@ -63,11 +63,17 @@ def test_aec_example_loop_on_gpu():
     assert np.isfinite(float(np.ravel(r["turbine_1"])[0]))
 
 
-@pytest.mark.parametrize("name,discrete", [("Turb6_Row2_", False), ("Ablaincourt_", False), ("Turb16_Row5_", True)])
-def test_vec_env_matches_B_reference_envs(layouts, name, discrete):
+@pytest.mark.parametrize("name,discrete,gs", [("Turb6_Row2_", False, None), ("Ablaincourt_", False, None),
+                                             ("Turb16_Row5_", True, None),
+                                             # the multi-slot kernel variants only large batches pick by themselves
+                                             ("Turb16_Row5_", False, "4x4"), ("Turb_TCRWP_", True, "8x4")])
+def test_vec_env_matches_B_reference_envs(layouts, name, discrete, gs, monkeypatch):
     import torch
 
     from wfcrl_env_amd import environments as envs
+
+    if gs:
+        monkeypatch.setenv("WF_KERNEL_GS", gs)
 
     B, T = 12, 26
     N = layouts[name]["num_turbines"]
@@ -75,6 +81,9 @@ def test_vec_env_matches_B_reference_envs(layouts, name, discrete):
     venv = envs.make(name + "Floris", controls=dict(controls), env_batch=B, max_num_steps=T,
                      continuous_control=not discrete, load_coef=0.25)
     obs = venv.reset(seed=77)
+    if gs:
+        k = venv.fi.kernel_info()
+        assert f'{k["lanes_per_env"]}x{k["slots_per_lane"]}' == gs
     fw = obs["freewind_measurements"].cpu().numpy()
     # seeded batch draw order: weibull x B, then normal x B
     rng = np.random.default_rng(77)
