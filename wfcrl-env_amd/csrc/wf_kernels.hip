@@ -434,15 +434,17 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   const int env = env_ok ? env_raw : (B - 1);
   const int N = c.N;
 
-  const float ws = (float)ws_in[(size_t)env * wind_stride];
+  // table path = one wind for the whole batch: everything derived from it is wave-uniform and lives in SGPRs
+  auto uni = [](float v) { return TAB ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))) : v; };
+  const float ws = uni((float)ws_in[(size_t)env * wind_stride]);
   const double wd_d = fmod(wd_in[(size_t)env * wind_stride], 360.0);
-  const float wd = (float)(wd_d < 0.0 ? wd_d + 360.0 : wd_d);
-  const float Ui[3] = {ws * c.shearf[0], ws * c.shearf[1], ws * c.shearf[2]};
+  const float wd = uni((float)(wd_d < 0.0 ? wd_d + 360.0 : wd_d));
+  const float Ui[3] = {uni(ws * c.shearf[0]), uni(ws * c.shearf[1]), uni(ws * c.shearf[2])};
   const float offk = c.off[2] * kGs;
-  const float U02c = Ui[0] * Ui[0] * Ui[0] + Ui[2] * Ui[2] * Ui[2], U1c = Ui[1] * Ui[1] * Ui[1];
+  const float U02c = uni(Ui[0] * Ui[0] * Ui[0] + Ui[2] * Ui[2] * Ui[2]), U1c = uni(Ui[1] * Ui[1] * Ui[1]);
   // overlap test "deficit * Uinit_k > threshold" [A.3-8] as a threshold on the deficit itself
-  const float thrB[3] = {__fdiv_rn(c.overlap_thr, Ui[0]) * kBig, __fdiv_rn(c.overlap_thr, Ui[1]) * kBig,
-                         __fdiv_rn(c.overlap_thr, Ui[2]) * kBig};
+  const float thrB[3] = {uni(__fdiv_rn(c.overlap_thr, Ui[0]) * kBig), uni(__fdiv_rn(c.overlap_thr, Ui[1]) * kBig),
+                         uni(__fdiv_rn(c.overlap_thr, Ui[2]) * kBig)};
 
   const size_t gofs = (size_t)env * geom_stride;
   const size_t yofs = (size_t)env * N;
