@@ -378,7 +378,7 @@ template <int G, int S, bool TAB, int WPB>
 constexpr int min_blocks_per_cu() {
   constexpr size_t lds = sizeof(TableLds) + WPB * sizeof(GeoLds<64 / G, G * S, !TAB>) +
                          (TAB ? 2 * 4 * WF_PAIR_ROW_FLOATS(G * S) + 4 * G * S : 16);
-  return (S <= 3 && WPB == 4 && 3 * lds <= 160 * 1024) ? 3 : 2;
+  return ((S <= 3 && 3 * (4 / WPB) * lds <= 160 * 1024) ? 3 : 2) * (4 / WPB);  // WPB is 4, or 2 in staging experiments
 }
 
 template <int G, int S, bool MC1, bool TAB, int WPB>
