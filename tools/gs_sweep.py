@@ -1,3 +1,5 @@
+"""GPU box: time alternative (lanes per farm, slots per lane) variants of the step kernel on the same layout
+(WF_KERNEL_GS override), 65536 farms, shared wind — the occupancy-vs-instruction-count evidence of DESIGN.md §3/§4."""
 import os, subprocess, sys
 code = r'''
 import os, sys, json, torch
