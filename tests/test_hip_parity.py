@@ -454,18 +454,24 @@ def test_every_kernel_variant_matches_the_oracle(G, S, monkeypatch):
     _check(per_farm, c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64)))
 
 
+@pytest.mark.parametrize("wdir", [270.0, 90.0, 0.0])
 @pytest.mark.parametrize("gs,shape", [("4x4", (5, 3)), ("4x3", (3, 4)), ("8x2", (4, 4)), ("8x4", (4, 8)), ("16x2", (2, 12)),
                                       ("4x4", (1, 15)), ("16x5", (10, 8))])
-def test_exact_x_ties_across_kernel_blocks(gs, shape, monkeypatch):
+def test_exact_x_ties_across_kernel_blocks(gs, shape, wdir, monkeypatch):
     """Axis-aligned grids at wd = 270 have exact x' ties: tied turbines exchange transverse
     velocities in both directions, also when the tie group straddles two (or more) lane-group blocks of the kernel,
     whose earlier block has been written out by the time the later sources run.  Both transverse-pass paths."""
     from oracle import c_oracle
     from wfcrl_env_amd.backend import WfStep
 
+    # 5 D x 4 D grid: besides the ties, every third column sits exactly 15 D downstream — ON the reach threshold of the
+    # wake-added TI, which FLORIS tests as x_t <= x_i + 15 D in float64: at wd = 90 / 0 the rounding of the rotation
+    # (sin(pi) = 1.2e-16) decides it, and the kernel has to decide the same way
     ncol, nrow = shape  # ncol columns along the wind, nrow tied turbines per column
     x = np.repeat(np.arange(ncol) * 630.0, nrow)
     y = np.tile(np.arange(nrow) * 504.0, ncol)
+    if wdir == 0.0:
+        x, y = y, x
     N = x.size
     rng = np.random.default_rng(N * 131 + ncol)
     B = 5
@@ -474,11 +480,11 @@ def test_exact_x_ties_across_kernel_blocks(gs, shape, monkeypatch):
     w = WfStep(x, y, env_batch=B)
     info = w.kernel_info()
     assert f'{info["lanes_per_env"]}x{info["slots_per_lane"]}' == gs
-    w.set_wind(8.0, 270.0)
+    w.set_wind(8.0, wdir)
     shared = w.step(yaw)
-    w.set_wind(np.full(B, 8.0), np.full(B, 270.0))
+    w.set_wind(np.full(B, 8.0), np.full(B, wdir))
     per_farm = w.step(yaw)
     w.close()
-    ref = c_oracle.farm_step_batch(x, y, 8.0, 270.0, yaw.astype(np.float64))
+    ref = c_oracle.farm_step_batch(x, y, 8.0, wdir, yaw.astype(np.float64))
     _check(shared, ref)
     _check(per_farm, ref)

@@ -256,7 +256,7 @@ int build_consts(wf_handle* h) {
   c.ch_ai = (float)m.ch_ai; c.ch_down = (float)m.ch_downstream;
   c.amb = (float)m.ambient_ti; c.amb2 = (float)(m.ambient_ti * m.ambient_ti);
   c.gch_gain = (float)m.gch_gain; c.overlap_thr = (float)m.overlap_thresh;
-  c.twoD = (float)(2.0 * D); c.fifteenD = (float)(15.0 * D);
+  c.twoD = (float)(2.0 * D); c.fifteenD = (float)(15.0 * D); c.fifteenD_d = 15.0 * D;
   c.rho = (float)m.ref_density; c.pw = (float)(m.pP / 3.0);
   c.dens_f = (float)std::cbrt(m.air_density / m.ref_density);
 
@@ -320,6 +320,7 @@ int pair_table(wf_handle* h, const float** out) {
     const double off[3] = {-D / 4, 0.0, D / 4};
     double uinf = 0;
     for (int k = 0; k < 3; ++k) uinf += std::pow((HH + off[k]) / HH, m.shear) / 3.0;
+    pc.fifteenD = 15.0 * D;
     pc.gam_top = (1.0 / 16.0) * D * std::pow((HH + D / 2) / HH, m.shear) * uinf;  // (1/2pi)(pi/8) D vel_top uinf
     pc.gam_bot = (1.0 / 16.0) * D * std::pow((HH - D / 2) / HH, m.shear) * uinf;
     for (int k = 0; k < 3; ++k) {

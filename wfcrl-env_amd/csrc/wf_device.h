@@ -44,6 +44,9 @@ struct WfConsts {
   int n_table;
   float bucket_h_inv, bucket_x0;
   int max_probe;
+  // 15 D in float64: the reach of the wake-added TI is tested as FLORIS does, x_t <= x_i + 15 D on the float64
+  // coordinates (on regular grids whole multiples of D sit on this threshold and the rounding of the rotation decides)
+  double fifteenD_d;
 };
 
 // Power/thrust table in global memory, staged to LDS by each block.
@@ -83,7 +86,8 @@ struct WfEnvArgs {
 // Layout per pair (WF_PAIR_STRIDE = 44 floats = 11 float4; 44 words is a conflict-free LDS stride for 16-byte reads
 // of consecutive lanes): grid point (j,k) is the float4 {aV, bV, aW, bW} at [(3j+k)*4 .. +3]; then
 //   [36] dx = x'_t - x'_i (float64 difference, rounded once; < 0: target upstream, -1 for padding targets)
-//   [37] dy = y'_t - y'_i        [38] (dx'/D)^ch_downstream of the Crespo-Hernandez term [A.3-8]      [39..43] 0
+//   [37] dy = y'_t - y'_i        [38] (dx'/D)^ch_downstream of the Crespo-Hernandez term [A.3-8], 0 where
+//   dx > 15 D in float64 (out of reach of the wake-added TI)                                           [39..43] 0
 // A source's row (all targets) is padded to a multiple of 1 KiB: the step kernel stages it into LDS with 1-KiB
 // global_load_lds wave-instructions.
 #define WF_PAIR_STRIDE 44
@@ -101,4 +105,5 @@ struct WfPairConsts {
   double decay_a[3];
   double ch_down;
   double gam_top, gam_bot;  // tip-vortex circulations per unit (sin cos Ct ws), over 2 pi  [A.3-1]
+  double fifteenD;          // reach of the wake-added TI [A.3-8]: beyond it the record's TI power is stored as 0
 };

@@ -349,7 +349,9 @@ __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __rest
   }
   const double dxp = (dx > 0.1) ? dx : dx + 1.0;  // Crespo-Hernandez distance with FLORIS' masks [A.3-8]
   for (int q = 39; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
-  o[WF_PAIR_TIPOW] = (float)pow(dxp / pc.D, pc.ch_down);
+  // reach of the wake-added TI exactly as FLORIS tests it:  x_t <= x_i + 15 D  in float64 (on regular grids whole
+  // multiples of D sit on this threshold and the rounding of the rotation decides)
+  o[WF_PAIR_TIPOW] = (gx[t] <= gx[i] + pc.fifteenD) ? (float)pow(dxp / pc.D, pc.ch_down) : 0.0f;
   o[WF_PAIR_DX] = (float)dx;
   o[WF_PAIR_DY] = (float)dy;
 }
@@ -766,6 +768,10 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           ex = *reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DX]);
           dx = (p > 0 || t >= first_i) ? ex.x : -1.0f;  // un-staged pieces hold stale rows (slot 0 only)
         } else dx = (float)(L.x[eiw][t] - x_i);
+        // within reach of the wake-added TI: decided on the float64 distance (table path: stored as tipow = 0)
+        bool in15;
+        if constexpr (TAB) in15 = ex.z > 0.0f;
+        else in15 = L.x[eiw][t] <= x_i + c.fifteenD_d;  // FLORIS' own form of the test, float64
         // slots p >= 1: all real turbines have dx >= 0 (see pass 1), and at 0 <= dx <= 0.1 (ties) everything below is
         // an exact no-op: amp_on = 0 zeroes the deficits and the TI candidate is the ambient value
         const bool act = (p == 0) ? (dx > 0.0f) : (t < N);
@@ -820,7 +826,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           }
           // Wake-added TI reaches a target only within 15 D downstream and 2 D laterally [A.3-8]; elsewhere the
           // candidate is the ambient value, which never exceeds the running maximum: skipped when no lane needs it.
-          if (!__any((dx <= c.fifteenD) && (fabsf(dy) < c.twoD + c.off[2]))) continue;
+          if (!__any(in15 && (fabsf(dy) < c.twoD + c.off[2]))) continue;
           float cnt = 0.0f;  // grid points with deficit * Uinit_k > threshold
 #pragma unroll
           for (int j = 0; j < 3; ++j) cnt += (above(e0[j], thrB[0]) + above(e1[j], thrB[1])) + above(e0[j], thrB[2]);
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
             tipow = fexp2(c.ch_down * flog2(dxp * c.invD));
           }
           const float ti = ch_pref * tipow;
-          const float tia = (dx <= c.fifteenD) ? ti * (cnt * (1.0f / 9.0f)) : 0.0f;
+          const float tia = in15 ? ti * (cnt * (1.0f / 9.0f)) : 0.0f;
           const float cand = fsqrt(fmaf(tia, tia, c.amb2));
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
