@@ -488,3 +488,17 @@ def test_exact_x_ties_across_kernel_blocks(gs, shape, wdir, monkeypatch):
     ref = c_oracle.farm_step_batch(x, y, 8.0, wdir, yaw.astype(np.float64))
     _check(shared, ref)
     _check(per_farm, ref)
+
+
+def test_randomised_parity_fuzz_sample():
+    """A fixed-seed sample of tools/fuzz_parity.py (random regular / jittered / holed grids and clouds, axis-aligned and
+    random wind directions, every kernel variant, shared and per-farm wind, default and non-default models): no run
+    outside the parity tolerances except the bounded signature of a threshold flip, and few of those."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    nflip, nbad = fz.run(120, 2024)
+    assert nbad == 0
+    assert nflip <= 3

@@ -60,13 +60,12 @@ def classify(w):
     return "BAD"
 
 
-def main():
+def run(n_cases, seed, only=-1):
     from oracle import c_oracle
+    from oracle.floris_gch_numpy import ModelParams
     from wfcrl_env_amd.backend import WfStep
 
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    only = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # replay one case of the sequence, verbosely
+    rng = np.random.default_rng(seed)  # only >= 0: replay one case of the sequence, verbosely
     nbad = nflip = 0
     for case in range(n_cases):
         x, y = make_layout(rng)
@@ -78,9 +77,20 @@ def main():
         yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
         wd0 = float(rng.choice([0.0, 90.0, 180.0, 270.0, 360.0, rng.uniform(0, 360), rng.uniform(250, 290)]))
         ws0 = float(rng.uniform(4, 20))
+        # every fourth case: a non-default model (low hub = general mirror cores, other D: 15 D no longer an integer
+        # number of grid steps, other ambient TI / shear / deflection offsets)
+        model, mp = {}, None
+        if rng.random() < 0.25:
+            D = float(rng.choice([126.0, 100.5, 150.0]))
+            model = dict(rotor_diameter=D, hub_height=float(rng.choice([0.56, 0.714, 0.9]) * D),
+                         ambient_ti=float(rng.choice([0.06, 0.1])), shear=float(rng.choice([0.12, 0.0, 0.2])),
+                         ad=float(rng.choice([0.0, 0.01])), bd=float(rng.choice([0.0, -0.002])))
+            mp = ModelParams(D=model["rotor_diameter"], HH=model["hub_height"], ambient_ti=model["ambient_ti"],
+                             shear=model["shear"], ad=model["ad"], bd=model["bd"])
+            x, y = x * (D / 126.0), y * (D / 126.0)  # keeps the grids on the thresholds
         run = only < 0 or case == only
         if run:
-            w = WfStep(x, y, env_batch=B)
+            w = WfStep(x, y, env_batch=B, model=dict(model) if model else None)
             info = w.kernel_info()
             assert (info["lanes_per_env"], info["slots_per_lane"]) == (G, S)
         for mode in ("shared", "per_farm"):
@@ -93,13 +103,13 @@ def main():
                 continue
             w.set_wind(ws if mode == "per_farm" else ws0, wd if mode == "per_farm" else wd0)
             got = w.step(yaw)
-            ref = c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64))
+            ref = c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64), mp) if mp else c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64))
             r = worst(got, ref)
             k = classify(r)
             nflip += k == "flip"
             if k != "ok":
                 nbad += k == "BAD"
-                print(k, dict(case=case, N=N, G=G, S=S, B=B, mode=mode, wd0=wd0, ws0=ws0,
+                print(k, dict(case=case, N=N, G=G, S=S, B=B, mode=mode, wd0=wd0, ws0=ws0, model=model,
                               table=w.kernel_info()["pair_table"]), r, flush=True)
             if only >= 0:
                 np.set_printoptions(linewidth=220, precision=5, suppress=True)
@@ -110,9 +120,12 @@ def main():
                       "\ngot ws", got["wind_speed"][b], "\nref ws", ref["wind_speed"][b], "\ngot TI", got["load"][b, :, 0], "\nref TI", ref["load"][b, :, 0])
         if run:
             w.close()
+    os.environ.pop("WF_KERNEL_GS", None)
     print(f"fuzz: {n_cases} cases x 2 wind modes: {nflip} threshold flips, {nbad} violations")
-    sys.exit(1 if nbad else 0)
+    return nflip, nbad
 
 
 if __name__ == "__main__":
-    main()
+    a = sys.argv
+    _, bad = run(int(a[1]) if len(a) > 1 else 200, int(a[2]) if len(a) > 2 else 1, int(a[3]) if len(a) > 3 else -1)
+    sys.exit(1 if bad else 0)
