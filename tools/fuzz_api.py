@@ -1,0 +1,158 @@
+"""GPU box: randomised fuzz of the handle's state machine — long random sequences of wf_set_layout / wf_set_batch /
+wf_set_model / wf_set_wind (shared, per farm, device pointers) / wf_wind_sample / wf_wind_series(+_step) /
+wf_env_reset interleaved with wf_step (host and device buffers) and wf_env_step, every result checked against the
+float64 oracle evaluated on the state the sequence should have produced (stale geometry, a stale pair table, a stale
+kernel variant or stale env state all show up as a mismatch).
+usage: python tools/fuzz_api.py [n_sessions] [ops_per_session] [seed]"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+
+from fuzz_parity import classify, make_layout, worst  # noqa: E402  (same directory)
+
+
+def mdp_step_f32(st, action, p):
+    """One float32 MDP transition as the reference performs it (simple_env.py:64-72, mdp.py:291-319)."""
+    yaw, acc, moves = st["yaw"].copy(), st["acc"].copy(), st["moves"].copy()
+    moves_new = moves + 1
+    f32 = np.float32
+    frac = ((acc / f32(p["actuator_rate"])) / moves_new[:, None].astype(f32)) / f32(p["dt"])
+    a = np.where(frac >= f32(p["budget"]), f32(0), action.astype(f32))
+    if p["discrete"]:
+        a = (a - f32(1)) * f32(p["yaw_step"])
+    else:
+        a = np.clip(a, -f32(p["yaw_step"]), f32(p["yaw_step"]))
+    yaw_new = np.clip(yaw + a, f32(p["yaw_lo"]), f32(p["yaw_hi"])).astype(f32)
+    return yaw_new
+
+
+def run(n_sessions, n_ops, seed):
+    import torch
+
+    from oracle import c_oracle
+    from oracle.floris_gch_numpy import ModelParams
+    from wfcrl_env_amd.backend import WfStep
+
+    rng = np.random.default_rng(seed)
+    nbad = nflip = nchecks = 0
+    for sess in range(n_sessions):
+        x, y = make_layout(rng)
+        B = int(rng.integers(1, 20))
+        w = WfStep(x, y, env_batch=B)
+        mp, model = None, {}
+        envp = dict(yaw_lo=-40.0, yaw_hi=40.0, yaw_step=5.0, actuator_rate=0.3, dt=60.0, budget=0.1, load_coef=0.1, discrete=False)
+        w.env_config(**envp)
+        w.set_wind(8.0, 270.0)
+        w.env_reset()
+        log = []
+
+        def oracle(yaw64):
+            ws, wd = w.get_wind()
+            return (c_oracle.farm_step_batch(x, y, ws, wd, yaw64, mp) if mp else c_oracle.farm_step_batch(x, y, ws, wd, yaw64)), ws
+
+        def check(tag, got, ref):
+            nonlocal nbad, nflip, nchecks
+            nchecks += 1
+            got = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in got.items()}
+            k = classify(worst(got, ref))
+            nflip += k == "flip"
+            if k == "BAD":
+                nbad += 1
+                print("BAD", dict(session=sess, seed=seed, N=x.size, B=B, tag=tag, info=w.kernel_info()), worst(got, ref), "\n   ops:", log[-12:], flush=True)
+
+        for _ in range(n_ops):
+            op = rng.choice(["step", "step", "step_torch", "wind_shared", "wind_per_farm", "wind_device", "wind_sample", "series",
+                             "series_step", "batch", "model", "layout", "env_step", "env_step", "env_reset", "env_config"])
+            log.append(str(op))
+            N = x.size
+            if op in ("layout", "batch", "wind_shared", "wind_per_farm", "wind_device", "wind_sample"):
+                w._series_left = 0  # any other way of setting the wind leaves series mode
+                w._ws_prev = None
+            if op == "layout":
+                x, y = make_layout(rng)
+                w.set_layout(x, y)
+                B = int(rng.integers(1, 20))
+                w.set_batch(B)
+                w.env_batch = B
+                w.set_wind(float(rng.uniform(4, 15)), float(rng.choice([270.0, 90.0, rng.uniform(0, 360)])))
+                w.env_reset()
+            elif op == "batch":
+                B = int(rng.choice([1, rng.integers(1, 40), rng.integers(200, 3000)]))
+                w.set_batch(B)
+                w.env_batch = B
+                w.set_wind(float(rng.uniform(4, 15)), float(rng.uniform(0, 360)))
+                w.env_reset()
+            elif op == "model":
+                if rng.random() < 0.4:
+                    model, mp = {}, None
+                else:
+                    D = 126.0
+                    model = dict(hub_height=float(rng.choice([70.0, 90.0, 110.0])), ambient_ti=float(rng.choice([0.06, 0.09])),
+                                 shear=float(rng.choice([0.12, 0.0])))
+                    mp = ModelParams(HH=model["hub_height"], ambient_ti=model["ambient_ti"], shear=model["shear"])
+                w.set_model(dict(model))
+            elif op == "wind_shared":
+                w.set_wind(float(rng.uniform(4, 20)), float(rng.choice([270.0, 0.0, 90.0, rng.uniform(0, 360)])))
+            elif op == "wind_per_farm":
+                w.set_wind(rng.uniform(4, 20, B), rng.uniform(0, 360, B))
+            elif op == "wind_device":
+                n = B if rng.random() < 0.5 else 1
+                w.set_wind(torch.from_numpy(rng.uniform(4, 20, n)).cuda(), torch.from_numpy(rng.uniform(0, 360, n)).cuda())
+            elif op == "wind_sample":
+                w.sample_wind(int(rng.integers(0, 2**31)))
+            elif op == "series":
+                T = int(rng.integers(2, 12))
+                series = np.stack([rng.uniform(4, 20, T), rng.uniform(0, 360, T)], axis=1)
+                w.set_wind_series(series, start=rng.integers(0, T, B).astype(np.int32) if rng.random() < 0.5 else None,
+                                  seed=int(rng.integers(0, 1000)))
+                w._series_left = T - 1
+                w._ws_prev = None
+            elif op == "series_step":
+                if getattr(w, "_series_left", 0) > 0:
+                    w._ws_prev = w.get_wind()[0]  # the reward is normalised by the free wind BEFORE the step (a9)
+                    w.wind_series_step()
+                    w._series_left -= 1
+                else:
+                    log[-1] = "series_step(skipped)"
+            elif op == "env_reset":
+                w.env_reset()
+            elif op == "env_config":
+                envp = dict(yaw_lo=-float(rng.choice([30, 40])), yaw_hi=float(rng.choice([30, 40])), yaw_step=float(rng.choice([4, 5])),
+                            actuator_rate=0.3, dt=60.0, budget=float(rng.choice([0.1, 0.02])), load_coef=float(rng.choice([0.1, 0.5])),
+                            discrete=bool(rng.random() < 0.4))
+                w.env_config(**envp)
+                w.env_reset()
+            elif op in ("step", "step_torch"):
+                yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
+                got = w.step(torch.from_numpy(yaw).cuda()) if op == "step_torch" else w.step(yaw)
+                ref, _ = oracle(yaw.astype(np.float64))
+                check(op, got, ref)
+            elif op == "env_step":
+                st = w.env_get_state()
+                act = (rng.integers(0, 3, (B, N)) if envp["discrete"] else rng.uniform(-8, 8, (B, N))).astype(np.float32)
+                use_torch = rng.random() < 0.5
+                got = w.env_step(torch.from_numpy(act).cuda() if use_torch else act)
+                got = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in got.items()}
+                yaw_new = mdp_step_f32(st, act, envp)
+                if not np.array_equal(got["yaw"], yaw_new):
+                    nbad += 1
+                    print("BAD yaw transition", dict(session=sess, seed=seed, N=N, B=B, envp=envp), np.abs(got["yaw"] - yaw_new).max(), log[-12:], flush=True)
+                ref, ws = oracle(yaw_new.astype(np.float64))
+                check("env_step", got, ref)
+                wsn = w._ws_prev if getattr(w, "_ws_prev", None) is not None else ws
+                r_ref = (ref["power"] / 1e6 * 1e3 / wsn[:, None] ** 3).mean(axis=1) - envp["load_coef"] * np.abs(ref["load"]).mean(axis=(1, 2))
+                if k_bad := (np.abs(got["reward"] - r_ref) > 5e-5 * np.abs(r_ref) + 1e-7).sum():
+                    if k_bad > max(1, 0.01 * B):
+                        nbad += 1
+                        print("BAD reward", dict(session=sess, seed=seed, N=N, B=B, envp=envp), float(np.abs(got["reward"] / r_ref - 1).max()), log[-12:], flush=True)
+        w.close()
+    print(f"api fuzz: {n_sessions} sessions x {n_ops} ops, {nchecks} oracle checks: {nflip} threshold flips, {nbad} violations")
+    return nflip, nbad
+
+
+if __name__ == "__main__":
+    a = sys.argv
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    _, bad = run(int(a[1]) if len(a) > 1 else 30, int(a[2]) if len(a) > 2 else 40, int(a[3]) if len(a) > 3 else 1)
+    sys.exit(1 if bad else 0)

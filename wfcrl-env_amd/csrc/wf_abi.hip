@@ -575,6 +575,7 @@ int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* di
   WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
   h->wind_count = h->B;
   h->series_T = 0;
+  h->pair_dirty = true;  // env_batch 1: "one wind per farm" is also "one wind for the batch" (table path)
   return WF_OK;
 }
 
@@ -619,6 +620,7 @@ int wf_wind_series_step(wf_handle* h) {
                                      h->d_ws, h->d_wd, h->stream));
   WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
   h->wind_count = h->B;
+  h->pair_dirty = true;  // see wf_wind_sample
   return WF_OK;
 }
 
