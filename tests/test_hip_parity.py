@@ -502,3 +502,19 @@ def test_randomised_parity_fuzz_sample():
     nflip, nbad = fz.run(120, 2024)
     assert nbad == 0
     assert nflip <= 3
+
+
+def test_randomised_api_sequence_fuzz_sample():
+    """A fixed-seed sample of tools/fuzz_api.py: random sequences of layout / batch / model / wind (shared, per farm,
+    device pointers, device sampling, series playback) / env calls on one handle, every step and fused env step
+    checked against the oracle on the state the sequence should have produced (stale geometry, pair table, kernel
+    variant or env state would show)."""
+    import importlib.util
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    spec = importlib.util.spec_from_file_location("fuzz_api", os.path.join(ROOT, "tools", "fuzz_api.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    nflip, nbad = fz.run(14, 40, 7)
+    assert nbad == 0
