@@ -9,6 +9,8 @@ cd $R
 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 tools/all_configs.py 40 > $O/all_configs.txt 2>&1
 python3 tools/gpu_check.py > $O/parity_stats.txt 2>&1
+python3 tools/gs_sweep.py 2>&1 | grep ms/step > $O/variant_sweep.txt
+(for sd in 21 22; do python3 tools/fuzz_parity.py 1000 $sd 2>&1 | grep -E "^BAD|^fuzz"; done; python3 tools/fuzz_api.py 60 50 21 2>&1 | grep -E "^BAD|^api fuzz") > $O/fuzz.txt
 bash tools/run_pmc.sh $tag > /dev/null 2>&1
 python3 tools/parse_pmc.py $tag > $O/pmc_cfg4.json
 rm -rf $R/gpurun_out/pmc_$tag
