@@ -6,6 +6,8 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
 
+# free-stream speeds; FUZZ_WS=lo,hi widens them past cut-in / cut-out and the ends of the Ct / power table
+WS_RANGE = tuple(float(v) for v in os.environ.get("FUZZ_WS", "4,20").split(","))
 VARIANTS = [(g, s) for g, smax in ((4, 4), (8, 4), (16, 6), (32, 4), (64, 4)) for s in range(1, smax + 1)]
 
 
@@ -79,7 +81,7 @@ def run(n_cases, seed, only=-1):
         B = int(rng.integers(1, 9))
         yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
         wd0 = float(rng.choice([0.0, 90.0, 180.0, 270.0, 360.0, rng.uniform(0, 360), rng.uniform(250, 290)]))
-        ws0 = float(rng.uniform(4, 20))
+        ws0 = float(rng.uniform(*WS_RANGE))
         # every fourth case: a non-default model (low hub = general mirror cores, other D: 15 D no longer an integer
         # number of grid steps, other ambient TI / shear / deflection offsets)
         model, mp = {}, None
@@ -100,7 +102,7 @@ def run(n_cases, seed, only=-1):
             if mode == "shared":
                 ws, wd = np.array([ws0]), np.array([wd0])
             else:
-                ws = rng.uniform(4, 20, B)
+                ws = rng.uniform(*WS_RANGE, B)
                 wd = np.where(rng.random(B) < 0.5, wd0, rng.uniform(0, 360, B))
             if not run:
                 continue
