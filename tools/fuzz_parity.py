@@ -13,6 +13,12 @@ VARIANTS = [(g, s) for g, smax in ((4, 4), (8, 4), (16, 6), (32, 4), (64, 4)) fo
 
 def make_layout(rng):
     kind = rng.integers(0, 4)
+    if rng.random() < float(os.environ.get("FUZZ_BIG", "0.03")):  # up to the 256-turbine limit of the ABI
+        nc, nr = rng.integers(8, 17), rng.integers(8, 17)
+        x = np.repeat(np.arange(nc) * 630.0, nr) + (rng.uniform(-50, 50, nc * nr) if rng.random() < 0.5 else 0.0)
+        y = np.tile(np.arange(nr) * 504.0, nc)
+        keep = np.arange(x.size) < 256
+        return x[keep], y[keep]
     if kind == 0:  # regular grid, exact ties at axis-aligned directions
         nc, nr = rng.integers(1, 12), rng.integers(1, 10)
         x = np.repeat(np.arange(nc) * rng.choice([504.0, 630.0, 882.0]), nr)
