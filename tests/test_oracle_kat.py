@@ -114,3 +114,36 @@ def test_turbine_table_corroboration_point():
     assert abs(ct - 0.7634300) < 5e-8
     assert abs(power - 1695368.8) < 0.5
     assert abs(a - 0.2568077) < 5e-8
+
+
+def test_c_and_numpy_oracles_agree_on_tie_and_threshold_layouts():
+    """The two independent restatements must also agree where the model is discontinuous: regular grids with exact x'
+    ties and turbines exactly 15 D apart at axis-aligned wind directions (where sin(pi) = 1.2e-16 in the rotation
+    decides the masks), holed and jittered grids, random clouds, default and non-default models — the layouts of
+    tools/fuzz_parity.py."""
+    import importlib.util
+    import os
+
+    from conftest import ROOT
+    from oracle import c_oracle
+    from oracle.floris_gch_numpy import ModelParams, farm_step
+
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(5)
+    n = 0
+    while n < 40:
+        x, y = fz.make_layout(rng)
+        if x.size > 45:
+            continue
+        n += 1
+        yaw = rng.uniform(-35, 35, x.size)
+        wd = float(rng.choice([0.0, 90.0, 180.0, 270.0, rng.uniform(0, 360)]))
+        ws = float(rng.uniform(3, 20))
+        mp = ModelParams(HH=float(rng.choice([70.0, 110.0])), ambient_ti=0.09, shear=0.2, ad=0.01, bd=-0.002) if n % 3 == 0 else None
+        a = c_oracle.farm_step_batch(x, y, ws, wd, yaw[None, :], mp) if mp else c_oracle.farm_step_batch(x, y, ws, wd, yaw[None, :])
+        b = farm_step(x, y, ws, wd, yaw, mp) if mp else farm_step(x, y, ws, wd, yaw)
+        for k in ("power", "wind_speed", "wind_direction", "load"):
+            bb = np.asarray(b[k])
+            assert np.abs(np.asarray(a[k])[0] - bb).max() <= 1e-11 * max(1.0, np.abs(bb).max()), (n, k)
