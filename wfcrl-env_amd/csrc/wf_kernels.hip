@@ -37,6 +37,14 @@
 #ifndef WF_TAB_WAVES
 #define WF_TAB_WAVES 4
 #endif
+// The library is built from this file twice (csrc/Makefile): WF_KSET=1 carries the step-kernel variants with four or
+// five target slots per lane — the throughput variants of mid-size and large farms, which have registers to spare at
+// two waves per SIMD — compiled with LLVM's iterative-ilp scheduling strategy (-3 % on HornsRev1; the register-tight
+// variants spill 40-140 VGPRs under it), plus the small kernels and the variant dispatcher; WF_KSET=2 carries the
+// other variants with the default scheduler.  WF_KSET=0 (default): everything in one translation unit.
+#ifndef WF_KSET
+#define WF_KSET 0
+#endif
 
 namespace {
 
@@ -175,6 +183,7 @@ __device__ __forceinline__ void column_deficit(const WfConsts& c, const SrcConst
 
 }  // namespace
 
+#if WF_KSET != 2
 // ---------------------------------------------------------------------------------------------
 // Geometry: wd % 360, rotation about the layout's bounding-box centre, stable ascending sort [A.1]
 // One block per wind condition; float64 throughout.
@@ -364,6 +373,8 @@ extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double
   hipLaunchKernelGGL(wf_pair_table_kernel, dim3(pc->N), dim3(threads), 0, s, *pc, gx, gy, tab, first_active);
   return hipGetLastError();
 }
+
+#endif  // WF_KSET != 2
 
 // ---------------------------------------------------------------------------------------------
 // The farm step
@@ -1017,37 +1028,32 @@ const void* tab_kernel() {
   {G_, S_, (const void*)&wf_step_kernel<G_, S_, true, false, 4>, (const void*)&wf_step_kernel<G_, S_, false, false, 4>, \
    tab_kernel<G_, S_>()}
 static const WfVariant kVariants[] = {
-    WF_VARIANT(4, 1),  WF_VARIANT(4, 2),  WF_VARIANT(4, 3),  WF_VARIANT(4, 4),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(8, 3),  WF_VARIANT(8, 4),
-    WF_VARIANT(16, 3), WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(16, 6), WF_VARIANT(32, 3),
-    WF_VARIANT(32, 4), WF_VARIANT(64, 3), WF_VARIANT(64, 4), WF_VARIANT(16, 1), WF_VARIANT(16, 2), WF_VARIANT(32, 1),
-    WF_VARIANT(32, 2), WF_VARIANT(64, 1), WF_VARIANT(64, 2),
+#if WF_KSET != 2
+    WF_VARIANT(4, 4),  WF_VARIANT(8, 4),  WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(32, 4), WF_VARIANT(64, 4),
+#endif
+#if WF_KSET != 1
+    WF_VARIANT(4, 1),  WF_VARIANT(4, 2),  WF_VARIANT(4, 3),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(8, 3),
+    WF_VARIANT(16, 1), WF_VARIANT(16, 2), WF_VARIANT(16, 3), WF_VARIANT(16, 6), WF_VARIANT(32, 1), WF_VARIANT(32, 2),
+    WF_VARIANT(32, 3), WF_VARIANT(64, 1), WF_VARIANT(64, 2), WF_VARIANT(64, 3),
+#endif
 };
+constexpr int kNumLocal = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
-extern "C" int wfk_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
-extern "C" void wfk_variant(int i, int* G, int* S, const void** fn) {
+// variant i of THIS translation unit
+static void local_variant(int i, int* G, int* S, const void** fn) {
   *G = kVariants[i].G;
   *S = kVariants[i].S;
   *fn = kVariants[i].fn;
 }
-extern "C" int wfk_variant_has_table(int i) { return kVariants[i].fn_tab != nullptr; }
-extern "C" int wfk_tab_waves() { return kTabWaves; }
 // kind 0: MC1 on-the-fly, 1: general mirror cores, 2: shared-wind pair table
-extern "C" const void* wfk_variant_fn(int i, int kind) {
+static const void* local_variant_fn(int i, int kind) {
   return kind == 2 ? kVariants[i].fn_tab : (kind == 1 ? kVariants[i].fn_all : kVariants[i].fn);
 }
-
-extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
-                                          const double* wd, double* gx, float* gy, int* gidx, hipStream_t s) {
-  const int threads = ((N + 63) / 64) * 64;
-  hipLaunchKernelGGL(wf_geometry_kernel, dim3(n_env), dim3(threads), 0, s, N, lx, ly, xc, yc, wd, gx, gy, gidx);
-  return hipGetLastError();
-}
-
-extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
-                                      const float* gy, const int* gidx, int geom_stride, const double* ws,
-                                      const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
-                                      float* o_wd, float* load, int B, const WfEnvArgs* env, const float* pair_tab,
-                                      const int* pair_first, hipStream_t s, int* grid_out) {
+static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx, const float* gy,
+                                    const int* gidx, int geom_stride, const double* ws, const double* wd, int wind_stride,
+                                    const float* yaw, float* power, float* o_ws, float* o_wd, float* load, int B,
+                                    const WfEnvArgs* env, const float* pair_tab, const int* pair_first, hipStream_t s,
+                                    int* grid_out) {
   const WfVariant& v = kVariants[variant];
   const bool use_tab = pair_tab && v.fn_tab;
   const int wpb = use_tab ? kTabWaves : 4;
@@ -1062,3 +1068,58 @@ extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTa
   if (fn != v.fn_tab) pair_tab = nullptr;
   return hipLaunchKernel(fn, dim3(grid), dim3(64 * wpb), args, 0, s);
 }
+
+#define WF_STEP_ARGS                                                                                                  \
+  int variant, const WfConsts *c, const WfTables *tab, const double *gx, const float *gy, const int *gidx,           \
+      int geom_stride, const double *ws, const double *wd, int wind_stride, const float *yaw, float *power,          \
+      float *o_ws, float *o_wd, float *load, int B, const WfEnvArgs *env, const float *pair_tab,                     \
+      const int *pair_first, hipStream_t s, int *grid_out
+#define WF_STEP_PASS(v_)                                                                                              \
+  v_, c, tab, gx, gy, gidx, geom_stride, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, pair_tab,         \
+      pair_first, s, grid_out
+
+#if WF_KSET == 2
+// second translation unit: its variants are reached through the dispatcher of the first
+extern "C" int wfk2_num_variants() { return kNumLocal; }
+extern "C" void wfk2_variant(int i, int* G, int* S, const void** fn) { local_variant(i, G, S, fn); }
+extern "C" int wfk2_variant_has_table(int i) { return kVariants[i].fn_tab != nullptr; }
+extern "C" const void* wfk2_variant_fn(int i, int kind) { return local_variant_fn(i, kind); }
+extern "C" hipError_t wfk2_launch_step(WF_STEP_ARGS) { return local_launch_step(WF_STEP_PASS(variant)); }
+#else
+#if WF_KSET == 1
+extern "C" int wfk2_num_variants();
+extern "C" void wfk2_variant(int i, int* G, int* S, const void** fn);
+extern "C" int wfk2_variant_has_table(int i);
+extern "C" const void* wfk2_variant_fn(int i, int kind);
+extern "C" hipError_t wfk2_launch_step(WF_STEP_ARGS);
+#else
+static int wfk2_num_variants() { return 0; }
+static void wfk2_variant(int, int*, int*, const void**) {}
+static int wfk2_variant_has_table(int) { return 0; }
+static const void* wfk2_variant_fn(int, int) { return nullptr; }
+static hipError_t wfk2_launch_step(WF_STEP_ARGS) { return hipErrorInvalidValue; }
+#endif
+// variant index space of the library: [0, kNumLocal) here, then the second translation unit's
+extern "C" int wfk_num_variants() { return kNumLocal + wfk2_num_variants(); }
+extern "C" void wfk_variant(int i, int* G, int* S, const void** fn) {
+  if (i < kNumLocal) local_variant(i, G, S, fn); else wfk2_variant(i - kNumLocal, G, S, fn);
+}
+extern "C" int wfk_variant_has_table(int i) {
+  return i < kNumLocal ? (kVariants[i].fn_tab != nullptr) : wfk2_variant_has_table(i - kNumLocal);
+}
+extern "C" int wfk_tab_waves() { return kTabWaves; }
+extern "C" const void* wfk_variant_fn(int i, int kind) {
+  return i < kNumLocal ? local_variant_fn(i, kind) : wfk2_variant_fn(i - kNumLocal, kind);
+}
+
+extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
+                                          const double* wd, double* gx, float* gy, int* gidx, hipStream_t s) {
+  const int threads = ((N + 63) / 64) * 64;
+  hipLaunchKernelGGL(wf_geometry_kernel, dim3(n_env), dim3(threads), 0, s, N, lx, ly, xc, yc, wd, gx, gy, gidx);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t wfk_launch_step(WF_STEP_ARGS) {
+  return variant < kNumLocal ? local_launch_step(WF_STEP_PASS(variant)) : wfk2_launch_step(WF_STEP_PASS(variant - kNumLocal));
+}
+#endif
