@@ -37,11 +37,12 @@
 #ifndef WF_TAB_WAVES
 #define WF_TAB_WAVES 4
 #endif
-// The library is built from this file twice (csrc/Makefile): WF_KSET=1 carries the step-kernel variants with four or
-// five target slots per lane — the throughput variants of mid-size and large farms, which have registers to spare at
-// two waves per SIMD — compiled with LLVM's iterative-ilp scheduling strategy (-3 % on HornsRev1; the register-tight
-// variants spill 40-140 VGPRs under it), plus the small kernels and the variant dispatcher; WF_KSET=2 carries the
-// other variants with the default scheduler.  WF_KSET=0 (default): everything in one translation unit.
+// The library is built from this file twice (csrc/Makefile): WF_KSET=1 carries the step-kernel variants with one, two,
+// four or five target slots per lane — they have registers to spare at their occupancy — compiled with LLVM's
+// iterative-ilp scheduling strategy (-3 % on HornsRev1/65536, -2 % on the B = 1 latency), plus the small kernels
+// and the variant dispatcher; WF_KSET=2 carries the register-tight variants (three slots at three waves per SIMD,
+// six slots), which spill 40-140 VGPRs under that strategy, with the default scheduler.  WF_KSET=0 (default):
+// everything in one translation unit.
 #ifndef WF_KSET
 #define WF_KSET 0
 #endif
@@ -1030,11 +1031,11 @@ const void* tab_kernel() {
 static const WfVariant kVariants[] = {
 #if WF_KSET != 2
     WF_VARIANT(4, 4),  WF_VARIANT(8, 4),  WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(32, 4), WF_VARIANT(64, 4),
+    WF_VARIANT(4, 1),  WF_VARIANT(4, 2),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(16, 1), WF_VARIANT(16, 2),
+    WF_VARIANT(32, 1), WF_VARIANT(32, 2), WF_VARIANT(64, 1), WF_VARIANT(64, 2),
 #endif
 #if WF_KSET != 1
-    WF_VARIANT(4, 1),  WF_VARIANT(4, 2),  WF_VARIANT(4, 3),  WF_VARIANT(8, 1),  WF_VARIANT(8, 2),  WF_VARIANT(8, 3),
-    WF_VARIANT(16, 1), WF_VARIANT(16, 2), WF_VARIANT(16, 3), WF_VARIANT(16, 6), WF_VARIANT(32, 1), WF_VARIANT(32, 2),
-    WF_VARIANT(32, 3), WF_VARIANT(64, 1), WF_VARIANT(64, 2), WF_VARIANT(64, 3),
+    WF_VARIANT(4, 3),  WF_VARIANT(8, 3),  WF_VARIANT(16, 3), WF_VARIANT(16, 6), WF_VARIANT(32, 3), WF_VARIANT(64, 3),
 #endif
 };
 constexpr int kNumLocal = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
