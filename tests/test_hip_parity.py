@@ -4,7 +4,7 @@ Tolerances (fp32 device arithmetic vs float64 oracle; north_star: per-turbine po
   power      |dP| / max(P, 1 kW)  <= 1e-4  for all but max(2, 3e-4 n) of the n (env, turbine) samples and
              <= 5e-3 for all: a 1-ulp difference can flip the overlap-count mask `deficit*U > 0.05` of SURVEY
              A.3-8, which moves one turbine's TI by 1/9 of the added term — rare, bounded, rate measured by
-             tools/gpu_check.py; the median must be <= 1e-6
+             tests/tools/gpu_check.py; the median must be <= 1e-6
   wind_speed relative            <= 2e-5
   wind_dir   absolute            <= 2e-4 deg (float32 resolution at 270 deg is 3e-5)
   TI         absolute            <= 5e-6 ; std u, v, w absolute <= 1e-4 m/s
@@ -491,12 +491,12 @@ def test_exact_x_ties_across_kernel_blocks(gs, shape, wdir, monkeypatch):
 
 
 def test_randomised_parity_fuzz_sample():
-    """A fixed-seed sample of tools/fuzz_parity.py (random regular / jittered / holed grids and clouds, axis-aligned and
+    """A fixed-seed sample of tests/tools/fuzz_parity.py (random regular / jittered / holed grids and clouds, axis-aligned and
     random wind directions, every kernel variant, shared and per-farm wind, default and non-default models): no run
     outside the parity tolerances except the bounded signature of a threshold flip, and few of those."""
     import importlib.util
 
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     nflip, nbad = fz.run(120, 2024)
@@ -505,15 +505,15 @@ def test_randomised_parity_fuzz_sample():
 
 
 def test_randomised_api_sequence_fuzz_sample():
-    """A fixed-seed sample of tools/fuzz_api.py: random sequences of layout / batch / model / wind (shared, per farm,
+    """A fixed-seed sample of tests/tools/fuzz_api.py: random sequences of layout / batch / model / wind (shared, per farm,
     device pointers, device sampling, series playback) / env calls on one handle, every step and fused env step
     checked against the oracle on the state the sequence should have produced (stale geometry, pair table, kernel
     variant or env state would show)."""
     import importlib.util
     import sys
 
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    spec = importlib.util.spec_from_file_location("fuzz_api", os.path.join(ROOT, "tools", "fuzz_api.py"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    spec = importlib.util.spec_from_file_location("fuzz_api", os.path.join(ROOT, "tests", "tools", "fuzz_api.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     nflip, nbad = fz.run(14, 40, 7)

@@ -120,7 +120,7 @@ def test_c_and_numpy_oracles_agree_on_tie_and_threshold_layouts():
     """The two independent restatements must also agree where the model is discontinuous: regular grids with exact x'
     ties and turbines exactly 15 D apart at axis-aligned wind directions (where sin(pi) = 1.2e-16 in the rotation
     decides the masks), holed and jittered grids, random clouds, default and non-default models — the layouts of
-    tools/fuzz_parity.py."""
+    tests/tools/fuzz_parity.py."""
     import importlib.util
     import os
 
@@ -128,7 +128,7 @@ def test_c_and_numpy_oracles_agree_on_tie_and_threshold_layouts():
     from oracle import c_oracle
     from oracle.floris_gch_numpy import ModelParams, farm_step
 
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     rng = np.random.default_rng(5)

@@ -3,7 +3,7 @@ wf_set_model / wf_set_wind (shared, per farm, device pointers) / wf_wind_sample 
 wf_env_reset interleaved with wf_step (host and device buffers) and wf_env_step, every result checked against the
 float64 oracle evaluated on the state the sequence should have produced (stale geometry, a stale pair table, a stale
 kernel variant or stale env state all show up as a mismatch).
-usage: python tools/fuzz_api.py [n_sessions] [ops_per_session] [seed]"""
+usage: python tests/tools/fuzz_api.py [n_sessions] [ops_per_session] [seed]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

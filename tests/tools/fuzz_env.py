@@ -2,7 +2,7 @@
 single-farm envs with the reference's semantics (simple_env / mdp mirror) running on the float64 oracle
 (tests/helpers.py): random layout, controls, discrete / continuous actions, load_coef, episode length, reset by seed
 (host-side draws in the reference's order) or by options, actions that overshoot the step and trip the actuation
-budget.  usage: python tools/fuzz_env.py [n_episodes] [seed]"""
+budget.  usage: python tests/tools/fuzz_env.py [n_episodes] [seed]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 sys.path.insert(0, os.path.join(os.getcwd(), "tests"))

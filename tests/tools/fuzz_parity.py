@@ -1,7 +1,7 @@
 """GPU box: randomised parity fuzz of the HIP path against the float64 C oracle — random layouts (regular grids with
 exact ties, jittered grids, random clouds with a minimum spacing), wind directions including the axis-aligned ones,
 every kernel variant that can hold the farm, shared and per-farm wind, plain step and fused env step outputs.
-usage: python tools/fuzz_parity.py [n_cases] [seed]      (exit code 1 on the first violation)"""
+usage: python tests/tools/fuzz_parity.py [n_cases] [seed]      (exit code 1 on the first violation)"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np

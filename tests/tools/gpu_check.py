@@ -1,7 +1,7 @@
 """Dev script (GPU box): parity of the HIP step against the C oracle on seeded random inputs + rough timing."""
 import json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from wfcrl_env_amd.backend import WfStep
 from oracle import c_oracle

@@ -1,7 +1,7 @@
 """GPU box: stress / soak checks (not part of the test-suite because of their size)."""
 import json, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from wfcrl_env_amd.backend import WfStep
 from wfcrl_env_amd import environments as envs

@@ -1,5 +1,5 @@
 """GPU box: exact x' ties across kernel blocks (axis-aligned grids at wd = 270) on forced multi-slot variants,
-all outputs against the float64 oracle.  usage: python tools/tie_check.py [GxS]"""
+all outputs against the float64 oracle.  usage: python tests/tools/tie_check.py [GxS]"""
 import os, json, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np

@@ -1,16 +1,16 @@
 #!/bin/bash
 # GPU box: everything profiles/ cites for one kernel version.  Usage: tools/record_profiles.sh <tag>
 #   bench line (with cpu_baseline), the same command under rocprofv3 --kernel-trace --stats, PMC counters in
-#   separate passes (tools/run_pmc.sh), every BASELINE config, parity statistics (tools/gpu_check.py).
+#   separate passes (tools/run_pmc.sh), every BASELINE config, parity statistics (tests/tools/gpu_check.py).
 tag=$1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag
 mkdir -p $O
 cd $R
 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 tools/all_configs.py 40 > $O/all_configs.txt 2>&1
-python3 tools/gpu_check.py > $O/parity_stats.txt 2>&1
+python3 tests/tools/gpu_check.py > $O/parity_stats.txt 2>&1
 python3 tools/gs_sweep.py 2>&1 | grep ms/step > $O/variant_sweep.txt
-(for sd in 21 22; do python3 tools/fuzz_parity.py 1000 $sd 2>&1 | grep -E "^BAD|^fuzz"; done; python3 tools/fuzz_api.py 60 50 21 2>&1 | grep -E "^BAD|^api fuzz") > $O/fuzz.txt
+(for sd in 21 22; do python3 tests/tools/fuzz_parity.py 1000 $sd 2>&1 | grep -E "^BAD|^fuzz"; done; python3 tests/tools/fuzz_api.py 60 50 21 2>&1 | grep -E "^BAD|^api fuzz") > $O/fuzz.txt
 bash tools/run_pmc.sh $tag > /dev/null 2>&1
 python3 tools/parse_pmc.py $tag > $O/pmc_cfg4.json
 rm -rf $R/gpurun_out/pmc_$tag
