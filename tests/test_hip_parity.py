@@ -518,3 +518,14 @@ def test_randomised_api_sequence_fuzz_sample():
     spec.loader.exec_module(fz)
     nflip, nbad = fz.run(14, 40, 7)
     assert nbad == 0
+
+
+def test_integration_md_stub_runs_as_printed():
+    """The ctypes binding printed in INTEGRATION.md section 2 (what a maintainer of the reference would paste) is extracted
+    from the markdown and run against the reference's known-answer vector."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "integration_stub_check.py")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "stub: ok" in r.stdout, r.stdout + r.stderr
