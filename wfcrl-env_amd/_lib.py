@@ -94,7 +94,7 @@ def build(force: bool = False) -> Path:
     srcs.append(PKG_DIR.parent / "include" / "wfstep.h")
     stale = (not LIB_PATH.exists()) or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
     if force or stale:
-        subprocess.run(["make", "-C", str(PKG_DIR / "csrc")] + (["-B"] if force else []), check=True)
+        subprocess.run(["make", "-j3", "-C", str(PKG_DIR / "csrc")] + (["-B"] if force else []), check=True)
     return LIB_PATH
 
 
