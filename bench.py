@@ -249,7 +249,7 @@ def main():
     if venv_ms is not None:
         res["fused_env_step"] = {"ms_per_step": venv_ms, "env_steps_per_sec_per_gpu": B / (venv_ms * 1e-3),
                                  "outputs": "reward[B], yaw/wind_speed/wind_direction[B,N]"}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # CPU baseline + accuracy sample: rank 0 of the single-GPU run only
         from oracle import c_oracle
 
         nthreads = min(c_oracle.max_threads(), effective_cpus())
