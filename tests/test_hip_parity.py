@@ -377,10 +377,18 @@ def test_shared_wind_pair_table_path_and_its_fallbacks(layouts, monkeypatch):
     w.set_wind(9.0, 281.0)
     assert w.kernel_info()["pair_table"] == 1
     a = w.step(yaw)
-    w.set_wind(np.full(B, 9.0), np.full(B, 281.0))  # same wind given per farm: on-the-fly path
+    # the same wind given per farm, as two spellings of the direction so that it does not register as shared:
+    # on-the-fly path
+    w.set_wind(np.full(B, 9.0), 281.0 + 360.0 * (np.arange(B) % 2))
     assert w.kernel_info()["pair_table"] == 0
     b = w.step(yaw)
+    # one direction, a speed per farm (host arrays): geometry and pair table are shared, the speed is not
+    ws_b = rng.uniform(5, 14, B)
+    w.set_wind(ws_b, np.full(B, 281.0))
+    assert w.kernel_info()["pair_table"] == 1
+    cdir = w.step(yaw)
     w.close()
+    _check(cdir, c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], ws_b, np.full(B, 281.0), yaw.astype(np.float64)))
     ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], 9.0, 281.0, yaw.astype(np.float64))
     _check(a, ref)
     _check(b, ref)
@@ -482,7 +490,8 @@ def test_exact_x_ties_across_kernel_blocks(gs, shape, wdir, monkeypatch):
     assert f'{info["lanes_per_env"]}x{info["slots_per_lane"]}' == gs
     w.set_wind(8.0, wdir)
     shared = w.step(yaw)
-    w.set_wind(np.full(B, 8.0), np.full(B, wdir))
+    w.set_wind(np.full(B, 8.0), wdir + 360.0 * (np.arange(B) % 2))  # two spellings: not taken for a shared direction
+    assert w.kernel_info()["pair_table"] == 0
     per_farm = w.step(yaw)
     w.close()
     ref = c_oracle.farm_step_batch(x, y, 8.0, wdir, yaw.astype(np.float64))

@@ -95,7 +95,8 @@ def run(n_sessions, n_ops, seed):
             elif op == "wind_shared":
                 w.set_wind(float(rng.uniform(4, 20)), float(rng.choice([270.0, 0.0, 90.0, rng.uniform(0, 360)])))
             elif op == "wind_per_farm":
-                w.set_wind(rng.uniform(4, 20, B), rng.uniform(0, 360, B))
+                wdv = rng.uniform(0, 360, B) if rng.random() < 0.6 else np.full(B, float(rng.choice([270.0, 90.0, rng.uniform(0, 360)])))
+                w.set_wind(rng.uniform(4, 20, B), wdv)  # 40 %: one direction, a speed per farm (shared geometry + table)
             elif op == "wind_device":
                 n = B if rng.random() < 0.5 else 1
                 w.set_wind(torch.from_numpy(rng.uniform(4, 20, n)).cuda(), torch.from_numpy(rng.uniform(0, 360, n)).cuda())

@@ -114,6 +114,7 @@ struct wf_handle {
   float* d_pair_tab = nullptr;
   int* d_pair_first = nullptr;  // per source: first sorted target index with dx >= 0
   bool pair_dirty = true;
+  bool shared_dir = false;  // one wind per farm, but the same direction for all: shared geometry + pair table
 };
 
 namespace {
@@ -302,7 +303,7 @@ int build_consts(wf_handle* h) {
 // or WF_NO_PAIR_TABLE set for A/B runs).
 int pair_table(wf_handle* h, const float** out) {
   *out = nullptr;
-  if (h->wind_count != 1 || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || getenv("WF_NO_PAIR_TABLE"))
+  if ((h->wind_count != 1 && !h->shared_dir) || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || getenv("WF_NO_PAIR_TABLE"))
     return WF_OK;
   int vG, vS; const void* vfn;
   wfk_variant(h->variant, &vG, &vS, &vfn);
@@ -469,7 +470,7 @@ int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
   WF_HIP(h, hipMemcpy(h->d_lx, x, sizeof(double) * n, hipMemcpyHostToDevice));
   WF_HIP(h, hipMemcpy(h->d_ly, y, sizeof(double) * n, hipMemcpyHostToDevice));
   if (n != h->N) { free_batch(h); h->B = 0; }
-  h->N = n; h->variant = v; h->wind_count = 0; h->model_dirty = true;
+  h->N = n; h->variant = v; h->wind_count = 0; h->shared_dir = false; h->model_dirty = true;
   return WF_OK;
 }
 
@@ -498,7 +499,7 @@ int wf_set_batch(wf_handle* h, int B) {
     WF_HIP(h, hipMalloc(&h->d_gidx, sizeof(int) * bn));
     h->cap_env = B; h->cap_bn = bn;
   }
-  h->B = B; h->wind_count = 0;
+  h->B = B; h->wind_count = 0; h->shared_dir = false;
   return WF_OK;
 }
 
@@ -510,10 +511,15 @@ int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int
   if (!on_device)
     for (int i = 0; i < count; ++i)
       if (!(ws[i] > 0.0) || !std::isfinite(wd[i])) return fail(h, WF_E_INVALID, "wind speed must be > 0 and direction finite");
+  // Host arrays with one direction for every farm (e.g. sampled speeds under a fixed direction): the rotation, the
+  // sort and the pair table depend on the direction only, so this is the shared-wind path with a speed per farm.
+  bool same_dir = count > 1 && !on_device;
+  for (int i = 1; same_dir && i < count; ++i) same_dir = wd[i] == wd[0];
+  h->shared_dir = same_dir;
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   WF_HIP(h, hipMemcpyAsync(h->d_ws, ws, sizeof(double) * count, kind, h->stream));
   WF_HIP(h, hipMemcpyAsync(h->d_wd, wd, sizeof(double) * count, kind, h->stream));
-  WF_HIP(h, wfk_launch_geometry(count, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+  WF_HIP(h, wfk_launch_geometry(same_dir ? 1 : count, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
   if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));  // caller's host arrays may go away
   h->wind_count = count;
   h->series_T = 0;
@@ -530,7 +536,7 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
     if (rc != WF_OK) return rc;
   }
   const size_t bn = (size_t)h->B * h->N;
-  const int gstride = (h->wind_count == 1) ? 0 : h->N;
+  const int gstride = (h->wind_count == 1 || h->shared_dir) ? 0 : h->N;
   const int wstride = (h->wind_count == 1) ? 0 : 1;
   const float* ptab = nullptr;
   {
@@ -574,6 +580,7 @@ int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* di
   WF_HIP(h, wfk_launch_wind_sample(h->B, seed, dv, h->d_ws, h->d_wd, h->stream));
   WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
   h->wind_count = h->B;
+  h->shared_dir = false;
   h->series_T = 0;
   h->pair_dirty = true;  // env_batch 1: "one wind per farm" is also "one wind for the batch" (table path)
   return WF_OK;
@@ -620,6 +627,7 @@ int wf_wind_series_step(wf_handle* h) {
                                      h->d_ws, h->d_wd, h->stream));
   WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
   h->wind_count = h->B;
+  h->shared_dir = false;
   h->pair_dirty = true;  // see wf_wind_sample
   return WF_OK;
 }
@@ -709,7 +717,7 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
   if (rc != WF_OK) return rc;
   if (h->model_dirty && (rc = build_consts(h)) != WF_OK) return rc;
   const size_t bn = (size_t)h->B * h->N, B = (size_t)h->B;
-  const int gstride = (h->wind_count == 1) ? 0 : h->N;
+  const int gstride = (h->wind_count == 1 || h->shared_dir) ? 0 : h->N;
   const int wstride = (h->wind_count == 1) ? 0 : 1;
   WfEnvArgs ea{};
   ea.yaw_state = h->d_env_yaw; ea.acc = h->d_env_acc; ea.moves = h->d_env_moves;
@@ -788,7 +796,7 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   wfk_variant(h->variant, &G, &S, &fn);
   // the instantiation the next step would launch: pair table (shared wind), general mirror cores, or default
   if (h->model_dirty && h->N > 0) { int rc = build_consts(h); if (rc != WF_OK) return rc; }
-  const bool tab = h->wind_count == 1 && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && !getenv("WF_NO_PAIR_TABLE");
+  const bool tab = (h->wind_count == 1 || h->shared_dir) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && !getenv("WF_NO_PAIR_TABLE");
   fn = wfk_variant_fn(h->variant, tab ? 2 : (h->consts.mirror_core_n <= 1 ? 0 : 1));
   info->pair_table = tab ? 1 : 0;
   hipFuncAttributes a;

@@ -448,8 +448,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   const int env = env_ok ? env_raw : (B - 1);
   const int N = c.N;
 
-  // table path = one wind for the whole batch: everything derived from it is wave-uniform and lives in SGPRs
-  auto uni = [](float v) { return TAB ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))) : v; };
+  // one wind for the whole batch (wind_stride 0; the table path also serves one direction with a speed per farm):
+  // everything derived from it is wave-uniform
+  auto uni = [&](float v) { return (TAB && wind_stride == 0) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))) : v; };
   const float ws = uni((float)ws_in[(size_t)env * wind_stride]);
   const double wd_d = fmod(wd_in[(size_t)env * wind_stride], 360.0);
   const float wd = uni((float)(wd_d < 0.0 ? wd_d + 360.0 : wd_d));
