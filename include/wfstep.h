@@ -90,7 +90,8 @@ int wf_set_batch(wf_handle* h, int env_batch);
 /* Replaces FlorisInterface.update_wind -> fi.reinitialize (interface.py:663-671).
  * count == 1: one (ws, wd) shared by the whole batch; count == env_batch: one per instance.
  * Performs wd % 360, the layout rotation and the upstream->downstream sort on the device (float64).
- * Host pointers unless on_device != 0. */
+ * Host pointers unless on_device != 0.  Host arrays whose directions are all equal (a speed per instance under one
+ * direction) share the rotation, the sort and the pair-coefficient table like count == 1. */
 int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int on_device);
 
 /* Replaces fi.calculate_wake(yaw_angles) + fi.get_turbine_powers() + local_wind_measurements() +

@@ -797,7 +797,7 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   // the instantiation the next step would launch: pair table (shared wind), general mirror cores, or default
   if (h->model_dirty && h->N > 0) { int rc = build_consts(h); if (rc != WF_OK) return rc; }
   const bool tab = (h->wind_count == 1 || h->shared_dir) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && !getenv("WF_NO_PAIR_TABLE");
-  fn = wfk_variant_fn(h->variant, tab ? 2 : (h->consts.mirror_core_n <= 1 ? 0 : 1));
+  fn = wfk_variant_fn(h->variant, tab ? (h->shared_dir ? 3 : 2) : (h->consts.mirror_core_n <= 1 ? 0 : 1));
   info->pair_table = tab ? 1 : 0;
   hipFuncAttributes a;
   WF_HIP(h, hipSetDevice(h->device));

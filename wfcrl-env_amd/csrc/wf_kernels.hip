@@ -448,9 +448,10 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   const int env = env_ok ? env_raw : (B - 1);
   const int N = c.N;
 
-  // one wind for the whole batch (wind_stride 0; the table path also serves one direction with a speed per farm):
-  // everything derived from it is wave-uniform
-  auto uni = [&](float v) { return (TAB && wind_stride == 0) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))) : v; };
+  // one wind for the whole batch: everything derived from it is wave-uniform and lives in SGPRs (the table path also
+  // serves one direction with a speed per farm: instantiation MC1 = false)
+  constexpr bool UWS = TAB && MC1;  // table path with a shared wind speed (MC1 is otherwise unused there)
+  auto uni = [](float v) { return UWS ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))) : v; };
   const float ws = uni((float)ws_in[(size_t)env * wind_stride]);
   const double wd_d = fmod(wd_in[(size_t)env * wind_stride], 360.0);
   const float wd = uni((float)(wd_d < 0.0 ? wd_d + 360.0 : wd_d));
@@ -1010,7 +1011,8 @@ struct WfVariant {
   int G, S;
   const void* fn;      // MC1 = true
   const void* fn_all;  // MC1 = false (general mirror cores)
-  const void* fn_tab;  // shared-wind pair table
+  const void* fn_tab;     // shared-wind pair table
+  const void* fn_tab_ws;  // pair table of a shared wind direction, a wind speed per farm
 };
 
 // The table path is instantiated only where two blocks per CU still fit in the 160 KiB LDS and N <= WF_PAIR_MAX_N.
@@ -1021,14 +1023,16 @@ constexpr bool tab_fits() {
          (8 / kTabWaves) * (sizeof(TableLds) + kTabWaves * sizeof(GeoLds<64 / G, G * S, false>) +
                             2 * 4 * WF_PAIR_ROW_FLOATS(G * S) + 4 * G * S) <= 160 * 1024;
 }
-template <int G, int S>
+// On the table path the MC1 parameter (meaningless there: no vortex core is evaluated) selects whether the wind
+// speed is shared as well (true: its derived constants live in SGPRs) or given per farm (false).
+template <int G, int S, bool SHARED_SPEED>
 const void* tab_kernel() {
-  if constexpr (tab_fits<G, S>()) return (const void*)&wf_step_kernel<G, S, true, true, kTabWaves>;
+  if constexpr (tab_fits<G, S>()) return (const void*)&wf_step_kernel<G, S, SHARED_SPEED, true, kTabWaves>;
   else return nullptr;
 }
 #define WF_VARIANT(G_, S_)                                                                              \
   {G_, S_, (const void*)&wf_step_kernel<G_, S_, true, false, 4>, (const void*)&wf_step_kernel<G_, S_, false, false, 4>, \
-   tab_kernel<G_, S_>()}
+   tab_kernel<G_, S_, true>(), tab_kernel<G_, S_, false>()}
 static const WfVariant kVariants[] = {
 #if WF_KSET != 2
     WF_VARIANT(4, 4),  WF_VARIANT(8, 4),  WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(32, 4), WF_VARIANT(64, 4),
@@ -1047,9 +1051,9 @@ static void local_variant(int i, int* G, int* S, const void** fn) {
   *S = kVariants[i].S;
   *fn = kVariants[i].fn;
 }
-// kind 0: MC1 on-the-fly, 1: general mirror cores, 2: shared-wind pair table
+// kind 0: MC1 on-the-fly, 1: general mirror cores, 2: shared-wind pair table, 3: pair table with a speed per farm
 static const void* local_variant_fn(int i, int kind) {
-  return kind == 2 ? kVariants[i].fn_tab : (kind == 1 ? kVariants[i].fn_all : kVariants[i].fn);
+  return kind == 3 ? kVariants[i].fn_tab_ws : (kind == 2 ? kVariants[i].fn_tab : (kind == 1 ? kVariants[i].fn_all : kVariants[i].fn));
 }
 static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx, const float* gy,
                                     const int* gidx, int geom_stride, const double* ws, const double* wd, int wind_stride,
@@ -1066,8 +1070,8 @@ static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTabl
   WfEnvArgs ea;
   if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
   void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &pair_tab, &pair_first};
-  const void* fn = (pair_tab && v.fn_tab) ? v.fn_tab : (cc.mirror_core_n <= 1 ? v.fn : v.fn_all);
-  if (fn != v.fn_tab) pair_tab = nullptr;
+  const void* fn = use_tab ? (wind_stride == 0 ? v.fn_tab : v.fn_tab_ws) : (cc.mirror_core_n <= 1 ? v.fn : v.fn_all);
+  if (!use_tab) pair_tab = nullptr;
   return hipLaunchKernel(fn, dim3(grid), dim3(64 * wpb), args, 0, s);
 }
 
