@@ -10,6 +10,8 @@ python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 tools/all_configs.py 40 > $O/all_configs.txt 2>&1
 python3 tests/tools/gpu_check.py > $O/parity_stats.txt 2>&1
 python3 tools/gs_sweep.py 2>&1 | grep ms/step > $O/variant_sweep.txt
+python3 tools/time_wind_modes.py 2>&1 | grep ms/step > $O/wind_modes.txt
+python3 tools/latency_b1.py 2>&1 | grep update_command > $O/latency_b1.txt
 (for sd in 21 22; do python3 tests/tools/fuzz_parity.py 1000 $sd 2>&1 | grep -E "^BAD|^fuzz"; done; python3 tests/tools/fuzz_api.py 60 50 21 2>&1 | grep -E "^BAD|^api fuzz") > $O/fuzz.txt
 bash tools/run_pmc.sh $tag > /dev/null 2>&1
 python3 tools/parse_pmc.py $tag > $O/pmc_cfg4.json
