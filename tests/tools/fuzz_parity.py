@@ -65,7 +65,7 @@ def classify(w):
     # a flip moves one turbine's TI by 1/9 of a wake-added term (a whole term for the lateral gate) and, through its
     # wake expansion, the few
     # turbines right behind it: bounded magnitude, and very few samples of a large batch
-    if (w["power_max"] <= 5e-2 and w["ws"] <= 2e-2 and w["wd"] <= 5e-2 and w["ti"] <= 2e-2 and w["std"] <= 5e-2
+    if (w["power_max"] <= 5e-2 and w["ws"] <= 2e-2 and w["wd"] <= 0.2 and w["ti"] <= 2e-2 and w["std"] <= 5e-2
             and w["ws_n_gt"] <= max(12, 2e-4 * w["n"]) and w["power_n_gt"] <= max(12, 3e-4 * w["n"])):  # a row's worth
         return "flip"
     return "BAD"
