@@ -257,7 +257,7 @@ int build_consts(wf_handle* h) {
   c.ch_ai = (float)m.ch_ai; c.ch_down = (float)m.ch_downstream;
   c.amb = (float)m.ambient_ti; c.amb2 = (float)(m.ambient_ti * m.ambient_ti);
   c.gch_gain = (float)m.gch_gain; c.overlap_thr = (float)m.overlap_thresh;
-  c.twoD = (float)(2.0 * D); c.fifteenD = (float)(15.0 * D); c.fifteenD_d = 15.0 * D;
+  c.twoD = (float)(2.0 * D); c.fifteenD_d = 15.0 * D;
   c.rho = (float)m.ref_density; c.pw = (float)(m.pP / 3.0);
   c.dens_f = (float)std::cbrt(m.air_density / m.ref_density);
 

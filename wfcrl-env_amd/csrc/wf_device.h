@@ -37,7 +37,7 @@ struct WfConsts {
   float kdef;              // D^2/8
   // crespo-hernandez + overlap gating                                               [A.3-8]
   float ch_c, ch_ai, ch_down;  // ch_c = constant * ambient^initial
-  float amb, amb2, gch_gain, overlap_thr, twoD, fifteenD;
+  float amb, amb2, gch_gain, overlap_thr, twoD;
   // outputs                                                                         [A.4]
   float rho, pw, dens_f;   // ref density, pP/3, (air_density/ref_density)^(1/3)
   // power / thrust table

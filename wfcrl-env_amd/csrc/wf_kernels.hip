@@ -10,18 +10,23 @@
 // Mapping: a VALU-bound pairwise recurrence with an N-stage sequential dependency, not a
 // contraction — no MFMA.
 //   * one farm instance is owned by a GROUP of G lanes of a 64-wide wavefront (64/G farms per wave); lane `sub`
-//     of the group owns the S target turbines  t = p*G + sub  (p = register slot);
-//   * the per-turbine state (SOSFS wake^2, V, W on the 3x3 rotor grid, TI per grid column = 30 floats) lives in
-//     VGPRs for the whole solve; HBM is touched once for yaw in and once for the 7 outputs; yaw (with its sin/cos)
-//     and the sorted geometry are staged per wave in LDS;
+//     of the group owns S target turbines; register slot p holds turbine  t = (blk + p)*G + sub  while the sources
+//     of block blk are being processed;
+//   * the per-turbine state (sum of squared deficits: 6, V and W on the 3x3 rotor grid: 9 + 9, TI per grid column: 3
+//     = 27 floats) lives in VGPRs for the whole solve; HBM is touched once for yaw in and once for the 7 outputs;
+//     yaw (with its sin/cos) and the sorted geometry are staged per wave in LDS;
 //   * the upstream->downstream recurrence runs over sources i = 0..N-1: the owner lane's rotor means are broadcast
 //     in the group with ds_bpermute (__shfl), every lane derives the source's constants and applies the source to
 //     its own targets in two passes (transverse velocities; then deflection + deficit + SOSFS + wake-added TI);
-//     slots whose turbines are all upstream of the source are skipped by a wave-uniform execz branch; the register
-//     slots rotate after each block of G sources so the source always sits in slot 0 (static indices, no scratch);
+//     when the G sources of a block are done nothing later touches the block: its outputs are written (after the
+//     transverse velocities of later sources that tie with it in x') and the slots shift down by one (static register
+//     indices, no scratch);
+//   * decisions that are discontinuities of the model are taken on the float64 coordinates, as the reference takes
+//     them: the order and sign of x'_t - x'_i, the 15 D reach of the wake-added TI (x_t <= x_i + 15 D);
 //   * template parameters: <G, S> lane group / slots per lane (chosen by the host from N and the batch size);
-//     MC1  compile-time skip of ground-mirror vortex cores that are exactly 1.0f in float32;
-//     TAB  shared-wind path: the geometry-only coefficients of the transverse pass come from a float64
+//     MC1  compile-time skip of ground-mirror vortex cores that are exactly 1.0f in float32 (on the table path,
+//          where no core is evaluated: shared wind speed (true) or a speed per farm (false));
+//     TAB  shared-wind-direction path: the geometry-only coefficients of the transverse pass come from a float64
 //          pair-coefficient table (wf_pair_table_kernel) whose rows are staged into a double-buffered LDS slab with
 //          global_load_lds_dwordx4 (LDS-DMA) one source ahead, one __syncthreads() per source;
 //     WPB  waves per block.
