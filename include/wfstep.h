@@ -109,6 +109,25 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wind_speed, flo
 
 int wf_sync(wf_handle* h);
 
+/* ---- Risk flags: where float32 cannot reproduce a float64 decision of the reference -------------------------
+ * The model has one state-dependent discontinuity: the overlap count of the wake-added turbulence, "deficit * Uinit >
+ * 0.05" per rotor-grid point (FLORIS 3.5 solver: `area_overlap = sum(velocity_deficit * u_initial > 0.05) / n`,
+ * SURVEY.md Appendix A.3-8).  The kernels evaluate the deficit in float32 (relative error ~1e-6 after the recurrence);
+ * when a deficit lies within a relative band `rel_band` of the threshold, a float64 evaluation may count the point
+ * the other way and move the turbine's TI by 1/9 of the added term.  Every step therefore records, per farm instance,
+ *   WF_RISK_OVERLAP     a (source, target, grid point) deficit within the guard band of the threshold, at a pair where
+ *                       the count matters (inside the 15 D reach and the 2 D lateral gate);
+ *   WF_RISK_POWER_KNEE  a turbine on a segment of the power table whose slope amplifies a float32-sized wind-speed
+ *                       error past 1e-4 of max(P, 1 kW) (cut-in 2.5-3 m/s, cut-out 25-25.01 m/s of nrel_5MW).
+ * Farms with flag 0 match the float64 path within the parity tolerances; flagged farms may differ by a bounded amount
+ * (tests/test_hip_parity.py).  All geometric discontinuities (upstream/downstream order, dx > 0.1, 15 D reach, 2 D
+ * lateral gate) are decided in float64 on the device and need no flag.
+ * wf_get_risk_flags copies the flags of the last wf_step / wf_env_step (env_batch ints). */
+#define WF_RISK_OVERLAP 1
+#define WF_RISK_POWER_KNEE 2
+int wf_set_risk_guard(wf_handle* h, double rel_band); /* default 2e-5; 0 disables WF_RISK_OVERLAP */
+int wf_get_risk_flags(wf_handle* h, int* flags, int on_device);
+
 /* ---- Fused env step (not in the reference, which does this in Python per farm) ----
  * Device-resident env state per farm instance: absolute yaw [B*N], actuation accumulator [B*N], move
  * counter [B].  One wf_env_step launch performs, per farm,

@@ -44,6 +44,7 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(str(build()))
         _LIB.wfo_step_batch.restype = C.c_int
+        _LIB.wfo_step_batch_ex.restype = C.c_int
         _LIB.wfo_max_threads.restype = C.c_int
     return _LIB
 
@@ -52,8 +53,12 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None, nthreads: int = 0):
-    """Same contract as floris_gch_numpy.farm_step_batch, evaluated by the C restatement."""
+def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None, nthreads: int = 0, margin: bool = False,
+                    tie_reverse: bool = False):
+    """Same contract as floris_gch_numpy.farm_step_batch, evaluated by the C restatement.
+    margin=True adds out["margin"] (B,): the smallest relative distance of any relevant deficit to the overlap
+    threshold (floris_gch.c: farm_step_one).  tie_reverse: exact x' ties in descending instead of ascending original
+    index (FLORIS' argsort leaves that order implementation-defined)."""
     p = p or ModelParams()
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)
@@ -84,9 +89,12 @@ def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None, nthreads: i
         "wind_direction": np.empty((B, N)),
         "load": np.empty((B, N, 4)),
     }
-    rc = lib().wfo_step_batch(
+    if margin:
+        out["margin"] = np.empty(B)
+    rc = lib().wfo_step_batch_ex(
         C.byref(cp), C.c_int(N), _dp(x), _dp(y), C.c_int(B), _dp(ws), _dp(wd), C.c_int(stride), _dp(yaw),
         _dp(out["power"]), _dp(out["wind_speed"]), _dp(out["wind_direction"]), _dp(out["load"]), C.c_int(nthreads),
+        _dp(out["margin"]) if margin else None, C.c_int(int(bool(tie_reverse))),
     )
     if rc != 0:
         raise RuntimeError(f"wfo_step_batch failed: {rc}")

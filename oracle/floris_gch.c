@@ -71,9 +71,17 @@ static inline void vortex(double G, double yL, double zc, double eps, double dec
   *w += sign * (-k * yL);
 }
 
+/* margin (may be NULL): out, the smallest relative distance |deficit*Uinit - overlap_thresh| / overlap_thresh over all
+ * (source, target, grid point) triples whose overlap count can matter (target within the 15 D reach and, for at least
+ * one grid column, inside the 2 D lateral gate) — how close this farm comes to the one state-dependent discontinuity
+ * of the model [A.3-8].  tie_reverse: order of turbines with EQUAL x' (FLORIS' np.argsort default is not a stable
+ * sort, so the order of exact ties is implementation-defined there): 0 = by ascending original index (stable),
+ * 1 = by descending original index. */
 static void farm_step_one(const wfo_params* p, int N, const double* x, const double* y, double ws, double wd,
                           const double* yaw, double* power, double* wind_speed, double* wind_dir, double* load,
-                          double* work /* 3N doubles */, double* vwbuf /* 18N doubles */, int* order, tstate* st) {
+                          double* work /* 3N doubles */, double* vwbuf /* 18N doubles */, int* order, tstate* st,
+                          double* margin, int tie_reverse) {
+  double min_margin = 1.0e300;
   const double D = p->D, HH = p->HH, R = p->D / 2.0;
   wd = pymod(wd, 360.0); /* reference interface.py:664 */
 
@@ -98,7 +106,10 @@ static void farm_step_one(const wfo_params* p, int N, const double* x, const dou
       ys[t] = xo * s + yo * c + yc;
       order[t] = t;
     }
-    /* stable insertion sort of indices by x' [A.1-2] */
+    /* stable insertion sort of indices by x' [A.1-2]; tie_reverse: start from descending indices, so that equal x'
+     * keep the descending order */
+    if (tie_reverse)
+      for (int t = 0; t < N; ++t) order[t] = N - 1 - t;
     for (int a = 1; a < N; ++a) {
       int k = order[a];
       int b = a - 1;
@@ -321,6 +332,15 @@ static void farm_step_one(const wfo_params* p, int N, const double* x, const dou
           if (isnan(ti)) ti = 0.0;
           if (isinf(ti) && ti > 0) ti = 0.0;
           const double overlap = (double)cnt / 9.0;
+          if (margin && X > x_i && X <= x_i + 15.0 * D) {
+            int gated = 0;
+            for (int j = 0; j < 3; ++j) gated |= fabs(y_i - (ys[t] + off[j])) < 2.0 * D;
+            if (gated)
+              for (int q = 0; q < 9; ++q) {
+                const double mg = fabs(defU[q] - p->overlap_thresh) / p->overlap_thresh;
+                if (mg < min_margin) min_margin = mg;
+              }
+          }
           for (int j = 0; j < 3; ++j) {
             const double Y = ys[t] + off[j];
             double m = (X > x_i ? 1.0 : 0.0) * (fabs(y_i - Y) < 2.0 * D ? 1.0 : 0.0) * (X <= x_i + 15.0 * D ? 1.0 : 0.0);
@@ -371,13 +391,14 @@ static void farm_step_one(const wfo_params* p, int N, const double* x, const dou
     load[o * 4 + 2] = sqrt(sv / 9.0);
     load[o * 4 + 3] = sqrt(sw / 9.0);
   }
+  if (margin) *margin = min_margin;
 }
 
 /* Batch entry: ws/wd have B entries when wind_stride = 1, one entry when 0. yaw is B x N row-major.
  * Returns 0 on success. nthreads <= 0 -> OpenMP default. */
-int wfo_step_batch(const wfo_params* p, int N, const double* x, const double* y, int B, const double* ws,
-                   const double* wd, int wind_stride, const double* yaw, double* power, double* wind_speed,
-                   double* wind_dir, double* load, int nthreads) {
+int wfo_step_batch_ex(const wfo_params* p, int N, const double* x, const double* y, int B, const double* ws,
+                      const double* wd, int wind_stride, const double* yaw, double* power, double* wind_speed,
+                      double* wind_dir, double* load, int nthreads, double* margin /* B or NULL */, int tie_reverse) {
   if (!p || N <= 0 || B < 0) return -1;
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -397,12 +418,19 @@ int wfo_step_batch(const wfo_params* p, int N, const double* x, const double* y,
       for (int b = 0; b < B; ++b) {
         const size_t w = (size_t)b * (wind_stride ? 1 : 0);
         farm_step_one(p, N, x, y, ws[w], wd[w], yaw + (size_t)b * N, power + (size_t)b * N,
-                      wind_speed + (size_t)b * N, wind_dir + (size_t)b * N, load + (size_t)b * N * 4, work, vwbuf, order, st);
+                      wind_speed + (size_t)b * N, wind_dir + (size_t)b * N, load + (size_t)b * N * 4, work, vwbuf, order, st,
+                      margin ? margin + b : NULL, tie_reverse);
       }
     }
     free(work); free(vwbuf); free(order); free(st);
   }
   return err;
+}
+
+int wfo_step_batch(const wfo_params* p, int N, const double* x, const double* y, int B, const double* ws,
+                   const double* wd, int wind_stride, const double* yaw, double* power, double* wind_speed,
+                   double* wind_dir, double* load, int nthreads) {
+  return wfo_step_batch_ex(p, N, x, y, B, ws, wd, wind_stride, yaw, power, wind_speed, wind_dir, load, nthreads, NULL, 0);
 }
 
 int wfo_max_threads(void) {

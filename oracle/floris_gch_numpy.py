@@ -155,9 +155,14 @@ def rotate_layout(x, y, wd):
     return xr, yr
 
 
-def sort_order(xr):
-    """Ascending x' [A.1-2].  FLORIS uses np.argsort default (ties implementation-defined);
-    this restatement fixes ties by original index (stable), and the HIP path does the same."""
+def sort_order(xr, tie_reverse=False):
+    """Ascending x' [A.1-2].  FLORIS uses np.argsort default (introsort / SIMD sort: the order of exact ties is
+    implementation-defined); this restatement fixes ties by ascending original index (stable), and the HIP path does the
+    same.  tie_reverse=True orders exact ties by descending original index instead — the other extreme, used by
+    tests/test_oracle_kat.py to quantify how much the reference's own result can depend on that order."""
+    if tie_reverse:
+        n = len(xr)
+        return (n - 1 - np.argsort(xr[::-1], kind="stable")).astype(np.intp)
     return np.argsort(xr, kind="stable")
 
 
@@ -165,7 +170,7 @@ def sort_order(xr):
 # One farm step
 # --------------------------------------------------------------------------------------
 
-def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=False):
+def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=False, tie_reverse=False):
     """One steady-state solve + measurement extraction for ONE farm.
 
     x, y : (N,) layout [m];  ws [m/s];  wd [deg, meteorological];  yaw : (N,) absolute deg.
@@ -183,7 +188,7 @@ def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=Fal
 
     # ---- geometry [A.1]
     xr, yr = rotate_layout(x, y, wd)
-    order = sort_order(xr)
+    order = sort_order(xr, tie_reverse)
     xs, ys, yaws = xr[order], yr[order], yaw[order]
     off = np.linspace(-D / 4.0, D / 4.0, 3)  # radius_ratio 0.5 * R
     X = np.broadcast_to(xs[:, None, None], (N, 3, 3)).copy()
@@ -375,7 +380,7 @@ def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=Fal
     return out
 
 
-def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None):
+def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None, tie_reverse=False):
     """Loop `farm_step` over a batch: ws, wd scalars or (B,), yaw (B, N). Small B only."""
     yaw = np.atleast_2d(np.asarray(yaw, dtype=np.float64))
     B, N = yaw.shape
@@ -388,7 +393,7 @@ def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None):
         "load": np.empty((B, N, 4)),
     }
     for b in range(B):
-        r = farm_step(x, y, float(ws[b]), float(wd[b]), yaw[b], p)
+        r = farm_step(x, y, float(ws[b]), float(wd[b]), yaw[b], p, tie_reverse=tie_reverse)
         for k in out:
             out[k][b] = r[k]
     return out

@@ -1,13 +1,12 @@
 """GPU: parity of the HIP path, called through the C ABI (ctypes), against the float64 oracle.
 
-Tolerances (fp32 device arithmetic vs float64 oracle; north_star: per-turbine power within 1e-4):
-  power      |dP| / max(P, 1 kW)  <= 1e-4  for all but max(2, 3e-4 n) of the n (env, turbine) samples and
-             <= 5e-3 for all: a 1-ulp difference can flip the overlap-count mask `deficit*U > 0.05` of SURVEY
-             A.3-8, which moves one turbine's TI by 1/9 of the added term — rare, bounded, rate measured by
-             tests/tools/gpu_check.py; the median must be <= 1e-6
-  wind_speed relative            <= 2e-5
-  wind_dir   absolute            <= 2e-4 deg (float32 resolution at 270 deg is 3e-5)
-  TI         absolute            <= 5e-6 ; std u, v, w absolute <= 1e-4 m/s
+The contract is in tests/parity.py (fp32 device arithmetic vs float64 oracle; north_star: per-turbine power within
+1e-4): STRICT on every farm whose risk flags are 0 — power |dP| / max(P, 1 kW) <= 1e-4, wind speed 2e-5 relative, wind
+direction 2e-4 deg, TI 5e-6, std u/v/w 1e-4 m/s, on every turbine, no count allowance.  A farm is flagged by the
+kernel itself (include/wfstep.h WF_RISK_*) when a deficit comes within the guard band of the overlap threshold
+`deficit * Uinit > 0.05` (the one state-dependent discontinuity of the model) or a turbine sits on a knee
+of the power table; flagged farms must stay inside the bounded signature of such an event, must be few, and the flag
+must not be spurious (the oracle's own margin to the threshold is checked).
 """
 import json
 import os
@@ -22,15 +21,23 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(ROOT, "tests", "golden", "oracle_goldens.npz")
 
 
-def _check(got, ref, strict_all=5e-3):
-    p = np.abs(got["power"].astype(np.float64) - ref["power"]) / np.maximum(ref["power"], 1e3)
-    assert np.median(p) <= 1e-6, np.median(p)
-    assert (p > 1e-4).sum() <= max(2, 3e-4 * p.size), ((p > 1e-4).sum(), p.size, p.max())
-    assert p.max() <= strict_all, p.max()
-    assert (np.abs(got["wind_speed"] - ref["wind_speed"]) / ref["wind_speed"]).max() <= 2e-5
-    assert np.abs(got["wind_direction"] - ref["wind_direction"]).max() <= 2e-4
-    assert np.abs(got["load"][..., 0] - ref["load"][..., 0]).max() <= 5e-6
-    assert np.abs(got["load"][..., 1:] - ref["load"][..., 1:]).max() <= 1e-4
+def _check(got, ref, max_flagged_frac=0.05):
+    """`got` carries the kernel's risk flags under "flags" (see _with_flags)."""
+    import parity
+
+    return parity.check(got, ref, got["flags"], max_flagged_frac)
+
+
+def _with_flags(w, out):
+    out = dict(out)
+    out["flags"] = w.risk_flags()
+    return out
+
+
+def _oracle(x, y, ws, wd, yaw, mp=None):
+    from oracle import c_oracle
+
+    return c_oracle.farm_step_batch(x, y, ws, wd, np.asarray(yaw, dtype=np.float64), mp, margin=True)
 
 
 def _step(x, y, ws, wd, yaw):
@@ -38,7 +45,7 @@ def _step(x, y, ws, wd, yaw):
 
     w = WfStep(x, y, env_batch=yaw.shape[0])
     w.set_wind(ws, wd)
-    out = w.step(yaw)
+    out = _with_flags(w, w.step(yaw))
     info = w.kernel_info()
     w.close()
     return out, info
@@ -88,8 +95,62 @@ def test_parity_random_yaw_and_wind(layouts, name, B, mode):
         wd = rng.normal(270, 20, B) % 360
     out, info = _step(l["xcoords"], l["ycoords"], ws, wd, yaw)
     assert info["lanes_per_env"] * info["slots_per_lane"] >= N
-    ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], ws, wd, yaw.astype(np.float64))
+    ref = _oracle(l["xcoords"], l["ycoords"], ws, wd, yaw)
     _check(out, ref)
+
+
+def test_baseline_config2_named_turb16_tcrwp(layouts):
+    """BASELINE.json configs[2] as named: `Turb16_TCRWP_Floris` = the first 16 turbines of the TCRWP layout (the
+    reference's README spelling; its registry only has Turb16_Row5 and Turb_TCRWP — SURVEY Appendix C2), random yaw
+    actions as a random walk, shared 8 m/s / 270 deg and per-farm wind."""
+    t = layouts["Turb_TCRWP_"]
+    x, y = t["xcoords"][:16], t["ycoords"][:16]
+    rng = np.random.default_rng(1236)
+    B = 512
+    yaw = np.zeros((B, 16), np.float32)
+    from wfcrl_env_amd.backend import WfStep
+
+    w = WfStep(x, y, env_batch=B)
+    for mode in ("shared", "per_env"):
+        if mode == "shared":
+            ws, wd = np.array([8.0]), np.array([270.0])
+        else:
+            ws, wd = np.clip(8 * rng.weibull(8, B), 3, 28), rng.normal(270, 20, B) % 360
+        w.set_wind(ws, wd)
+        for _ in range(3):
+            yaw = np.clip(yaw + rng.uniform(-5, 5, (B, 16)), -40, 40).astype(np.float32)
+            _check(_with_flags(w, w.step(yaw)), _oracle(x, y, ws, wd, yaw))
+    w.close()
+
+
+def test_risk_flags_mark_exactly_the_farms_near_the_threshold(layouts):
+    """The kernel's WF_RISK_OVERLAP flag against the oracle's own margin to the overlap threshold, on a case with many
+    partial overlaps (oblique directions), for several guard bands: every farm whose float64 margin is well inside the
+    band is flagged, no farm whose margin is far outside is, and with the band at 0 nothing is flagged."""
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    rng = np.random.default_rng(31)
+    B = 2048
+    yaw = rng.uniform(-30, 30, (B, 80)).astype(np.float32)
+    ws, wd = rng.uniform(6, 12, B), rng.uniform(0, 360, B)
+    ref = _oracle(l["xcoords"], l["ycoords"], ws, wd, yaw)
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w.set_wind(ws, wd)
+    for band in (0.0, 2e-5, 1e-3, 1e-2):
+        w.set_risk_guard(band)
+        out = w.step(yaw)
+        fl = (w.risk_flags() & 1) != 0
+        if band == 0.0:
+            assert not fl.any()
+            continue
+        # float32 rounding of the deficit (<~ 1e-5 relative after the recurrence) and the +-5 % row dependence of the band
+        assert fl[ref["margin"] < 0.9 * band - 2e-5].all(), band
+        assert not fl[ref["margin"] > 1.1 * band + 1e-4].any(), band
+        if band >= 1e-3:
+            assert fl.any()
+    w.set_risk_guard(2e-5)
+    w.close()
 
 
 def test_procedural_rows_and_single_turbine():
@@ -101,7 +162,7 @@ def test_procedural_rows_and_single_turbine():
         y = [0.0] * n
         yaw = rng.uniform(-40, 40, (64, n)).astype(np.float32)
         out, _ = _step(x, y, 8.0, 270.0, yaw)
-        ref = c_oracle.farm_step_batch(x, y, 8.0, 270.0, yaw.astype(np.float64))
+        ref = _oracle(x, y, 8.0, 270.0, yaw)
         _check(out, ref)
 
 
@@ -116,7 +177,7 @@ def test_wind_edge_cases(layouts):
     yaw[2] = -40.0
     for ws, wd in [(3.0, 270.0), (24.9, 300.0), (28.0, 250.0), (11.4, -90.0), (8.0, 630.0), (8.0, 271.0), (5.0, 0.0)]:
         out, _ = _step(l["xcoords"], l["ycoords"], ws, wd, yaw)
-        ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], ws, wd, yaw.astype(np.float64))
+        ref = _oracle(l["xcoords"], l["ycoords"], ws, wd, yaw)
         for v in out.values():
             assert np.isfinite(v).all()
         _check(out, ref)
@@ -137,13 +198,13 @@ def test_max_turbines_and_ragged_batch():
     wd = np.array([268.0, 281.0, 255.0])
     out, info = _step(x, y, ws, wd, yaw)
     assert (info["lanes_per_env"], info["slots_per_lane"]) == (64, 4)
-    ref = c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64))
+    ref = _oracle(x, y, ws, wd, yaw)
     _check(out, ref)
     for B in (1, 31, 33):
         l = json.load(open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")))["Ablaincourt_"]
         yaw = rng.uniform(-40, 40, (B, 7)).astype(np.float32)
         out, _ = _step(l["xcoords"], l["ycoords"], 8.0, 270.0, yaw)
-        ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], 8.0, 270.0, yaw.astype(np.float64))
+        ref = _oracle(l["xcoords"], l["ycoords"], 8.0, 270.0, yaw)
         _check(out, ref)
 
 
@@ -164,6 +225,7 @@ def test_full_size_properties_hornsrev1(layouts):
     d = w.step(yaw.cuda())
     w.sync()
     out = {k: v.cpu().numpy() for k, v in d.items()}
+    flags = w.risk_flags()
     for v in out.values():
         assert np.isfinite(v).all()
     # (1) an env's result does not depend on where it sits in the batch: bit-exact
@@ -181,8 +243,10 @@ def test_full_size_properties_hornsrev1(layouts):
     assert out["load"][..., 0].min() >= 0.06 - 1e-7
     # (5) a random subset against the oracle
     idx = np.random.default_rng(0).choice(B, 96, replace=False)
-    ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], 8.0, 270.0, yaw.numpy()[idx].astype(np.float64))
-    _check({k: v[idx] for k, v in out.items()}, ref)
+    ref = _oracle(l["xcoords"], l["ycoords"], 8.0, 270.0, yaw.numpy()[idx])
+    _check(dict({k: v[idx] for k, v in out.items()}, flags=flags[idx]), ref)
+    # (6) the flagged fraction of the BASELINE configuration itself: HornsRev1 at 270 deg has no partial overlaps
+    assert (flags != 0).mean() <= 0.01, (flags != 0).mean()
     w.close()
 
 
@@ -203,8 +267,8 @@ def test_time_varying_direction_sweep_hornsrev2(layouts):
         for wd in (np.array([wd_t]), wd_t + jitter):
             ws = np.full_like(wd, 8.0)
             w.set_wind(ws, wd)
-            out = w.step(yaw)
-            ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], ws, wd, yaw.astype(np.float64))
+            out = _with_flags(w, w.step(yaw))
+            ref = _oracle(l["xcoords"], l["ycoords"], ws, wd, yaw)
             _check(out, ref)
     w.close()
 
@@ -256,11 +320,11 @@ def test_custom_model_table_is_data(layouts):
     wd = rng.normal(270, 20, 200) % 360
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=200, model=custom)
     w.set_wind(ws, wd)
-    out = w.step(yaw)
+    out = _with_flags(w, w.step(yaw))
     w.close()
     p = ModelParams(ambient_ti=0.08, shear=0.14, D=120.0, HH=85.0, TSR=7.5, ka=0.3, kb=0.005, alpha=0.6, beta=0.08,
                     table_ws=ws_tab, table_ct=ct_tab, table_cp=cp_tab)
-    ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], ws, wd, yaw.astype(np.float64), p)
+    ref = _oracle(l["xcoords"], l["ycoords"], ws, wd, yaw, p)
     _check(out, ref)
 
 
@@ -279,9 +343,9 @@ def test_low_hub_model_uses_general_mirror_core_kernel(layouts):
     wd = rng.normal(270, 25, B) % 360
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, model=dict(hub_height=70.0))
     w.set_wind(ws, wd)
-    out = w.step(yaw)
+    out = _with_flags(w, w.step(yaw))
     w.close()
-    ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], ws, wd, yaw.astype(np.float64), ModelParams(HH=70.0))
+    ref = _oracle(l["xcoords"], l["ycoords"], ws, wd, yaw, ModelParams(HH=70.0))
     _check(out, ref)
     # the flag itself: exp(-(2*70 - 94.5 + 0.001)^2 / 25.2^2) = 3.8e-2 and the next class 6e-5 are both > 2^-25
     import math
@@ -307,7 +371,7 @@ def test_interface_from_yaml_on_gpu(layouts, tmp_path):
     assert (it.wind_speed, it.wind_dir, it.num_turbines) == (9.5, 255.0, 7)
     yaw = np.array([20.0, -10.0, 5.0, 0.0, 15.0, -25.0, 0.0])
     it.update_command(yaw)
-    ref = c_oracle.farm_step_batch(case.xcoords, case.ycoords, 9.5, 255.0, yaw[None], ModelParams(ambient_ti=0.09, shear=0.15))
+    ref = _oracle(case.xcoords, case.ycoords, 9.5, 255.0, yaw[None], ModelParams(ambient_ti=0.09, shear=0.15))
     assert np.abs(it.avg_powers() / ref["power"][0] - 1).max() < 1e-4
     assert np.abs(it.get_measure("wind_direction") - ref["wind_direction"][0]).max() < 2e-4
     assert np.abs(it.get_measure("load") / 1e7 - ref["load"][0]).max() < 1e-4
@@ -344,13 +408,13 @@ def test_random_layouts_including_degenerate_ones():
         wd = rng.uniform(0, 360, B)
         wd[:4] = [270.0, 0.0, 90.0, 180.0]
         out, info = _step(x, y, ws, wd, yaw)
-        ref = c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64))
+        ref = _oracle(x, y, ws, wd, yaw)
         for v in out.values():
             assert np.isfinite(v).all(), n
         # directions that are exact multiples of 90 deg other than 270 make x' ties depend on 1e-13 rounding noise
         # of the rotation (also inside FLORIS itself): compare those farms on power only, loosely
         exact = slice(4, None)
-        _check({k: v[exact] for k, v in out.items()}, {k: v[exact] for k, v in ref.items()})
+        _check({k: v[exact] for k, v in out.items()}, {k: v[exact] for k, v in ref.items()}, max_flagged_frac=0.15)
         p = np.abs(out["power"][:4] - ref["power"][:4]) / np.maximum(ref["power"][:4], 1e3)
         assert p.max() < 5e-3, (n, p.max())
     packed = [(rng.uniform(0, 600, 13), rng.uniform(-200, 200, 13)),
@@ -376,24 +440,25 @@ def test_shared_wind_pair_table_path_and_its_fallbacks(layouts, monkeypatch):
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
     w.set_wind(9.0, 281.0)
     assert w.kernel_info()["pair_table"] == 1
-    a = w.step(yaw)
+    a = _with_flags(w, w.step(yaw))
     # the same wind given per farm, as two spellings of the direction so that it does not register as shared:
     # on-the-fly path
     w.set_wind(np.full(B, 9.0), 281.0 + 360.0 * (np.arange(B) % 2))
     assert w.kernel_info()["pair_table"] == 0
-    b = w.step(yaw)
+    b = _with_flags(w, w.step(yaw))
     # one direction, a speed per farm (host arrays): geometry and pair table are shared, the speed is not
     ws_b = rng.uniform(5, 14, B)
     w.set_wind(ws_b, np.full(B, 281.0))
     assert w.kernel_info()["pair_table"] == 1
-    cdir = w.step(yaw)
+    cdir = _with_flags(w, w.step(yaw))
     w.close()
-    _check(cdir, c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], ws_b, np.full(B, 281.0), yaw.astype(np.float64)))
-    ref = c_oracle.farm_step_batch(l["xcoords"], l["ycoords"], 9.0, 281.0, yaw.astype(np.float64))
+    _check(cdir, _oracle(l["xcoords"], l["ycoords"], ws_b, np.full(B, 281.0), yaw))
+    ref = _oracle(l["xcoords"], l["ycoords"], 9.0, 281.0, yaw)
     _check(a, ref)
     _check(b, ref)
-    assert np.abs(a["power"] / np.maximum(b["power"], 1e3) - 1)[b["power"] > 1e3].max() < 2e-5
-    assert np.abs(a["load"] - b["load"]).max() < 2e-5
+    both = (a["flags"] == 0) & (b["flags"] == 0)  # the two paths round differently: compare where neither is at risk
+    assert np.abs(a["power"] / np.maximum(b["power"], 1e3) - 1)[both][b["power"][both] > 1e3].max() < 2e-5
+    assert np.abs(a["load"] - b["load"])[both].max() < 2e-5
     # env switch for A/B runs
     monkeypatch.setenv("WF_NO_PAIR_TABLE", "1")
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
@@ -408,22 +473,22 @@ def test_shared_wind_pair_table_path_and_its_fallbacks(layouts, monkeypatch):
     w = WfStep(x, y, env_batch=6)
     w.set_wind(8.0, 265.0)
     assert w.kernel_info()["pair_table"] == 0
-    out = w.step(yaw)
+    out = _with_flags(w, w.step(yaw))
     w.close()
-    _check(out, c_oracle.farm_step_batch(x, y, 8.0, 265.0, yaw.astype(np.float64)))
+    _check(out, _oracle(x, y, 8.0, 265.0, yaw))
     # low hub (general mirror cores) through the table
     l16 = layouts["Turb16_Row5_"]
     yaw = rng.uniform(-35, 35, (40, 16)).astype(np.float32)
     w = WfStep(l16["xcoords"], l16["ycoords"], env_batch=40, model=dict(hub_height=70.0))
     w.set_wind(7.5, 270.0)
     assert w.kernel_info()["pair_table"] == 1
-    out = w.step(yaw)
+    out = _with_flags(w, w.step(yaw))
     # a model change invalidates the table
     w.set_model(dict(hub_height=90.0))
-    out90 = w.step(yaw)
+    out90 = _with_flags(w, w.step(yaw))
     w.close()
-    _check(out, c_oracle.farm_step_batch(l16["xcoords"], l16["ycoords"], 7.5, 270.0, yaw.astype(np.float64), ModelParams(HH=70.0)))
-    _check(out90, c_oracle.farm_step_batch(l16["xcoords"], l16["ycoords"], 7.5, 270.0, yaw.astype(np.float64)))
+    _check(out, _oracle(l16["xcoords"], l16["ycoords"], 7.5, 270.0, yaw, ModelParams(HH=70.0)))
+    _check(out90, _oracle(l16["xcoords"], l16["ycoords"], 7.5, 270.0, yaw))
 
 
 _VARIANTS = [(g, s) for g, smax in ((4, 4), (8, 4), (16, 6), (32, 4), (64, 4)) for s in range(1, smax + 1)]
@@ -450,16 +515,16 @@ def test_every_kernel_variant_matches_the_oracle(G, S, monkeypatch):
     info = w.kernel_info()
     assert (info["lanes_per_env"], info["slots_per_lane"]) == (G, S)
     w.set_wind(9.5, 263.0)
-    shared = w.step(yaw)
+    shared = _with_flags(w, w.step(yaw))
     tab = w.kernel_info()["pair_table"]
     ws, wd = rng.uniform(6, 12, B), rng.uniform(250, 290, B)
     w.set_wind(ws, wd)
     assert w.kernel_info()["pair_table"] == 0
-    per_farm = w.step(yaw)
+    per_farm = _with_flags(w, w.step(yaw))
     w.close()
     assert tab in (0, 1)  # the table path exists where its LDS slab fits (wf_kernels.hip: tab_fits)
-    _check(shared, c_oracle.farm_step_batch(x, y, 9.5, 263.0, yaw.astype(np.float64)))
-    _check(per_farm, c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64)))
+    _check(shared, _oracle(x, y, 9.5, 263.0, yaw))
+    _check(per_farm, _oracle(x, y, ws, wd, yaw))
 
 
 @pytest.mark.parametrize("wdir", [270.0, 90.0, 0.0])
@@ -489,12 +554,12 @@ def test_exact_x_ties_across_kernel_blocks(gs, shape, wdir, monkeypatch):
     info = w.kernel_info()
     assert f'{info["lanes_per_env"]}x{info["slots_per_lane"]}' == gs
     w.set_wind(8.0, wdir)
-    shared = w.step(yaw)
+    shared = _with_flags(w, w.step(yaw))
     w.set_wind(np.full(B, 8.0), wdir + 360.0 * (np.arange(B) % 2))  # two spellings: not taken for a shared direction
     assert w.kernel_info()["pair_table"] == 0
-    per_farm = w.step(yaw)
+    per_farm = _with_flags(w, w.step(yaw))
     w.close()
-    ref = c_oracle.farm_step_batch(x, y, 8.0, wdir, yaw.astype(np.float64))
+    ref = _oracle(x, y, 8.0, wdir, yaw)
     _check(shared, ref)
     _check(per_farm, ref)
 
@@ -509,7 +574,7 @@ def test_randomised_parity_fuzz_sample():
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     nflip, nbad = fz.run(120, 2024)
-    assert nbad == 0
+    assert nbad == 0  # every mismatch on a farm the kernel flagged itself, within the bounded signature
     assert nflip <= 3
 
 

@@ -15,6 +15,8 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libwfstep.so"
 
 WF_OK = 0
+WF_RISK_OVERLAP = 1     # a deficit within the guard band of the overlap threshold (include/wfstep.h)
+WF_RISK_POWER_KNEE = 2  # a turbine on a steep segment (cut-in / cut-out) of the power table
 WF_E = {-1: "WF_E_INVALID", -2: "WF_E_UNSUPPORTED", -3: "WF_E_NODEVICE", -4: "WF_E_HIP", -5: "WF_E_NOMEM"}
 
 _MODEL_DOUBLES = (
@@ -71,6 +73,8 @@ ABI = {
     "wf_set_wind": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "wf_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int]),
     "wf_sync": (C.c_int, [_P]),
+    "wf_set_risk_guard": (C.c_int, [_P, C.c_double]),
+    "wf_get_risk_flags": (C.c_int, [_P, _P, C.c_int]),
     "wf_wind_sample": (C.c_int, [_P, C.c_ulonglong, C.POINTER(WindDist)]),
     "wf_wind_series": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_ulonglong]),
     "wf_wind_series_step": (C.c_int, [_P]),

@@ -230,6 +230,25 @@ class WfStep:
     def sync(self):
         check(self._lib.wf_sync(self._h), self._h)
 
+    def set_risk_guard(self, rel_band: float):
+        """Relative half-width of the guard band around the overlap threshold (include/wfstep.h, WF_RISK_OVERLAP)."""
+        check(self._lib.wf_set_risk_guard(self._h, float(rel_band)), self._h)
+
+    def risk_flags(self, as_torch: bool = False):
+        """WF_RISK_* bits of every farm for the last step: int32 (B,).  0 = every float64 decision of the reference
+        was reproduced with a margin; see include/wfstep.h."""
+        B = self.env_batch
+        if as_torch:
+            import torch
+
+            self._follow_torch_stream()
+            f = torch.empty(B, dtype=torch.int32, device=f"cuda:{self.device_id}")
+            check(self._lib.wf_get_risk_flags(self._h, f.data_ptr(), 1), self._h)
+            return f
+        f = np.empty(B, np.int32)
+        check(self._lib.wf_get_risk_flags(self._h, f.ctypes.data, 0), self._h)
+        return f
+
     def timing_begin(self):
         check(self._lib.wf_timing_begin(self._h), self._h)
 

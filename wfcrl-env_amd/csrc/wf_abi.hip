@@ -23,14 +23,14 @@ extern "C" int wfk_variant_has_table(int i);
 extern "C" int wfk_tab_waves();
 extern "C" const void* wfk_variant_fn(int i, int kind);
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
-                                          const double* wd, double* gx, float* gy, int* gidx, hipStream_t s);
+                                          const double* wd, double* gx, double* gy, int* gidx, hipStream_t s);
 extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
-                                      const float* gy, const int* gidx, int geom_stride, const double* ws,
+                                      const double* gy, const int* gidx, int geom_stride, const double* ws,
                                       const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
                                       float* o_wd, float* load, int B, const WfEnvArgs* env, const float* pair_tab,
-                                      const int* pair_first, hipStream_t s, int* grid_out);
-extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double* gx, const float* gy, float* tab,
-                                            int* first_active, hipStream_t s);
+                                      const int* pair_first, const WfGroupArgs* grp, hipStream_t s, int* grid_out);
+extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, int n_groups, const double* gx, const double* gy,
+                                            float* tab, int* first_active, hipStream_t s);
 
 extern "C" hipError_t wfk_launch_wind_sample(int B, unsigned long long seed, const double* dist, double* ws, double* wd,
                                              hipStream_t s);
@@ -95,8 +95,10 @@ struct wf_handle {
   double *d_lx = nullptr, *d_ly = nullptr;
   double *d_ws = nullptr, *d_wd = nullptr;  // [B]
   double* d_gx = nullptr;                   // [B*N] (or [N] when wind is shared)
-  float* d_gy = nullptr;
+  double* d_gy = nullptr;                   // sorted y' (float64: the lateral gate is decided on it)
   int* d_gidx = nullptr;
+  int* d_flags = nullptr;                   // [B] WF_RISK_* bits of the last step
+  double guard_rel = 2.0e-5;                // relative half-width of the overlap-threshold guard band
   float *d_yaw = nullptr, *d_out = nullptr;  // staging for host callers: yaw [B*N], out [B*N*7]
   float *h_yaw = nullptr, *h_out = nullptr;  // pinned
   size_t cap_env = 0, cap_bn = 0;
@@ -130,7 +132,8 @@ int fail(wf_handle* h, int code, const std::string& msg) {
   } while (0)
 
 void free_batch(wf_handle* h) {
-  hipFree(h->d_ws); hipFree(h->d_wd); hipFree(h->d_gx); hipFree(h->d_gy); hipFree(h->d_gidx);
+  hipFree(h->d_ws); hipFree(h->d_wd); hipFree(h->d_gx); hipFree(h->d_gy); hipFree(h->d_gidx); hipFree(h->d_flags);
+  h->d_flags = nullptr;
   hipFree(h->d_yaw); hipFree(h->d_out);
   hipFree(h->d_env_yaw); hipFree(h->d_env_acc); hipFree(h->d_env_act); hipFree(h->d_env_out); hipFree(h->d_env_moves);
   if (h->h_env_act) hipHostFree(h->h_env_act);
@@ -142,7 +145,7 @@ void free_batch(wf_handle* h) {
   h->d_series_ws = h->d_series_wd = h->d_ws_prev = nullptr; h->d_series_start = nullptr; h->series_T = 0;
   if (h->h_yaw) hipHostFree(h->h_yaw);
   if (h->h_out) hipHostFree(h->h_out);
-  h->d_ws = h->d_wd = h->d_gx = nullptr; h->d_gy = nullptr; h->d_gidx = nullptr;
+  h->d_ws = h->d_wd = h->d_gx = h->d_gy = nullptr; h->d_gidx = nullptr;
   h->d_yaw = h->d_out = h->h_yaw = h->h_out = nullptr;
   h->cap_env = h->cap_bn = 0;
 }
@@ -258,6 +261,9 @@ int build_consts(wf_handle* h) {
   c.amb = (float)m.ambient_ti; c.amb2 = (float)(m.ambient_ti * m.ambient_ti);
   c.gch_gain = (float)m.gch_gain; c.overlap_thr = (float)m.overlap_thresh;
   c.twoD = (float)(2.0 * D); c.fifteenD_d = 15.0 * D;
+  for (int k = 0; k < 3; ++k) c.off_d[k] = off[k];
+  c.twoD_d = 2.0 * D;
+  c.guard_rel = (float)h->guard_rel;
   c.rho = (float)m.ref_density; c.pw = (float)(m.pP / 3.0);
   c.dens_f = (float)std::cbrt(m.air_density / m.ref_density);
 
@@ -274,6 +280,15 @@ int build_consts(wf_handle* h) {
     const bool seg = i + 1 < n;
     t.ct_slope[i] = seg ? (float)((h->tct[i + 1] - h->tct[i]) / (h->tws[i + 1] - h->tws[i])) : 0.f;
     t.pw_slope[i] = seg ? (float)((pwv[i + 1] - pwv[i]) / (h->tws[i + 1] - h->tws[i])) : 0.f;
+  }
+  // Knees of the power curve: segment j is "steep" when its relative condition number v |P'| / max(P, 1 kW) exceeds
+  // WF_STEEP_KAPPA — a wind-speed error of float32 size (~3e-6 relative after the recurrence) then exceeds 1e-4 of
+  // max(P, 1 kW).  For the nrel_5MW table these are the cut-in segment 2.5-3.0 m/s and the cut-out drop 25.0-25.01 m/s.
+  c.steep[0] = c.steep[1] = 0u;
+  for (int i = 0; i + 1 < n; ++i) {
+    const double slope = std::fabs(pwv[i + 1] - pwv[i]) / (h->tws[i + 1] - h->tws[i]) * m.ref_density;
+    const double pmin = std::fmax(std::fmin(pwv[i], pwv[i + 1]) * m.ref_density, 1.0e3);
+    if (slope * h->tws[i + 1] / pmin > 30.0) c.steep[i >> 5] |= 1u << (i & 31);
   }
   const double x0 = h->tws[0], x1 = h->tws[n - 1];
   const double bh = (x1 - x0) / WF_BUCKETS;
@@ -322,6 +337,7 @@ int pair_table(wf_handle* h, const float** out) {
     double uinf = 0;
     for (int k = 0; k < 3; ++k) uinf += std::pow((HH + off[k]) / HH, m.shear) / 3.0;
     pc.fifteenD = 15.0 * D;
+    pc.twoD = 2.0 * D;
     pc.gam_top = (1.0 / 16.0) * D * std::pow((HH + D / 2) / HH, m.shear) * uinf;  // (1/2pi)(pi/8) D vel_top uinf
     pc.gam_bot = (1.0 / 16.0) * D * std::pow((HH - D / 2) / HH, m.shear) * uinf;
     for (int k = 0; k < 3; ++k) {
@@ -331,10 +347,25 @@ int pair_table(wf_handle* h, const float** out) {
       const double lm = m.kappa * z / (1.0 + m.kappa * z / (D / 8.0));
       pc.decay_a[k] = 4.0 * lm * lm * std::fabs(dudz) / uinf / pc.eps2;
     }
-    WF_HIP(h, wfk_launch_pair_table(&pc, h->d_gx, h->d_gy, h->d_pair_tab, h->d_pair_first, h->stream));
+    WF_HIP(h, wfk_launch_pair_table(&pc, 1, h->d_gx, h->d_gy, h->d_pair_tab, h->d_pair_first, h->stream));
     h->pair_dirty = false;
   }
   *out = h->d_pair_tab;
+  return WF_OK;
+}
+
+// One launch of the step kernel on the handle's stream with the handle's current geometry / wind / table state.
+int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
+  const int gstride = (h->wind_count == 1 || h->shared_dir) ? 0 : h->N;
+  const int wstride = (h->wind_count == 1) ? 0 : 1;
+  const float* ptab = nullptr;
+  int rc = pair_table(h, &ptab);
+  if (rc != WF_OK) return rc;
+  WfGroupArgs ga{};
+  ga.mod = 1;
+  ga.risk_flags = h->d_flags;
+  WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
+                            wstride, yaw, power, wspd, wdir, load, h->B, ea, ptab, h->d_pair_first, &ga, h->stream, &h->grid));
   return WF_OK;
 }
 
@@ -495,7 +526,8 @@ int wf_set_batch(wf_handle* h, int B) {
     WF_HIP(h, hipMalloc(&h->d_ws, sizeof(double) * B));
     WF_HIP(h, hipMalloc(&h->d_wd, sizeof(double) * B));
     WF_HIP(h, hipMalloc(&h->d_gx, sizeof(double) * bn));
-    WF_HIP(h, hipMalloc(&h->d_gy, sizeof(float) * bn));
+    WF_HIP(h, hipMalloc(&h->d_gy, sizeof(double) * bn));
+    WF_HIP(h, hipMalloc(&h->d_flags, sizeof(int) * B));
     WF_HIP(h, hipMalloc(&h->d_gidx, sizeof(int) * bn));
     h->cap_env = B; h->cap_bn = bn;
   }
@@ -536,18 +568,7 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
     if (rc != WF_OK) return rc;
   }
   const size_t bn = (size_t)h->B * h->N;
-  const int gstride = (h->wind_count == 1 || h->shared_dir) ? 0 : h->N;
-  const int wstride = (h->wind_count == 1) ? 0 : 1;
-  const float* ptab = nullptr;
-  {
-    int rc = pair_table(h, &ptab);
-    if (rc != WF_OK) return rc;
-  }
-  if (on_device) {
-    WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
-                              wstride, yaw, power, wspd, wdir, load, h->B, nullptr, ptab, h->d_pair_first, h->stream, &h->grid));
-    return WF_OK;
-  }
+  if (on_device) return launch_step(h, yaw, power, wspd, wdir, load, nullptr);
   if (!h->d_yaw) {
     WF_HIP(h, hipMalloc(&h->d_yaw, sizeof(float) * bn));
     WF_HIP(h, hipHostMalloc(&h->h_yaw, sizeof(float) * bn, hipHostMallocDefault));
@@ -556,9 +577,10 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
   if (!h->h_out) WF_HIP(h, hipHostMalloc(&h->h_out, sizeof(float) * bn * 7, hipHostMallocDefault));
   std::memcpy(h->h_yaw, yaw, sizeof(float) * bn);
   WF_HIP(h, hipMemcpyAsync(h->d_yaw, h->h_yaw, sizeof(float) * bn, hipMemcpyHostToDevice, h->stream));
-  WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
-                            wstride, h->d_yaw, h->d_out, h->d_out + bn, h->d_out + 2 * bn, h->d_out + 3 * bn, h->B,
-                            nullptr, ptab, h->d_pair_first, h->stream, &h->grid));
+  {
+    int rc = launch_step(h, h->d_yaw, h->d_out, h->d_out + bn, h->d_out + 2 * bn, h->d_out + 3 * bn, nullptr);
+    if (rc != WF_OK) return rc;
+  }
   WF_HIP(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(float) * bn * 7, hipMemcpyDeviceToHost, h->stream));
   WF_HIP(h, hipStreamSynchronize(h->stream));
   if (power) std::memcpy(power, h->h_out, sizeof(float) * bn);
@@ -717,20 +739,15 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
   if (rc != WF_OK) return rc;
   if (h->model_dirty && (rc = build_consts(h)) != WF_OK) return rc;
   const size_t bn = (size_t)h->B * h->N, B = (size_t)h->B;
-  const int gstride = (h->wind_count == 1 || h->shared_dir) ? 0 : h->N;
-  const int wstride = (h->wind_count == 1) ? 0 : 1;
   WfEnvArgs ea{};
   ea.yaw_state = h->d_env_yaw; ea.acc = h->d_env_acc; ea.moves = h->d_env_moves;
   ea.yaw_step = h->env.yaw_step; ea.yaw_lo = h->env.yaw_lo; ea.yaw_hi = h->env.yaw_hi;
   ea.rate = h->env.actuator_rate; ea.dt = h->env.dt; ea.budget = h->env.budget;
   ea.load_coef = h->env.load_coef; ea.discrete = h->env.discrete;
   ea.ws_prev = (h->series_T > 0 && h->series_t >= 1) ? h->d_ws_prev : nullptr;
-  const float* ptab = nullptr;
-  if ((rc = pair_table(h, &ptab)) != WF_OK) return rc;
   if (on_device) {
     ea.action = action; ea.reward = reward;
-    WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
-                              wstride, nullptr, power, wspd, wdir, load, h->B, &ea, ptab, h->d_pair_first, h->stream, &h->grid));
+    if ((rc = launch_step(h, nullptr, power, wspd, wdir, load, &ea)) != WF_OK) return rc;
     if (yaw) WF_HIP(h, hipMemcpyAsync(yaw, h->d_env_yaw, sizeof(float) * bn, hipMemcpyDeviceToDevice, h->stream));
     return WF_OK;
   }
@@ -748,10 +765,8 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
     ea.action = h->d_env_act;
   }
   ea.reward = reward ? h->d_env_out : nullptr;
-  WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
-                            wstride, nullptr, power ? h->d_out : nullptr, wspd ? h->d_out + bn : nullptr,
-                            wdir ? h->d_out + 2 * bn : nullptr, load ? h->d_out + 3 * bn : nullptr, h->B, &ea, ptab,
-                            h->d_pair_first, h->stream, &h->grid));
+  if ((rc = launch_step(h, nullptr, power ? h->d_out : nullptr, wspd ? h->d_out + bn : nullptr,
+                        wdir ? h->d_out + 2 * bn : nullptr, load ? h->d_out + 3 * bn : nullptr, &ea)) != WF_OK) return rc;
   if (reward) WF_HIP(h, hipMemcpyAsync(h->h_env_out, h->d_env_out, sizeof(float) * B, hipMemcpyDeviceToHost, h->stream));
   if (yaw) WF_HIP(h, hipMemcpyAsync(h->h_env_out + B, h->d_env_yaw, sizeof(float) * bn, hipMemcpyDeviceToHost, h->stream));
   if (power || wspd || wdir || load)
@@ -763,6 +778,24 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
   if (wspd) std::memcpy(wspd, h->h_out + bn, sizeof(float) * bn);
   if (wdir) std::memcpy(wdir, h->h_out + 2 * bn, sizeof(float) * bn);
   if (load) std::memcpy(load, h->h_out + 3 * bn, sizeof(float) * bn * 4);
+  return WF_OK;
+}
+
+int wf_set_risk_guard(wf_handle* h, double rel_band) {
+  if (!h) return WF_E_INVALID;
+  if (!(rel_band >= 0.0) || !(rel_band < 0.5)) return fail(h, WF_E_INVALID, "risk guard band must be in [0, 0.5)");
+  h->guard_rel = rel_band;
+  h->consts.guard_rel = (float)rel_band;
+  return WF_OK;
+}
+
+int wf_get_risk_flags(wf_handle* h, int* flags, int on_device) {
+  if (!h || !flags) return WF_E_INVALID;
+  if (h->B <= 0 || !h->d_flags) return fail(h, WF_E_INVALID, "wf_set_batch must be called first");
+  WF_HIP(h, hipSetDevice(h->device));
+  WF_HIP(h, hipMemcpyAsync(flags, h->d_flags, sizeof(int) * h->B, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                           h->stream));
+  if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));
   return WF_OK;
 }
 

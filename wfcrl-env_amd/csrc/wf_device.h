@@ -47,6 +47,13 @@ struct WfConsts {
   // 15 D in float64: the reach of the wake-added TI is tested as FLORIS does, x_t <= x_i + 15 D on the float64
   // coordinates (on regular grids whole multiples of D sit on this threshold and the rounding of the rotation decides)
   double fifteenD_d;
+  // lateral gate of the wake-added TI, |y_i - (y_t + off_j)| < 2 D, evaluated in float64 as FLORIS does [A.3-8]
+  double off_d[3], twoD_d;
+  // risk flags (include/wfstep.h WF_RISK_*): relative half-width of the guard band around the overlap threshold
+  // "deficit * Uinit > overlap_thr", and the segments of the power table whose slope amplifies a float32-sized
+  // wind-speed error past the power tolerance (bit j of steep[j / 32] = segment j)
+  float guard_rel;
+  unsigned steep[2];
 };
 
 // Power/thrust table in global memory, staged to LDS by each block.
@@ -76,6 +83,18 @@ struct WfEnvArgs {
   int discrete;
 };
 
+// Grouped launch (one pair table + sorted geometry per distinct wind direction) and the per-farm risk
+// flags.  All pointers may be null.
+struct WfGroupArgs {
+  const int* perm;       // [n_blocks * farms per block] farm index per launch slot, -1 = padding; null = identity
+  const int* blk_group;  // [n_blocks] direction group of the block's farms, -1 = unused block; null = ungrouped
+  int shift, mod;        // table / geometry index of group g = (g + shift) % mod  (series playback: shift = tick)
+  int n_blocks;
+  int* risk_flags;       // [B] out: WF_RISK_* bits of each farm; null = not written
+};
+#define WF_RISK_OVERLAP 1
+#define WF_RISK_POWER_KNEE 2
+
 // Pair-coefficient table (shared wind only): for source i and target t (sorted indices) the
 // transverse-velocity contribution is linear in the source's circulations.  The tip vortices' circulations share
 // the farm-dependent factor Gy = sin(yaw) cos(yaw) Ct ws  (Gt = gam_top*Gy, Gb = -gam_bot*Gy), so they fold into ONE
@@ -87,13 +106,16 @@ struct WfEnvArgs {
 // of consecutive lanes): grid point (j,k) is the float4 {aV, bV, aW, bW} at [(3j+k)*4 .. +3]; then
 //   [36] dx = x'_t - x'_i (float64 difference, rounded once; < 0: target upstream, -1 for padding targets)
 //   [37] dy = y'_t - y'_i        [38] (dx'/D)^ch_downstream of the Crespo-Hernandez term [A.3-8], 0 where
-//   dx > 15 D in float64 (out of reach of the wake-added TI)                                           [39..43] 0
+//   dx > 15 D in float64 (out of reach of the wake-added TI)
+//   [39] int bits: bit j (0..2) = grid column j of the target inside the lateral gate |y_i - (y_t + off_j)| < 2 D,
+//        bit 3 = x_t > x_i + 0.1 (velocity deficit on) — both decided in float64 as FLORIS does     [40..43] 0
 // A source's row (all targets) is padded to a multiple of 1 KiB: the step kernel stages it into LDS with 1-KiB
 // global_load_lds wave-instructions.
 #define WF_PAIR_STRIDE 44
 #define WF_PAIR_DX 36
 #define WF_PAIR_DY 37
 #define WF_PAIR_TIPOW 38
+#define WF_PAIR_BITS 39
 #define WF_PAIR_MAX_N 128
 #define WF_PAIR_ROW_FLOATS(n) ((((n) * WF_PAIR_STRIDE * 4 + 1023) / 1024) * 256)
 
@@ -106,4 +128,5 @@ struct WfPairConsts {
   double ch_down;
   double gam_top, gam_bot;  // tip-vortex circulations per unit (sin cos Ct ws), over 2 pi  [A.3-1]
   double fifteenD;          // reach of the wake-added TI [A.3-8]: beyond it the record's TI power is stored as 0
+  double twoD;              // lateral gate of the wake-added TI [A.3-8]
 };

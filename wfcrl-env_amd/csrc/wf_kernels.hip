@@ -116,19 +116,18 @@ __device__ __forceinline__ float table_ct(const WfConsts& c, const TableLds& T, 
   r = (v > T.knot[c.n_table - 1]) ? 0.9999f : r;
   return fminf(fmaxf(r, 0.0001f), 0.9999f);
 }
-__device__ __forceinline__ float table_pw(const WfConsts& c, const TableLds& T, float v) {
+__device__ __forceinline__ float table_pw(const WfConsts& c, const TableLds& T, float v, int& seg) {
   int j = table_segment(c, T, v);
+  seg = j;
   float r = fmaf(T.pws[j], v - T.knot[j], T.pw[j]);
   r = (v < T.knot[0] || v > T.knot[c.n_table - 1]) ? 0.0f : r;
   return r;
 }
 
-// 1.0f if e > thr else 0.0f, as one VALU instruction: fma with the clamp output modifier (thrB = thr * kBig; the
-// smallest positive e - thr is one ulp of thr ~ 2^-33, so the scaled difference is either <= 0 or >= 2^17)
+// Overlap test "e > thr" as 0/1 without a VCC round trip: fma with the clamp output modifier, d = e*kBig - thr*kBig
+// clamped to [0, 1] (the smallest positive e - thr is one ulp of thr ~ 2^-33, so the scaled difference is either <= 0
+// or >= 2^17); |d| also measures the distance to the threshold for the risk flag.
 constexpr float kBig = 1125899906842624.0f;  // 2^50
-__device__ __forceinline__ float above(float e, float thrB) {
-  return __builtin_amdgcn_fmed3f(fmaf(e, kBig, -thrB), 0.0f, 1.0f);
-}
 
 // Register-resident per-turbine state of one lane: S target slots x (9 + 9 + 9 + 3) floats.
 template <int S>
@@ -146,7 +145,7 @@ struct Slots {
 template <int EPW, int NP, bool WITH_XY>
 struct GeoLds {
   double x[WITH_XY ? EPW : 1][WITH_XY ? NP : 1];  // sorted x' (float64: the sign of dx decides every mask)
-  float y[WITH_XY ? EPW : 1][WITH_XY ? NP : 1];   // sorted y' - yc    (table mode takes dx, dy from the pair table)
+  double y[WITH_XY ? EPW : 1][WITH_XY ? NP : 1];  // sorted y' (float64: the 2 D lateral gate is decided on it; table mode takes dx, dy, gates from the pair table)
   float yaw[EPW][NP]; // commanded yaw in sorted order, degrees
   float cg[EPW][NP], sg[EPW][NP];  // cos / sin of the commanded yaw (evaluated once per turbine)
 };
@@ -196,7 +195,7 @@ __device__ __forceinline__ void column_deficit(const WfConsts& c, const SrcConst
 // ---------------------------------------------------------------------------------------------
 __global__ void wf_geometry_kernel(int N, const double* __restrict__ lx, const double* __restrict__ ly, double xc,
                                    double yc, const double* __restrict__ wd, double* __restrict__ gx,
-                                   float* __restrict__ gy, int* __restrict__ gidx) {
+                                   double* __restrict__ gy, int* __restrict__ gidx) {
   __shared__ double sx[WF_TABLE_PAD * 4];
   const int e = blockIdx.x;
   const int t = threadIdx.x;
@@ -223,7 +222,7 @@ __global__ void wf_geometry_kernel(int N, const double* __restrict__ lx, const d
     }
     const size_t o = (size_t)e * N + rank;
     gx[o] = xr;
-    gy[o] = (float)(yr - yc);
+    gy[o] = yr;  // absolute y' in float64: the lateral gate |y_i - y| < 2 D is decided on it [A.3-8]
     gidx[o] = t;
   }
 }
@@ -321,18 +320,22 @@ extern "C" hipError_t wfk_launch_series_gather(int B, int T, int t, const int* s
 // Pair-coefficient table for a wind condition shared by the whole batch: everything in the transverse-velocity
 // pass [A.3-4] that does not depend on the farm's state.  One thread per (source i, target t); float64.
 // ---------------------------------------------------------------------------------------------
-__global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __restrict__ gx, const float* __restrict__ gy,
+__global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __restrict__ gx, const double* __restrict__ gy,
                                      float* __restrict__ tab, int* __restrict__ first_active) {
-  const int i = blockIdx.x, t = threadIdx.x;
+  // blockIdx.y = direction group (one table per distinct wind direction; 1 group for a shared wind)
+  const int i = blockIdx.x, t = threadIdx.x, grp = blockIdx.y;
   if (t >= pc.NP) return;
-  float* o = tab + (size_t)i * WF_PAIR_ROW_FLOATS(pc.NP) + (size_t)t * WF_PAIR_STRIDE;
+  gx += (size_t)grp * pc.N;
+  gy += (size_t)grp * pc.N;
+  first_active += (size_t)grp * pc.N;
+  float* o = tab + ((size_t)grp * pc.N + i) * WF_PAIR_ROW_FLOATS(pc.NP) + (size_t)t * WF_PAIR_STRIDE;
   if (t >= pc.N) {  // padding target of the kernel variant: permanently "upstream"
     for (int q = 0; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
     o[WF_PAIR_DX] = -1.0f;
     return;
   }
   const double dx = gx[t] - gx[i];
-  const double dy = (double)gy[t] - (double)gy[i];
+  const double dy = gy[t] - gy[i];
   if (dx >= 0.0) atomicMin(&first_active[i], t);  // lowest sorted index the source reaches (ties included)
   if (dx < 0.0) {  // upstream target: nothing reaches it; only the sign of dx is ever looked at
     for (int q = 0; q < WF_PAIR_STRIDE; ++q) o[q] = 0.0f;
@@ -369,14 +372,20 @@ __global__ void wf_pair_table_kernel(const WfPairConsts pc, const double* __rest
   o[WF_PAIR_TIPOW] = (gx[t] <= gx[i] + pc.fifteenD) ? (float)pow(dxp / pc.D, pc.ch_down) : 0.0f;
   o[WF_PAIR_DX] = (float)dx;
   o[WF_PAIR_DY] = (float)dy;
+  // the other two discontinuities of the pair, decided on the float64 coordinates in FLORIS' own form [A.3-6, A.3-8]:
+  // bit j: grid column j inside the lateral gate |y_i - (y_t + off_j)| < 2 D; bit 3: X > x_i + 0.1 (the deficit is on)
+  int bits = 0;
+  for (int j = 0; j < 3; ++j) bits |= (fabs(gy[i] - (gy[t] + pc.off[j])) < pc.twoD) ? (1 << j) : 0;
+  bits |= (gx[t] > gx[i] + 0.1) ? 8 : 0;
+  o[WF_PAIR_BITS] = __int_as_float(bits);
 }
 
-extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, const double* gx, const float* gy, float* tab,
-                                            int* first_active, hipStream_t s) {
+extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, int n_groups, const double* gx, const double* gy,
+                                            float* tab, int* first_active, hipStream_t s) {
   const int threads = ((pc->NP + 63) / 64) * 64;
-  hipError_t e = hipMemsetAsync(first_active, 0x7f, sizeof(int) * pc->N, s);  // "infinity" for atomicMin
+  hipError_t e = hipMemsetAsync(first_active, 0x7f, sizeof(int) * pc->N * (size_t)n_groups, s);  // "infinity" for atomicMin
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wf_pair_table_kernel, dim3(pc->N), dim3(threads), 0, s, *pc, gx, gy, tab, first_active);
+  hipLaunchKernelGGL(wf_pair_table_kernel, dim3(pc->N, n_groups), dim3(threads), 0, s, *pc, gx, gy, tab, first_active);
   return hipGetLastError();
 }
 
@@ -402,11 +411,11 @@ constexpr int min_blocks_per_cu() {
 
 template <int G, int S, bool MC1, bool TAB, int WPB>
 __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) void wf_step_kernel(
-    const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const float* __restrict__ gy,
+    const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const double* __restrict__ gy,
     const int* __restrict__ gidx, int geom_stride, const double* __restrict__ ws_in, const double* __restrict__ wd_in,
     int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power, float* __restrict__ o_ws,
     float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea,
-    const float* __restrict__ pair_tab, const int* __restrict__ pair_first) {
+    const float* __restrict__ pair_tab, const int* __restrict__ pair_first, const WfGroupArgs ga) {
   constexpr int EPW = 64 / G;  // envs per wave
   constexpr int NP = G * S;    // turbine capacity of this variant
   __shared__ TableLds T;
@@ -415,6 +424,19 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   constexpr int ROWF = TAB ? WF_PAIR_ROW_FLOATS(NP) : 4;
   __shared__ __attribute__((aligned(16))) float prow[2][ROWF];
   __shared__ int pfirst[TAB ? NP : 1];  // per source: first sorted target index it reaches (dx >= 0, ties included)
+  __shared__ unsigned risk_lds[WPB][EPW];  // per farm: WF_RISK_* bits raised during the solve
+  // Direction groups (a pair table + sorted geometry per distinct wind direction): all farms of a block belong to one
+  // group; blocks beyond the padded farm list carry group -1.
+  int grp = 0;
+  if (ga.blk_group) {
+    grp = ga.blk_group[blockIdx.x];
+    if (grp < 0) return;  // whole block, before any barrier
+    grp = (grp + ga.shift) % ga.mod;
+    if constexpr (TAB) {
+      pair_tab += (size_t)grp * c.N * WF_PAIR_ROW_FLOATS(NP);
+      pair_first += (size_t)grp * c.N;
+    }
+  }
   if constexpr (TAB) {
     for (int k = threadIdx.x; k < NP; k += blockDim.x) pfirst[k] = (k < c.N) ? pair_first[k] : 0;
     __syncthreads();
@@ -448,9 +470,11 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   const int sub = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
   const int eiw = lane / G;  // env index inside the wave
-  const int env_raw = (blockIdx.x * (blockDim.x >> 6) + wave) * EPW + eiw;
-  const bool env_ok = env_raw < B;
+  int env_raw = (blockIdx.x * (blockDim.x >> 6) + wave) * EPW + eiw;
+  if (ga.perm) env_raw = ga.perm[env_raw];  // padded farm list of the grouped launch: -1 = no farm
+  const bool env_ok = env_raw >= 0 && env_raw < B;
   const int env = env_ok ? env_raw : (B - 1);
+  if (sub == 0) risk_lds[wave][eiw] = 0u;
   const int N = c.N;
 
   // one wind for the whole batch: everything derived from it is wave-uniform and lives in SGPRs (the table path also
@@ -467,7 +491,8 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   const float thrB[3] = {uni(__fdiv_rn(c.overlap_thr, Ui[0]) * kBig), uni(__fdiv_rn(c.overlap_thr, Ui[1]) * kBig),
                          uni(__fdiv_rn(c.overlap_thr, Ui[2]) * kBig)};
 
-  const size_t gofs = (size_t)env * geom_stride;
+  const float guardB = uni(c.guard_rel * (c.overlap_thr * kBig) * frcp(Ui[1]));  // |e - thr| < guard_rel * thr, scaled like thrB
+  const size_t gofs = ga.blk_group ? (size_t)grp * N : (size_t)env * geom_stride;
   const size_t yofs = (size_t)env * N;
   GeoLds<EPW, NP, !TAB>& L = geo[wave];
   // fused MDP transition: budget gate -> clip increment -> clip setpoint -> accumulate
@@ -638,8 +663,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       float TIs[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) TIs[j] = __shfl(st.TI[0][j], src);
-      double x_i = 0.0;
-      float y_i = 0.0f;
+      double x_i = 0.0, y_i = 0.0;
       int first_i = 0;
       if constexpr (TAB) first_i = __builtin_amdgcn_readfirstlane(pfirst[i]);
       if constexpr (!TAB) {
@@ -682,7 +706,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
          if constexpr (TAB) {
           apply_tab(p, reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]), Gy, Gwr);
          } else {
-          apply_fly(p, dx, L.y[eiw][t] - y_i, Gt, Gb, Gwr);
+          apply_fly(p, dx, (float)(L.y[eiw][t] - y_i), Gt, Gb, Gwr);
          }
         }
         if (p == 0) {
@@ -782,15 +806,24 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         if (p > 0 && p >= live) break;
         const int t = (blk + p) * G + sub;
         float dx;
-        float4 ex = {0.0f, 0.0f, 0.0f, 0.0f};  // {dx, dy, tipow, -}
+        float4 ex = {0.0f, 0.0f, 0.0f, 0.0f};  // {dx, dy, tipow, decision bits}
+        // Discontinuities of the pair are decided on the float64 coordinates, in FLORIS' own form (table path: by
+        // wf_pair_table_kernel, stored in the record): within reach of the wake-added TI  x_t <= x_i + 15 D  (tipow > 0),
+        // velocity deficit on  x_t > x_i + 0.1  (bit 3), lateral gate of grid column j  |y_i - (y_t + off_j)| < 2 D
+        // (bits 0-2; on the fly they are evaluated inside the wake-added-TI block, where they are needed).
+        bool in15;
+        int bits;
         if constexpr (TAB) {
           ex = *reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE + WF_PAIR_DX]);
           dx = (p > 0 || t >= first_i) ? ex.x : -1.0f;  // un-staged pieces hold stale rows (slot 0 only)
-        } else dx = (float)(L.x[eiw][t] - x_i);
-        // within reach of the wake-added TI: decided on the float64 distance (table path: stored as tipow = 0)
-        bool in15;
-        if constexpr (TAB) in15 = ex.z > 0.0f;
-        else in15 = L.x[eiw][t] <= x_i + c.fifteenD_d;  // FLORIS' own form of the test, float64
+          in15 = ex.z > 0.0f;
+          bits = __float_as_int(ex.w);
+        } else {
+          const double xt = L.x[eiw][t];
+          dx = (float)(xt - x_i);
+          in15 = xt <= x_i + c.fifteenD_d;
+          bits = (xt > x_i + 0.1) ? 8 : 0;
+        }
         // slots p >= 1: all real turbines have dx >= 0 (see pass 1), and at 0 <= dx <= 0.1 (ties) everything below is
         // an exact no-op: amp_on = 0 zeroes the deficits and the TI candidate is the ambient value
         const bool act = (p == 0) ? (dx > 0.0f) : (t < N);
@@ -802,9 +835,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
 #endif
           float dy;
           if constexpr (TAB) dy = ex.y;
-          else dy = L.y[eiw][t] - y_i;
+          else dy = (float)(L.y[eiw][t] - y_i);
           const float lin = fmaf(c.bd, dx, c.ad);
-          const float amp_on = (dx > 0.1f) ? 1.0f : 0.0f;
+          const float amp_on = (bits & 8) ? 1.0f : 0.0f;
           float e1[3], e0[3];
           if (uni) {
             // column-independent part once
@@ -845,10 +878,26 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           }
           // Wake-added TI reaches a target only within 15 D downstream and 2 D laterally [A.3-8]; elsewhere the
           // candidate is the ambient value, which never exceeds the running maximum: skipped when no lane needs it.
-          if (!__any(in15 && (fabsf(dy) < c.twoD + c.off[2]))) continue;
-          float cnt = 0.0f;  // grid points with deficit * Uinit_k > threshold
+          if constexpr (TAB) {
+            if (!__any(in15 && (bits & 7))) continue;
+          } else {
+            if (!__any(in15 && (fabsf(dy) < c.twoD + c.off[2] + 1.0f))) continue;  // float32 prefilter with a margin
+            const double yt = L.y[eiw][t];
 #pragma unroll
-          for (int j = 0; j < 3; ++j) cnt += (above(e0[j], thrB[0]) + above(e1[j], thrB[1])) + above(e0[j], thrB[2]);
+            for (int j = 0; j < 3; ++j) bits |= (fabs(y_i - (yt + c.off_d[j])) < c.twoD_d) ? (1 << j) : 0;
+          }
+          // overlap count: grid points with deficit * Uinit_k > threshold; `near` tracks how close any of them comes to
+          // the threshold (this is the one state-dependent discontinuity of the model: float32 cannot reproduce the
+          // float64 decision inside a band of rounding width around it — such farms are flagged, WF_RISK_OVERLAP)
+          float cnt = 0.0f, near = 3.0e38f;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float d0 = fmaf(e0[j], kBig, -thrB[0]), d1 = fmaf(e1[j], kBig, -thrB[1]), d2 = fmaf(e0[j], kBig, -thrB[2]);
+            cnt += (__builtin_amdgcn_fmed3f(d0, 0.0f, 1.0f) + __builtin_amdgcn_fmed3f(d1, 0.0f, 1.0f)) +
+                   __builtin_amdgcn_fmed3f(d2, 0.0f, 1.0f);
+            near = fminf(fminf(near, fabsf(d0)), fminf(fabsf(d1), fabsf(d2)));
+          }
+          if (in15 && (bits & 7) && near < guardB) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_OVERLAP);
           // Crespo-Hernandez with overlap gating [A.3-8]
           float tipow;
           if constexpr (TAB) {
@@ -863,7 +912,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             // TI and cand are non-negative: the maximum is taken on the bit patterns (no NaN canonicalisation)
-            const float cm = (fabsf(dy + c.off[j]) < c.twoD) ? cand : 0.0f;
+            const float cm = (bits & (1 << j)) ? cand : 0.0f;
             st.TI[p][j] = __uint_as_float(max(__float_as_uint(st.TI[p][j]), __float_as_uint(cm)));
           }
         }
@@ -916,7 +965,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           const float* rec = pair_tab + (size_t)i2 * WF_PAIR_ROW_FLOATS(NP) + (size_t)t0 * WF_PAIR_STRIDE;
           if (rec[WF_PAIR_DX] >= 0.0f) apply_tab(0, reinterpret_cast<const float4*>(rec), Gy, Gwr);
         } else {
-          if (dx0 >= 0.0f) apply_fly(0, dx0, L.y[eiw][t0] - L.y[eiw][i2], Gt, Gb, Gwr);
+          if (dx0 >= 0.0f) apply_fly(0, dx0, (float)(L.y[eiw][t0] - L.y[eiw][i2]), Gt, Gb, Gwr);
         }
       }
     }
@@ -964,7 +1013,10 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
         const float cy = L.cg[eiw][t];
         const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cy));
-        const float pwr = c.rho * table_pw(c, T, veff);
+        int seg;
+        const float pwr = c.rho * table_pw(c, T, veff, seg);
+        // knees of the power curve (cut-in, cut-out): a wind-speed error of float32 size is amplified past the power tolerance
+        if ((c.steep[seg >> 5] >> (seg & 31)) & 1u) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_POWER_KNEE);
         float4 l;
         l.x = (st.TI[0][0] + st.TI[0][1] + st.TI[0][2]) * (1.0f / 3.0f);
         l.y = fsqrt(su * (1.0f / 9.0f));
@@ -993,6 +1045,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
     }
   }  // blk
 
+  if (ga.risk_flags && sub == 0 && env_ok) ga.risk_flags[env] = (int)risk_lds[wave][eiw];
   if (ea.reward) {
     // r = mean_j(P_j[MW] * 1e3 / ws^3) - load_coef * mean|loads|      (simple_env.py:78-84)
 #pragma unroll
@@ -1060,34 +1113,36 @@ static void local_variant(int i, int* G, int* S, const void** fn) {
 static const void* local_variant_fn(int i, int kind) {
   return kind == 3 ? kVariants[i].fn_tab_ws : (kind == 2 ? kVariants[i].fn_tab : (kind == 1 ? kVariants[i].fn_all : kVariants[i].fn));
 }
-static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx, const float* gy,
+static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx, const double* gy,
                                     const int* gidx, int geom_stride, const double* ws, const double* wd, int wind_stride,
                                     const float* yaw, float* power, float* o_ws, float* o_wd, float* load, int B,
-                                    const WfEnvArgs* env, const float* pair_tab, const int* pair_first, hipStream_t s,
-                                    int* grid_out) {
+                                    const WfEnvArgs* env, const float* pair_tab, const int* pair_first,
+                                    const WfGroupArgs* grp, hipStream_t s, int* grid_out) {
   const WfVariant& v = kVariants[variant];
   const bool use_tab = pair_tab && v.fn_tab;
   const int wpb = use_tab ? kTabWaves : 4;
   const int envs_per_block = wpb * (64 / v.G);
-  const int grid = (B + envs_per_block - 1) / envs_per_block;
+  WfGroupArgs ga = *grp;
+  // grouped launch: the farm list is padded per group to whole blocks (ga.n_blocks of them, some possibly unused)
+  const int grid = ga.blk_group ? ga.n_blocks : (B + envs_per_block - 1) / envs_per_block;
   if (grid_out) *grid_out = grid;
   WfConsts cc = *c;
   WfEnvArgs ea;
   if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
-  void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &pair_tab, &pair_first};
+  void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &pair_tab, &pair_first, &ga};
   const void* fn = use_tab ? (wind_stride == 0 ? v.fn_tab : v.fn_tab_ws) : (cc.mirror_core_n <= 1 ? v.fn : v.fn_all);
   if (!use_tab) pair_tab = nullptr;
   return hipLaunchKernel(fn, dim3(grid), dim3(64 * wpb), args, 0, s);
 }
 
 #define WF_STEP_ARGS                                                                                                  \
-  int variant, const WfConsts *c, const WfTables *tab, const double *gx, const float *gy, const int *gidx,           \
+  int variant, const WfConsts *c, const WfTables *tab, const double *gx, const double *gy, const int *gidx,          \
       int geom_stride, const double *ws, const double *wd, int wind_stride, const float *yaw, float *power,          \
       float *o_ws, float *o_wd, float *load, int B, const WfEnvArgs *env, const float *pair_tab,                     \
-      const int *pair_first, hipStream_t s, int *grid_out
+      const int *pair_first, const WfGroupArgs *grp, hipStream_t s, int *grid_out
 #define WF_STEP_PASS(v_)                                                                                              \
   v_, c, tab, gx, gy, gidx, geom_stride, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, pair_tab,         \
-      pair_first, s, grid_out
+      pair_first, grp, s, grid_out
 
 #if WF_KSET == 2
 // second translation unit: its variants are reached through the dispatcher of the first
@@ -1124,7 +1179,7 @@ extern "C" const void* wfk_variant_fn(int i, int kind) {
 }
 
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
-                                          const double* wd, double* gx, float* gy, int* gidx, hipStream_t s) {
+                                          const double* wd, double* gx, double* gy, int* gidx, hipStream_t s) {
   const int threads = ((N + 63) / 64) * 64;
   hipLaunchKernelGGL(wf_geometry_kernel, dim3(n_env), dim3(threads), 0, s, N, lx, ly, xc, yc, wd, gx, gy, gidx);
   return hipGetLastError();
