@@ -117,8 +117,9 @@ int wf_sync(wf_handle* h);
  * the other way and move the turbine's TI by 1/9 of the added term.  Every step therefore records, per farm instance,
  *   WF_RISK_OVERLAP     a (source, target, grid point) deficit within the guard band of the threshold, at a pair where
  *                       the count matters (inside the 15 D reach and the 2 D lateral gate);
- *   WF_RISK_POWER_KNEE  a turbine on a segment of the power table whose slope amplifies a float32-sized wind-speed
- *                       error past 1e-4 of max(P, 1 kW) (cut-in 2.5-3 m/s, cut-out 25-25.01 m/s of nrel_5MW).
+ *   WF_RISK_POWER_KNEE  a turbine at a point of the power curve whose relative condition number v |P'| / max(P, 1 kW)
+ *                       exceeds 30, where a float32-sized wind-speed error (~3e-6) is amplified past 1e-4 of
+ *                       max(P, 1 kW): just above cut-in (P < ~7 kW) and on the cut-out drop of nrel_5MW.
  * Farms with flag 0 match the float64 path within the parity tolerances; flagged farms may differ by a bounded amount
  * (tests/test_hip_parity.py).  All geometric discontinuities (upstream/downstream order, dx > 0.1, 15 D reach, 2 D
  * lateral gate) are decided in float64 on the device and need no flag.

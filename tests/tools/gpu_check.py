@@ -3,6 +3,8 @@ import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import parity
 from wfcrl_env_amd.backend import WfStep
 from oracle import c_oracle
 
@@ -36,8 +38,13 @@ for name in names:
         w = WfStep(x, y, env_batch=B)
         w.set_wind(ws, wd)
         got = w.step(yaw)
-        ref = c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64))
+        flags = w.risk_flags()
+        ref = c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64), margin=True)
         e = errs(got, ref)
+        sm = parity.summarize(got, ref, flags)
+        e.update(class_=parity.classify(sm), flagged_frac=sm["n_flagged"] / sm["n"], flagged_overlap=int(((flags & 1) != 0).sum()),
+                 flagged_knee=int(((flags & 2) != 0).sum()), n_mismatch_flagged=sm["n_mismatch_flagged"],
+                 worst_unflagged=sm["worst_unflagged"], n_farms=sm["n"])
         print(name, mode, w.kernel_info(), json.dumps(e), flush=True)
         w.close()
 

@@ -7,7 +7,7 @@ starts = [(i, m) for i, m in starts if m and l_is_label(lines[i])] if False else
 for n, (i, m) in enumerate(starts):
     key = f"{m.group(1)}x{m.group(2)}"
     if key not in want: continue
-    end = next(j for j in range(i, len(lines)) if ".end_amdhsa_kernel" in lines[j] or "s_endpgm" in lines[j])
+    end = next(j for j in range(i, len(lines)) if lines[j].startswith(".Lfunc_end"))
     body = lines[i:end]
     c = collections.Counter()
     for l in body:

@@ -261,9 +261,11 @@ int build_consts(wf_handle* h) {
   c.amb = (float)m.ambient_ti; c.amb2 = (float)(m.ambient_ti * m.ambient_ti);
   c.gch_gain = (float)m.gch_gain; c.overlap_thr = (float)m.overlap_thresh;
   c.twoD = (float)(2.0 * D); c.fifteenD_d = 15.0 * D;
-  for (int k = 0; k < 3; ++k) c.off_d[k] = off[k];
-  c.twoD_d = 2.0 * D;
-  c.guard_rel = (float)h->guard_rel;
+  c.q_d = D / 4.0;
+  c.guard_inv = h->guard_rel > 0.0 ? (float)(1.0 / h->guard_rel) : 1125899906842624.0f;
+  c.inv_overlap_thr = (float)(1.0 / m.overlap_thresh);
+  c.yc_d = h->yc;
+  c.knee_kappa = 30.0f;  // 30 x (wind-speed error ~3e-6) ~ 1e-4 of max(P, 1 kW)
   c.rho = (float)m.ref_density; c.pw = (float)(m.pP / 3.0);
   c.dens_f = (float)std::cbrt(m.air_density / m.ref_density);
 
@@ -280,15 +282,6 @@ int build_consts(wf_handle* h) {
     const bool seg = i + 1 < n;
     t.ct_slope[i] = seg ? (float)((h->tct[i + 1] - h->tct[i]) / (h->tws[i + 1] - h->tws[i])) : 0.f;
     t.pw_slope[i] = seg ? (float)((pwv[i + 1] - pwv[i]) / (h->tws[i + 1] - h->tws[i])) : 0.f;
-  }
-  // Knees of the power curve: segment j is "steep" when its relative condition number v |P'| / max(P, 1 kW) exceeds
-  // WF_STEEP_KAPPA — a wind-speed error of float32 size (~3e-6 relative after the recurrence) then exceeds 1e-4 of
-  // max(P, 1 kW).  For the nrel_5MW table these are the cut-in segment 2.5-3.0 m/s and the cut-out drop 25.0-25.01 m/s.
-  c.steep[0] = c.steep[1] = 0u;
-  for (int i = 0; i + 1 < n; ++i) {
-    const double slope = std::fabs(pwv[i + 1] - pwv[i]) / (h->tws[i + 1] - h->tws[i]) * m.ref_density;
-    const double pmin = std::fmax(std::fmin(pwv[i], pwv[i + 1]) * m.ref_density, 1.0e3);
-    if (slope * h->tws[i + 1] / pmin > 30.0) c.steep[i >> 5] |= 1u << (i & 31);
   }
   const double x0 = h->tws[0], x1 = h->tws[n - 1];
   const double bh = (x1 - x0) / WF_BUCKETS;
@@ -454,7 +447,7 @@ int wf_set_model(wf_handle* h, const wf_model_params* p) {
         {p->hub_height, "hub_height"}, {p->tsr, "TSR"}, {p->pP, "pP"}, {p->gen_eff, "generator_efficiency"},
         {p->ref_density, "ref_density_cp_ct"}, {p->ka * p->ambient_ti + p->kb, "ka*TI + kb"},
         {p->alpha, "alpha"}, {p->eps_gain, "eps_gain"}, {p->num_eps, "num_eps"}, {p->kappa, "kappa"},
-        {p->ch_constant, "crespo_hernandez.constant"}};
+        {p->ch_constant, "crespo_hernandez.constant"}, {p->overlap_thresh, "overlap_thresh"}};
     for (const auto& q : positive)
       if (!(q.v > 0.0) || !std::isfinite(q.v))
         return fail(h, WF_E_INVALID, std::string("model parameter must be finite and > 0: ") + q.name);
@@ -785,7 +778,7 @@ int wf_set_risk_guard(wf_handle* h, double rel_band) {
   if (!h) return WF_E_INVALID;
   if (!(rel_band >= 0.0) || !(rel_band < 0.5)) return fail(h, WF_E_INVALID, "risk guard band must be in [0, 0.5)");
   h->guard_rel = rel_band;
-  h->consts.guard_rel = (float)rel_band;
+  h->consts.guard_inv = rel_band > 0.0 ? (float)(1.0 / rel_band) : 1125899906842624.0f;
   return WF_OK;
 }
 

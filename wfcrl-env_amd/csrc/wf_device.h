@@ -48,12 +48,12 @@ struct WfConsts {
   // coordinates (on regular grids whole multiples of D sit on this threshold and the rounding of the rotation decides)
   double fifteenD_d;
   // lateral gate of the wake-added TI, |y_i - (y_t + off_j)| < 2 D, evaluated in float64 as FLORIS does [A.3-8]
-  double off_d[3], twoD_d;
+  double q_d;  // D/4 (grid offsets -q, 0, +q; 2 D = 8 q, all exact)
   // risk flags (include/wfstep.h WF_RISK_*): relative half-width of the guard band around the overlap threshold
-  // "deficit * Uinit > overlap_thr", and the segments of the power table whose slope amplifies a float32-sized
-  // wind-speed error past the power tolerance (bit j of steep[j / 32] = segment j)
-  float guard_rel;
-  unsigned steep[2];
+  // "deficit * Uinit > overlap_thr", and the relative condition number of the power curve v |P'| / max(P, 1 kW) above
+  // which a turbine counts as sitting on a knee of the curve
+  float guard_inv, inv_overlap_thr, knee_kappa;  // 1 / guard band (2^50 when the band is 0), 1 / overlap_thr
+  double yc_d;  // centre of rotation (y): the float32 lateral distances are taken on y' - yc
 };
 
 // Power/thrust table in global memory, staged to LDS by each block.

@@ -116,18 +116,13 @@ __device__ __forceinline__ float table_ct(const WfConsts& c, const TableLds& T, 
   r = (v > T.knot[c.n_table - 1]) ? 0.9999f : r;
   return fminf(fmaxf(r, 0.0001f), 0.9999f);
 }
-__device__ __forceinline__ float table_pw(const WfConsts& c, const TableLds& T, float v, int& seg) {
+__device__ __forceinline__ float table_pw(const WfConsts& c, const TableLds& T, float v, float& slope) {
   int j = table_segment(c, T, v);
-  seg = j;
   float r = fmaf(T.pws[j], v - T.knot[j], T.pw[j]);
-  r = (v < T.knot[0] || v > T.knot[c.n_table - 1]) ? 0.0f : r;
-  return r;
+  const bool outside = v < T.knot[0] || v > T.knot[c.n_table - 1];
+  slope = outside ? 0.0f : T.pws[j];
+  return outside ? 0.0f : r;
 }
-
-// Overlap test "e > thr" as 0/1 without a VCC round trip: fma with the clamp output modifier, d = e*kBig - thr*kBig
-// clamped to [0, 1] (the smallest positive e - thr is one ulp of thr ~ 2^-33, so the scaled difference is either <= 0
-// or >= 2^17); |d| also measures the distance to the threshold for the risk flag.
-constexpr float kBig = 1125899906842624.0f;  // 2^50
 
 // Register-resident per-turbine state of one lane: S target slots x (9 + 9 + 9 + 3) floats.
 template <int S>
@@ -145,7 +140,8 @@ struct Slots {
 template <int EPW, int NP, bool WITH_XY>
 struct GeoLds {
   double x[WITH_XY ? EPW : 1][WITH_XY ? NP : 1];  // sorted x' (float64: the sign of dx decides every mask)
-  double y[WITH_XY ? EPW : 1][WITH_XY ? NP : 1];  // sorted y' (float64: the 2 D lateral gate is decided on it; table mode takes dx, dy, gates from the pair table)
+  double yd[WITH_XY ? EPW : 1][WITH_XY ? NP : 1]; // sorted y' (float64: the 2 D lateral gate is decided on it; table mode takes dx, dy, gates from the pair table)
+  float y[WITH_XY ? EPW : 1][WITH_XY ? NP : 1];   // sorted y' - yc (float32 copy for the lateral distances)
   float yaw[EPW][NP]; // commanded yaw in sorted order, degrees
   float cg[EPW][NP], sg[EPW][NP];  // cos / sin of the commanded yaw (evaluated once per turbine)
 };
@@ -487,11 +483,12 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   const float Ui[3] = {uni(ws * c.shearf[0]), uni(ws * c.shearf[1]), uni(ws * c.shearf[2])};
   const float offk = c.off[2] * kGs;
   const float U02c = uni(Ui[0] * Ui[0] * Ui[0] + Ui[2] * Ui[2] * Ui[2]), U1c = uni(Ui[1] * Ui[1] * Ui[1]);
-  // overlap test "deficit * Uinit_k > threshold" [A.3-8] as a threshold on the deficit itself
-  const float thrB[3] = {uni(__fdiv_rn(c.overlap_thr, Ui[0]) * kBig), uni(__fdiv_rn(c.overlap_thr, Ui[1]) * kBig),
-                         uni(__fdiv_rn(c.overlap_thr, Ui[2]) * kBig)};
+  // overlap test "deficit * Uinit_k > threshold" [A.3-8] as a threshold on the deficit itself, with the guard band of
+  // the risk flag folded in (see the wake-added-TI block): scale ovs[k] = 1 / (2 g thr_k), offset ovc = 1/2 - 1/(2 g)
+  const float ovh = 0.5f * c.guard_inv;  // 1 / (2 g); g = 0 -> 2^49 (no band: f is 0 or 1 except at e == thr exactly)
+  const float ovs[3] = {uni(ovh * Ui[0] * c.inv_overlap_thr), uni(ovh * Ui[1] * c.inv_overlap_thr), uni(ovh * Ui[2] * c.inv_overlap_thr)};
+  const float ovc = 0.5f - ovh;
 
-  const float guardB = uni(c.guard_rel * (c.overlap_thr * kBig) * frcp(Ui[1]));  // |e - thr| < guard_rel * thr, scaled like thrB
   const size_t gofs = ga.blk_group ? (size_t)grp * N : (size_t)env * geom_stride;
   const size_t yofs = (size_t)env * N;
   GeoLds<EPW, NP, !TAB>& L = geo[wave];
@@ -508,7 +505,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
     const int tt = ok ? t : 0;
     if constexpr (!TAB) {
       L.x[eiw][t] = ok ? gx[gofs + tt] : -1.0e300;  // padding is never downstream of anything
-      L.y[eiw][t] = gy[gofs + tt];
+      const double ygd = gy[gofs + tt];
+      L.yd[eiw][t] = ygd;
+      L.y[eiw][t] = (float)(ygd - c.yc_d);
     }
     const size_t oi = yofs + gidx[gofs + tt];
     float yw;
@@ -663,7 +662,8 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       float TIs[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) TIs[j] = __shfl(st.TI[0][j], src);
-      double x_i = 0.0, y_i = 0.0;
+      double x_i = 0.0;
+      float y_i = 0.0f;
       int first_i = 0;
       if constexpr (TAB) first_i = __builtin_amdgcn_readfirstlane(pfirst[i]);
       if constexpr (!TAB) {
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
          if constexpr (TAB) {
           apply_tab(p, reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]), Gy, Gwr);
          } else {
-          apply_fly(p, dx, (float)(L.y[eiw][t] - y_i), Gt, Gb, Gwr);
+          apply_fly(p, dx, L.y[eiw][t] - y_i, Gt, Gb, Gwr);
          }
         }
         if (p == 0) {
@@ -763,16 +763,6 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       // once per target instead of once per column, from column 0's constants.  Wave-uniform choice,
       // identical results.
       const bool uni = __all((TIs[0] == TIs[1]) && (TIs[1] == TIs[2]));
-      ColConsts cc[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (j == 0 || !uni) {  // static indices (a runtime-indexed cc[] would live in scratch)
-          cc[j].x0d = x0num_d * frcp(fmaf(c.alpha4, TIs[j], c.beta2 * om_sc));
-          cc[j].kyd = fmaf(c.ka, TIs[j], c.kb);
-          cc[j].d0 = sc.tan_th0 * cc[j].x0d;
-          cc[j].pj = pfac * frcp(cc[j].kyd);
-        }
-      }
       // ---- D. yaw-added recovery [A.3-5] and deficit constants [A.3-6] -----------------------
       const float I0 = TIs[0];
       const float uI = ubar * I0;
@@ -790,15 +780,21 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       sc.kdef = ct * cg * c.kdef;
       const float ch_pref = c.ch_c * fexp2(c.ch_ai * flog2(a));
       const float x0num_v = c.D * cg * (1.0f + s_c) * (1.0f / 1.41421356237f);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (j == 0 || !uni) {
-          const float ti = TIs[j] + dTI;
-          cc[j].x0v = x0num_v * frcp(fmaf(c.alpha4, ti, c.beta2 * om_sc));
-          cc[j].ix0v = frcp(cc[j].x0v);
-          cc[j].kyv = fmaf(c.ka, ti, c.kb);
-        }
-      }
+      // Only column 0's constants are kept across the target loop; in the rare split-TI case the other two columns'
+      // are re-derived per target from (TIs[j], dTI) — 14 registers less at the pressure peak of the hot path.
+      const float b2om = c.beta2 * om_sc;
+      auto col_consts = [&](float ti_pre, float ti_post) {
+        ColConsts k;
+        k.x0d = x0num_d * frcp(fmaf(c.alpha4, ti_pre, b2om));
+        k.kyd = fmaf(c.ka, ti_pre, c.kb);
+        k.d0 = sc.tan_th0 * k.x0d;
+        k.pj = pfac * frcp(k.kyd);
+        k.x0v = x0num_v * frcp(fmaf(c.alpha4, ti_post, b2om));
+        k.ix0v = frcp(k.x0v);
+        k.kyv = fmaf(c.ka, ti_post, c.kb);
+        return k;
+      };
+      const ColConsts k0 = col_consts(TIs[0], TIs[0] + dTI);
 
       // ---- E. pass 2: deflection, deficit, SOSFS, wake-added turbulence ----------------------
 #pragma unroll
@@ -828,20 +824,19 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         // an exact no-op: amp_on = 0 zeroes the deficits and the TI candidate is the ambient value
         const bool act = (p == 0) ? (dx > 0.0f) : (t < N);
 #if defined(WF_ABLATE) && (WF_ABLATE & 2)
-        if (act) { st.esq[p][0] += sc.sy0v * cc[0].x0v * cc[1].kyv * cc[2].pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * cc[2].d0 * sc.snw * sc.kdef; }
+        if (act) { st.esq[p][0] += sc.sy0v * k0.x0v * k0.kyv * k0.pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * k0.d0 * sc.snw * sc.kdef; }
         if (false) {
 #else
         if (act) {
 #endif
           float dy;
           if constexpr (TAB) dy = ex.y;
-          else dy = (float)(L.y[eiw][t] - y_i);
+          else dy = L.y[eiw][t] - y_i;
           const float lin = fmaf(c.bd, dx, c.ad);
           const float amp_on = (bits & 8) ? 1.0f : 0.0f;
           float e1[3], e0[3];
           if (uni) {
             // column-independent part once
-            const ColConsts& k0 = cc[0];
             const float xs = fmaxf(dx - k0.x0d, 0.0f);
             const float syd = fmaf(k0.kyd, xs, sc.sy0d), szd = fmaf(k0.kyd, xs, sc.sz0d);
             const float s = fsqrt(syd * szd * sc.inv_s0d);
@@ -869,7 +864,8 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
             }
           } else {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) column_deficit(c, sc, cc[j], dx, dy + c.off[j], lin, amp_on, e1[j], e0[j]);
+            for (int j = 0; j < 3; ++j)
+              column_deficit(c, sc, j == 0 ? k0 : col_consts(TIs[j], TIs[j] + dTI), dx, dy + c.off[j], lin, amp_on, e1[j], e0[j]);
           }
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
@@ -882,22 +878,33 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
             if (!__any(in15 && (bits & 7))) continue;
           } else {
             if (!__any(in15 && (fabsf(dy) < c.twoD + c.off[2] + 1.0f))) continue;  // float32 prefilter with a margin
-            const double yt = L.y[eiw][t];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) bits |= (fabs(y_i - (yt + c.off_d[j])) < c.twoD_d) ? (1 << j) : 0;
+            // grid offsets -D/4, 0, +D/4 and 2 D = 8 (D/4): exact in float64 from the one constant D/4
+            const double yt = L.yd[eiw][t], yi_d = L.yd[eiw][i], twoD_d = 8.0 * c.q_d;
+            bits |= (fabs(yi_d - (yt - c.q_d)) < twoD_d) ? 1 : 0;
+            bits |= (fabs(yi_d - yt) < twoD_d) ? 2 : 0;
+            bits |= (fabs(yi_d - (yt + c.q_d)) < twoD_d) ? 4 : 0;
           }
           // overlap count: grid points with deficit * Uinit_k > threshold; `near` tracks how close any of them comes to
           // the threshold (this is the one state-dependent discontinuity of the model: float32 cannot reproduce the
           // float64 decision inside a band of rounding width around it — such farms are flagged, WF_RISK_OVERLAP)
-          float cnt = 0.0f, near = 3.0e38f;
+          // One fma with the clamp output modifier per grid point:  f = clamp(0.5 + (e - thr_k) / (2 g thr_k))  is exactly 0
+          // below the guard band |e / thr_k - 1| < g, exactly 1 above it and fractional inside (no VCC round trips).
+          // A point in the band shows as mantissa / low exponent bits in the OR of the nine bit patterns (0 and 1.0f =
+          // 0x3f800000 contribute none): the farm is flagged (WF_RISK_OVERLAP).  The count is the sum rounded to the
+          // nearest integer: exact whenever no point is in the band, and with one point in it that point counts iff
+          // f > 1/2, i.e. e > thr_k.
+          float cnt = 0.0f;
+          unsigned fbits = 0u;
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-            const float d0 = fmaf(e0[j], kBig, -thrB[0]), d1 = fmaf(e1[j], kBig, -thrB[1]), d2 = fmaf(e0[j], kBig, -thrB[2]);
-            cnt += (__builtin_amdgcn_fmed3f(d0, 0.0f, 1.0f) + __builtin_amdgcn_fmed3f(d1, 0.0f, 1.0f)) +
-                   __builtin_amdgcn_fmed3f(d2, 0.0f, 1.0f);
-            near = fminf(fminf(near, fabsf(d0)), fminf(fabsf(d1), fabsf(d2)));
+            const float f0 = __builtin_amdgcn_fmed3f(fmaf(e0[j], ovs[0], ovc), 0.0f, 1.0f);
+            const float f1 = __builtin_amdgcn_fmed3f(fmaf(e1[j], ovs[1], ovc), 0.0f, 1.0f);
+            const float f2 = __builtin_amdgcn_fmed3f(fmaf(e0[j], ovs[2], ovc), 0.0f, 1.0f);
+            cnt += (f0 + f1) + f2;
+            fbits |= __float_as_uint(f0) | __float_as_uint(f1) | __float_as_uint(f2);
           }
-          if (in15 && (bits & 7) && near < guardB) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_OVERLAP);
+          cnt = rintf(cnt);
+          if ((fbits & 0xc07fffffu) && in15 && (bits & 7)) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_OVERLAP);
           // Crespo-Hernandez with overlap gating [A.3-8]
           float tipow;
           if constexpr (TAB) {
@@ -965,7 +972,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           const float* rec = pair_tab + (size_t)i2 * WF_PAIR_ROW_FLOATS(NP) + (size_t)t0 * WF_PAIR_STRIDE;
           if (rec[WF_PAIR_DX] >= 0.0f) apply_tab(0, reinterpret_cast<const float4*>(rec), Gy, Gwr);
         } else {
-          if (dx0 >= 0.0f) apply_fly(0, dx0, (float)(L.y[eiw][t0] - L.y[eiw][i2]), Gt, Gb, Gwr);
+          if (dx0 >= 0.0f) apply_fly(0, dx0, L.y[eiw][t0] - L.y[eiw][i2], Gt, Gb, Gwr);
         }
       }
     }
@@ -1013,10 +1020,13 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
         const float cy = L.cg[eiw][t];
         const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cy));
-        int seg;
-        const float pwr = c.rho * table_pw(c, T, veff, seg);
-        // knees of the power curve (cut-in, cut-out): a wind-speed error of float32 size is amplified past the power tolerance
-        if ((c.steep[seg >> 5] >> (seg & 31)) & 1u) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_POWER_KNEE);
+        float pslope;
+        const float pwr = c.rho * table_pw(c, T, veff, pslope);
+        // knees of the power curve (just above cut-in, the cut-out drop): where the relative condition number
+        // v |P'| / max(P, 1 kW) exceeds knee_kappa, a wind-speed error of float32 size (~3e-6 relative after the
+        // recurrence) is amplified past the power tolerance
+        if (c.rho * fabsf(pslope) * veff > c.knee_kappa * fmaxf(pwr, 1.0e3f))
+          atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_POWER_KNEE);
         float4 l;
         l.x = (st.TI[0][0] + st.TI[0][1] + st.TI[0][2]) * (1.0f / 3.0f);
         l.y = fsqrt(su * (1.0f / 9.0f));
