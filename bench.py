@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — farm-steps/s of the HIP wind-farm step (BASELINE.json metric) + roofline + CPU baseline.
 
-  python bench.py [--gpus N --steps K --warmup W]
+  python bench.py [--gpus N --steps K --warmup W]            (N > 1: spawns one rank per GPU itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Workload (config.workload): BASELINE.json configs[3] — HornsRev1_Floris (80 turbines in the reference
-code, data_cases.py:269-334), env_batch 65536, ws 8 m/s, wd 270 deg, random-walk yaw
-(dyaw ~ U(-5,5) clipped to +-40).  It fits one GPU, so N=1 runs the whole config on
-one device; for N>1 every rank runs the same per-GPU batch on its own shard of independent farms
-(weak scaling, no data-path collective).  A "step" = one pass of the hot path (wf_step) over the batch,
-yaw already resident in HBM, outputs left in HBM.
+Workload (config.workload): BASELINE.json configs[3] — HornsRev1_Floris (80 turbines in the reference code,
+data_cases.py:269-334), env_batch 65536 IN TOTAL, ws 8 m/s, wd 270 deg, random-walk yaw (dyaw ~ U(-5,5) clipped to
++-40).  It fits one GPU, so N = 1 runs the whole config on one device.  For N > 1 the default is
+STRONG scaling — the config's total batch sharded into contiguous blocks of independent farms, 65536 / N per GPU, as
+BASELINE configs[3-4] state it ("sharded across 8 MI355X") — and the same run also times the WEAK variant (the full
+config batch on every GPU) and reports it beside the headline (`weak_scaling`); `--scaling weak` swaps the two.  No
+data-path collective either way.  A "step" = one pass of the hot path (wf_step) over the batch, yaw already resident
+in HBM, outputs left in HBM.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,13 +27,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # same guide: measured device copy rate
 VALU_PEAK_LANEOPS = 7.864e13   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (157.3 TFLOP/s / 2)
 
 CONFIGS = {
-    # name: (layout, per-GPU env batch)
+    # name: (layout, TOTAL env batch of the BASELINE config)
     "cfg2": ("Ablaincourt_", 4096),
     "cfg3": ("Turb16_Row5_", 16384),
-    "cfg3b": ("Turb16_TCRWP_", 16384),  # build-defined alias: first 16 TCRWP turbines
+    "cfg3b": ("Turb16_TCRWP_", 16384),  # configs[2] as named: first 16 TCRWP turbines
     "cfg4": ("HornsRev1_", 65536),
     "cfg5": ("HornsRev2_", 131072),
 }
@@ -63,19 +68,70 @@ def lane_ops_per_farm_step(N: int, pair_table: bool) -> float:
     return pairs * ((55.0 if pair_table else 421.0) + 126.0) + N * 350.0
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a fresh child process tree
+    (nothing in this process has touched the GPU) and relay rank 0's JSON line.  With fewer GPUs than ranks (a
+    one-GPU box) the ranks share devices and rendezvous over gloo: a test mode, flagged in the JSON line."""
+    import torch  # importing torch and counting devices does not initialise the GPU
+
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    if ndev < args.gpus:
+        env.setdefault("BENCH_DIST_BACKEND", "gloo")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def load_layout(layout_name):
+    with open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")) as f:
+        all_layouts = json.load(f)
+    if layout_name == "Turb16_TCRWP_":
+        t = all_layouts["Turb_TCRWP_"]
+        return {"num_turbines": 16, "xcoords": t["xcoords"][:16], "ycoords": t["ycoords"][:16]}
+    return all_layouts[layout_name]
+
+
+def counter_profile(config: str, B: int):
+    """PMC-derived per-launch figures of the step kernel from the committed rocprofv3 passes (profiles/pmc_index.json:
+    which file, which commit, which batch).  They are NOT measured by this run — counters need rocprofv3 around the
+    process — so they are reported with their source, and only for the batch they were collected at."""
+    try:
+        idx = json.load(open(os.path.join(ROOT, "profiles", "pmc_index.json")))
+        e = idx.get(f"{config}_B{B}")
+        if not e:
+            return None
+        pmc = json.load(open(os.path.join(ROOT, e["file"])))
+        return {"hbm_bytes": (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, "insts_valu": pmc["SQ_INSTS_VALU"],
+                "kernel_us": e.get("kernel_us"), "source": f'{e["file"]} (rocprofv3 --pmc, separate passes; kernel of commit '
+                f'{e["commit"]}; not measured in this run)'}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
-    ap.add_argument("--env-batch", type=int, default=0, help="per-GPU env batch (default: the config's)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the config's total batch sharded over the GPUs (default, BASELINE configs[3-4]); "
+                         "weak = the full config batch on every GPU.  The other one is timed too and reported beside it.")
+    ap.add_argument("--env-batch", type=int, default=0, help="total env batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-env-leg", action="store_true", help="skip the fused-env-step leg (profiling runs)")
+    ap.add_argument("--no-env-leg", action="store_true", help="skip the fused-env-step and env-level legs (profiling runs)")
     ap.add_argument("--per-env-wind", action="store_true",
                     help="cfg5 variant: wd_b(t) = wd(t) + U(-10,10) per farm (per-farm rotation + sort on the device)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     import torch
 
@@ -83,13 +139,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     # one rank per GPU (the driver's launch); BENCH_DIST_BACKEND=gloo + fewer GPUs than ranks is a test mode that
     # exercises the multi-rank flow on a single-GPU box (ranks then share devices)
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    local_rank = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    ndev = max(1, torch.cuda.device_count())
+    shared_devices = backend != "nccl" and ndev < world
+    local_rank = local_rank % ndev if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -104,171 +161,227 @@ def main():
     from wfcrl_env_amd.backend import WfStep
     from wfcrl_env_amd.sharding import shard_bounds
 
-    layout_name, B = CONFIGS[args.config]
+    layout_name, B_total = CONFIGS[args.config]
     if args.env_batch:
-        B = args.env_batch
-    with open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")) as f:
-        all_layouts = json.load(f)
-    if layout_name == "Turb16_TCRWP_":
-        t = all_layouts["Turb_TCRWP_"]
-        lay = {"num_turbines": 16, "xcoords": t["xcoords"][:16], "ycoords": t["ycoords"][:16]}
-    else:
-        lay = all_layouts[layout_name]
+        B_total = args.env_batch
+    lay = load_layout(layout_name)
     N = lay["num_turbines"]
-    # global env ids of this rank's shard (contiguous blocks)
-    lo, hi = shard_bounds(B * world, rank, world)
-    assert hi - lo == B
-
-    w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B, device_id=local_rank)
-    w.set_stream(torch.cuda.current_stream().cuda_stream, True)
-    # synthetic inputs, seeded per SURVEY §8d (1234 + cfg id) and per rank:
-    #   cfg2: absolute yaw ~ U(-40,40), fixed wind;  cfg3/cfg4: random-walk yaw (dyaw ~ U(-5,5), clipped to +-40),
-    #   fixed wind;  cfg5: random-walk yaw + wd(t) = 270 + 30 sin(2 pi t/200), shared by the farms (or per farm
-    #   with --per-env-wind), re-set every step on the device (rotation + sort kernel, no host sync)
     cfg_id = int(args.config[3])
-    gen = torch.Generator(device="cuda").manual_seed(1234 + cfg_id + 7919 * rank)
-    ring = []
-    yaw = torch.zeros((B, N), device="cuda", dtype=torch.float32)
-    for _ in range(8):
-        if cfg_id == 2:
-            yaw = torch.rand((B, N), device="cuda", generator=gen) * 80 - 40
-        else:
-            yaw = (yaw + (torch.rand((B, N), device="cuda", generator=gen) * 10 - 5)).clamp_(-40, 40)
-        ring.append(yaw.clone())
     sweep = cfg_id == 5
-    if sweep:
-        t_all = torch.arange(args.warmup + args.steps + 1, device="cuda", dtype=torch.float64)
-        wd_t = 270.0 + 30.0 * torch.sin(2 * torch.pi * t_all / 200.0)
-        nw = B if args.per_env_wind else 1
-        jitter = (torch.rand(nw, device="cuda", generator=gen, dtype=torch.float64) * 20 - 10) if args.per_env_wind \
-            else torch.zeros(1, device="cuda", dtype=torch.float64)
-        ws_dev = torch.full((nw,), 8.0, device="cuda", dtype=torch.float64)
-
-        def set_wind_at(t):
-            w.set_wind(ws_dev, wd_t[t] + jitter)
-    else:
-        def set_wind_at(t):
-            return None
-    w.set_wind(8.0, 270.0)
-    out = w.step(ring[0])
-    w.sync()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        set_wind_at(i)
-        w.step(ring[i % len(ring)], out)
-    barrier()
-    t0 = time.perf_counter()
-    w.timing_begin()
-    for i in range(args.steps):
-        set_wind_at(args.warmup + i)
-        w.step(ring[i % len(ring)], out)
-    kern_ms = w.timing_end() / args.steps  # HIP events on the stream the kernel is launched on
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # host-synchronised per step (what a Python RL loop that reads every observation sees)
-    t1 = time.perf_counter()
-    nsync = min(args.steps, 20)
-    for i in range(nsync):
-        set_wind_at(args.warmup + i)
-        w.step(ring[i % len(ring)], out)
+    def run_leg(mode):
+        """One timed leg.  strong: this rank owns the contiguous block shard_bounds(B_total, rank, world) of the
+        config's farms; weak: it owns B_total farms of a world x B_total batch.  Returns the leg's figures and the
+        live objects (handle, yaw ring, outputs) of rank-local use."""
+        if mode == "strong":
+            lo, hi = shard_bounds(B_total, rank, world)
+            total = B_total
+        else:
+            lo, hi = shard_bounds(B_total * world, rank, world)
+            total = B_total * world
+        B = hi - lo
+        w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B, device_id=local_rank)
+        w.set_stream(torch.cuda.current_stream().cuda_stream, True)
+        # synthetic inputs, seeded per SURVEY §8d (1234 + cfg id) and per rank:
+        #   cfg2: absolute yaw ~ U(-40,40), fixed wind;  cfg3/cfg4: random-walk yaw (dyaw ~ U(-5,5), clipped to +-40),
+        #   fixed wind;  cfg5: random-walk yaw + wd(t) = 270 + 30 sin(2 pi t/200), shared by the farms (or per farm
+        #   with --per-env-wind), re-set every step on the device (rotation + sort kernel, no host sync)
+        gen = torch.Generator(device="cuda").manual_seed(1234 + cfg_id + 7919 * rank)
+        ring = []
+        yaw = torch.zeros((B, N), device="cuda", dtype=torch.float32)
+        for _ in range(8):
+            if cfg_id == 2:
+                yaw = torch.rand((B, N), device="cuda", generator=gen) * 80 - 40
+            else:
+                yaw = (yaw + (torch.rand((B, N), device="cuda", generator=gen) * 10 - 5)).clamp_(-40, 40)
+            ring.append(yaw.clone())
+        if sweep:
+            t_all = torch.arange(args.warmup + args.steps + 1, device="cuda", dtype=torch.float64)
+            wd_t = 270.0 + 30.0 * torch.sin(2 * torch.pi * t_all / 200.0)
+            nw = B if args.per_env_wind else 1
+            jitter = (torch.rand(nw, device="cuda", generator=gen, dtype=torch.float64) * 20 - 10) if args.per_env_wind \
+                else torch.zeros(1, device="cuda", dtype=torch.float64)
+            ws_dev = torch.full((nw,), 8.0, device="cuda", dtype=torch.float64)
+
+            def set_wind_at(t):
+                w.set_wind(ws_dev, wd_t[t] + jitter)
+        else:
+            def set_wind_at(t):
+                return None
+        w.set_wind(8.0, 270.0)
+        out = w.step(ring[0])
         w.sync()
-    sync_ms = (time.perf_counter() - t1) / nsync * 1e3
-    if dist is not None:
-        t = torch.tensor([elapsed, kern_ms], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kern_ms = float(t[0]), float(t[1])
-        # the collective part of the job is over: every rank leaves the group now, so that rank 0's CPU-baseline
-        # leg (tens of seconds) runs with no peer waiting on it
+        for i in range(args.warmup):
+            set_wind_at(i)
+            w.step(ring[i % len(ring)], out)
+        barrier()
+        t0 = time.perf_counter()
+        w.timing_begin()
+        for i in range(args.steps):
+            set_wind_at(args.warmup + i)
+            w.step(ring[i % len(ring)], out)
+        kern_ms = w.timing_end() / args.steps  # HIP events on the stream the kernel is launched on
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # host-synchronised per step (what a Python RL loop that reads every observation sees)
+        t1 = time.perf_counter()
+        nsync = min(args.steps, 20)
+        for i in range(nsync):
+            set_wind_at(args.warmup + i)
+            w.step(ring[i % len(ring)], out)
+            w.sync()
+        sync_ms = (time.perf_counter() - t1) / nsync * 1e3
+        if dist is not None:
+            t = torch.tensor([elapsed, kern_ms], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, kern_ms = float(t[0]), float(t[1])
+        return dict(mode=mode, B=B, total=total, elapsed=elapsed, kern_ms=kern_ms, sync_ms=sync_ms, w=w, ring=ring, out=out)
+
+    main_leg = run_leg(args.scaling)
+    other_leg = None
+    if world > 1:
+        main_leg["w"].sync()
+        keep = main_leg if rank == 0 else None
+        if keep is None:
+            main_leg["w"].close()
+        other_leg = run_leg("weak" if args.scaling == "strong" else "strong")
+        other_leg["w"].close()
+        # the collective part of the job is over: every rank leaves the group now, so that rank 0's remaining legs
+        # (fused env step, env-level loop) run with no peer waiting on it
         dist.barrier()
         dist.destroy_process_group()
         dist = None
     if rank != 0:
-        w.close()
         return
+
+    w, ring, out, B = main_leg["w"], main_leg["ring"], main_leg["out"], main_leg["B"]
+    elapsed, kern_ms = main_leg["elapsed"], main_leg["kern_ms"]
+    info = w.kernel_info()
 
     # the same farms through the fused env step (SURVEY f1: transition + budget gate + reward in the launch,
     # only reward + local wind observations written): reported beside the headline, not as `value`
     venv_ms = None
-    try:
-        if args.no_env_leg:
-            raise RuntimeError("skipped")
-        w.env_config(load_coef=0.1)
-        w.env_reset()
-        act = [(r - ring[i - 1]) if i else r for i, r in enumerate(ring)]
-        eout = w.env_step(act[0], want=("reward", "yaw", "wind_speed", "wind_direction"))
-        w.sync()
-        w.timing_begin()
-        for i in range(args.steps):
-            w.env_step(act[i % len(act)], want=("reward", "yaw", "wind_speed", "wind_direction"), out=eout)
-        venv_ms = w.timing_end() / args.steps
-    except Exception as e:  # pragma: no cover
-        if not args.no_env_leg:
+    env_level = None
+    if not args.no_env_leg:
+        try:
+            w.env_config(load_coef=0.1)
+            w.env_reset()
+            act = [(r - ring[i - 1]) if i else r for i, r in enumerate(ring)]
+            eout = w.env_step(act[0], want=("reward", "yaw", "wind_speed", "wind_direction"))
+            w.sync()
+            w.timing_begin()
+            for i in range(args.steps):
+                w.env_step(act[i % len(act)], want=("reward", "yaw", "wind_speed", "wind_direction"), out=eout)
+            venv_ms = w.timing_end() / args.steps
+        except Exception as e:  # pragma: no cover
             print(f"bench.py: fused env step leg failed: {e}", file=sys.stderr)
+        # end to end from Python: the env object a learner holds — make("<layout>_Floris", env_batch=B) — stepped with
+        # device-resident random actions; wall clock per step including every Python-side cost of VecWindFarmEnv
+        try:
+            from wfcrl_env_amd import environments as envs
 
-    value = B * world * args.steps / elapsed
+            env_id = {"Turb16_TCRWP_": "Turb16_TCRWP_Floris"}.get(layout_name, layout_name + "Floris")
+            env = envs.make(env_id, env_batch=B, max_num_steps=10 ** 9, load_coef=0.1, log=False)
+            env.reset(seed=0, options={"wind_speed": 8.0, "wind_direction": 270.0})
+            acts = [(torch.rand((B, N), device="cuda") * 10 - 5) for _ in range(8)]
+            env_level = {}
+            for name, fn in (("step", env.step), ("step_light", env.step_light)):
+                for i in range(3):
+                    fn(acts[i])
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for i in range(args.steps):
+                    fn(acts[i % 8])
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t) / args.steps * 1e3
+                env_level[name] = {"ms_per_step": ms, "env_steps_per_sec": B / (ms * 1e-3), "over_kernel": ms / kern_ms - 1.0}
+            env_level["what"] = (f'make("{env_id}", env_batch={B}).step / .step_light with device-resident random actions, '
+                                 "wall clock per step over the same number of steps (asynchronous launches, one sync at the end)")
+            env.close()
+        except Exception as e:  # pragma: no cover
+            print(f"bench.py: env-level leg failed: {e}", file=sys.stderr)
+
+    value = main_leg["total"] * args.steps / elapsed
     algo_bytes = (32 * N + 8) * B  # SURVEY §8d: read 4N yaw + 8 wind, write 28N outputs, per farm-step
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            traffic = json.load(open(tfile)).get(f"{args.config}_B{B}", {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    info = w.kernel_info()
+    cp = counter_profile(args.config, B) if not sweep else None
     lops = lane_ops_per_farm_step(N, bool(info.get("pair_table")))
     lane_ops = lops * B
     valu_achieved = lane_ops / (kern_ms * 1e-3)
 
-    # accuracy beside the throughput: a bounded sample of this very batch against the float64 oracle
+    wl_wind = ("ws 8 m/s, wd(t) = 270 + 30 sin(2 pi t/200)" + (" + U(-10,10) per farm" if args.per_env_wind else " shared")
+               if sweep else "ws 8 m/s, wd 270")
     res = {"metric": "farm_steps_per_sec", "value": value, "unit": "farm-steps/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-           "ms_per_step_host_synced": sync_ms,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"{layout_name}Floris x env_batch {B} per GPU (BASELINE configs[{cfg_id - 1}]), "
-                                  + ("ws 8 m/s, wd(t) = 270 + 30 sin(2 pi t/200)" + (" + U(-10,10) per farm" if args.per_env_wind else " shared")
-                                     if sweep else "ws 8 m/s, wd 270") + (", yaw ~ U(-40,40)" if cfg_id == 2 else ", random-walk yaw"),
+           "ms_per_step_host_synced": main_leg["sync_ms"],
+           "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{layout_name}Floris x env_batch {main_leg['total']} in total (BASELINE configs[{cfg_id - 1}]), "
+                                  + wl_wind + (", yaw ~ U(-40,40)" if cfg_id == 2 else ", random-walk yaw"),
                       "layout": layout_name.rstrip("_"),
-                      "turbines": N, "env_batch_per_gpu": B, "env_batch_total": B * world, "parallelism": f"env-shard x{world}",
+                      "turbines": N, "env_batch_per_gpu": B, "env_batch_total": main_leg["total"],
+                      "parallelism": f"env-shard x{world}" + (f" ({world} ranks sharing {ndev} GPU(s) over gloo: test mode)" if shared_devices else ""),
                       "kernel": f"wf_step_kernel<G={info['lanes_per_env']},S={info['slots_per_lane']}>"
                                 + (" + shared-wind pair table" if info.get("pair_table") else ""),
                       "vgprs": info["vgprs"], "scratch_bytes": info["scratch_bytes"]},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
+                        "traffic": cp["hbm_bytes"] if cp else None,
+                        "traffic_source": cp["source"] if cp else None,
                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
                         "note": "path is VALU-bound (arithmetic intensity ~2 kFLOP/B): see valu_roofline"},
            "valu_roofline": {"bound": "valu_fp32", "achieved": valu_achieved, "peak": VALU_PEAK_LANEOPS,
                              "unit": "lane-ops/s", "frac": valu_achieved / VALU_PEAK_LANEOPS,
-                             "lane_ops_per_farm_step": lops}}
-
+                             "lane_ops_per_farm_step": lops,
+                             "frac_is": "analytic useful-work model (bench.py: lane_ops_per_farm_step)",
+                             # issue slots actually spent: SQ_INSTS_VALU wave-instructions x 64 lanes per launch
+                             "issue_frac": (cp["insts_valu"] * 64.0 / (kern_ms * 1e-3) / VALU_PEAK_LANEOPS) if cp else None,
+                             "issue_frac_source": cp["source"] if cp else None}}
+    if other_leg is not None:
+        res[f"{other_leg['mode']}_scaling"] = {
+            "value": other_leg["total"] * args.steps / other_leg["elapsed"], "unit": "farm-steps/s",
+            "ms_per_step": other_leg["elapsed"] / args.steps * 1e3, "env_batch_per_gpu": other_leg["B"],
+            "env_batch_total": other_leg["total"], "kernel_ms": other_leg["kern_ms"]}
     if venv_ms is not None:
         res["fused_env_step"] = {"ms_per_step": venv_ms, "env_steps_per_sec_per_gpu": B / (venv_ms * 1e-3),
                                  "outputs": "reward[B], yaw/wind_speed/wind_direction[B,N]"}
+    if env_level:
+        res["env_level"] = env_level
     if not args.no_cpu_baseline and world == 1:  # CPU baseline + accuracy sample: rank 0 of the single-GPU run only
         from oracle import c_oracle
 
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import parity
+
         nthreads = min(c_oracle.max_threads(), effective_cpus())
         ycpu = ring[0][: min(B, 4096)].cpu().numpy().astype(np.float64)
-        # accuracy sample: this very batch (fixed wind 8 m/s / 270 deg) against the float64 oracle
+        # accuracy sample: this very batch (fixed wind 8 m/s / 270 deg) against the float64 oracle, under the per-farm
+        # contract of tests/parity.py (strict on every farm the kernel did not flag itself)
         ns = min(256, ycpu.shape[0])
-        ref = c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[:ns])
+        ref = c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[:ns], margin=True)
         w.set_wind(8.0, 270.0)
         got = w.step(ring[0], out)
+        flags_all = w.risk_flags()
         w.sync()
         g = {k: v[:ns].cpu().numpy().astype(np.float64) for k, v in got.items()}
+        sm = parity.summarize(g, ref, flags_all[:ns])
         perr = np.abs(g["power"] - ref["power"]) / np.maximum(ref["power"], 1e3)
         res["power_rel_err"] = {"max": float(perr.max()), "p999": float(np.quantile(perr, 0.999)),
                                 "frac_gt_1e-4": float((perr > 1e-4).mean()),
+                                "max_unflagged": sm["worst_unflagged"]["power"],
+                                "flagged_farm_frac_sample": sm["n_flagged"] / sm["n"],
+                                "flagged_farm_frac_batch": float((flags_all != 0).mean()),
+                                "contract": parity.classify(sm),
                                 "wind_speed_rel_max": float((np.abs(g["wind_speed"] - ref["wind_speed"]) / ref["wind_speed"]).max()),
                                 "wind_direction_abs_max_deg": float(np.abs(g["wind_direction"] - ref["wind_direction"]).max()),
                                 "ti_abs_max": float(np.abs(g["load"][..., 0] - ref["load"][..., 0]).max()),
                                 "sample": f"{ns} envs x {N} turbines vs float64 oracle (oracle-pinned; the reference "
-                                          "pins only its yaw = 0 notebook vector, tests/golden/kat1_demo_notebook.json)"}
+                                          "pins only its yaw = 0 notebook vector, tests/golden/kat1_demo_notebook.json); "
+                                          "flagged = farms with a nonzero WF_RISK_* flag (include/wfstep.h)"}
         # timing: calibrate on a small sample, then ~cpu_seconds of work
         t = time.perf_counter()
         c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[: 4 * nthreads], nthreads=nthreads)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 1
+#define WF_ABI_VERSION 2
 
 /* status codes (0 = ok, negative = error; text via wf_last_error) */
 #define WF_OK 0
@@ -89,6 +89,8 @@ int wf_set_batch(wf_handle* h, int env_batch);
 
 /* Replaces FlorisInterface.update_wind -> fi.reinitialize (interface.py:663-671).
  * count == 1: one (ws, wd) shared by the whole batch; count == env_batch: one per instance.
+ * Host arrays are validated (ws > 0, wd finite); device arrays are NOT (no readback on the asynchronous path): a
+ * non-positive or non-finite wind there yields NaN outputs for that farm.
  * Performs wd % 360, the layout rotation and the upstream->downstream sort on the device (float64).
  * Host pointers unless on_device != 0.  Host arrays whose directions are all equal (a speed per instance under one
  * direction) share the rotation, the sort and the pair-coefficient table like count == 1. */
@@ -156,6 +158,13 @@ int wf_env_reset(wf_handle* h);
 int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, float* power, float* wind_speed,
                 float* wind_dir, float* load, int on_device);
 
+/* The reward of wf_env_step is normalised by the free-stream speed of the state BEFORE the step (reference
+ * wfcrl/simple_env.py:78-80: `self.mdp.state["freewind_measurements"][0]` is read before `step_interface`).  It equals
+ * the current wind except right after a series tick (handled inside wf_wind_series_step) and when the caller's start
+ * state holds a clipped wind (reference mdp.py:263-266 clips the whole start state to the observation bounds): pass
+ * that speed per farm here.  Used by the next wf_env_step that computes a reward, once. */
+int wf_env_set_prev_wind(wf_handle* h, const double* wind_speed /* env_batch */, int on_device);
+
 /* Checkpoint / resume of the device-resident env state: yaw [B*N], acc [B*N] (accumulated |dyaw|),
  * moves [B].  set == 0 copies the state out, set != 0 overwrites it.  NULL pointers are skipped. */
 int wf_env_state(wf_handle* h, float* yaw, float* acc, int* moves, int set, int on_device);
@@ -190,7 +199,7 @@ int wf_timing_end(wf_handle* h, float* elapsed_ms);
  * lane), its register/LDS footprint and the launch geometry. */
 typedef struct wf_kernel_info {
   int lanes_per_env, slots_per_lane, envs_per_block, threads_per_block, grid_blocks;
-  int vgprs, sgprs, lds_bytes, scratch_bytes;
+  int vgprs, lds_bytes, scratch_bytes; /* from hipFuncGetAttributes */
   int pair_table; /* 1: shared-wind pair-coefficient table path, 0: per-farm on-the-fly path */
 } wf_kernel_info;
 int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info);

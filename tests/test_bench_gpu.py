@@ -1,0 +1,49 @@
+"""GPU: bench.py's contract — the single-GPU line, and the multi-rank flow (self-launch through torch.distributed.run,
+strong + weak legs, max-over-ranks timing) exercised with 2 ranks on whatever GPUs the box has (on a one-GPU box the
+ranks share the device and rendezvous over gloo; bench.py selects that itself)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(*args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    d = _run("--config", "cfg2", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0.5")
+    assert d["metric"] == "farm_steps_per_sec" and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
+    assert d["value"] > 1e6 and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["config"]["env_batch_total"] == 4096 and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["frac_of_measured_copy"] > rf["frac"] and "traffic_source" in rf
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert d["power_rel_err"]["contract"] in ("ok", "flagged") and d["power_rel_err"]["max_unflagged"] <= 1e-4
+    assert d["env_level"]["step"]["env_steps_per_sec"] > 0 and d["env_level"]["step_light"]["ms_per_step"] > 0
+
+
+def test_two_ranks_self_launched_strong_and_weak():
+    d = _run("--gpus", "2", "--config", "cfg2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-env-leg")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["env_batch_total"] == 4096 and d["config"]["env_batch_per_gpu"] == 2048
+    assert d["value"] > 1e5
+    wk = d["weak_scaling"]
+    assert wk["env_batch_total"] == 8192 and wk["env_batch_per_gpu"] == 4096 and wk["value"] > 1e5
+    assert "cpu_baseline" not in d
+    d = _run("--gpus", "2", "--config", "cfg2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-env-leg",
+             "--scaling", "weak")
+    assert d["scaling"] == "weak" and d["config"]["env_batch_total"] == 8192 and d["strong_scaling"]["env_batch_total"] == 4096

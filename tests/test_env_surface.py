@@ -299,3 +299,68 @@ def test_reference_import_names_resolve_to_this_build(tmp_path):
     case = envs.registration.get_case("Turb3_Row1_", "Floris")
     path = create_floris_case(case.dict(), output_dir=tmp_path / "c")
     assert os.path.basename(path) == "case.yaml" and os.path.exists(path)
+
+
+def test_floris_interface_accepts_the_reference_constructor_signature(tmp_path):
+    """reference wfcrl/interface.py:462-471: FlorisInterface(num_turbines, simul_file, max_iter, log_file, wind_speed,
+    wind_direction, wind_time_series) — positional, keyword and mixed — next to this build's coordinate form."""
+    from wfcrl_env_amd.environments.data_cases import named_cases_dictionary
+    from wfcrl_env_amd.simul_utils import dump_case_yaml
+
+    case = named_cases_dictionary["Ablaincourt_"][1]
+    path = dump_case_yaml(case.dict(), tmp_path / "c")
+    a = OracleFlorisInterface(7, str(path))                                   # reference user code
+    b = OracleFlorisInterface(7, path, 50, None, 9.0, 260.0)                  # all positional, PathLike
+    c = OracleFlorisInterface(7, simul_file=str(path), max_iter=50, wind_speed=9.0)
+    d = OracleFlorisInterface(7, case.xcoords, case.ycoords, max_iter=50)     # coordinate form
+    e = OracleFlorisInterface(num_turbines=7, xcoords=case.xcoords, ycoords=case.ycoords)
+    assert (a.wind_speed, a.wind_dir, a.max_iter) == (8.0, 270.0, int(1e4))   # None -> what the file holds
+    assert (b.wind_speed, b.wind_dir, b.max_iter) == (9.0, 260.0, 50)
+    assert (c.wind_speed, c.wind_dir, c.max_iter) == (9.0, 270.0, 50)
+    for it in (a, d, e):
+        it.update_command(np.zeros(7))
+    assert np.allclose(a.avg_powers(), d.avg_powers()) and np.allclose(a.avg_powers(), e.avg_powers())
+    with pytest.raises(TypeError):
+        OracleFlorisInterface(7, str(path), 50, None, 9.0, 260.0, None, "extra")
+    with pytest.raises(TypeError):
+        OracleFlorisInterface(7, str(path), max_iter=50, xcoords=[0.0])
+    with pytest.raises(TypeError):
+        OracleFlorisInterface(7)
+    with pytest.raises(ValueError):
+        OracleFlorisInterface(5, str(path))  # the file's layout has 7 turbines
+
+
+def test_alias_package_is_one_module_tree():
+    """`wfcrl.*` and `wfcrl_env_amd.*` are the same module objects: isinstance checks hold across the two names."""
+    import wfcrl
+    import wfcrl.environments.registration as r1
+    import wfcrl_env_amd
+    import wfcrl_env_amd.environments.registration as r2
+    from wfcrl.interface import BaseInterface as B1
+    from wfcrl.rewards import StepPercentage as S1
+    from wfcrl_env_amd.interface import BaseInterface as B2
+    from wfcrl_env_amd.rewards import StepPercentage as S2
+
+    assert wfcrl is wfcrl_env_amd and r1 is r2 and S1 is S2 and B1 is B2
+
+
+def test_vec_env_step_percentage_follows_the_reference_shaper():
+    """Batched StepPercentage (vec_env._shape) against the reference class applied per env (rewards.py:30-46): seeded
+    from the shaper's reference, previous reward 0 -> 0.0, shaper state updated."""
+    from wfcrl_env_amd.rewards import StepPercentage
+    from wfcrl_env_amd.vec_env import VecWindFarmEnv
+
+    class _Shell:  # only what _shape touches
+        _shape = VecWindFarmEnv._shape
+
+    rs = [np.array([1.0, 0.0, 2.0]), np.array([1.5, 3.0, 0.0]), np.array([0.75, 3.0, 4.0])]
+    for start in (0.0, 2.0):
+        sh = _Shell()
+        sh.reward_shaper, sh._shaper_ref = StepPercentage(start), None
+        sh.reward_shaper.reset(start)
+        per_env = [StepPercentage(start) for _ in range(3)]
+        for r in rs:
+            want = np.array([float(p(float(v))) for p, v in zip(per_env, r)])
+            got = sh._shape(r.copy())
+            assert np.allclose(got, want) and np.isfinite(got).all(), (start, got, want)
+        assert np.allclose(sh.reward_shaper.reference, rs[-1])

@@ -55,7 +55,7 @@ class WindDist(C.Structure):
 class KernelInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "lanes_per_env", "slots_per_lane", "envs_per_block", "threads_per_block", "grid_blocks",
-        "vgprs", "sgprs", "lds_bytes", "scratch_bytes", "pair_table")]
+        "vgprs", "lds_bytes", "scratch_bytes", "pair_table")]
 
 
 # every symbol include/wfstep.h declares: name -> (restype, argtypes)
@@ -82,6 +82,7 @@ ABI = {
     "wf_env_config": (C.c_int, [_P, C.POINTER(EnvParams)]),
     "wf_env_reset": (C.c_int, [_P]),
     "wf_env_state": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),
+    "wf_env_set_prev_wind": (C.c_int, [_P, _P, C.c_int]),
     "wf_env_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int]),
     "wf_timing_begin": (C.c_int, [_P]),
     "wf_timing_end": (C.c_int, [_P, C.POINTER(C.c_float)]),

@@ -180,6 +180,12 @@ class WfStep:
     def env_reset(self):
         check(self._lib.wf_env_reset(self._h), self._h)
 
+    def env_set_prev_wind(self, wind_speed):
+        """Free-stream speed (B,) of the state before the coming env step, when it differs from the current wind
+        (include/wfstep.h: wf_env_set_prev_wind); used once."""
+        ws = np.ascontiguousarray(np.broadcast_to(np.asarray(wind_speed, np.float64), (self.env_batch,)))
+        check(self._lib.wf_env_set_prev_wind(self._h, ws.ctypes.data, 0), self._h)
+
     def env_get_state(self) -> dict:
         """Host copy of the device-resident env state: yaw (B, N), acc (B, N), moves (B,)."""
         B, N = self.env_batch, self.num_turbines

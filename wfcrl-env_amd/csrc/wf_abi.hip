@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -54,17 +55,16 @@ const double kCpFrom3[45] = {
     0.14561785, 0.13287856, 0.12130194, 0.11219941, 0.10311631, 0.09545392, 0.08813781, 0.08186763, 0.07585005,
     0.07071926, 0.06557558, 0.06148104, 0.05755207, 0.05413366, 0.05097969, 0.04806545, 0.04536883, 0.04287006};
 double g_tab_ws[51], g_tab_ct[51], g_tab_cp[51];
-bool g_tab_init = false;
-void init_default_table() {
-  if (g_tab_init) return;
+std::once_flag g_tab_once;
+void fill_default_table() {
   int n = 0;
   const double head[3] = {0.0, 2.0, 2.5};
   for (int i = 0; i < 3; ++i) { g_tab_ws[n] = head[i]; g_tab_ct[n] = 0.0; g_tab_cp[n] = 0.0; ++n; }
   for (int i = 0; i < 45; ++i) { g_tab_ws[n] = 3.0 + 0.5 * i; g_tab_ct[n] = kCtFrom3[i]; g_tab_cp[n] = kCpFrom3[i]; ++n; }
   const double tail[3] = {25.01, 25.02, 50.0};
   for (int i = 0; i < 3; ++i) { g_tab_ws[n] = tail[i]; g_tab_ct[n] = 0.0; g_tab_cp[n] = 0.0; ++n; }
-  g_tab_init = true;
 }
+void init_default_table() { std::call_once(g_tab_once, fill_default_table); }  // concurrent wf_create calls
 
 thread_local std::string g_create_error;
 
@@ -116,10 +116,33 @@ struct wf_handle {
   float* d_pair_tab = nullptr;
   int* d_pair_first = nullptr;  // per source: first sorted target index with dx >= 0
   bool pair_dirty = true;
+  bool no_pair_table = false;  // WF_NO_PAIR_TABLE (A/B runs), read once at wf_create
+  bool ws_prev_valid = false;  // d_ws_prev holds the free wind of the state before the coming env step (one use)
   bool shared_dir = false;  // one wind per farm, but the same direction for all: shared geometry + pair table
 };
 
 namespace {
+
+// Every entry point runs on the handle's device and leaves the caller's current device as it found it (a torch
+// process would otherwise see torch.cuda.current_device() change under it).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) {
+      err = hipSetDevice(device);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) hipSetDevice(prev);
+  }
+};
+#define WF_ON_DEVICE(h) \
+  DeviceGuard guard_((h)->device); \
+  if (guard_.err != hipSuccess) return fail(h, WF_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err))
 
 int fail(wf_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg; else g_create_error = msg;
@@ -311,7 +334,7 @@ int build_consts(wf_handle* h) {
 // or WF_NO_PAIR_TABLE set for A/B runs).
 int pair_table(wf_handle* h, const float** out) {
   *out = nullptr;
-  if ((h->wind_count != 1 && !h->shared_dir) || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || getenv("WF_NO_PAIR_TABLE"))
+  if ((h->wind_count != 1 && !h->shared_dir) || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->no_pair_table)
     return WF_OK;
   int vG, vS; const void* vfn;
   wfk_variant(h->variant, &vG, &vS, &vfn);
@@ -394,7 +417,9 @@ int wf_create(int device_id, wf_handle** out) {
   wf_handle* h = new (std::nothrow) wf_handle();
   if (!h) return fail(nullptr, WF_E_NOMEM, "out of host memory");
   h->device = device_id;
-  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+  h->no_pair_table = getenv("WF_NO_PAIR_TABLE") != nullptr;
+  DeviceGuard guard(device_id);
+  if ((e = guard.err) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
       (e = hipMalloc(&h->d_tab, sizeof(WfTables))) != hipSuccess) {
     std::string msg = std::string("wf_create: ") + hipGetErrorString(e);
@@ -414,7 +439,7 @@ int wf_create(int device_id, wf_handle** out) {
 
 int wf_destroy(wf_handle* h) {
   if (!h) return WF_OK;
-  hipSetDevice(h->device);
+  DeviceGuard guard(h->device);
   hipStreamSynchronize(h->stream);
   free_batch(h);
   hipFree(h->d_tab); hipFree(h->d_lx); hipFree(h->d_ly);
@@ -426,7 +451,7 @@ int wf_destroy(wf_handle* h) {
 
 int wf_set_stream(wf_handle* h, void* s, int external) {
   if (!h) return WF_E_INVALID;
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   hipStream_t next = external ? (hipStream_t)s : h->own_stream;
   if (next != h->stream) {
     WF_HIP(h, hipStreamSynchronize(h->stream));
@@ -478,7 +503,7 @@ int wf_set_model(wf_handle* h, const wf_model_params* p) {
 int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
   if (!h || !x || !y) return WF_E_INVALID;
   if (n < 1 || n > WF_MAX_TURBINES) return fail(h, WF_E_INVALID, "n_turbines must be in 1..256");
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   const int v = pick_variant(n, h->B);
   if (v < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
   h->lx.assign(x, x + n); h->ly.assign(y, y + n);
@@ -502,7 +527,7 @@ int wf_set_batch(wf_handle* h, int B) {
   if (!h) return WF_E_INVALID;
   if (h->N <= 0) return fail(h, WF_E_INVALID, "wf_set_layout must be called before wf_set_batch");
   if (B < 1) return fail(h, WF_E_INVALID, "env_batch must be >= 1");
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   WF_HIP(h, hipStreamSynchronize(h->stream));
   {
     const int v = pick_variant(h->N, B);
@@ -515,6 +540,9 @@ int wf_set_batch(wf_handle* h, int B) {
   }
   if ((size_t)B != h->cap_env) {
     free_batch(h);
+    // nothing is committed until every allocation has succeeded: a failure leaves the handle without a batch
+    // (wf_set_batch must be called again) instead of with half-allocated buffers under the old sizes
+    h->B = 0; h->wind_count = 0; h->shared_dir = false; h->ws_prev_valid = false;
     const size_t bn = (size_t)B * h->N;
     WF_HIP(h, hipMalloc(&h->d_ws, sizeof(double) * B));
     WF_HIP(h, hipMalloc(&h->d_wd, sizeof(double) * B));
@@ -524,7 +552,7 @@ int wf_set_batch(wf_handle* h, int B) {
     WF_HIP(h, hipMalloc(&h->d_gidx, sizeof(int) * bn));
     h->cap_env = B; h->cap_bn = bn;
   }
-  h->B = B; h->wind_count = 0; h->shared_dir = false;
+  h->B = B; h->wind_count = 0; h->shared_dir = false; h->ws_prev_valid = false;
   return WF_OK;
 }
 
@@ -532,7 +560,7 @@ int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int
   if (!h || !ws || !wd) return WF_E_INVALID;
   if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called before wf_set_wind");
   if (count != 1 && count != h->B) return fail(h, WF_E_INVALID, "wind count must be 1 or env_batch");
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   if (!on_device)
     for (int i = 0; i < count; ++i)
       if (!(ws[i] > 0.0) || !std::isfinite(wd[i])) return fail(h, WF_E_INVALID, "wind speed must be > 0 and direction finite");
@@ -548,6 +576,7 @@ int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int
   if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));  // caller's host arrays may go away
   h->wind_count = count;
   h->series_T = 0;
+  h->ws_prev_valid = false;
   h->pair_dirty = true;
   return WF_OK;
 }
@@ -555,7 +584,7 @@ int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int
 int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, int on_device) {
   if (!h || !yaw) return WF_E_INVALID;
   if (h->wind_count == 0) return fail(h, WF_E_INVALID, "wf_set_wind must be called before wf_step");
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   if (h->model_dirty) {
     int rc = build_consts(h);
     if (rc != WF_OK) return rc;
@@ -586,7 +615,7 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
 int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* dist) {
   if (!h) return WF_E_INVALID;
   if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called before wf_wind_sample");
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   const wf_wind_dist def{8.0, 8.0, 3.0, 28.0, 270.0, 20.0, 0.0, 360.0};
   const wf_wind_dist d = dist ? *dist : def;
   if (!(d.ws_scale > 0) || !(d.ws_shape > 0) || !(d.ws_lo > 0) || !(d.ws_lo <= d.ws_hi) || !(d.wd_std >= 0))
@@ -597,6 +626,7 @@ int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* di
   h->wind_count = h->B;
   h->shared_dir = false;
   h->series_T = 0;
+  h->ws_prev_valid = false;
   h->pair_dirty = true;  // env_batch 1: "one wind per farm" is also "one wind for the batch" (table path)
   return WF_OK;
 }
@@ -607,7 +637,7 @@ int wf_wind_series(wf_handle* h, int T, const double* ws, const double* wd, cons
   if (T < 1) return fail(h, WF_E_INVALID, "the wind series needs at least one row");
   for (int i = 0; i < T; ++i)
     if (!(ws[i] > 0.0) || !std::isfinite(wd[i])) return fail(h, WF_E_INVALID, "wind speed must be > 0 and direction finite");
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   WF_HIP(h, hipStreamSynchronize(h->stream));
   hipFree(h->d_series_ws); hipFree(h->d_series_wd); hipFree(h->d_series_start);
   h->d_series_ws = h->d_series_wd = nullptr; h->d_series_start = nullptr;
@@ -625,6 +655,7 @@ int wf_wind_series(wf_handle* h, int T, const double* ws, const double* wd, cons
   }
   h->series_T = T;
   h->series_t = -1;
+  h->ws_prev_valid = false;
   return wf_wind_series_step(h);
 }
 
@@ -632,11 +663,12 @@ int wf_wind_series_step(wf_handle* h) {
   if (!h) return WF_E_INVALID;
   if (h->series_T <= 0) return fail(h, WF_E_INVALID, "wf_wind_series must be called first");
   if (h->series_t + 1 >= h->series_T) return fail(h, WF_E_INVALID, "wind series exhausted");
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   h->series_t += 1;
   if (h->series_t >= 1) {  // keep the wind of the state before this tick for the reward normalisation
     if (!h->d_ws_prev) WF_HIP(h, hipMalloc(&h->d_ws_prev, sizeof(double) * h->B));
     WF_HIP(h, hipMemcpyAsync(h->d_ws_prev, h->d_ws, sizeof(double) * h->B, hipMemcpyDeviceToDevice, h->stream));
+    h->ws_prev_valid = true;  // consumed by the next wf_env_step that computes a reward
   }
   WF_HIP(h, wfk_launch_series_gather(h->B, h->series_T, h->series_t, h->d_series_start, h->d_series_ws, h->d_series_wd,
                                      h->d_ws, h->d_wd, h->stream));
@@ -650,7 +682,7 @@ int wf_wind_series_step(wf_handle* h) {
 int wf_get_wind(wf_handle* h, double* ws, double* wd, int on_device) {
   if (!h || !ws || !wd) return WF_E_INVALID;
   if (h->wind_count == 0) return fail(h, WF_E_INVALID, "no wind has been set");
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   if (h->wind_count == h->B) {
     WF_HIP(h, hipMemcpyAsync(ws, h->d_ws, sizeof(double) * h->B, kind, h->stream));
@@ -692,7 +724,7 @@ static int env_alloc(wf_handle* h) {
 
 int wf_env_reset(wf_handle* h) {
   if (!h) return WF_E_INVALID;
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   const bool fresh = h->d_env_yaw == nullptr;
   int rc = env_alloc(h);
   if (rc != WF_OK) return rc;
@@ -705,9 +737,21 @@ int wf_env_reset(wf_handle* h) {
   return WF_OK;
 }
 
+int wf_env_set_prev_wind(wf_handle* h, const double* ws, int on_device) {
+  if (!h || !ws) return WF_E_INVALID;
+  if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called first");
+  WF_ON_DEVICE(h);
+  if (!h->d_ws_prev) WF_HIP(h, hipMalloc(&h->d_ws_prev, sizeof(double) * h->B));
+  WF_HIP(h, hipMemcpyAsync(h->d_ws_prev, ws, sizeof(double) * h->B, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           h->stream));
+  if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));
+  h->ws_prev_valid = true;
+  return WF_OK;
+}
+
 int wf_env_state(wf_handle* h, float* yaw, float* acc, int* moves, int set, int on_device) {
   if (!h) return WF_E_INVALID;
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   int rc = env_alloc(h);
   if (rc != WF_OK) return rc;
   const size_t bn = (size_t)h->B * h->N;
@@ -727,7 +771,7 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
                 float* load, int on_device) {
   if (!h) return WF_E_INVALID;
   if (h->wind_count == 0) return fail(h, WF_E_INVALID, "wf_set_wind must be called before wf_env_step");
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   int rc = env_alloc(h);
   if (rc != WF_OK) return rc;
   if (h->model_dirty && (rc = build_consts(h)) != WF_OK) return rc;
@@ -737,7 +781,10 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
   ea.yaw_step = h->env.yaw_step; ea.yaw_lo = h->env.yaw_lo; ea.yaw_hi = h->env.yaw_hi;
   ea.rate = h->env.actuator_rate; ea.dt = h->env.dt; ea.budget = h->env.budget;
   ea.load_coef = h->env.load_coef; ea.discrete = h->env.discrete;
-  ea.ws_prev = (h->series_T > 0 && h->series_t >= 1) ? h->d_ws_prev : nullptr;
+  // free wind of the state BEFORE the step, when it differs from the current one (series tick, wf_env_set_prev_wind):
+  // valid for one reward only — a second env step without a new tick normalises by the current wind again
+  ea.ws_prev = (h->ws_prev_valid && h->d_ws_prev) ? h->d_ws_prev : nullptr;
+  if (reward) h->ws_prev_valid = false;
   if (on_device) {
     ea.action = action; ea.reward = reward;
     if ((rc = launch_step(h, nullptr, power, wspd, wdir, load, &ea)) != WF_OK) return rc;
@@ -785,7 +832,7 @@ int wf_set_risk_guard(wf_handle* h, double rel_band) {
 int wf_get_risk_flags(wf_handle* h, int* flags, int on_device) {
   if (!h || !flags) return WF_E_INVALID;
   if (h->B <= 0 || !h->d_flags) return fail(h, WF_E_INVALID, "wf_set_batch must be called first");
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   WF_HIP(h, hipMemcpyAsync(flags, h->d_flags, sizeof(int) * h->B, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                            h->stream));
   if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));
@@ -794,21 +841,21 @@ int wf_get_risk_flags(wf_handle* h, int* flags, int on_device) {
 
 int wf_sync(wf_handle* h) {
   if (!h) return WF_E_INVALID;
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   WF_HIP(h, hipStreamSynchronize(h->stream));
   return WF_OK;
 }
 
 int wf_timing_begin(wf_handle* h) {
   if (!h) return WF_E_INVALID;
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   WF_HIP(h, hipEventRecord(h->ev0, h->stream));
   return WF_OK;
 }
 
 int wf_timing_end(wf_handle* h, float* ms) {
   if (!h || !ms) return WF_E_INVALID;
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   WF_HIP(h, hipEventRecord(h->ev1, h->stream));
   WF_HIP(h, hipEventSynchronize(h->ev1));
   WF_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
@@ -822,17 +869,17 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   wfk_variant(h->variant, &G, &S, &fn);
   // the instantiation the next step would launch: pair table (shared wind), general mirror cores, or default
   if (h->model_dirty && h->N > 0) { int rc = build_consts(h); if (rc != WF_OK) return rc; }
-  const bool tab = (h->wind_count == 1 || h->shared_dir) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && !getenv("WF_NO_PAIR_TABLE");
+  const bool tab = (h->wind_count == 1 || h->shared_dir) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && !h->no_pair_table;
   fn = wfk_variant_fn(h->variant, tab ? (h->shared_dir ? 3 : 2) : (h->consts.mirror_core_n <= 1 ? 0 : 1));
   info->pair_table = tab ? 1 : 0;
   hipFuncAttributes a;
-  WF_HIP(h, hipSetDevice(h->device));
+  WF_ON_DEVICE(h);
   WF_HIP(h, hipFuncGetAttributes(&a, fn));
   info->lanes_per_env = G; info->slots_per_lane = S;
   const int wpb = tab ? wfk_tab_waves() : 4;
   info->envs_per_block = wpb * (64 / G); info->threads_per_block = 64 * wpb;
   info->grid_blocks = h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0;
-  info->vgprs = a.numRegs; info->sgprs = 0;
+  info->vgprs = a.numRegs;
   info->lds_bytes = (int)a.sharedSizeBytes; info->scratch_bytes = (int)a.localSizeBytes;
   return WF_OK;
 }

@@ -6,6 +6,7 @@ Same duck type, names, units and error behaviour; the FLORIS object (`self.fi`) 
 """
 from __future__ import annotations
 
+import os
 import warnings
 from abc import ABC
 from typing import List, Union
@@ -72,11 +73,61 @@ class HipFlorisInterface(BaseInterface):
         "freewind_measurements": None,
     }
 
-    def __init__(self, num_turbines: int, xcoords, ycoords, max_iter: int = int(1e4), log_file: str = None,
-                 wind_speed: float = None, wind_direction: float = None,
-                 wind_time_series: Union[str, np.ndarray] = None, device_id: int = 0, model: dict = None,
-                 seed: int = None):
-        super().__init__()
+    _REF_ARGS = ("simul_file", "max_iter", "log_file", "wind_speed", "wind_direction", "wind_time_series")
+    _OWN_ARGS = ("xcoords", "ycoords", "max_iter", "log_file", "wind_speed", "wind_direction", "wind_time_series",
+                 "device_id", "model", "seed")
+
+    def __init__(self, num_turbines: int, *args, **kw):
+        """Two call forms.
+
+        Reference form (wfcrl/interface.py:462-471), selected when the second argument is a path:
+            FlorisInterface(num_turbines, simul_file, max_iter=1e4, log_file=None, wind_speed=None,
+                            wind_direction=None, wind_time_series=None)
+        reads layout, wind and model constants from the FLORIS case.yaml (`simul_utils.load_case_yaml`); `wind_speed` /
+        `wind_direction` None mean "what the file holds" (the reference passes the None on to `update_wind`, which
+        raises TypeError at `None % 360`, interface.py:664 — its callers always go through `from_case` with explicit
+        values); in the coordinate form None means the template's 8 m/s / 270 deg (case.yaml:31-36).
+
+        Coordinate form of this build:
+            HipFlorisInterface(num_turbines, xcoords, ycoords, max_iter=1e4, log_file=None, wind_speed=None,
+                               wind_direction=None, wind_time_series=None, device_id=0, model=None, seed=None)
+        """
+        ref_form = (len(args) > 0 and isinstance(args[0], (str, os.PathLike))) or "simul_file" in kw
+        names = self._REF_ARGS if ref_form else self._OWN_ARGS
+        if len(args) > len(names):
+            raise TypeError(f"{type(self).__name__}() takes at most {len(names) + 1} positional arguments")
+        bound = dict(zip(names, args))
+        for k, v in kw.items():
+            if k in bound:
+                raise TypeError(f"{type(self).__name__}() got multiple values for argument '{k}'")
+            if k not in names and k not in self._OWN_ARGS[7:]:
+                raise TypeError(f"{type(self).__name__}() got an unexpected keyword argument '{k}'")
+            bound[k] = v
+        if ref_form:
+            from .simul_utils import load_case_yaml
+
+            c = load_case_yaml(bound.pop("simul_file"))
+            bound["xcoords"], bound["ycoords"] = c["xcoords"], c["ycoords"]
+            bound.setdefault("model", c["model"])
+            if bound.get("wind_speed") is None:
+                bound["wind_speed"] = c["speed"]
+            if bound.get("wind_direction") is None:
+                bound["wind_direction"] = c["direction"]
+        if bound.get("wind_time_series") is None:
+            if bound.get("wind_speed") is None:
+                bound["wind_speed"] = 8.0
+            if bound.get("wind_direction") is None:
+                bound["wind_direction"] = 270.0
+        missing = [k for k in ("xcoords", "ycoords") if k not in bound]
+        if missing:
+            raise TypeError(f"{type(self).__name__}() missing required argument(s): {', '.join(missing)}")
+        self._construct(num_turbines, **bound)
+
+    def _construct(self, num_turbines: int, xcoords, ycoords, max_iter: int = int(1e4), log_file: str = None,
+                   wind_speed: float = None, wind_direction: float = None,
+                   wind_time_series: Union[str, np.ndarray] = None, device_id: int = 0, model: dict = None,
+                   seed: int = None):
+        BaseInterface.__init__(self)
         if len(xcoords) != num_turbines or len(ycoords) != num_turbines:
             raise ValueError("xcoords and ycoords layout coordinates must have num_turbines entries")
         self.num_turbines = num_turbines
@@ -114,7 +165,7 @@ class HipFlorisInterface(BaseInterface):
             from .simul_utils import dump_case_yaml
 
             dump_case_yaml(case.dict(), output_dir)
-        return cls(num_turbines=case.num_turbines, xcoords=p["xcoords"], ycoords=p["ycoords"],
+        return cls(case.num_turbines, xcoords=p["xcoords"], ycoords=p["ycoords"],
                    max_iter=case.max_iter, log_file=log_file, wind_speed=float(p["speed"]),
                    wind_direction=float(p["direction"]), wind_time_series=p["wind_time_series"], **kw)
 
@@ -125,7 +176,7 @@ class HipFlorisInterface(BaseInterface):
         from .simul_utils import load_case_yaml
 
         c = load_case_yaml(simul_file)
-        return cls(num_turbines=len(c["xcoords"]), xcoords=c["xcoords"], ycoords=c["ycoords"], max_iter=max_iter,
+        return cls(len(c["xcoords"]), xcoords=c["xcoords"], ycoords=c["ycoords"], max_iter=max_iter,
                    log_file=log_file, wind_speed=c["speed"], wind_direction=c["direction"],
                    wind_time_series=wind_time_series, model=c["model"], **kw)
 

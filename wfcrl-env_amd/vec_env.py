@@ -30,7 +30,7 @@ class VecWindFarmEnv:
     def __init__(self, farm_case, controls: dict = None, env_batch: int = 1, continuous_control: bool = True,
                  reward_shaper=None, start_iter: int = 0, max_num_steps: int = 500, load_coef: float = 0.1,
                  device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None,
-                 wind_sampling: str = "host"):
+                 wind_sampling: str = "host", reuse_buffers: bool = True):
         controls = {"yaw": (-40, 40, 5)} if controls is None else dict(controls)
         if list(controls) != ["yaw"]:
             raise ValueError(f"Cannot control {list(controls)}. Interface HipFlorisInterface only allows for the "
@@ -90,6 +90,13 @@ class VecWindFarmEnv:
         self._num_iter = 0
         self._freewind = None
         self._shaper_ref = None
+        # Output tensors are preallocated and used alternately (torch path): what step t returned stays valid until step
+        # t + 2 overwrites it — enough for (obs, next_obs) pairs, copy what must live longer.  reuse_buffers=False
+        # allocates fresh tensors every step, as B reference envs would.
+        self.reuse_buffers = bool(reuse_buffers) and return_torch
+        self._bufs = [{}, {}]
+        self._flip = 0
+        self._const = {}
 
     # -- helpers ------------------------------------------------------------------------------------
     def _sample_wind(self, seed, options):
@@ -129,6 +136,12 @@ class VecWindFarmEnv:
         obs["wind_direction"] = out["wind_direction"]
         return obs
 
+    def _next_buf(self):
+        if not self.reuse_buffers:
+            return None
+        self._flip ^= 1
+        return self._bufs[self._flip]
+
     def _to_device(self, a):
         if not self.return_torch:
             return np.ascontiguousarray(a, dtype=np.float32)
@@ -139,15 +152,28 @@ class VecWindFarmEnv:
         return torch.as_tensor(np.asarray(a, dtype=np.float32), device=f"cuda:{self.fi.device_id}")
 
     def _shape(self, r):
+        """Batched reward shaping with the semantics of reference wfcrl/rewards.py:4-46, per env.  Dispatch is by class
+        name, so a shaper instance built from the `wfcrl.rewards` alias of this package is recognised as well."""
         s = self.reward_shaper
-        if isinstance(s, DoNothingReward):
+        kind = type(s).__name__
+        if kind == "DoNothingReward":
             return r
-        if isinstance(s, ReferencePercentage):
+        if kind == "ReferencePercentage":
             return (r - s.reference) / s.reference
-        if isinstance(s, StepPercentage):
+        if kind == "StepPercentage":
+            # per-env previous reward, seeded from the shaper's own `reference` (constructor / reset value); a previous
+            # reward of exactly 0 yields 0.0 (rewards.py:36-37), and the shaper object keeps the state like the
+            # reference's does
             ref = self._shaper_ref
-            shaped = r * 0 if ref is None else (r - ref) / ref
+            if ref is None:
+                base = s.reference
+                ref = base if np.ndim(base) > 0 else r * 0 + float(base)
+            zero = ref == 0
+            safe = ref + zero  # 1 where the previous reward is 0: no division by zero, result replaced below
+            shaped = (r - ref) / safe
+            shaped = shaped * (~zero) if hasattr(shaped, "clone") else np.where(zero, 0.0, shaped)
             self._shaper_ref = r.clone() if hasattr(r, "clone") else r.copy()
+            s.reference = self._shaper_ref
             return shaped
         return s(r)
 
@@ -191,6 +217,22 @@ class VecWindFarmEnv:
         for k in ("wind_speed", "wind_direction"):
             lo, hi = float(sp[k].low[0]), float(sp[k].high[0])
             obs[k] = obs[k].clamp(lo, hi) if self.return_torch else np.clip(obs[k], lo, hi)
+        # the whole start state is clipped to the observation bounds (mdp.py:263-266), the free wind included; the first
+        # reward is normalised by that clipped speed (simple_env.py:78-80 reads the state before the step)
+        lo, hi = sp["freewind_measurements"].low, sp["freewind_measurements"].high
+        fw = obs["freewind_measurements"]
+        if self.return_torch:
+            import torch
+
+            clipped = torch.minimum(torch.maximum(fw, torch.as_tensor(lo, dtype=fw.dtype, device=fw.device)),
+                                    torch.as_tensor(hi, dtype=fw.dtype, device=fw.device))
+            changed = bool((clipped[:, 0] != fw[:, 0]).any()) if self._series is None else False
+        else:
+            clipped = np.clip(fw, lo, hi)
+            changed = bool((clipped[:, 0] != fw[:, 0]).any()) if self._series is None else False
+        obs["freewind_measurements"] = clipped
+        if changed:
+            self.fi.env_set_prev_wind(clipped[:, 0].cpu().numpy() if self.return_torch else clipped[:, 0])
         return obs
 
     def step(self, actions):
@@ -200,17 +242,28 @@ class VecWindFarmEnv:
         if self._series is not None:
             self.fi.wind_series_step()  # ValueError("wind series exhausted") ~ the reference's StopIteration
             self._refresh_freewind()
-        out = self.fi.env_step(self._to_device(a))
+        buf = self._next_buf()
+        out = self.fi.env_step(self._to_device(a), out=buf)
         self._num_iter += 1
         truncated = self._num_iter == self.farm_case.max_iter
         reward = self._shape(out["reward"])
-        info = {"power": out["power"] * 1e-6, "load": out["load"]}
         if self.return_torch:
             import torch
 
-            trunc = torch.full((self.num_envs,), bool(truncated), device=out["reward"].device)
-            term = torch.zeros_like(trunc)
+            if buf is not None:
+                if "power_mw" not in buf:
+                    buf["power_mw"] = torch.empty_like(out["power"])
+                    buf.update(out)  # keep the tensors env_step allocated on first use
+                info = {"power": torch.mul(out["power"], 1e-6, out=buf["power_mw"]), "load": out["load"]}
+            else:
+                info = {"power": out["power"] * 1e-6, "load": out["load"]}
+            if not self._const:
+                dev = out["reward"].device
+                self._const = {False: torch.zeros(self.num_envs, dtype=torch.bool, device=dev),
+                               True: torch.ones(self.num_envs, dtype=torch.bool, device=dev)}
+            trunc, term = self._const[bool(truncated)], self._const[False]
         else:
+            info = {"power": out["power"] * 1e-6, "load": out["load"]}
             trunc = np.full(self.num_envs, bool(truncated))
             term = np.zeros(self.num_envs, bool)
         return self._obs(out), reward, term, trunc, info
@@ -222,7 +275,10 @@ class VecWindFarmEnv:
         if self._series is not None:
             self.fi.wind_series_step()
             self._refresh_freewind()
-        out = self.fi.env_step(self._to_device(a), want=("reward", "yaw", "wind_speed", "wind_direction"))
+        buf = self._next_buf()
+        out = self.fi.env_step(self._to_device(a), want=("reward", "yaw", "wind_speed", "wind_direction"), out=buf)
+        if buf is not None:
+            buf.update(out)
         self._num_iter += 1
         return self._obs(out), self._shape(out["reward"]), self._num_iter == self.farm_case.max_iter
 
