@@ -96,6 +96,12 @@ int wf_set_batch(wf_handle* h, int env_batch);
  * direction) share the rotation, the sort and the pair-coefficient table like count == 1. */
 int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int on_device);
 
+/* The same with separate counts: n_ws speeds and n_wd directions, each 1 or env_batch (n_ws == 1 requires n_wd == 1).
+ * n_wd == 1 with n_ws == env_batch states "one direction, a speed per farm" explicitly — the only way to say so for
+ * device arrays, which are never read back — and keeps the shared geometry and the pair-coefficient table path (e.g.
+ * BASELINE configs[4]'s direction sweep with a speed per farm). */
+int wf_set_wind_counts(wf_handle* h, const double* ws, int n_ws, const double* wd, int n_wd, int on_device);
+
 /* Replaces fi.calculate_wake(yaw_angles) + fi.get_turbine_powers() + local_wind_measurements() +
  * local_load_proxies() (interface.py:564, 623, 629-648).
  *   yaw        [B*N]    absolute yaw, degrees, caller's turbine order
@@ -179,10 +185,21 @@ typedef struct wf_wind_dist {
 } wf_wind_dist;
 int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* dist);
 
+/* Build-defined variant (not in the reference): the sampled direction of every farm is rounded to the nearest multiple
+ * of `step_deg` (which must divide 360), so the batch holds at most K = 360 / step_deg distinct directions.  Farms are
+ * grouped by direction; the sorted geometry and the pair-coefficient table of each grid direction are built once per
+ * layout / model and kept across resets, and every step takes the table path (about twice the throughput of a
+ * continuous direction per farm).  Falls back to wf_wind_sample when K is too large for the batch (padding each group
+ * to whole blocks would cost more than it saves). */
+int wf_wind_sample_binned(wf_handle* h, unsigned long long seed, const wf_wind_dist* dist, double step_deg);
+
 /* Time-series mode (wfcrl/interface.py:512-524): a shared series of T (ws, wd) rows; farm b plays it from
  * start[b] (host array of env_batch ints, or NULL: drawn uniformly in [0, T) from `seed`).  The call positions
  * every farm on its first row; each wf_wind_series_step advances all farms by one row.  Like the reference's
- * finite generator, stepping past T rows fails (WF_E_INVALID, "wind series exhausted"). */
+ * finite generator, stepping past T rows fails (WF_E_INVALID, "wind series exhausted").
+ * A shared series holds only T distinct winds: when T is small against env_batch the farms are grouped by start row,
+ * one sorted geometry + pair-coefficient table is built per ROW at this call, and the whole playback runs on the table
+ * path (wf_kernel_info.direction_groups = T); otherwise each farm's geometry is rebuilt every tick (on-the-fly path). */
 int wf_wind_series(wf_handle* h, int T, const double* ws, const double* wd, const int* start, unsigned long long seed);
 int wf_wind_series_step(wf_handle* h);
 
@@ -201,6 +218,7 @@ typedef struct wf_kernel_info {
   int lanes_per_env, slots_per_lane, envs_per_block, threads_per_block, grid_blocks;
   int vgprs, lds_bytes, scratch_bytes; /* from hipFuncGetAttributes */
   int pair_table; /* 1: shared-wind pair-coefficient table path, 0: per-farm on-the-fly path */
+  int direction_groups; /* > 0: farms grouped by that many distinct wind directions, one pair table each */
 } wf_kernel_info;
 int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info);
 

@@ -604,3 +604,90 @@ def test_integration_md_stub_runs_as_printed():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "integration_stub_check.py")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "stub: ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_direction_groups_series_binned_and_explicit_shared_direction(layouts):
+    """Per-farm wind that is not really per-farm stays on the pair-table path:
+    (a) a shared wind SERIES has only T distinct winds: farms are grouped by start row, one geometry + table per row
+        (reference wfcrl/interface.py:503-524 playback), checked at every tick against the oracle and against the
+        on-the-fly path of the same handle state;
+    (b) device arrays with ONE direction and a speed per farm (wf_set_wind_counts: never read back, so stated explicitly);
+    (c) binned reset sampling (build-defined): K grid directions, groups cached across resets."""
+    import torch
+
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    N, B, T = 80, 700, 7
+    rng = np.random.default_rng(2025)
+    x, y = l["xcoords"], l["ycoords"]
+    # (a) series
+    series = np.stack([rng.uniform(5, 14, T), rng.uniform(200, 340, T)], axis=1)
+    start = rng.integers(0, T, B).astype(np.int32)
+    start[:3] = [0, T - 1, T - 1]
+    w = WfStep(x, y, env_batch=B)
+    w.set_wind_series(series, start=start)
+    info = w.kernel_info()
+    assert info["pair_table"] == 1 and info["direction_groups"] == T and info["grid_blocks"] >= B // info["envs_per_block"]
+    for t in range(T):
+        if t:
+            w.wind_series_step()
+        ws, wd = w.get_wind()
+        assert np.array_equal(ws, series[(start + t) % T, 0]) and np.array_equal(wd, series[(start + t) % T, 1])
+        yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
+        got = _with_flags(w, w.step(yaw))
+        _check(got, _oracle(x, y, ws, wd, yaw))
+    with pytest.raises(ValueError, match="exhausted"):
+        w.wind_series_step()
+    # too many rows for the batch: falls back to a geometry per farm, same results contract
+    w.set_batch(40)
+    w.env_batch = 40
+    series2 = np.stack([rng.uniform(5, 14, 30), rng.uniform(200, 340, 30)], axis=1)
+    w.set_wind_series(series2, seed=5)
+    assert w.kernel_info()["direction_groups"] == 0 and w.kernel_info()["pair_table"] == 0
+    ws, wd = w.get_wind()
+    yaw = rng.uniform(-35, 35, (40, N)).astype(np.float32)
+    _check(_with_flags(w, w.step(yaw)), _oracle(x, y, ws, wd, yaw))
+    # device-generated starts take the grouped path too
+    w.set_batch(B)
+    w.env_batch = B
+    w.set_wind_series(series, seed=9)
+    assert w.kernel_info()["direction_groups"] == T
+    w.wind_series_step()
+    ws, wd = w.get_wind()
+    yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
+    _check(_with_flags(w, w.step(yaw)), _oracle(x, y, ws, wd, yaw))
+
+    # (b) one direction on the device, a speed per farm
+    ws_b = rng.uniform(5, 14, B)
+    w.set_wind(torch.from_numpy(ws_b).cuda(), torch.tensor([281.0], dtype=torch.float64, device="cuda"))
+    assert w.kernel_info()["pair_table"] == 1 and w.kernel_info()["direction_groups"] == 0
+    got = _with_flags(w, w.step(yaw))
+    _check(got, _oracle(x, y, ws_b, np.full(B, 281.0), yaw))
+    ws2, wd2 = w.get_wind()
+    assert np.array_equal(ws2, ws_b) and np.array_equal(wd2, np.full(B, 281.0))
+    # per-farm device directions stay on the fly
+    w.set_wind(torch.from_numpy(ws_b).cuda(), torch.from_numpy(np.full(B, 281.0)).cuda())
+    assert w.kernel_info()["pair_table"] == 0
+    got2 = _with_flags(w, w.step(yaw))
+    both = (got["flags"] == 0) & (got2["flags"] == 0)
+    assert np.abs(got["power"] / np.maximum(got2["power"], 1e3) - 1)[both].max() < 2e-5
+
+    # (c) binned reset directions
+    w.sample_wind(17, direction_step=5.0)
+    info = w.kernel_info()
+    assert info["direction_groups"] == 72 and info["pair_table"] == 1
+    ws, wd = w.get_wind()
+    assert np.all(np.abs(wd / 5.0 - np.round(wd / 5.0)) < 1e-12) and len(np.unique(wd)) > 10 and ws.std() > 0.5
+    _check(_with_flags(w, w.step(yaw)), _oracle(x, y, ws, wd, yaw))
+    w.sample_wind(18, direction_step=5.0)  # next reset: cached geometry / tables, new grouping
+    ws3, wd3 = w.get_wind()
+    assert not np.array_equal(wd3, wd)
+    _check(_with_flags(w, w.step(yaw)), _oracle(x, y, ws3, wd3, yaw))
+    w.set_model(dict(ambient_ti=0.08))  # invalidates the cached tables, not the grouping
+    from oracle.floris_gch_numpy import ModelParams
+
+    _check(_with_flags(w, w.step(yaw)), _oracle(x, y, ws3, wd3, yaw, ModelParams(ambient_ti=0.08)))
+    w.sample_wind(19)  # continuous directions again
+    assert w.kernel_info()["direction_groups"] == 0 and w.kernel_info()["pair_table"] == 0
+    w.close()

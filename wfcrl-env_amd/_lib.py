@@ -55,7 +55,7 @@ class WindDist(C.Structure):
 class KernelInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "lanes_per_env", "slots_per_lane", "envs_per_block", "threads_per_block", "grid_blocks",
-        "vgprs", "lds_bytes", "scratch_bytes", "pair_table")]
+        "vgprs", "lds_bytes", "scratch_bytes", "pair_table", "direction_groups")]
 
 
 # every symbol include/wfstep.h declares: name -> (restype, argtypes)
@@ -71,6 +71,8 @@ ABI = {
     "wf_set_layout": (C.c_int, [_P, C.c_int, _P, _P]),
     "wf_set_batch": (C.c_int, [_P, C.c_int]),
     "wf_set_wind": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
+    "wf_set_wind_counts": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int]),
+    "wf_wind_sample_binned": (C.c_int, [_P, C.c_ulonglong, C.POINTER(WindDist), C.c_double]),
     "wf_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int]),
     "wf_sync": (C.c_int, [_P]),
     "wf_set_risk_guard": (C.c_int, [_P, C.c_double]),

@@ -87,27 +87,34 @@ class WfStep:
             self.set_stream(s, True)
 
     def set_wind(self, wind_speed, wind_direction):
-        """Scalar (shared by the batch) or one value per env; NumPy/float or torch float64 CUDA tensors."""
+        """Scalar (shared by the batch) or one value per env; NumPy/float or torch float64 CUDA tensors.  A speed per
+        env with ONE direction (size-1 `wind_direction`) keeps the shared geometry and the pair-table path."""
         if _is_torch(wind_speed):
-            ws, wd = wind_speed.contiguous(), wind_direction.contiguous()
-            assert ws.dtype == wd.dtype and str(ws.dtype) == "torch.float64" and ws.is_cuda
+            ws, wd = wind_speed.contiguous().reshape(-1), wind_direction.contiguous().reshape(-1)
+            assert ws.dtype == wd.dtype and str(ws.dtype) == "torch.float64" and ws.is_cuda and wd.is_cuda
             self._follow_torch_stream()
-            check(self._lib.wf_set_wind(self._h, ws.data_ptr(), wd.data_ptr(), ws.numel(), 1), self._h)
+            check(self._lib.wf_set_wind_counts(self._h, ws.data_ptr(), ws.numel(), wd.data_ptr(), wd.numel(), 1), self._h)
             return
         ws = np.ascontiguousarray(np.atleast_1d(wind_speed), dtype=np.float64)
         wd = np.ascontiguousarray(np.atleast_1d(wind_direction), dtype=np.float64)
-        if ws.shape != wd.shape:
-            raise ValueError("wind_speed and wind_direction must have the same shape")
-        check(self._lib.wf_set_wind(self._h, ws.ctypes.data, wd.ctypes.data, ws.size, 0), self._h)
+        if ws.shape != wd.shape and wd.size != 1:
+            raise ValueError("wind_speed and wind_direction must have the same shape (or one direction for all)")
+        check(self._lib.wf_set_wind_counts(self._h, ws.ctypes.data, ws.size, wd.ctypes.data, wd.size, 0), self._h)
 
-    def sample_wind(self, seed: int, dist: dict | None = None):
-        """On-device per-farm reset sampling (reference distributions by default, mdp.py:237-258)."""
+    def sample_wind(self, seed: int, dist: dict | None = None, direction_step: float | None = None):
+        """On-device per-farm reset sampling (reference distributions by default, mdp.py:237-258).  `direction_step`
+        (degrees, must divide 360; build-defined): directions rounded to that grid, farms grouped by direction, every
+        step on the pair-table path (include/wfstep.h: wf_wind_sample_binned)."""
         d = None
         if dist is not None:
             base = dict(ws_scale=8.0, ws_shape=8.0, ws_lo=3.0, ws_hi=28.0, wd_mean=270.0, wd_std=20.0, wd_lo=0.0, wd_hi=360.0)
             base.update(dist)
             d = C.byref(WindDist(**base))
-        check(self._lib.wf_wind_sample(self._h, C.c_ulonglong(int(seed) & (2**64 - 1)), d), self._h)
+        s = C.c_ulonglong(int(seed) & (2**64 - 1))
+        if direction_step:
+            check(self._lib.wf_wind_sample_binned(self._h, s, d, float(direction_step)), self._h)
+        else:
+            check(self._lib.wf_wind_sample(self._h, s, d), self._h)
 
     def set_wind_series(self, series, start=None, seed: int = 0):
         """series: (T, 2) [speed, direction]; start: (B,) ints or None (random per farm from `seed`)."""

@@ -35,6 +35,10 @@ extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, int n_groups
 
 extern "C" hipError_t wfk_launch_wind_sample(int B, unsigned long long seed, const double* dist, double* ws, double* wd,
                                              hipStream_t s);
+extern "C" hipError_t wfk_launch_fill(int n, double* a, hipStream_t s);  // a[1..n) = a[0]
+extern "C" hipError_t wfk_launch_wind_sample_binned(int B, unsigned long long seed, const double* dist, double step, double* ws,
+                                                    double* wd, int* bin, hipStream_t s);
+extern "C" hipError_t wfk_launch_bin_centres(int K, double step, double* wd, hipStream_t s);
 extern "C" hipError_t wfk_launch_series_start(int B, int T, unsigned long long seed, int* start, hipStream_t s);
 extern "C" hipError_t wfk_launch_series_gather(int B, int T, int t, const int* start, const double* s_ws,
                                                const double* s_wd, double* ws, double* wd, hipStream_t s);
@@ -119,6 +123,17 @@ struct wf_handle {
   bool no_pair_table = false;  // WF_NO_PAIR_TABLE (A/B runs), read once at wf_create
   bool ws_prev_valid = false;  // d_ws_prev holds the free wind of the state before the coming env step (one use)
   bool shared_dir = false;  // one wind per farm, but the same direction for all: shared geometry + pair table
+  // Direction groups: farms partitioned by a small set of K distinct wind directions (series rows, binned reset
+  // directions); one sorted geometry + pair table per group, farms launched group by group (padded to whole blocks)
+  int n_groups = 0;            // 0 = ungrouped
+  int group_shift = 0;         // geometry / table of group g is (g + group_shift) % n_groups  (series: the tick)
+  int n_blocks = 0;            // blocks of the grouped launch
+  int *d_perm = nullptr, *d_blk_group = nullptr;
+  size_t perm_cap = 0, blk_cap = 0;
+  size_t pair_groups_cap = 0;  // groups the pair-table allocation holds
+  double* d_group_wd = nullptr;  // [K] direction of each group (binned sampling; series mode uses d_series_wd)
+  double grid_step = 0.0;      // binned sampling: direction grid the cached group geometry / tables were built for
+  int* d_bins = nullptr;       // [B] bin of each farm (binned sampling)
 };
 
 namespace {
@@ -165,6 +180,9 @@ void free_batch(wf_handle* h) {
   h->d_env_moves = nullptr;
   hipFree(h->d_series_ws); hipFree(h->d_series_wd); hipFree(h->d_series_start); hipFree(h->d_ws_prev);
   hipFree(h->d_pair_tab); hipFree(h->d_pair_first); h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_dirty = true;
+  hipFree(h->d_perm); hipFree(h->d_blk_group); hipFree(h->d_group_wd); hipFree(h->d_bins);
+  h->d_perm = h->d_blk_group = h->d_bins = nullptr; h->d_group_wd = nullptr;
+  h->perm_cap = h->blk_cap = h->pair_groups_cap = 0; h->n_groups = 0; h->grid_step = 0.0;
   h->d_series_ws = h->d_series_wd = h->d_ws_prev = nullptr; h->d_series_start = nullptr; h->series_T = 0;
   if (h->h_yaw) hipHostFree(h->h_yaw);
   if (h->h_out) hipHostFree(h->h_out);
@@ -334,14 +352,18 @@ int build_consts(wf_handle* h) {
 // or WF_NO_PAIR_TABLE set for A/B runs).
 int pair_table(wf_handle* h, const float** out) {
   *out = nullptr;
-  if ((h->wind_count != 1 && !h->shared_dir) || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->no_pair_table)
+  if ((h->wind_count != 1 && !h->shared_dir && h->n_groups == 0) || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->no_pair_table)
     return WF_OK;
   int vG, vS; const void* vfn;
   wfk_variant(h->variant, &vG, &vS, &vfn);
   const int NP = vG * vS;
-  if (!h->d_pair_tab) {
-    WF_HIP(h, hipMalloc(&h->d_pair_tab, sizeof(float) * (size_t)h->N * WF_PAIR_ROW_FLOATS(NP)));
-    WF_HIP(h, hipMalloc(&h->d_pair_first, sizeof(int) * h->N));
+  const size_t ng = h->n_groups > 0 ? (size_t)h->n_groups : 1;
+  if (!h->d_pair_tab || h->pair_groups_cap < ng) {
+    hipFree(h->d_pair_tab); hipFree(h->d_pair_first);
+    h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_groups_cap = 0;
+    WF_HIP(h, hipMalloc(&h->d_pair_tab, sizeof(float) * ng * h->N * WF_PAIR_ROW_FLOATS(NP)));
+    WF_HIP(h, hipMalloc(&h->d_pair_first, sizeof(int) * ng * h->N));
+    h->pair_groups_cap = ng;
     h->pair_dirty = true;
   }
   if (h->pair_dirty) {
@@ -363,10 +385,72 @@ int pair_table(wf_handle* h, const float** out) {
       const double lm = m.kappa * z / (1.0 + m.kappa * z / (D / 8.0));
       pc.decay_a[k] = 4.0 * lm * lm * std::fabs(dudz) / uinf / pc.eps2;
     }
-    WF_HIP(h, wfk_launch_pair_table(&pc, 1, h->d_gx, h->d_gy, h->d_pair_tab, h->d_pair_first, h->stream));
+    WF_HIP(h, wfk_launch_pair_table(&pc, (int)ng, h->d_gx, h->d_gy, h->d_pair_tab, h->d_pair_first, h->stream));
     h->pair_dirty = false;
   }
   *out = h->d_pair_tab;
+  return WF_OK;
+}
+
+// Farms per block of the table-path launch of the handle's kernel variant.
+int farms_per_block(const wf_handle* h) {
+  int vG, vS; const void* vfn;
+  wfk_variant(h->variant, &vG, &vS, &vfn);
+  return wfk_tab_waves() * (64 / vG);
+}
+
+// Would a grouped launch over K direction groups pay off?  Every group is padded to whole blocks (half a block wasted
+// per group on average) against the ~2x cost of the on-the-fly path.
+bool groups_pay_off(const wf_handle* h, int K) {
+  if (h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->no_pair_table || K < 1) return false;
+  if ((size_t)K * h->N > h->cap_bn) return false;  // group geometry lives in the per-farm geometry buffers
+  const double waste = 0.5 * farms_per_block(h) * K / (double)h->B;
+  int vG, vS; const void* vfn;
+  wfk_variant(h->variant, &vG, &vS, &vfn);
+  const size_t bytes = (size_t)K * h->N * WF_PAIR_ROW_FLOATS(vG * vS) * sizeof(float);
+  return waste < 0.5 && bytes <= ((size_t)8 << 30);
+}
+
+// Partition the farms by `group_of_farm` (host, B entries in [0, K)): farm list sorted by group and padded per group to
+// whole blocks (d_perm, -1 = padding), group of each block (d_blk_group).  Then the sorted geometry of the K
+// directions `d_wd_groups` (device) is built into the geometry buffers; the pair tables follow lazily (pair_table()).
+int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_wd_groups, bool rebuild_geometry) {
+  const int epb = farms_per_block(h);
+  std::vector<int> count(K, 0);
+  for (int b = 0; b < h->B; ++b) {
+    if (group_of_farm[b] < 0 || group_of_farm[b] >= K) return fail(h, WF_E_INVALID, "direction group out of range");
+    ++count[group_of_farm[b]];
+  }
+  std::vector<int> first_slot(K, 0), blk_group;
+  int slots = 0;
+  for (int g = 0; g < K; ++g) {
+    first_slot[g] = slots;
+    const int nb = (count[g] + epb - 1) / epb;
+    for (int q = 0; q < nb; ++q) blk_group.push_back(g);
+    slots += nb * epb;
+  }
+  std::vector<int> perm(slots > 0 ? slots : 1, -1), cursor(first_slot);
+  for (int b = 0; b < h->B; ++b) perm[cursor[group_of_farm[b]]++] = b;
+  if (perm.size() > h->perm_cap) {
+    hipFree(h->d_perm); h->d_perm = nullptr; h->perm_cap = 0;
+    WF_HIP(h, hipMalloc(&h->d_perm, sizeof(int) * perm.size()));
+    h->perm_cap = perm.size();
+  }
+  if (blk_group.size() > h->blk_cap) {
+    hipFree(h->d_blk_group); h->d_blk_group = nullptr; h->blk_cap = 0;
+    WF_HIP(h, hipMalloc(&h->d_blk_group, sizeof(int) * blk_group.size()));
+    h->blk_cap = blk_group.size();
+  }
+  WF_HIP(h, hipStreamSynchronize(h->stream));  // a launch in flight may still read the previous lists
+  WF_HIP(h, hipMemcpy(h->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice));
+  WF_HIP(h, hipMemcpy(h->d_blk_group, blk_group.data(), sizeof(int) * blk_group.size(), hipMemcpyHostToDevice));
+  h->n_blocks = (int)blk_group.size();
+  h->n_groups = K;
+  h->group_shift = 0;
+  if (rebuild_geometry) {
+    WF_HIP(h, wfk_launch_geometry(K, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd_groups, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+    h->pair_dirty = true;
+  }
   return WF_OK;
 }
 
@@ -380,6 +464,10 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   WfGroupArgs ga{};
   ga.mod = 1;
   ga.risk_flags = h->d_flags;
+  if (h->n_groups > 0) {
+    ga.perm = h->d_perm; ga.blk_group = h->d_blk_group; ga.n_blocks = h->n_blocks;
+    ga.shift = h->group_shift; ga.mod = h->n_groups;
+  }
   WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                             wstride, yaw, power, wspd, wdir, load, h->B, ea, ptab, h->d_pair_first, &ga, h->stream, &h->grid));
   return WF_OK;
@@ -520,6 +608,7 @@ int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
   WF_HIP(h, hipMemcpy(h->d_ly, y, sizeof(double) * n, hipMemcpyHostToDevice));
   if (n != h->N) { free_batch(h); h->B = 0; }
   h->N = n; h->variant = v; h->wind_count = 0; h->shared_dir = false; h->model_dirty = true;
+  h->n_groups = 0; h->grid_step = 0.0;
   return WF_OK;
 }
 
@@ -534,7 +623,7 @@ int wf_set_batch(wf_handle* h, int B) {
     if (v < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
     if (v != h->variant) {  // the pair table is laid out for the variant's capacity
       hipFree(h->d_pair_tab); hipFree(h->d_pair_first);
-      h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_dirty = true;
+      h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_dirty = true; h->pair_groups_cap = 0;
       h->variant = v;
     }
   }
@@ -553,32 +642,46 @@ int wf_set_batch(wf_handle* h, int B) {
     h->cap_env = B; h->cap_bn = bn;
   }
   h->B = B; h->wind_count = 0; h->shared_dir = false; h->ws_prev_valid = false;
+  h->n_groups = 0; h->grid_step = 0.0;
+  return WF_OK;
+}
+
+int wf_set_wind_counts(wf_handle* h, const double* ws, int n_ws, const double* wd, int n_wd, int on_device) {
+  if (!h || !ws || !wd) return WF_E_INVALID;
+  if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called before wf_set_wind");
+  if ((n_ws != 1 && n_ws != h->B) || (n_wd != 1 && n_wd != h->B)) return fail(h, WF_E_INVALID, "wind count must be 1 or env_batch");
+  if (n_ws == 1 && n_wd != 1) return fail(h, WF_E_INVALID, "a direction per farm needs a speed per farm");
+  WF_ON_DEVICE(h);
+  if (!on_device) {
+    for (int i = 0; i < n_ws; ++i)
+      if (!(ws[i] > 0.0)) return fail(h, WF_E_INVALID, "wind speed must be > 0 and direction finite");
+    for (int i = 0; i < n_wd; ++i)
+      if (!std::isfinite(wd[i])) return fail(h, WF_E_INVALID, "wind speed must be > 0 and direction finite");
+  }
+  // One direction for every farm (explicitly: n_wd == 1; or host arrays whose directions are all equal, e.g. sampled
+  // speeds under a fixed direction): the rotation, the sort and the pair table depend on the direction only, so this
+  // is the shared-wind path with a speed per farm.
+  bool same_dir = n_ws > 1 && (n_wd == 1 || !on_device);
+  for (int i = 1; same_dir && i < n_wd; ++i) same_dir = wd[i] == wd[0];
+  const int count = n_ws;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  WF_HIP(h, hipMemcpyAsync(h->d_ws, ws, sizeof(double) * n_ws, kind, h->stream));
+  WF_HIP(h, hipMemcpyAsync(h->d_wd, wd, sizeof(double) * n_wd, kind, h->stream));
+  if (n_wd == 1 && n_ws > 1)  // the step kernel reads a direction per farm next to the speed per farm
+    WF_HIP(h, wfk_launch_fill(h->B, h->d_wd, h->stream));
+  WF_HIP(h, wfk_launch_geometry(same_dir ? 1 : count, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+  if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));  // caller's host arrays may go away
+  h->shared_dir = same_dir;
+  h->wind_count = count;
+  h->series_T = 0;
+  h->n_groups = 0;
+  h->ws_prev_valid = false;
+  h->pair_dirty = true;
   return WF_OK;
 }
 
 int wf_set_wind(wf_handle* h, const double* ws, const double* wd, int count, int on_device) {
-  if (!h || !ws || !wd) return WF_E_INVALID;
-  if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called before wf_set_wind");
-  if (count != 1 && count != h->B) return fail(h, WF_E_INVALID, "wind count must be 1 or env_batch");
-  WF_ON_DEVICE(h);
-  if (!on_device)
-    for (int i = 0; i < count; ++i)
-      if (!(ws[i] > 0.0) || !std::isfinite(wd[i])) return fail(h, WF_E_INVALID, "wind speed must be > 0 and direction finite");
-  // Host arrays with one direction for every farm (e.g. sampled speeds under a fixed direction): the rotation, the
-  // sort and the pair table depend on the direction only, so this is the shared-wind path with a speed per farm.
-  bool same_dir = count > 1 && !on_device;
-  for (int i = 1; same_dir && i < count; ++i) same_dir = wd[i] == wd[0];
-  h->shared_dir = same_dir;
-  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  WF_HIP(h, hipMemcpyAsync(h->d_ws, ws, sizeof(double) * count, kind, h->stream));
-  WF_HIP(h, hipMemcpyAsync(h->d_wd, wd, sizeof(double) * count, kind, h->stream));
-  WF_HIP(h, wfk_launch_geometry(same_dir ? 1 : count, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
-  if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));  // caller's host arrays may go away
-  h->wind_count = count;
-  h->series_T = 0;
-  h->ws_prev_valid = false;
-  h->pair_dirty = true;
-  return WF_OK;
+  return wf_set_wind_counts(h, ws, count, wd, count, on_device);
 }
 
 int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, int on_device) {
@@ -626,8 +729,47 @@ int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* di
   h->wind_count = h->B;
   h->shared_dir = false;
   h->series_T = 0;
+  h->n_groups = 0;
   h->ws_prev_valid = false;
   h->pair_dirty = true;  // env_batch 1: "one wind per farm" is also "one wind for the batch" (table path)
+  return WF_OK;
+}
+
+int wf_wind_sample_binned(wf_handle* h, unsigned long long seed, const wf_wind_dist* dist, double step_deg) {
+  if (!h) return WF_E_INVALID;
+  if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called before wf_wind_sample_binned");
+  if (!(step_deg > 0.0) || !(step_deg <= 90.0)) return fail(h, WF_E_INVALID, "direction step must be in (0, 90] degrees");
+  const int K = (int)std::llround(360.0 / step_deg);
+  if (std::fabs(K * step_deg - 360.0) > 1e-9) return fail(h, WF_E_INVALID, "direction step must divide 360 degrees");
+  WF_ON_DEVICE(h);
+  const wf_wind_dist def{8.0, 8.0, 3.0, 28.0, 270.0, 20.0, 0.0, 360.0};
+  const wf_wind_dist d = dist ? *dist : def;
+  if (!(d.ws_scale > 0) || !(d.ws_shape > 0) || !(d.ws_lo > 0) || !(d.ws_lo <= d.ws_hi) || !(d.wd_std >= 0))
+    return fail(h, WF_E_INVALID, "invalid wind distribution parameters");
+  if (!groups_pay_off(h, K)) {  // too many bins for this batch (or no table path): sample un-binned directions
+    int rc = wf_wind_sample(h, seed, dist);
+    return rc;
+  }
+  const double dv[8] = {d.ws_scale, d.ws_shape, d.ws_lo, d.ws_hi, d.wd_mean, d.wd_std, d.wd_lo, d.wd_hi};
+  if (!h->d_bins) WF_HIP(h, hipMalloc(&h->d_bins, sizeof(int) * h->B));
+  WF_HIP(h, wfk_launch_wind_sample_binned(h->B, seed, dv, step_deg, h->d_ws, h->d_wd, h->d_bins, h->stream));
+  std::vector<int> bins(h->B);
+  WF_HIP(h, hipMemcpyAsync(bins.data(), h->d_bins, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
+  WF_HIP(h, hipStreamSynchronize(h->stream));
+  // geometry and pair tables of the K grid directions depend on layout and model only: built once, kept across resets
+  const bool cached = h->grid_step == step_deg && h->n_groups == K && h->series_T == 0;
+  if (!cached) {
+    hipFree(h->d_group_wd); h->d_group_wd = nullptr;
+    WF_HIP(h, hipMalloc(&h->d_group_wd, sizeof(double) * K));
+    WF_HIP(h, wfk_launch_bin_centres(K, step_deg, h->d_group_wd, h->stream));
+  }
+  int rc = build_groups(h, bins.data(), K, h->d_group_wd, !cached);
+  if (rc != WF_OK) return rc;
+  h->grid_step = step_deg;
+  h->wind_count = h->B;
+  h->shared_dir = false;
+  h->series_T = 0;
+  h->ws_prev_valid = false;
   return WF_OK;
 }
 
@@ -656,6 +798,20 @@ int wf_wind_series(wf_handle* h, int T, const double* ws, const double* wd, cons
   h->series_T = T;
   h->series_t = -1;
   h->ws_prev_valid = false;
+  h->n_groups = 0;
+  h->grid_step = 0.0;
+  // A shared series has only T distinct winds: farms are grouped by their start row (farms with the same start see the
+  // same row at every tick), one sorted geometry + pair table per ROW, and the table path serves the whole playback.
+  if (groups_pay_off(h, T)) {
+    std::vector<int> st(h->B);
+    if (start) std::memcpy(st.data(), start, sizeof(int) * h->B);
+    else {
+      WF_HIP(h, hipMemcpyAsync(st.data(), h->d_series_start, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
+      WF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    int rc = build_groups(h, st.data(), T, h->d_series_wd, true);
+    if (rc != WF_OK) return rc;
+  }
   return wf_wind_series_step(h);
 }
 
@@ -672,10 +828,14 @@ int wf_wind_series_step(wf_handle* h) {
   }
   WF_HIP(h, wfk_launch_series_gather(h->B, h->series_T, h->series_t, h->d_series_start, h->d_series_ws, h->d_series_wd,
                                      h->d_ws, h->d_wd, h->stream));
-  WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
   h->wind_count = h->B;
   h->shared_dir = false;
-  h->pair_dirty = true;  // see wf_wind_sample
+  if (h->n_groups > 0) {
+    h->group_shift = h->series_t;  // group g (= start row g) is on row (g + t) % T now: geometry and tables are per row
+  } else {
+    WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+    h->pair_dirty = true;  // see wf_wind_sample
+  }
   return WF_OK;
 }
 
@@ -869,16 +1029,17 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   wfk_variant(h->variant, &G, &S, &fn);
   // the instantiation the next step would launch: pair table (shared wind), general mirror cores, or default
   if (h->model_dirty && h->N > 0) { int rc = build_consts(h); if (rc != WF_OK) return rc; }
-  const bool tab = (h->wind_count == 1 || h->shared_dir) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && !h->no_pair_table;
-  fn = wfk_variant_fn(h->variant, tab ? (h->shared_dir ? 3 : 2) : (h->consts.mirror_core_n <= 1 ? 0 : 1));
+  const bool tab = (h->wind_count == 1 || h->shared_dir || h->n_groups > 0) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && !h->no_pair_table;
+  fn = wfk_variant_fn(h->variant, tab ? (h->wind_count == 1 ? 2 : 3) : (h->consts.mirror_core_n <= 1 ? 0 : 1));
   info->pair_table = tab ? 1 : 0;
+  info->direction_groups = h->n_groups;
   hipFuncAttributes a;
   WF_ON_DEVICE(h);
   WF_HIP(h, hipFuncGetAttributes(&a, fn));
   info->lanes_per_env = G; info->slots_per_lane = S;
   const int wpb = tab ? wfk_tab_waves() : 4;
   info->envs_per_block = wpb * (64 / G); info->threads_per_block = 64 * wpb;
-  info->grid_blocks = h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0;
+  info->grid_blocks = h->n_groups > 0 ? h->n_blocks : (h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0);
   info->vgprs = a.numRegs;
   info->lds_bytes = (int)a.sharedSizeBytes; info->scratch_bytes = (int)a.localSizeBytes;
   return WF_OK;

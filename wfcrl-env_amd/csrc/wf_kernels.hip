@@ -278,6 +278,39 @@ __global__ void wf_wind_sample_kernel(int B, unsigned long long seed, double ws_
   wd[b] = d;
 }
 
+// Binned reset sampling: as wf_wind_sample_kernel, with the direction rounded to the nearest point of a grid of
+// `step` degrees (bin index = round(wd / step) mod K): K = 360 / step distinct directions in the whole batch.
+__global__ void wf_wind_sample_binned_kernel(int B, unsigned long long seed, double ws_scale, double ws_shape, double ws_lo,
+                                             double ws_hi, double wd_mean, double wd_std, double wd_lo, double wd_hi,
+                                             double step, int K, double* __restrict__ ws, double* __restrict__ wd,
+                                             int* __restrict__ bin) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  unsigned r0[4], r1[4];
+  philox4x32_10(seed, (unsigned long long)b, 0u, r0);
+  philox4x32_10(seed, (unsigned long long)b, 1u, r1);
+  const double e = -log(u01(r0[0], r0[1]));
+  double s = ws_scale * pow(e, 1.0 / ws_shape);
+  s = fmin(fmax(s, ws_lo), ws_hi);
+  const double rad = sqrt(-2.0 * log(u01(r0[2], r0[3])));
+  double d = wd_mean + wd_std * rad * cos(2.0 * M_PI * u01(r1[0], r1[1]));
+  d = fmod(d, 360.0);
+  if (d < 0.0) d += 360.0;
+  d = fmin(fmax(d, wd_lo), wd_hi);
+  int k = (int)llrint(d / step) % K;  // 360 -> bin 0
+  ws[b] = s;
+  wd[b] = k * step;
+  bin[b] = k;
+}
+__global__ void wf_bin_centres_kernel(int K, double step, double* __restrict__ wd) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) wd[k] = k * step;
+}
+__global__ void wf_fill_kernel(int n, double* __restrict__ a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 1 && i < n) a[i] = a[0];
+}
+
 __global__ void wf_series_start_kernel(int B, int T, unsigned long long seed, int* __restrict__ start) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -300,6 +333,21 @@ extern "C" hipError_t wfk_launch_wind_sample(int B, unsigned long long seed, con
                                              hipStream_t s) {
   hipLaunchKernelGGL(wf_wind_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, seed, dist[0], dist[1], dist[2],
                      dist[3], dist[4], dist[5], dist[6], dist[7], ws, wd);
+  return hipGetLastError();
+}
+extern "C" hipError_t wfk_launch_wind_sample_binned(int B, unsigned long long seed, const double* dist, double step, double* ws,
+                                                    double* wd, int* bin, hipStream_t s) {
+  const int K = (int)llround(360.0 / step);
+  hipLaunchKernelGGL(wf_wind_sample_binned_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, seed, dist[0], dist[1], dist[2],
+                     dist[3], dist[4], dist[5], dist[6], dist[7], step, K, ws, wd, bin);
+  return hipGetLastError();
+}
+extern "C" hipError_t wfk_launch_bin_centres(int K, double step, double* wd, hipStream_t s) {
+  hipLaunchKernelGGL(wf_bin_centres_kernel, dim3((K + 255) / 256), dim3(256), 0, s, K, step, wd);
+  return hipGetLastError();
+}
+extern "C" hipError_t wfk_launch_fill(int n, double* a, hipStream_t s) {
+  hipLaunchKernelGGL(wf_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, a);
   return hipGetLastError();
 }
 extern "C" hipError_t wfk_launch_series_start(int B, int T, unsigned long long seed, int* start, hipStream_t s) {

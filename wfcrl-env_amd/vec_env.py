@@ -30,7 +30,7 @@ class VecWindFarmEnv:
     def __init__(self, farm_case, controls: dict = None, env_batch: int = 1, continuous_control: bool = True,
                  reward_shaper=None, start_iter: int = 0, max_num_steps: int = 500, load_coef: float = 0.1,
                  device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None,
-                 wind_sampling: str = "host", reuse_buffers: bool = True):
+                 wind_sampling: str = "host", reuse_buffers: bool = True, wind_direction_step: float = None):
         controls = {"yaw": (-40, 40, 5)} if controls is None else dict(controls)
         if list(controls) != ["yaw"]:
             raise ValueError(f"Cannot control {list(controls)}. Interface HipFlorisInterface only allows for the "
@@ -79,6 +79,9 @@ class VecWindFarmEnv:
         if wind_sampling not in ("host", "device"):
             raise ValueError("wind_sampling must be 'host' (NumPy stream of the reference) or 'device' (Philox on the GPU)")
         self.wind_sampling = wind_sampling
+        # build-defined option of device sampling: reset directions rounded to a grid of that many degrees (must divide
+        # 360), so that every step stays on the pair-table path (backend.WfStep.sample_wind)
+        self.wind_direction_step = wind_direction_step
         ts = self.farm_case.wind_time_series
         has_series = ts is not None and (ts.size > 0 if isinstance(ts, np.ndarray) else bool(ts))
         if has_series:
@@ -189,7 +192,7 @@ class VecWindFarmEnv:
         elif self.wind_sampling == "device" and not (options and ("wind_speed" in options or "wind_direction" in options)) \
                 and not (self.farm_case.set_wind_speed or self.farm_case.set_wind_direction):
             s = seed if seed is not None else int(np.random.randint(0, 2**31 - 1))
-            self.fi.sample_wind(s)
+            self.fi.sample_wind(s, direction_step=self.wind_direction_step)
         else:
             ws, wd = self._sample_wind(seed, options)
             if np.all(ws == ws[0]) and np.all(wd == wd[0]):
