@@ -49,17 +49,24 @@ typedef struct wf_model_params {
   double air_density, ambient_ti, shear, veer; /* veer must be 0 */
   /* turbine — FLORIS turbine_library/nrel_5MW */
   double rotor_diameter, hub_height, tsr, pP, pT, gen_eff, ref_density;
-  /* gauss velocity / deflection — case.yaml:52-59,76-80 (both blocks carry the same values) */
+  /* gauss velocity model — case.yaml:76-80 (alpha, beta, ka, kb); gauss deflection model — case.yaml:52-59 (ad, bd,
+   * dm and its OWN alpha, beta, ka, kb: the defl_* fields further down; the reference template gives both the same) */
   double alpha, beta, ka, kb, ad, bd, dm;
   /* crespo_hernandez — case.yaml:84-89 */
   double ch_initial, ch_constant, ch_ai, ch_downstream;
   /* GCH internals of FLORIS 3.5 */
   double eps_gain, num_eps, kappa, gch_gain, overlap_thresh, near_wake_c;
+  /* gauss deflection model's own wake-expansion set — case.yaml:55-59 */
+  double defl_alpha, defl_beta, defl_ka, defl_kb;
   /* power_thrust_table, n_table <= WF_MAX_TABLE, wind speeds strictly ascending */
   int n_table;
   const double* table_ws;
   const double* table_ct;
   const double* table_cp;
+  /* switches of FLORIS' sequential solver — case.yaml:46-50 (nonzero = enabled; all enabled in the reference template):
+   * secondary steering adds wake_added_yaw to the yaw the deflection model sees; yaw-added recovery adds the mixing term
+   * to the source's TI; transverse velocities are the V / W fields (off: they stay zero). */
+  int enable_secondary_steering, enable_yaw_added_recovery, enable_transverse_velocities;
 } wf_model_params;
 
 int wf_version(void);

@@ -23,11 +23,15 @@ class _Params(C.Structure):
         "alpha", "beta", "ka", "kb", "ad", "bd", "dm",
         "ch_initial", "ch_constant", "ch_ai", "ch_downstream",
         "eps_gain", "num_eps", "kappa", "gch_gain", "overlap_thresh", "near_wake_c",
+        "defl_alpha", "defl_beta", "defl_ka", "defl_kb",
     )] + [
         ("n_table", C.c_int),
         ("table_ws", C.POINTER(C.c_double)),
         ("table_ct", C.POINTER(C.c_double)),
         ("table_pow", C.POINTER(C.c_double)),
+        ("enable_secondary_steering", C.c_int),
+        ("enable_yaw_added_recovery", C.c_int),
+        ("enable_transverse_velocities", C.c_int),
     ]
 
 
@@ -79,8 +83,10 @@ def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None, nthreads: i
     tct = np.ascontiguousarray(p.table_ct, dtype=np.float64)
     tpw = np.ascontiguousarray(p.power_table(), dtype=np.float64)
     cp = _Params()
-    for name, _ in _Params._fields_[:28]:
+    for name, _ in _Params._fields_[:32]:
         setattr(cp, name, float(getattr(p, name)))
+    for name in ("enable_secondary_steering", "enable_yaw_added_recovery", "enable_transverse_velocities"):
+        setattr(cp, name, int(bool(getattr(p, name))))
     cp.n_table = len(tws)
     cp.table_ws, cp.table_ct, cp.table_pow = _dp(tws), _dp(tct), _dp(tpw)
     out = {

@@ -31,10 +31,12 @@ typedef struct {
   double alpha, beta, ka, kb, ad, bd, dm;
   double ch_initial, ch_constant, ch_ai, ch_downstream;
   double eps_gain, num_eps, kappa, gch_gain, overlap_thresh, near_wake_c;
+  double defl_alpha, defl_beta, defl_ka, defl_kb; /* gauss deflection model's own set (case.yaml:52-59) */
   int n_table;
   const double* table_ws;
   const double* table_ct;
   const double* table_pow; /* 1/2 A Cp eta ws^3 (W per unit density) */
+  int enable_secondary_steering, enable_yaw_added_recovery, enable_transverse_velocities; /* case.yaml:46-50 */
 } wfo_params;
 
 #define DEG2RAD (M_PI / 180.0)
@@ -189,7 +191,7 @@ static void farm_step_one(const wfo_params* p, int N, const double* x, const dou
     double val = 2.0 * (Vmean - v_core) / (v_top + v_bot);
     if (val < -1.0) val = -1.0;
     if (val > 1.0) val = 1.0;
-    const double g_eff = g + (0.5 * asin(val)) / DEG2RAD;
+    const double g_eff = p->enable_secondary_steering ? g + (0.5 * asin(val)) / DEG2RAD : g;
 
     /* source-side constants of the deflection model [A.3-3] (TI BEFORE mixing), per grid point q */
     const double gd = -g_eff, cgd = cosd(gd);
@@ -210,7 +212,7 @@ static void farm_step_one(const wfo_params* p, int N, const double* x, const dou
     for (int t = 0; t < N; ++t) {
       const double dx = xs[t] - x_i;
       for (int q = 0; q < 9; ++q) vw[t][q] = ww[t][q] = 0.0;
-      if (dx < 0.0) continue;
+      if (dx < 0.0 || !p->enable_transverse_velocities) continue;
       for (int j = 0; j < 3; ++j)
         for (int k = 0; k < 3; ++k) {
           const double z = Z[k];
@@ -241,7 +243,8 @@ static void farm_step_one(const wfo_params* p, int N, const double* x, const dou
       vbar /= 9.0; wbar /= 9.0;
       const double I_tot = sqrt((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) / ubar;
       const double I_mix = I_tot - I;
-      for (int q = 0; q < 9; ++q) S->TI[q] += p->gch_gain * I_mix;
+      if (p->enable_yaw_added_recovery)
+        for (int q = 0; q < 9; ++q) S->TI[q] += p->gch_gain * I_mix;
     }
     double TIpost[9];
     memcpy(TIpost, S->TI, sizeof(TIpost));
@@ -267,8 +270,8 @@ static void farm_step_one(const wfo_params* p, int N, const double* x, const dou
               const double TIq = TIpre[q];
               const double uR = Ui * ct * cgd / (2.0 * (1.0 - s_cc));
               const double u0 = Ui * s_c;
-              const double x0 = D * cgd * (1.0 + s_cc) / (sqrt2 * (4.0 * p->alpha * TIq + 2.0 * p->beta * (1.0 - s_c))) + x_i;
-              const double ky = p->ka * TIq + p->kb, kz = ky;
+              const double x0 = D * cgd * (1.0 + s_cc) / (sqrt2 * (4.0 * p->defl_alpha * TIq + 2.0 * p->defl_beta * (1.0 - s_c))) + x_i;
+              const double ky = p->defl_ka * TIq + p->defl_kb, kz = ky;
               const double C0 = 1.0 - u0 / Ui;
               const double M0 = C0 * (2.0 - C0);
               const double E0 = C0 * C0 - 3.0 * exp(1.0 / 12.0) * C0 + 3.0 * exp(1.0 / 3.0);

@@ -87,14 +87,24 @@ class ModelParams:
     pT: float = 1.88
     gen_eff: float = 1.0
     ref_density: float = 1.225
-    # gauss velocity + deflection (case.yaml:52-59, 76-80)
+    # gauss velocity model (case.yaml:76-80)
     alpha: float = 0.58
     beta: float = 0.077
     ka: float = 0.38
     kb: float = 0.004
+    # gauss deflection model (case.yaml:52-59): its own alpha / beta / ka / kb (None = same as the velocity model's,
+    # which is what the reference template writes)
     ad: float = 0.0
     bd: float = 0.0
     dm: float = 1.0
+    defl_alpha: float = None
+    defl_beta: float = None
+    defl_ka: float = None
+    defl_kb: float = None
+    # switches of FLORIS' solver (case.yaml:46-50; all true in the reference template)
+    enable_secondary_steering: bool = True
+    enable_yaw_added_recovery: bool = True
+    enable_transverse_velocities: bool = True
     # crespo-hernandez (case.yaml:84-89)
     ch_initial: float = 0.1
     ch_constant: float = 0.5
@@ -111,6 +121,11 @@ class ModelParams:
     table_ws: list = field(default_factory=lambda: list(TABLE_WS))
     table_ct: list = field(default_factory=lambda: list(TABLE_CT))
     table_cp: list = field(default_factory=lambda: list(TABLE_CP))
+
+    def __post_init__(self):
+        for k in ("alpha", "beta", "ka", "kb"):
+            if getattr(self, "defl_" + k) is None:
+                setattr(self, "defl_" + k, getattr(self, k))
 
     def power_table(self) -> np.ndarray:
         """P_tab[m] = 1/2 * A * Cp[m] * eta * ws[m]^3   [A.4] (interpolated on POWER, not Cp)."""
@@ -241,7 +256,8 @@ def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=Fal
         v_core = np.mean(vortex(G_wr, yL_own, Z[i] - HH + p.num_eps)[0])
         val = 2.0 * (np.mean(V[i]) - v_core) / (v_top + v_bot)
         val = min(max(val, -1.0), 1.0)
-        g_eff = g + np.degrees(0.5 * np.arcsin(val))
+        # FLORIS solver: `if model_manager.enable_secondary_steering: effective_yaw_i += wake_added_yaw(...)`
+        g_eff = g + np.degrees(0.5 * np.arcsin(val)) if p.enable_secondary_steering else g
 
         TI_i = TI[i][None, :, :]  # per grid point (j,k), broadcast against every target
 
@@ -252,9 +268,9 @@ def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=Fal
         s_c = np.sqrt(1.0 - ct)
         uR = Uinit * ct * cgd / (2.0 * (1.0 - s_cc))
         u0 = Uinit * s_c
-        x0 = D * cgd * (1.0 + s_cc) / (sqrt2 * (4.0 * p.alpha * TI_i + 2.0 * p.beta * (1.0 - s_c))) + x_i
-        ky = p.ka * TI_i + p.kb
-        kz = p.ka * TI_i + p.kb
+        x0 = D * cgd * (1.0 + s_cc) / (sqrt2 * (4.0 * p.defl_alpha * TI_i + 2.0 * p.defl_beta * (1.0 - s_c))) + x_i
+        ky = p.defl_ka * TI_i + p.defl_kb
+        kz = p.defl_ka * TI_i + p.defl_kb
         C0 = 1.0 - u0 / Uinit
         M0 = C0 * (2.0 - C0)
         E0 = C0**2 - 3.0 * np.exp(1.0 / 12.0) * C0 + 3.0 * np.exp(1.0 / 3.0)
@@ -297,6 +313,9 @@ def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=Fal
         vw = np.where(dx < 0.0, 0.0, vw)
         ww = np.where(dx < 0.0, 0.0, ww)
         ww = np.where(ww < 0.0, 0.0, ww)  # quirk (5) [A.6]
+        if not p.enable_transverse_velocities:  # solver: v_wake / w_wake keep their zeros
+            vw = np.zeros((N, 3, 3))
+            ww = np.zeros((N, 3, 3))
 
         # 5. yaw-added recovery [A.3-5]
         I = TI[i, 0, 0]
@@ -305,7 +324,8 @@ def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=Fal
         wbar = np.mean(W[i] + ww[i])
         I_tot = np.sqrt((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar**2 + wbar**2)) / ubar
         I_mix = I_tot - I
-        TI[i] = TI[i] + p.gch_gain * I_mix
+        if p.enable_yaw_added_recovery:
+            TI[i] = TI[i] + p.gch_gain * I_mix
         TI_i = TI[i][None, :, :]
 
         # 6. velocity deficit [A.3-6]  (uses -g commanded and TI AFTER mixing)

@@ -245,13 +245,18 @@ def test_case_yaml_round_trip_and_rejections(tmp_path):
     m = load_case_yaml(cfg)["model"]
     assert (m["rotor_diameter"], m["hub_height"], m["tsr"], m["gen_eff"], m["ambient_ti"]) == (120.0, 85.0, 7.5, 0.95, 0.08)
     assert m["table_ws"] == [0.0, 3.0, 12.0, 25.0]
+    # the deflection and the velocity model carry their own gauss sets; the solver switches are data too
+    cfg["wake"]["wake_velocity_parameters"]["gauss"]["ka"] = 0.5
+    cfg["wake"]["wake_deflection_parameters"]["gauss"]["alpha"] = 0.4
+    cfg["wake"]["enable_secondary_steering"] = False
+    m = load_case_yaml(cfg)["model"]
+    assert (m["ka"], m["defl_ka"], m["alpha"], m["defl_alpha"]) == (0.5, 0.38, 0.58, 0.4)
+    assert (m["enable_secondary_steering"], m["enable_yaw_added_recovery"], m["enable_transverse_velocities"]) == (False, True, True)
     for mutate, msg in [
         (lambda c: c["wake"]["model_strings"].__setitem__("velocity_model", "jensen"), "velocity_model"),
-        (lambda c: c["wake"].__setitem__("enable_secondary_steering", False), "enable_secondary_steering"),
         (lambda c: c["solver"].__setitem__("turbine_grid_points", 5), "turbine_grid_points"),
         (lambda c: c["flow_field"].__setitem__("wind_veer", 2.0), "veer"),
         (lambda c: c["farm"].__setitem__("turbine_type", ["iea_10MW"]), "nrel_5MW"),
-        (lambda c: c["wake"]["wake_velocity_parameters"]["gauss"].__setitem__("ka", 0.5), "differ"),
     ]:
         bad = yaml.safe_load(yaml.safe_dump(case_config(case.dict())))
         mutate(bad)

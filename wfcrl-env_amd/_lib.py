@@ -25,7 +25,9 @@ _MODEL_DOUBLES = (
     "alpha", "beta", "ka", "kb", "ad", "bd", "dm",
     "ch_initial", "ch_constant", "ch_ai", "ch_downstream",
     "eps_gain", "num_eps", "kappa", "gch_gain", "overlap_thresh", "near_wake_c",
+    "defl_alpha", "defl_beta", "defl_ka", "defl_kb",
 )
+_MODEL_SWITCHES = ("enable_secondary_steering", "enable_yaw_added_recovery", "enable_transverse_velocities")
 
 
 class ModelParams(C.Structure):
@@ -36,7 +38,7 @@ class ModelParams(C.Structure):
         ("table_ws", C.POINTER(C.c_double)),
         ("table_ct", C.POINTER(C.c_double)),
         ("table_cp", C.POINTER(C.c_double)),
-    ]
+    ] + [(n, C.c_int) for n in _MODEL_SWITCHES]
 
 
 class EnvParams(C.Structure):

@@ -22,6 +22,7 @@ def default_model() -> dict:
     p = ModelParams()
     check(_lib.load().wf_default_model(C.byref(p)))
     d = {n: getattr(p, n) for n in _lib._MODEL_DOUBLES}
+    d.update({n: bool(getattr(p, n)) for n in _lib._MODEL_SWITCHES})
     n = p.n_table
     d["table_ws"] = [p.table_ws[i] for i in range(n)]
     d["table_ct"] = [p.table_ct[i] for i in range(n)]
@@ -45,10 +46,19 @@ class WfStep:
     # -- configuration ---------------------------------------------------------------------------
     def set_model(self, model: dict):
         base = default_model()
+        model = dict(model)
+        for k in ("alpha", "beta", "ka", "kb"):  # one gauss set given: the deflection model follows it (as in the template)
+            if k in model and "defl_" + k not in model:
+                model["defl_" + k] = model[k]
+        unknown = set(model) - set(base)
+        if unknown:
+            raise ValueError(f"unknown model parameter(s): {sorted(unknown)}")
         base.update(model)
         p = ModelParams()
         for n in _lib._MODEL_DOUBLES:
             setattr(p, n, float(base[n]))
+        for n in _lib._MODEL_SWITCHES:
+            setattr(p, n, int(bool(base[n])))
         tws = np.ascontiguousarray(base["table_ws"], dtype=np.float64)
         tct = np.ascontiguousarray(base["table_ct"], dtype=np.float64)
         tcp = np.ascontiguousarray(base["table_cp"], dtype=np.float64)

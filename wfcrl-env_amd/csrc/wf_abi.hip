@@ -293,6 +293,10 @@ int build_consts(wf_handle* h) {
   c.gam_wr = (float)(inv2pi * 0.25 * 2.0 * M_PI * D / m.tsr);
   c.alpha4 = (float)(4.0 * m.alpha); c.beta2 = (float)(2.0 * m.beta);
   c.ka = (float)m.ka; c.kb = (float)m.kb; c.ad = (float)m.ad; c.bd = (float)m.bd; c.dm03 = (float)(0.3 * m.dm);
+  c.alpha4_d = (float)(4.0 * m.defl_alpha); c.beta2_d = (float)(2.0 * m.defl_beta);
+  c.ka_d = (float)m.defl_ka; c.kb_d = (float)m.defl_kb;
+  c.switches = (m.enable_secondary_steering ? WF_SW_STEERING : 0) | (m.enable_yaw_added_recovery ? WF_SW_RECOVERY : 0) |
+               (m.enable_transverse_velocities ? WF_SW_TRANSVERSE : 0);
   c.e0c1 = (float)(3.0 * std::exp(1.0 / 12.0)); c.e0c2 = (float)(3.0 * std::exp(1.0 / 3.0));
   c.sz0v = (float)(D / (2.0 * std::sqrt(2.0)));
   c.near_c = (float)(m.near_wake_c * D);
@@ -489,6 +493,8 @@ int wf_default_model(wf_model_params* p) {
   p->ch_initial = 0.1; p->ch_constant = 0.5; p->ch_ai = 0.8; p->ch_downstream = -0.32;
   p->eps_gain = 0.2; p->num_eps = 0.001; p->kappa = 0.41; p->gch_gain = 2.0; p->overlap_thresh = 0.05;
   p->near_wake_c = 0.501;
+  p->defl_alpha = p->alpha; p->defl_beta = p->beta; p->defl_ka = p->ka; p->defl_kb = p->kb;
+  p->enable_secondary_steering = p->enable_yaw_added_recovery = p->enable_transverse_velocities = 1;
   p->n_table = 51; p->table_ws = g_tab_ws; p->table_ct = g_tab_ct; p->table_cp = g_tab_cp;
   return WF_OK;
 }
@@ -559,12 +565,13 @@ int wf_set_model(wf_handle* h, const wf_model_params* p) {
         {p->air_density, "air_density"}, {p->ambient_ti, "turbulence_intensity"}, {p->rotor_diameter, "rotor_diameter"},
         {p->hub_height, "hub_height"}, {p->tsr, "TSR"}, {p->pP, "pP"}, {p->gen_eff, "generator_efficiency"},
         {p->ref_density, "ref_density_cp_ct"}, {p->ka * p->ambient_ti + p->kb, "ka*TI + kb"},
+        {p->defl_ka * p->ambient_ti + p->defl_kb, "deflection ka*TI + kb"}, {p->defl_alpha, "deflection alpha"},
         {p->alpha, "alpha"}, {p->eps_gain, "eps_gain"}, {p->num_eps, "num_eps"}, {p->kappa, "kappa"},
         {p->ch_constant, "crespo_hernandez.constant"}, {p->overlap_thresh, "overlap_thresh"}};
     for (const auto& q : positive)
       if (!(q.v > 0.0) || !std::isfinite(q.v))
         return fail(h, WF_E_INVALID, std::string("model parameter must be finite and > 0: ") + q.name);
-    const double finite[] = {p->shear, p->beta, p->ad, p->bd, p->dm, p->ch_initial, p->ch_ai, p->ch_downstream, p->gch_gain,
+    const double finite[] = {p->defl_beta, p->shear, p->beta, p->ad, p->bd, p->dm, p->ch_initial, p->ch_ai, p->ch_downstream, p->gch_gain,
                              p->overlap_thresh, p->near_wake_c, p->pT};
     for (double v : finite)
       if (!std::isfinite(v)) return fail(h, WF_E_INVALID, "model parameters must be finite");

@@ -729,7 +729,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
 #pragma unroll
       for (int p = 0; p < S; ++p) {
-        if (p > 0 && p >= live) break;
+        if ((p > 0 && p >= live) || !(c.switches & WF_SW_TRANSVERSE)) break;  // switch off: V and W stay zero
         const int t = (blk + p) * G + sub;
         // Slot 0 holds the source's own block: its lanes sort out upstream / tied / downstream by the sign of dx.
         // Slots p >= 1 hold later blocks of the ascending sort: every real turbine there is at or downstream of
@@ -772,6 +772,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       // secondary steering
       float val = 2.0f * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
       val = fminf(fmaxf(val, -1.0f), 1.0f);
+      if (!(c.switches & WF_SW_STEERING)) val = 0.0f;  // the deflection model sees the commanded yaw
       const float asv = __any(fabsf(val) > 0.3f) ? asinf(val) : asin_small(val);
       const float gd = -(yaw_i * kDeg2Rad + 0.5f * asv);  // radians, deflection sign convention
       // cos(gd) = cos(yaw + h), h = asin(val)/2: half-angle identities instead of a second libm call
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const float inv_ubar = frcp(ubar);
       const float Itot = fsqrt(fmaf(uI, uI, mix2)) * inv_ubar;
       const float Imix = mix2 * inv_ubar * inv_ubar * frcp(Itot + I0);  // == Itot - I0, no cancellation
-      const float dTI = c.gch_gain * Imix;
+      const float dTI = (c.switches & WF_SW_RECOVERY) ? c.gch_gain * Imix : 0.0f;
       if (lane == src) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) st.TI[0][j] += dTI;
@@ -830,11 +831,11 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const float x0num_v = c.D * cg * (1.0f + s_c) * (1.0f / 1.41421356237f);
       // Only column 0's constants are kept across the target loop; in the rare split-TI case the other two columns'
       // are re-derived per target from (TIs[j], dTI) — 14 registers less at the pressure peak of the hot path.
-      const float b2om = c.beta2 * om_sc;
+      const float b2om = c.beta2 * om_sc, b2om_d = c.beta2_d * om_sc;
       auto col_consts = [&](float ti_pre, float ti_post) {
         ColConsts k;
-        k.x0d = x0num_d * frcp(fmaf(c.alpha4, ti_pre, b2om));
-        k.kyd = fmaf(c.ka, ti_pre, c.kb);
+        k.x0d = x0num_d * frcp(fmaf(c.alpha4_d, ti_pre, b2om_d));
+        k.kyd = fmaf(c.ka_d, ti_pre, c.kb_d);
         k.d0 = sc.tan_th0 * k.x0d;
         k.pj = pfac * frcp(k.kyd);
         k.x0v = x0num_v * frcp(fmaf(c.alpha4, ti_post, b2om));
@@ -984,7 +985,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
     // source's circulations depend on its wake sum only, which is final (everything between the tied turbines is
     // tied as well, and the deficit pass is a no-op at dx = 0), so they are evaluated ahead of the source's turn.
     // Exact ties are what axis-aligned grid layouts have at wd = 270.
-    if (blk + 1 < nblk) {
+    if (blk + 1 < nblk && (c.switches & WF_SW_TRANSVERSE)) {
       const int t0 = blk * G + sub;
       for (int k = 0; (blk + 1) * G + k < N; ++k) {
         const int i2 = (blk + 1) * G + k;

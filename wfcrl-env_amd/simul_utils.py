@@ -105,9 +105,6 @@ def load_case_yaml(path_or_dict) -> dict:
         got = wake["model_strings"].get(key)
         if got != want:
             raise UnsupportedCaseError(f"wake.model_strings.{key} = {got!r} is not implemented (only {want!r})")
-    for flag in ("enable_secondary_steering", "enable_yaw_added_recovery", "enable_transverse_velocities"):
-        if not wake.get(flag, False):
-            raise UnsupportedCaseError(f"wake.{flag} = false is not implemented (the reference template enables it)")
     if len(flow.get("wind_speeds", [0])) != 1 or len(flow.get("wind_directions", [0])) != 1:
         raise UnsupportedCaseError("exactly one wind speed and one wind direction per case (as the reference uses)")
     if float(flow.get("wind_veer", 0.0)) != 0.0:
@@ -126,12 +123,13 @@ def load_case_yaml(path_or_dict) -> dict:
                  shear=float(flow["wind_shear"]), veer=0.0)
     gd = wake["wake_deflection_parameters"]["gauss"]
     gv = wake["wake_velocity_parameters"]["gauss"]
-    for k in ("alpha", "beta", "ka", "kb"):
-        if float(gd[k]) != float(gv[k]):
-            raise UnsupportedCaseError(f"gauss deflection and velocity parameter {k!r} differ ({gd[k]} vs {gv[k]}): "
-                                       "one shared set is implemented, as in the reference template")
+    for k in ("alpha", "beta", "ka", "kb"):  # each model has its own set (case.yaml:55-59 and 76-80)
         model[k] = float(gv[k])
+        model["defl_" + k] = float(gd[k])
     model.update(ad=float(gd.get("ad", 0.0)), bd=float(gd.get("bd", 0.0)), dm=float(gd.get("dm", 1.0)))
+    # solver switches (case.yaml:46-50); FLORIS defaults a missing key to false
+    for flag in ("enable_secondary_steering", "enable_yaw_added_recovery", "enable_transverse_velocities"):
+        model[flag] = bool(wake.get(flag, False))
     ch = wake["wake_turbulence_parameters"]["crespo_hernandez"]
     model.update(ch_initial=float(ch["initial"]), ch_constant=float(ch["constant"]), ch_ai=float(ch["ai"]),
                  ch_downstream=float(ch["downstream"]))
