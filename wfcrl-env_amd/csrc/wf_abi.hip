@@ -295,8 +295,8 @@ int build_consts(wf_handle* h) {
   c.ka = (float)m.ka; c.kb = (float)m.kb; c.ad = (float)m.ad; c.bd = (float)m.bd; c.dm03 = (float)(0.3 * m.dm);
   c.alpha4_d = (float)(4.0 * m.defl_alpha); c.beta2_d = (float)(2.0 * m.defl_beta);
   c.ka_d = (float)m.defl_ka; c.kb_d = (float)m.defl_kb;
-  c.switches = (m.enable_secondary_steering ? WF_SW_STEERING : 0) | (m.enable_yaw_added_recovery ? WF_SW_RECOVERY : 0) |
-               (m.enable_transverse_velocities ? WF_SW_TRANSVERSE : 0);
+  c.sw_steer = m.enable_secondary_steering ? 2.0f : 0.0f;
+  c.sw_tv = m.enable_transverse_velocities ? 1.0f : 0.0f;
   c.e0c1 = (float)(3.0 * std::exp(1.0 / 12.0)); c.e0c2 = (float)(3.0 * std::exp(1.0 / 3.0));
   c.sz0v = (float)(D / (2.0 * std::sqrt(2.0)));
   c.near_c = (float)(m.near_wake_c * D);
@@ -304,7 +304,7 @@ int build_consts(wf_handle* h) {
   c.ch_c = (float)(m.ch_constant * std::pow(m.ambient_ti, m.ch_initial));
   c.ch_ai = (float)m.ch_ai; c.ch_down = (float)m.ch_downstream;
   c.amb = (float)m.ambient_ti; c.amb2 = (float)(m.ambient_ti * m.ambient_ti);
-  c.gch_gain = (float)m.gch_gain; c.overlap_thr = (float)m.overlap_thresh;
+  c.gch_gain = m.enable_yaw_added_recovery ? (float)m.gch_gain : 0.0f; c.overlap_thr = (float)m.overlap_thresh;
   c.twoD = (float)(2.0 * D); c.fifteenD_d = 15.0 * D;
   c.q_d = D / 4.0;
   c.guard_inv = h->guard_rel > 0.0 ? (float)(1.0 / h->guard_rel) : 1125899906842624.0f;

@@ -32,7 +32,10 @@ struct WfConsts {
   // gauss deflection / deficit                                                      [A.3-3, A.3-6]
   float alpha4, beta2, ka, kb, ad, bd, dm03;   // alpha4 .. kb: the velocity model's set
   float alpha4_d, beta2_d, ka_d, kb_d;          // the deflection model's own set (case.yaml:55-59)
-  int switches;                                 // WF_SW_*: solver switches of case.yaml:46-50
+  // solver switches of case.yaml:46-50 as multipliers (no branches in the kernel): secondary steering scales the added
+  // yaw's argument (2, or 0 when off), transverse velocities scale the applied circulations (1 / 0); yaw-added
+  // recovery off is gch_gain = 0
+  float sw_steer, sw_tv;
   float e0c1, e0c2;        // 3 e^(1/12), 3 e^(1/3)
   float sz0v;              // D/2 * sqrt(uR/(Uinf+u0)) of the deficit model == D/(2 sqrt 2)
   float near_c;            // 0.501 * D
@@ -57,10 +60,6 @@ struct WfConsts {
   float guard_inv, inv_overlap_thr, knee_kappa;  // 1 / guard band (2^50 when the band is 0), 1 / overlap_thr
   double yc_d;  // centre of rotation (y): the float32 lateral distances are taken on y' - yc
 };
-
-#define WF_SW_STEERING 1    // enable_secondary_steering
-#define WF_SW_RECOVERY 2    // enable_yaw_added_recovery
-#define WF_SW_TRANSVERSE 4  // enable_transverse_velocities
 
 // Power/thrust table in global memory, staged to LDS by each block.
 struct WfTables {

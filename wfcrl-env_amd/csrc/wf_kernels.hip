@@ -666,7 +666,10 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
     }
   };
   // circulations (over 2 pi) of source i from the sum over its rotor grid of u^3 [A.3-1, A.3-4]
-  auto circulations = [&](float m3, int i, float& Gt, float& Gb, float& Gwr, float& Gy, float& ubar, float& ct,
+  // enable_transverse_velocities off (c.sw_tv = 0, else 1): the circulations the transverse pass applies (Gt, Gb, Gy,
+  // Gwt) are zeroed, so V and W stay exactly zero; the wake-rotation circulation Gwr itself still enters the secondary
+  // steering [A.3-2]
+  auto circulations = [&](float m3, int i, float& Gt, float& Gb, float& Gwr, float& Gwt, float& Gy, float& ubar, float& ct,
                           float& a, float& gt, float& gb) {
     ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
     const float cg = L.cg[eiw][i], sg = L.sg[eiw][i];
@@ -676,10 +679,11 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
     Gwr = c.gam_wr * (a - a * a) * ubar;
     gt = c.gam_top * ws * ct;
     gb = c.gam_bot * ws * ct;
-    const float scg = sg * cg;  // commanded yaw
+    const float scg = sg * cg * c.sw_tv;  // commanded yaw
     Gt = scg * gt;
     Gb = -scg * gb;
     Gy = scg * ct * ws;  // table path: Gt = gam_top*Gy, Gb = -gam_bot*Gy folded into the coefficients
+    Gwt = Gwr * c.sw_tv;
   };
 
   const int nblk = (N + G - 1) / G;
@@ -721,15 +725,15 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const float yaw_i = L.yaw[eiw][i];
 
       // ---- B. source constants, part 1 [A.3-1 .. A.3-4] ------------------------------------
-      float ubar, ct, a, Gwr, gt, gb, Gt, Gb, Gy;
-      circulations(m3, i, Gt, Gb, Gwr, Gy, ubar, ct, a, gt, gb);
+      float ubar, ct, a, Gwr, Gwt, gt, gb, Gt, Gb, Gy;
+      circulations(m3, i, Gt, Gb, Gwr, Gwt, Gy, ubar, ct, a, gt, gb);
       const float cg = L.cg[eiw][i], sg = L.sg[eiw][i];
 
       // ---- C. pass 1: transverse velocities on every target at or downstream of the source --
       float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
 #pragma unroll
       for (int p = 0; p < S; ++p) {
-        if ((p > 0 && p >= live) || !(c.switches & WF_SW_TRANSVERSE)) break;  // switch off: V and W stay zero
+        if (p > 0 && p >= live) break;
         const int t = (blk + p) * G + sub;
         // Slot 0 holds the source's own block: its lanes sort out upstream / tied / downstream by the sign of dx.
         // Slots p >= 1 hold later blocks of the ascending sort: every real turbine there is at or downstream of
@@ -752,9 +756,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         if (act) {
 #endif
          if constexpr (TAB) {
-          apply_tab(p, reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]), Gy, Gwr);
+          apply_tab(p, reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]), Gy, Gwt);
          } else {
-          apply_fly(p, dx, L.y[eiw][t] - y_i, Gt, Gb, Gwr);
+          apply_fly(p, dx, L.y[eiw][t] - y_i, Gt, Gb, Gwt);
          }
         }
         if (p == 0) {
@@ -770,9 +774,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
 
       // ---- B2. steering + deflection constants [A.3-2, A.3-3] (kept out of pass 1's live range) ----
       // secondary steering
-      float val = 2.0f * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
+      // (c.sw_steer is 1, or 0 with enable_secondary_steering off: the deflection model then sees the commanded yaw)
+      float val = c.sw_steer * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
       val = fminf(fmaxf(val, -1.0f), 1.0f);
-      if (!(c.switches & WF_SW_STEERING)) val = 0.0f;  // the deflection model sees the commanded yaw
       const float asv = __any(fabsf(val) > 0.3f) ? asinf(val) : asin_small(val);
       const float gd = -(yaw_i * kDeg2Rad + 0.5f * asv);  // radians, deflection sign convention
       // cos(gd) = cos(yaw + h), h = asin(val)/2: half-angle identities instead of a second libm call
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const float inv_ubar = frcp(ubar);
       const float Itot = fsqrt(fmaf(uI, uI, mix2)) * inv_ubar;
       const float Imix = mix2 * inv_ubar * inv_ubar * frcp(Itot + I0);  // == Itot - I0, no cancellation
-      const float dTI = (c.switches & WF_SW_RECOVERY) ? c.gch_gain * Imix : 0.0f;
+      const float dTI = c.gch_gain * Imix;  // gch_gain is 0 with enable_yaw_added_recovery off
       if (lane == src) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) st.TI[0][j] += dTI;
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
     // source's circulations depend on its wake sum only, which is final (everything between the tied turbines is
     // tied as well, and the deficit pass is a no-op at dx = 0), so they are evaluated ahead of the source's turn.
     // Exact ties are what axis-aligned grid layouts have at wd = 270.
-    if (blk + 1 < nblk && (c.switches & WF_SW_TRANSVERSE)) {
+    if (blk + 1 < nblk) {
       const int t0 = blk * G + sub;
       for (int k = 0; (blk + 1) * G + k < N; ++k) {
         const int i2 = (blk + 1) * G + k;
@@ -1014,14 +1018,14 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           fc = fmaf(uc * uc, uc, fc);
         }
         const float m3 = __shfl(fmaf(U02c, fe, U1c * fc), gbase + l2);
-        float ubar, ct, a, Gwr, gt, gb, Gt, Gb, Gy;
-        circulations(m3, i2, Gt, Gb, Gwr, Gy, ubar, ct, a, gt, gb);
+        float ubar, ct, a, Gwr, Gwt, gt, gb, Gt, Gb, Gy;
+        circulations(m3, i2, Gt, Gb, Gwr, Gwt, Gy, ubar, ct, a, gt, gb);
         if constexpr (TAB) {
           // the source's table row is not staged yet: its (source, target) record comes straight from L2
           const float* rec = pair_tab + (size_t)i2 * WF_PAIR_ROW_FLOATS(NP) + (size_t)t0 * WF_PAIR_STRIDE;
-          if (rec[WF_PAIR_DX] >= 0.0f) apply_tab(0, reinterpret_cast<const float4*>(rec), Gy, Gwr);
+          if (rec[WF_PAIR_DX] >= 0.0f) apply_tab(0, reinterpret_cast<const float4*>(rec), Gy, Gwt);
         } else {
-          if (dx0 >= 0.0f) apply_fly(0, dx0, L.y[eiw][t0] - L.y[eiw][i2], Gt, Gb, Gwr);
+          if (dx0 >= 0.0f) apply_fly(0, dx0, L.y[eiw][t0] - L.y[eiw][i2], Gt, Gb, Gwt);
         }
       }
     }
