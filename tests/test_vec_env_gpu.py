@@ -375,3 +375,70 @@ def test_vec_env_shared_wind_uses_table_path_and_matches_reference_envs(layouts)
             assert np.abs(obs["wind_direction"][b].cpu().numpy() - o["wind_direction"]).max() < 2e-4
             assert bool(trunc[b]) == tr
     venv.close()
+
+
+@pytest.mark.parametrize("name,discrete", [("Turb6_Row2_", False), ("Ablaincourt_", True)])
+def test_batched_aec_env_matches_B_reference_aec_envs(layouts, name, discrete):
+    """The batched AEC flavour (make("Dec_<layout>_Floris", env_batch=B)) step for step — agent by agent — against B
+    reference-semantics MAWindFarmEnv instances on the oracle (reference wfcrl/multiagent_env.py:159-254): same agent
+    order, `last()` tuples (cumulative cooperative reward, truncation), per-agent observations, the per-agent actuation
+    budget with its one-cycle-old accumulator, in-place zeroing of blocked actions, and the dead-step protocol."""
+    import torch
+
+    from wfcrl_env_amd import environments as envs
+    from wfcrl_env_amd.environments.registration import get_case, get_default_control
+    from wfcrl_env_amd.multiagent_env import MAWindFarmEnv
+    from wfcrl_env_amd.rewards import StepPercentage
+
+    B, T = 6, 24
+    N = layouts[name]["num_turbines"]
+    controls = {"yaw": (-30, 30, 4)} if discrete else {"yaw": (-40, 40, 5)}
+    kw = dict(max_num_steps=T, continuous_control=not discrete, load_coef=0.3)
+    venv = envs.make("Dec_" + name + "Floris", controls=dict(controls), env_batch=B, reward_shaper=StepPercentage(), **kw)
+    assert type(venv).__name__ == "VecAECLogWrapper" and venv.possible_agents == [f"turbine_{k}" for k in range(1, N + 1)]
+    venv.reset(seed=5)
+    fw = venv.state()["freewind_measurements"].cpu().numpy()
+    refs = []
+    for b in range(B):
+        e = MAWindFarmEnv(interface=OracleFlorisInterface, farm_case=get_case(name, "Floris").clone(),
+                          controls=dict(controls), reward_shaper=StepPercentage(), **kw)
+        e.reset(options={"wind_speed": fw[b, 0], "wind_direction": fw[b, 1]})
+        refs.append(e)
+    rng = np.random.default_rng(3)
+    blocked_seen = 0
+    n_calls = 0
+    for agent in venv.agent_iter():
+        assert all(e.agent_selection == agent for e in refs)
+        obs, rew, term, trunc, info = venv.last()
+        for b, e in enumerate(refs):
+            o, r, t, tr, i = e.last()
+            assert tr == trunc and t == term
+            for k in ("yaw", "wind_speed", "wind_direction"):
+                assert abs(float(obs[k][b]) - float(o[k])) <= (0 if k == "yaw" else 2e-4 * max(1.0, abs(float(o[k])))), (agent, k)
+            rr = float(np.ravel(r)[0]) if np.ndim(r) else float(r)
+            assert abs(float(rew[b] if hasattr(rew, "__len__") else rew) - rr) <= 2e-3 * abs(rr) + 1e-5, (agent, b, rew, r)
+            if "power" in i:
+                assert abs(float(info["power"][b]) - float(i["power"])) <= 2e-4 * max(float(i["power"]), 1e-3)
+        if trunc or term:
+            venv.step(None)
+            for e in refs:
+                e.step(None)
+            continue
+        if discrete:
+            a = rng.integers(0, 3, B).astype(np.float32)
+        else:
+            a = rng.uniform(-7, 7, B).astype(np.float32)
+        ta = torch.from_numpy(a.copy()).cuda()
+        venv.step({"yaw": ta})
+        n_calls += 1
+        got = ta.cpu().numpy()
+        for b, e in enumerate(refs):
+            ab = np.array([a[b]], dtype=np.float32)
+            e.step({"yaw": ab})
+            assert got[b] == ab[0], (agent, b)  # blocked actions are zeroed in the caller's array, in both
+            blocked_seen += int(ab[0] == 0.0 and a[b] != 0.0)
+    assert n_calls == (T - 1) * N and not venv.agents and all(not e.agents for e in refs)
+    assert blocked_seen > 0  # the budget gate must have acted, or the comparison is vacuous
+    h = venv.history["turbine_2"]
+    assert len(h["reward"]) == len(refs[0].history["turbine_2"]["reward"]) if hasattr(refs[0], "history") else len(h["reward"]) > 0
+    venv.close()

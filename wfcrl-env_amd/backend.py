@@ -203,9 +203,19 @@ class WfStep:
         ws = np.ascontiguousarray(np.broadcast_to(np.asarray(wind_speed, np.float64), (self.env_batch,)))
         check(self._lib.wf_env_set_prev_wind(self._h, ws.ctypes.data, 0), self._h)
 
-    def env_get_state(self) -> dict:
-        """Host copy of the device-resident env state: yaw (B, N), acc (B, N), moves (B,)."""
+    def env_get_state(self, as_torch: bool = False) -> dict:
+        """Copy of the device-resident env state: yaw (B, N), acc (B, N), moves (B,) — host NumPy arrays, or torch CUDA
+        tensors (device-to-device, asynchronous on torch's current stream) with as_torch=True."""
         B, N = self.env_batch, self.num_turbines
+        if as_torch:
+            import torch
+
+            self._follow_torch_stream()
+            dev = f"cuda:{self.device_id}"
+            st = {"yaw": torch.empty((B, N), dtype=torch.float32, device=dev), "acc": torch.empty((B, N), dtype=torch.float32, device=dev),
+                  "moves": torch.empty(B, dtype=torch.int32, device=dev)}
+            check(self._lib.wf_env_state(self._h, st["yaw"].data_ptr(), st["acc"].data_ptr(), st["moves"].data_ptr(), 0, 1), self._h)
+            return st
         st = {"yaw": np.empty((B, N), np.float32), "acc": np.empty((B, N), np.float32), "moves": np.empty(B, np.int32)}
         check(self._lib.wf_env_state(self._h, st["yaw"].ctypes.data, st["acc"].ctypes.data, st["moves"].ctypes.data, 0, 0), self._h)
         return st

@@ -83,6 +83,13 @@ def make(env_id: str, controls: Union[dict, list] = ["yaw"], log=True, **env_kwa
     if batch is not None:
         from ..vec_env import VecWindFarmEnv
 
+        if decentralised:  # "Dec_<layout>_Floris" with env_batch: the batched AEC flavour (one launch per agent cycle)
+            from ..vec_adapters import VecAECLogWrapper, VecAECWindFarmEnv
+
+            inner = VecWindFarmEnv(case, controls, env_batch=batch, start_iter=first_control_iter,
+                                   actuation_budget=float("inf"), **env_kwargs)
+            env = VecAECWindFarmEnv(inner)
+            return VecAECLogWrapper(env) if log else env
         return VecWindFarmEnv(case, controls, env_batch=batch, start_iter=first_control_iter, **env_kwargs)
 
     flavour, logger = (MAWindFarmEnv, AECLogWrapper) if decentralised else (WindFarmEnv, LogWrapper)

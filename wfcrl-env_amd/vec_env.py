@@ -30,7 +30,8 @@ class VecWindFarmEnv:
     def __init__(self, farm_case, controls: dict = None, env_batch: int = 1, continuous_control: bool = True,
                  reward_shaper=None, start_iter: int = 0, max_num_steps: int = 500, load_coef: float = 0.1,
                  device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None,
-                 wind_sampling: str = "host", reuse_buffers: bool = True, wind_direction_step: float = None):
+                 wind_sampling: str = "host", reuse_buffers: bool = True, wind_direction_step: float = None,
+                 actuation_budget: float = 0.1):
         controls = {"yaw": (-40, 40, 5)} if controls is None else dict(controls)
         if list(controls) != ["yaw"]:
             raise ValueError(f"Cannot control {list(controls)}. Interface HipFlorisInterface only allows for the "
@@ -56,7 +57,7 @@ class VecWindFarmEnv:
         self.fi = backend if backend is not None else WfStep(p["xcoords"], p["ycoords"], env_batch=self.num_envs,
                                                               device_id=device_id, model=model)
         self.fi.env_config(yaw_lo=spec[0], yaw_hi=spec[1], yaw_step=spec[2],
-                           actuator_rate=WindFarmMDP.ACTUATORS_RATE["yaw"], dt=self.dt, budget=0.1,
+                           actuator_rate=WindFarmMDP.ACTUATORS_RATE["yaw"], dt=self.dt, budget=actuation_budget,
                            load_coef=load_coef, discrete=not continuous_control)
         n = self.num_turbines
         # per-env spaces, identical to the reference's (mdp.py:108-153)
