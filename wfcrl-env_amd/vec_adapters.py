@@ -183,7 +183,11 @@ class VecAECWindFarmEnv(AECEnv):
         if type(seen).__module__.startswith("torch"):
             import torch
 
-            blocked = ((seen / rate) / float(self._num_steps[agent])) / float(dt) >= 0.1
+            # tensor / tensor divisions: torch turns `tensor / python_scalar` into a multiplication by the reciprocal,
+            # which rounds differently from NumPy's float32 division exactly where discrete actions put the accumulator
+            # ON the threshold
+            c = torch.tensor([rate, float(self._num_steps[agent]), float(dt), 0.1], dtype=torch.float32, device=seen.device)
+            blocked = ((seen / c[0]) / c[1]) / c[2] >= c[3]
             if not type(a).__module__.startswith("torch"):
                 a = torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=seen.device)
             a = a.to(torch.float32)
