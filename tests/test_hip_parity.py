@@ -728,3 +728,72 @@ def test_model_surface_of_the_case_yaml(layouts, model):
     with pytest.raises(ValueError, match="unknown model parameter"):
         w.set_model(dict(enable_everything=True))
     w.close()
+
+
+@pytest.mark.parametrize("G", [4, 8, 16])
+@pytest.mark.parametrize("name,wdir", [("HornsRev1_", 270.0), ("HornsRev2_", 243.0), ("Turb_TCRWP_", 281.0), ("Ormonde_", 200.0)])
+def test_one_block_at_a_time_kernel(layouts, name, wdir, G, monkeypatch):
+    """wf_step_ll_kernel (csrc/wf_kernels_ll.hip: one target block in registers, earlier sources replayed from the source
+    log) at every lane-group width, against the oracle and against wf_step_kernel on the same inputs: shared wind, one
+    direction with a speed per farm, ragged batches, the fused env step."""
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts[name]
+    N = l["num_turbines"]
+    if N <= G:
+        pytest.skip("single block")
+    rng = np.random.default_rng(N * 10 + G)
+    B = 133  # not a multiple of the farms per block
+    yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
+    monkeypatch.setenv("WF_LL_G", str(G))
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w.set_wind(8.5, wdir)
+    info = w.kernel_info()
+    assert info["one_block_kernel"] == 1 and info["lanes_per_env"] == G and info["pair_table"] == 1
+    a = _with_flags(w, w.step(yaw))
+    _check(a, _oracle(l["xcoords"], l["ycoords"], 8.5, wdir, yaw))
+    ws = rng.uniform(4, 16, B)
+    w.set_wind(ws, np.full(B, wdir))
+    b = _with_flags(w, w.step(yaw))
+    _check(b, _oracle(l["xcoords"], l["ycoords"], ws, np.full(B, wdir), yaw))
+    # fused env step through the same kernel
+    w.env_config(load_coef=0.2)
+    w.env_reset()
+    act = rng.uniform(-5, 5, (B, N)).astype(np.float32)
+    e = w.env_step(act)
+    assert np.array_equal(e["yaw"], act)
+    ref = _oracle(l["xcoords"], l["ycoords"], ws, np.full(B, wdir), act)
+    r_ref = (ref["power"] / 1e6 * 1e3 / ws[:, None] ** 3).mean(axis=1) - 0.2 * np.abs(ref["load"]).reshape(B, -1).mean(axis=1)
+    ok = w.risk_flags() == 0
+    assert np.abs(e["reward"] - r_ref)[ok].max() < 5e-5 * np.abs(r_ref).max()
+    w.close()
+    # the register-slot kernel on the same inputs
+    monkeypatch.setenv("WF_LL", "0")
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w.set_wind(8.5, wdir)
+    assert w.kernel_info()["one_block_kernel"] == 0
+    a0 = _with_flags(w, w.step(yaw))
+    w.close()
+    both = (a["flags"] == 0) & (a0["flags"] == 0)
+    assert np.abs(a["power"] / np.maximum(a0["power"], 1e3) - 1)[both].max() < 2e-5
+    assert np.abs(a["wind_direction"] - a0["wind_direction"])[both].max() < 2e-4
+
+
+@pytest.mark.parametrize("G", [4, 8])
+def test_one_block_kernel_hands_cross_block_ties_back(layouts, G, monkeypatch):
+    """Axis-aligned grids at wd = 270 have exact x' ties that straddle lane-group blocks: the device-side flag of the
+    target-block table routes such a direction to wf_step_kernel (no host round trip); other directions of the same
+    handle take the one-block kernel.  Same results contract either way."""
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["Turb32_Row5_"]
+    rng = np.random.default_rng(G)
+    B = 64
+    yaw = rng.uniform(-30, 30, (B, 32)).astype(np.float32)
+    monkeypatch.setenv("WF_LL_G", str(G))
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    for wdir in (270.0, 263.0, 270.0):
+        w.set_wind(8.0, wdir)
+        assert w.kernel_info()["one_block_kernel"] == 1
+        _check(_with_flags(w, w.step(yaw)), _oracle(l["xcoords"], l["ycoords"], 8.0, wdir, yaw))
+    w.close()

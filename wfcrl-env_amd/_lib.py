@@ -57,7 +57,7 @@ class WindDist(C.Structure):
 class KernelInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "lanes_per_env", "slots_per_lane", "envs_per_block", "threads_per_block", "grid_blocks",
-        "vgprs", "lds_bytes", "scratch_bytes", "pair_table", "direction_groups")]
+        "vgprs", "lds_bytes", "scratch_bytes", "pair_table", "direction_groups", "one_block_kernel")]
 
 
 # every symbol include/wfstep.h declares: name -> (restype, argtypes)
@@ -99,11 +99,11 @@ _lib = None
 
 def build(force: bool = False) -> Path:
     """Compile csrc/ into libwfstep.so with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [PKG_DIR / "csrc" / n for n in ("wf_kernels.hip", "wf_abi.hip", "wf_device.h")]
+    srcs = [PKG_DIR / "csrc" / n for n in ("wf_kernels.hip", "wf_kernels_ll.hip", "wf_abi.hip", "wf_device.h", "wf_kernel_common.h")]
     srcs.append(PKG_DIR.parent / "include" / "wfstep.h")
     stale = (not LIB_PATH.exists()) or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
     if force or stale:
-        subprocess.run(["make", "-j3", "-C", str(PKG_DIR / "csrc")] + (["-B"] if force else []), check=True)
+        subprocess.run(["make", "-j4", "-C", str(PKG_DIR / "csrc")] + (["-B"] if force else []), check=True)
     return LIB_PATH
 
 

@@ -35,6 +35,15 @@ extern "C" hipError_t wfk_launch_pair_table(const WfPairConsts* pc, int n_groups
 
 extern "C" hipError_t wfk_launch_wind_sample(int B, unsigned long long seed, const double* dist, double* ws, double* wd,
                                              hipStream_t s);
+extern "C" size_t wfk_ll_table_floats(int N, int G);
+extern "C" int wfk_ll_farms_per_block(int G);
+extern "C" hipError_t wfk_launch_pair_table_ll(const WfPairConsts* pc, int G, int n_groups, const double* gx, const double* gy,
+                                               float* tab, int* cross_tie, hipStream_t s);
+extern "C" hipError_t wfk_launch_step_ll(int G, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
+                                         const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
+                                         float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
+                                         const int* cross_tie, float* src_log, const WfGroupArgs* grp, hipStream_t s);
+extern "C" hipError_t wfk_ll_func_attributes(int G, int shared_speed, hipFuncAttributes* a);
 extern "C" hipError_t wfk_launch_fill(int n, double* a, hipStream_t s);  // a[1..n) = a[0]
 extern "C" hipError_t wfk_launch_wind_sample_binned(int B, unsigned long long seed, const double* dist, double step, double* ws,
                                                     double* wd, int* bin, hipStream_t s);
@@ -127,13 +136,22 @@ struct wf_handle {
   // directions); one sorted geometry + pair table per group, farms launched group by group (padded to whole blocks)
   int n_groups = 0;            // 0 = ungrouped
   int group_shift = 0;         // geometry / table of group g is (g + group_shift) % n_groups  (series: the tick)
-  int n_blocks = 0;            // blocks of the grouped launch
+  int n_blocks = 0;            // entries of d_blk_group (one per group_unit farms)
+  int n_slots = 0;             // launch slots of the grouped launch (entries of d_perm)
   int *d_perm = nullptr, *d_blk_group = nullptr;
   size_t perm_cap = 0, blk_cap = 0;
   size_t pair_groups_cap = 0;  // groups the pair-table allocation holds
   double* d_group_wd = nullptr;  // [K] direction of each group (binned sampling; series mode uses d_series_wd)
   double grid_step = 0.0;      // binned sampling: direction grid the cached group geometry / tables were built for
   int* d_bins = nullptr;       // [B] bin of each farm (binned sampling)
+  // One-block-at-a-time kernel (wf_kernels_ll.hip) for the pair-table path of farms with several lane-group blocks:
+  // its own table layout, the per-farm source log, and the per-direction flag that hands a direction with x' ties
+  // across a block boundary back to wf_step_kernel
+  int ll_G = 0;                // 0: not used for this layout / batch
+  float* d_ll_tab = nullptr;   // [groups][wfk_ll_table_floats]
+  int* d_ll_flag = nullptr;    // [groups] 1 = cross-block tie
+  float* d_src_log = nullptr;  // [launch slots][N][WF_LOG_STRIDE]
+  size_t ll_groups_cap = 0, log_slots_cap = 0;
 };
 
 namespace {
@@ -180,6 +198,8 @@ void free_batch(wf_handle* h) {
   h->d_env_moves = nullptr;
   hipFree(h->d_series_ws); hipFree(h->d_series_wd); hipFree(h->d_series_start); hipFree(h->d_ws_prev);
   hipFree(h->d_pair_tab); hipFree(h->d_pair_first); h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_dirty = true;
+  hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
+  h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
   hipFree(h->d_perm); hipFree(h->d_blk_group); hipFree(h->d_group_wd); hipFree(h->d_bins);
   h->d_perm = h->d_blk_group = h->d_bins = nullptr; h->d_group_wd = nullptr;
   h->perm_cap = h->blk_cap = h->pair_groups_cap = 0; h->n_groups = 0; h->grid_step = 0.0;
@@ -229,6 +249,22 @@ int pick_variant(int N, int B) {
     }
   }
   return find_variant(G, S);
+}
+
+// Lane-group width of the one-block-at-a-time kernel for N turbines and B farms, 0 = keep wf_step_kernel.  It pays once
+// the farm spans several blocks (the register-slot kernel is then pinned at two waves per SIMD by its 27 S state
+// registers) and the batch fills the chip; WF_LL=0 disables it, WF_LL_G=<4|8|16> forces a width (A/B runs).
+int pick_ll(int N, int B) {
+  const char* off = getenv("WF_LL");
+  if (off && off[0] == '0') return 0;
+  if (N > WF_PAIR_MAX_N) return 0;
+  const char* force = getenv("WF_LL_G");
+  if (force) {
+    const int g = atoi(force);
+    return ((g == 4 || g == 8 || g == 16) && N > g) ? g : 0;
+  }
+  if (N <= 32 || B < 4096) return 0;
+  return 8;
 }
 
 int build_consts(wf_handle* h) {
@@ -390,17 +426,37 @@ int pair_table(wf_handle* h, const float** out) {
       pc.decay_a[k] = 4.0 * lm * lm * std::fabs(dudz) / uinf / pc.eps2;
     }
     WF_HIP(h, wfk_launch_pair_table(&pc, (int)ng, h->d_gx, h->d_gy, h->d_pair_tab, h->d_pair_first, h->stream));
+    if (h->ll_G) {  // the same records in target-block order, and the per-direction cross-block-tie flag
+      if (!h->d_ll_tab || h->ll_groups_cap < ng) {
+        hipFree(h->d_ll_tab); hipFree(h->d_ll_flag);
+        h->d_ll_tab = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = 0;
+        WF_HIP(h, hipMalloc(&h->d_ll_tab, sizeof(float) * ng * wfk_ll_table_floats(h->N, h->ll_G)));
+        WF_HIP(h, hipMalloc(&h->d_ll_flag, sizeof(int) * ng));
+        h->ll_groups_cap = ng;
+      }
+      WF_HIP(h, wfk_launch_pair_table_ll(&pc, h->ll_G, (int)ng, h->d_gx, h->d_gy, h->d_ll_tab, h->d_ll_flag, h->stream));
+    }
     h->pair_dirty = false;
   }
   *out = h->d_pair_tab;
   return WF_OK;
 }
 
-// Farms per block of the table-path launch of the handle's kernel variant.
+// Farms per block of the table-path launch of the handle's kernel variant (wf_step_kernel), and of the
+// one-block-at-a-time kernel when it is in use.  A grouped launch pads every group to a multiple of the larger of the
+// two (both are powers of two), and its block -> group list has one entry per `group_unit` farms (the smaller).
 int farms_per_block(const wf_handle* h) {
   int vG, vS; const void* vfn;
   wfk_variant(h->variant, &vG, &vS, &vfn);
   return wfk_tab_waves() * (64 / vG);
+}
+int group_pad(const wf_handle* h) {
+  const int a = farms_per_block(h), b = h->ll_G ? wfk_ll_farms_per_block(h->ll_G) : 0;
+  return a > b ? a : b;
+}
+int group_unit(const wf_handle* h) {
+  const int a = farms_per_block(h), b = h->ll_G ? wfk_ll_farms_per_block(h->ll_G) : a;
+  return a < b ? a : b;
 }
 
 // Would a grouped launch over K direction groups pay off?  Every group is padded to whole blocks (half a block wasted
@@ -408,7 +464,7 @@ int farms_per_block(const wf_handle* h) {
 bool groups_pay_off(const wf_handle* h, int K) {
   if (h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->no_pair_table || K < 1) return false;
   if ((size_t)K * h->N > h->cap_bn) return false;  // group geometry lives in the per-farm geometry buffers
-  const double waste = 0.5 * farms_per_block(h) * K / (double)h->B;
+  const double waste = 0.5 * group_pad(h) * K / (double)h->B;
   int vG, vS; const void* vfn;
   wfk_variant(h->variant, &vG, &vS, &vfn);
   const size_t bytes = (size_t)K * h->N * WF_PAIR_ROW_FLOATS(vG * vS) * sizeof(float);
@@ -419,7 +475,7 @@ bool groups_pay_off(const wf_handle* h, int K) {
 // whole blocks (d_perm, -1 = padding), group of each block (d_blk_group).  Then the sorted geometry of the K
 // directions `d_wd_groups` (device) is built into the geometry buffers; the pair tables follow lazily (pair_table()).
 int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_wd_groups, bool rebuild_geometry) {
-  const int epb = farms_per_block(h);
+  const int epb = group_pad(h), unit = group_unit(h);
   std::vector<int> count(K, 0);
   for (int b = 0; b < h->B; ++b) {
     if (group_of_farm[b] < 0 || group_of_farm[b] >= K) return fail(h, WF_E_INVALID, "direction group out of range");
@@ -430,7 +486,7 @@ int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_
   for (int g = 0; g < K; ++g) {
     first_slot[g] = slots;
     const int nb = (count[g] + epb - 1) / epb;
-    for (int q = 0; q < nb; ++q) blk_group.push_back(g);
+    for (int q = 0; q < nb * (epb / unit); ++q) blk_group.push_back(g);
     slots += nb * epb;
   }
   std::vector<int> perm(slots > 0 ? slots : 1, -1), cursor(first_slot);
@@ -449,6 +505,7 @@ int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_
   WF_HIP(h, hipMemcpy(h->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice));
   WF_HIP(h, hipMemcpy(h->d_blk_group, blk_group.data(), sizeof(int) * blk_group.size(), hipMemcpyHostToDevice));
   h->n_blocks = (int)blk_group.size();
+  h->n_slots = slots;
   h->n_groups = K;
   h->group_shift = 0;
   if (rebuild_geometry) {
@@ -468,9 +525,26 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   WfGroupArgs ga{};
   ga.mod = 1;
   ga.risk_flags = h->d_flags;
+  ga.blk_unit = 1;
   if (h->n_groups > 0) {
     ga.perm = h->d_perm; ga.blk_group = h->d_blk_group; ga.n_blocks = h->n_blocks;
     ga.shift = h->group_shift; ga.mod = h->n_groups;
+    ga.blk_unit = group_unit(h); ga.n_slots = h->n_slots;
+  }
+  if (ptab && h->ll_G) {
+    // the one-block-at-a-time kernel serves every direction without a cross-block tie; wf_step_kernel, enqueued right
+    // behind it, serves the others (device-side predicate, no host round trip)
+    const int fpb = wfk_ll_farms_per_block(h->ll_G);
+    const size_t slots = h->n_groups > 0 ? (size_t)h->n_slots : (size_t)((h->B + fpb - 1) / fpb) * fpb;
+    if (slots > h->log_slots_cap) {
+      WF_HIP(h, hipStreamSynchronize(h->stream));
+      hipFree(h->d_src_log); h->d_src_log = nullptr; h->log_slots_cap = 0;
+      WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * h->N * WF_LOG_STRIDE));
+      h->log_slots_cap = slots;
+    }
+    WF_HIP(h, wfk_launch_step_ll(h->ll_G, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
+                                 load, h->B, ea, h->d_ll_tab, h->d_ll_flag, h->d_src_log, &ga, h->stream));
+    ga.pred = h->d_ll_flag;
   }
   WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                             wstride, yaw, power, wspd, wdir, load, h->B, ea, ptab, h->d_pair_first, &ga, h->stream, &h->grid));
@@ -601,6 +675,12 @@ int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
   WF_ON_DEVICE(h);
   const int v = pick_variant(n, h->B);
   if (v < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
+  const int llg = pick_ll(n, h->B);
+  if (llg != h->ll_G || n != h->N) {  // the target-block table and the source log are laid out for (N, G)
+    hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
+    h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
+    h->ll_G = llg;
+  }
   h->lx.assign(x, x + n); h->ly.assign(y, y + n);
   double xmin = x[0], xmax = x[0], ymin = y[0], ymax = y[0];
   for (int i = 1; i < n; ++i) {
@@ -628,6 +708,12 @@ int wf_set_batch(wf_handle* h, int B) {
   {
     const int v = pick_variant(h->N, B);
     if (v < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
+    const int llg = pick_ll(h->N, B);
+    if (llg != h->ll_G) {
+      hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
+      h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
+      h->ll_G = llg; h->pair_dirty = true;
+    }
     if (v != h->variant) {  // the pair table is laid out for the variant's capacity
       hipFree(h->d_pair_tab); hipFree(h->d_pair_first);
       h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_dirty = true; h->pair_groups_cap = 0;
@@ -1046,7 +1132,17 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   info->lanes_per_env = G; info->slots_per_lane = S;
   const int wpb = tab ? wfk_tab_waves() : 4;
   info->envs_per_block = wpb * (64 / G); info->threads_per_block = 64 * wpb;
-  info->grid_blocks = h->n_groups > 0 ? h->n_blocks : (h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0);
+  info->grid_blocks = h->n_groups > 0 ? (h->n_slots + info->envs_per_block - 1) / info->envs_per_block
+                                      : (h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0);
+  info->one_block_kernel = (tab && h->ll_G) ? 1 : 0;
+  if (info->one_block_kernel) {
+    // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
+    // fields above would describe) is enqueued behind it for the directions that have one
+    WF_HIP(h, wfk_ll_func_attributes(h->ll_G, h->wind_count == 1 ? 1 : 0, &a));
+    info->lanes_per_env = h->ll_G; info->slots_per_lane = 1;
+    info->envs_per_block = wfk_ll_farms_per_block(h->ll_G); info->threads_per_block = 256;
+    info->grid_blocks = (int)(((h->n_groups > 0 ? (size_t)h->n_slots : (size_t)h->B) + info->envs_per_block - 1) / info->envs_per_block);
+  }
   info->vgprs = a.numRegs;
   info->lds_bytes = (int)a.sharedSizeBytes; info->scratch_bytes = (int)a.localSizeBytes;
   return WF_OK;

@@ -94,7 +94,11 @@ struct WfGroupArgs {
   const int* perm;       // [n_blocks * farms per block] farm index per launch slot, -1 = padding; null = identity
   const int* blk_group;  // [n_blocks] direction group of the block's farms, -1 = unused block; null = ungrouped
   int shift, mod;        // table / geometry index of group g = (g + shift) % mod  (series playback: shift = tick)
-  int n_blocks;
+  int n_blocks;          // blocks of the grouped launch at blk_unit farms per block
+  int blk_unit;          // farms per entry of blk_group (a kernel with F farms per block reads entry block * F / blk_unit)
+  int n_slots;           // launch slots of the grouped launch (= entries of perm)
+  const int* pred;       // [groups] when non-null, wf_step_kernel serves only the groups with pred[g] != 0 (the others
+                         // are served by wf_step_ll_kernel, launched with the opposite predicate)
   int* risk_flags;       // [B] out: WF_RISK_* bits of each farm; null = not written
 };
 #define WF_RISK_OVERLAP 1
@@ -123,6 +127,26 @@ struct WfGroupArgs {
 #define WF_PAIR_BITS 39
 #define WF_PAIR_MAX_N 128
 #define WF_PAIR_ROW_FLOATS(n) ((((n) * WF_PAIR_STRIDE * 4 + 1023) / 1024) * 256)
+
+// Target-block order of the same records for wf_step_ll_kernel (wf_kernels_ll.hip): block J (targets J G .. J G + G - 1)
+// holds the records of its sources i = 0 .. min(N, (J + 1) G) - 1, source-major, padded to whole chunks of 64 records
+// (64 / G sources = 11 KiB, the unit of the LDS staging); blocks follow each other.  Offset of block J in floats:
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline size_t wf_ll_block_offset(int J, int N, int G) {
+  const int CH = 64 / G;
+  size_t off = 0;
+  for (int b = 0; b < J; ++b) {
+    const int n_src = (b + 1) * G < N ? (b + 1) * G : N;
+    off += (size_t)((n_src + CH - 1) / CH) * 64 * WF_PAIR_STRIDE;
+  }
+  return off;
+}
+// Source log of wf_step_ll_kernel: WF_LOG_FLOATS floats per (farm, source), one 128-byte line each (no two records
+// share a cache line: a line is first touched by its writer).
+#define WF_LOG_FLOATS 24
+#define WF_LOG_STRIDE 32
 
 struct WfPairConsts {
   int N;   // turbines

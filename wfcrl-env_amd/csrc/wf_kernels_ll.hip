@@ -1,0 +1,603 @@
+// wf_kernels_ll.hip — the farm step on the pair-table path, one target block at a time ("left-looking").
+//
+// Same model, same arithmetic and the same discontinuity handling as wf_step_kernel (wf_kernels.hip; references and
+// [A.x] tags there); what differs is the order in which the (source, target) pairs of the triangular recurrence are
+// visited, and with it what has to stay in registers:
+//   * wf_step_kernel ("right-looking") applies a source to ALL downstream targets at once: the state of S target slots
+//     (27 S floats) lives in VGPRs for the whole solve, which pins the S >= 4 variants at two waves per SIMD;
+//   * here ONE target block of G turbines (27 floats per lane) is in registers at a time.  Block J is first swept by all
+//     sources of the earlier blocks, whose constants (24 floats per source and farm: circulations, deflection / deficit /
+//     turbulence constants) are replayed from a per-farm SOURCE LOG in device memory, written when that source had its
+//     turn; then the block's own G sources run the sequential recurrence exactly as wf_step_kernel's slot 0 does
+//     (source phase, transverse pass, yaw-added recovery, deficit pass), appending to the log; then the block's outputs
+//     are written.  State no longer limits occupancy (three waves per SIMD at <= 168 VGPRs), the lane group can be
+//     narrower (G = 8: eight farms per wave share every per-source instruction, and 92 % instead of 84 % of the lanes
+//     are busy on the triangle at N = 80), and no register slots have to be shifted.
+//   * pair-table records are laid out per target block, [J][source i][target of J], so that the 64 records of a chunk
+//     (64 / G consecutive sources of one block) are one contiguous 11-KiB piece, staged into a double-buffered LDS slab
+//     with global_load_lds_dwordx4 one chunk ahead (one __syncthreads() per chunk);
+//   * the price is the log traffic: 96 B written per source and farm, re-read once per later block (L2 / MALL resident:
+//     it is consumed by the wave that wrote it, at most a few hundred microseconds later).
+// Precondition: no x' tie across a block boundary (a later block's source at dx = 0 from an earlier block's target owes
+// that target its transverse velocities [A.3-4], which this order cannot deliver).  wf_pair_table_ll_kernel detects it
+// per wind direction and raises a device flag; this kernel then leaves the launch to wf_step_kernel, which is always
+// enqueued behind it with the opposite predicate (no host round trip).  Exact ties are what axis-aligned grid layouts
+// have at wd = 270; HornsRev1/2 have none.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "wf_kernel_common.h"
+
+namespace {
+
+// sin / cos of the commanded yaw from the angle in radians: |yaw| <= 45 deg for every admissible command, where the
+// Taylor polynomials below are exact to < 3e-9; larger angles (never produced by the env) take libm, wave-uniformly.
+__device__ __forceinline__ void sincos_yaw(float x, float& s, float& c) {
+  const float x2 = x * x;
+  s = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.0f);
+  c = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, -2.7557319e-7f, 2.4801587e-5f), -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
+  if (__any(fabsf(x) > 0.8f)) {
+    float s2, c2;
+    sincosf(x, &s2, &c2);
+    s = (fabsf(x) > 0.8f) ? s2 : s;
+    c = (fabsf(x) > 0.8f) ? c2 : c;
+  }
+}
+
+// What a source leaves behind for the target blocks after its own (WF_LOG_FLOATS floats, six float4).
+struct SrcLog {
+  float Gy, Gwt, sy0d, sz0d;        // circulations of the transverse pass (table path), deflection sigma_0
+  float inv_s0d, lnA, lnB, sM;      // deflection far-wake constants
+  float tan_th0, sy0v, snw, kdef;   // deflection angle; deficit sigma_y0, near-wake sigma, amplitude factor
+  float x0d, kyd, d0, pj;           // column 0: deflection near-wake length, expansion rate, delta_0, log prefactor
+  float x0v, ix0v, kyv, ch_pref;    // column 0: deficit near-wake length, 1/, expansion rate; Crespo-Hernandez prefactor
+  float TI0, TI1, TI2, dTI;         // the source's column TIs before mixing and the yaw-added-recovery increment
+};
+static_assert(sizeof(SrcLog) == WF_LOG_FLOATS * 4, "source log record");
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Pair table in target-block order.  One thread per (source i, target t); the record is the one wf_pair_table_kernel
+// writes (wf_device.h: WF_PAIR_*), at  block_offset(J) + (i * G + t - J G) * 44,  J = t / G, for i < (J + 1) G.
+// ---------------------------------------------------------------------------------------------
+__global__ void wf_pair_table_ll_kernel(const WfPairConsts pc, int G, const double* __restrict__ gx,
+                                        const double* __restrict__ gy, float* __restrict__ tab, size_t group_floats,
+                                        int* __restrict__ cross_tie) {
+  const int i = blockIdx.x, t = threadIdx.x, grp = blockIdx.y;
+  const int nblk = (pc.N + G - 1) / G;
+  if (t >= nblk * G) return;
+  gx += (size_t)grp * pc.N;
+  gy += (size_t)grp * pc.N;
+  const int J = t / G;
+  if (i >= (J + 1) * G) {  // a source of a later block: never applied to this target — unless it ties with it in x'
+    if (t < pc.N && gx[t] - gx[i] >= 0.0) atomicOr(&cross_tie[grp], 1);
+    return;
+  }
+  float* o = tab + (size_t)grp * group_floats + wf_ll_block_offset(J, pc.N, G) + ((size_t)i * G + (t - J * G)) * WF_PAIR_STRIDE;
+  wf_pair_record(pc, gx, gy, i, t, o);
+}
+
+extern "C" size_t wfk_ll_table_floats(int N, int G) { return wf_ll_block_offset((N + G - 1) / G, N, G); }
+
+extern "C" hipError_t wfk_launch_pair_table_ll(const WfPairConsts* pc, int G, int n_groups, const double* gx, const double* gy,
+                                               float* tab, int* cross_tie, hipStream_t s) {
+  const int nblk = (pc->N + G - 1) / G;
+  const int threads = ((nblk * G + 63) / 64) * 64;
+  hipError_t e = hipMemsetAsync(cross_tie, 0, sizeof(int) * (size_t)n_groups, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(wf_pair_table_ll_kernel, dim3(pc->N, n_groups), dim3(threads), 0, s, *pc, G, gx, gy, tab,
+                     wfk_ll_table_floats(pc->N, G), cross_tie);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The farm step, one target block at a time
+// ---------------------------------------------------------------------------------------------
+// G: lanes per farm = turbines per block.  UWS: one wind speed for the whole batch (its derived constants live in SGPRs).
+// WPB waves per block; all of them walk the same chunk sequence, one barrier per chunk.
+template <int G, bool UWS, int WPB>
+__global__ __launch_bounds__(64 * WPB, 3 * 4 / WPB) void wf_step_ll_kernel(
+    const WfConsts c, const WfTables* __restrict__ tab, const int* __restrict__ gidx, const double* __restrict__ ws_in,
+    const double* __restrict__ wd_in, int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power,
+    float* __restrict__ o_ws, float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea,
+    const float* __restrict__ ll_tab, size_t group_floats, const int* __restrict__ cross_tie, float* __restrict__ src_log,
+    int n_pad, const WfGroupArgs ga) {
+  constexpr int EPW = 64 / G;   // farms per wave
+  constexpr int CH = 64 / G;    // sources per staged chunk (64 records)
+  constexpr int CHUNK_FLOATS = 64 * WF_PAIR_STRIDE;
+  __shared__ TableLds T;
+  __shared__ __attribute__((aligned(16))) float prow[2][CHUNK_FLOATS];
+  __shared__ unsigned risk_lds[WPB][EPW];
+  extern __shared__ float yaw_lds[];  // [WPB][EPW][n_pad] commanded yaw in sorted order, degrees
+
+  int grp = 0;
+  if (ga.blk_group) {
+    grp = ga.blk_group[(blockIdx.x * (WPB * EPW)) / ga.blk_unit];
+    if (grp < 0) return;  // whole block, before any barrier
+    grp = (grp + ga.shift) % ga.mod;
+  }
+  if (cross_tie[grp]) return;  // this direction has an x' tie across a block boundary: wf_step_kernel serves it
+  ll_tab += (size_t)grp * group_floats;
+
+  // chunk q of this direction's table -> LDS buffer q & 1 (the chunks of all target blocks are contiguous, in the order
+  // they are consumed)
+  auto stage_chunk = [&](int q) {
+    const char* g0 = reinterpret_cast<const char*>(ll_tab) + (size_t)q * (CHUNK_FLOATS * 4);
+    char* l0 = reinterpret_cast<char*>(&prow[q & 1][0]);
+    for (int ch = (int)(threadIdx.x >> 6); ch < CHUNK_FLOATS * 4 / 1024; ch += WPB) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + ch * 1024 + (threadIdx.x & 63) * 16),
+                                       (__attribute__((address_space(3))) void*)(l0 + ch * 1024), 16, 0, 0);
+    }
+  };
+  stage_chunk(0);
+  for (int k = threadIdx.x; k < WF_TABLE_PAD; k += blockDim.x) {
+    T.knot[k] = tab->knot[k];
+    T.ct[k] = tab->ct[k];
+    T.cts[k] = tab->ct_slope[k];
+    T.pw[k] = tab->pw[k];
+    T.pws[k] = tab->pw_slope[k];
+  }
+  for (int k = threadIdx.x; k < WF_BUCKETS; k += blockDim.x) T.bucket[k] = tab->bucket[k];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int sub = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int eiw = lane / G;
+  const int slot = (blockIdx.x * WPB + wave) * EPW + eiw;  // launch slot of the farm: indexes the source log
+  int env_raw = slot;
+  if (ga.perm) env_raw = ga.perm[env_raw];
+  const bool env_ok = env_raw >= 0 && env_raw < B;
+  const int env = env_ok ? env_raw : (B - 1);
+  if (sub == 0) risk_lds[wave][eiw] = 0u;
+  const int N = c.N;
+  const int nblk = (N + G - 1) / G;
+
+  auto uni = [](float v) { return UWS ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))) : v; };
+  const float ws = uni((float)ws_in[(size_t)env * wind_stride]);
+  const double wd_d = fmod(wd_in[(size_t)env * wind_stride], 360.0);
+  const float wd = uni((float)(wd_d < 0.0 ? wd_d + 360.0 : wd_d));
+  const float Ui[3] = {uni(ws * c.shearf[0]), uni(ws * c.shearf[1]), uni(ws * c.shearf[2])};
+  const float offk = c.off[2] * kGs;
+  const float U02c = uni(Ui[0] * Ui[0] * Ui[0] + Ui[2] * Ui[2] * Ui[2]), U1c = uni(Ui[1] * Ui[1] * Ui[1]);
+  const float ovh = 0.5f * c.guard_inv;
+  const float ovs[3] = {uni(ovh * Ui[0] * c.inv_overlap_thr), uni(ovh * Ui[1] * c.inv_overlap_thr), uni(ovh * Ui[2] * c.inv_overlap_thr)};
+  const float ovc = 0.5f - ovh;
+
+  const size_t gofs = (size_t)grp * N;  // sorted geometry of the direction (group 0 for a shared wind)
+  const size_t yofs = (size_t)env * N;
+  float* yawL = yaw_lds + ((size_t)wave * EPW + eiw) * n_pad;
+  // commanded yaw of every turbine, in sorted order; fused MDP transition as in wf_step_kernel
+  const bool env_mode = ea.yaw_state != nullptr;
+  int moves_new = 0;
+  if (env_mode && ea.action) moves_new = ea.moves[env] + 1;
+  for (int J = 0; J < nblk; ++J) {
+    const int t = J * G + sub;
+    const bool ok = t < N;
+    const size_t oi = yofs + gidx[gofs + (ok ? t : 0)];
+    float yw;
+    if (env_mode) {
+      yw = ea.yaw_state[oi];
+      if (ea.action) {
+        float a = ea.action[oi];
+        float acc = ea.acc[oi];
+        const float frac = __fdiv_rn(__fdiv_rn(__fdiv_rn(acc, ea.rate), (float)moves_new), ea.dt);
+        if (frac >= ea.budget) a = 0.0f;
+        if (ea.discrete) a = (a - 1.0f) * ea.yaw_step;
+        if (!ea.discrete) a = fminf(fmaxf(a, -ea.yaw_step), ea.yaw_step);
+        yw = fminf(fmaxf(yw + a, ea.yaw_lo), ea.yaw_hi);
+        acc += fabsf(a);
+        if (ok && env_ok) {
+          ea.yaw_state[oi] = yw;
+          ea.acc[oi] = acc;
+        }
+      }
+    } else {
+      yw = yaw_in[oi];
+    }
+    yawL[t] = yw;
+  }
+  if (env_mode && ea.action && sub == 0 && env_ok) ea.moves[env] = moves_new;
+  __syncthreads();
+
+  // ---- per-turbine state of the ONE target block in registers (as Slots<1> of wf_step_kernel) ----
+  float esq[6], V[9], W[9], TI[3];
+  const float amb0 = fsqrt(c.amb2);
+
+  // transverse velocities of one source on this lane's target [A.3-4]: record = 9 float4 {aV, bV, aW, bW}
+  auto apply_tab = [&](const float4* pr, float Gy, float Gwt) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float4 cf[3] = {pr[3 * j], pr[3 * j + 1], pr[3 * j + 2]};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int q = j * 3 + k;
+        V[q] = fmaf(Gwt, cf[k].y, fmaf(Gy, cf[k].x, V[q]));
+        const float ww = fmaf(Gwt, cf[k].w, Gy * cf[k].z);
+        W[q] += fmaxf(ww, 0.0f);  // W[W<0] = 0, quirk (5)
+      }
+    }
+  };
+
+  // deflection + deficit + SOSFS + wake-added turbulence of one source on this lane's target [A.3-3, 6, 7, 8]
+  // (the body of wf_step_kernel's pass 2 for one slot; S holds the source's constants, ex = {dx, dy, tipow, bits})
+  auto pass2 = [&](const SrcLog& S, const float4 ex, bool act) {
+    if (!act) return;
+    const float dx = ex.x, dy = ex.y;
+    const bool in15 = ex.z > 0.0f;
+    const int bits = __float_as_int(ex.w);
+    const float lin = fmaf(c.bd, dx, c.ad);
+    const float amp_on = (bits & 8) ? 1.0f : 0.0f;
+    SrcConsts sc;
+    sc.sy0d = S.sy0d; sc.sz0d = S.sz0d; sc.inv_s0d = S.inv_s0d; sc.lnA = S.lnA; sc.lnB = S.lnB; sc.sM = S.sM;
+    sc.tan_th0 = S.tan_th0; sc.sy0v = S.sy0v; sc.snw = S.snw; sc.kdef = S.kdef;
+    float e1[3], e0[3];
+    const bool same = __all((S.TI0 == S.TI1) && (S.TI1 == S.TI2));
+    if (same) {
+      const float xs = fmaxf(dx - S.x0d, 0.0f);
+      const float syd = fmaf(S.kyd, xs, sc.sy0d), szd = fmaf(S.kyd, xs, sc.sz0d);
+      const float s = fsqrt(syd * szd * sc.inv_s0d);
+      const float arg = sc.lnA * fmaf(1.6f, s, -sc.sM) * frcp(sc.lnB * fmaf(1.6f, s, sc.sM));
+      const float d_far = fmaf(S.pj, flog2(arg), S.d0);
+      const float delta = ((dx > S.x0d) ? d_far : dx * sc.tan_th0) + lin;
+      const bool far = dx >= S.x0v;
+      const float up = dx * S.ix0v;
+      const float xf = dx - S.x0v;
+      const float sy = far ? fmaf(S.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
+      const float sz = far ? fmaf(S.kyv, xf, c.sz0v) : fmaf(up, c.sz0v - sc.snw, sc.snw);
+      const float isy = frcp(sy), isz = frcp(sz);
+      const float xarg = sc.kdef * isy * isz;
+      const float C = (xarg >= 1.0f) ? 1.0f : xarg * frcp(1.0f + fsqrt(fmaxf(1.0f - xarg, 0.0f)));
+      const float zz = offk * isz;
+      const float ez = fexp2(-(zz * zz));
+      const float amp = amp_on * C;
+      const float y1 = (dy - delta) * isy * kGs, oy = offk * isy;
+      const float yy[3] = {y1 - oy, y1, y1 + oy};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        e1[j] = amp * fexp2(-(yy[j] * yy[j]));
+        e0[j] = e1[j] * ez;
+      }
+    } else {
+      // split-TI source (rare): the other two columns' constants are re-derived from the log — the numerators of the
+      // near-wake lengths and the log prefactor follow from column 0's values
+      const float s_c = fsqrt(fmaxf(1.0f - S.sM * S.sM, 0.0f));       // sM^2 = ct
+      const float om_sc = S.sM * S.sM * frcp(1.0f + s_c);
+      const float b2om = c.beta2 * om_sc, b2om_d = c.beta2_d * om_sc;
+      const float x0num_d = S.x0d * fmaf(c.alpha4_d, S.TI0, b2om_d);
+      const float x0num_v = S.x0v * fmaf(c.alpha4, S.TI0 + S.dTI, b2om);
+      const float pfac = S.pj * S.kyd;
+      const float tis[3] = {S.TI0, S.TI1, S.TI2};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        ColConsts k;
+        if (j == 0) {
+          k.x0d = S.x0d; k.kyd = S.kyd; k.d0 = S.d0; k.pj = S.pj; k.x0v = S.x0v; k.ix0v = S.ix0v; k.kyv = S.kyv;
+        } else {
+          k.x0d = x0num_d * frcp(fmaf(c.alpha4_d, tis[j], b2om_d));
+          k.kyd = fmaf(c.ka_d, tis[j], c.kb_d);
+          k.d0 = sc.tan_th0 * k.x0d;
+          k.pj = pfac * frcp(k.kyd);
+          k.x0v = x0num_v * frcp(fmaf(c.alpha4, tis[j] + S.dTI, b2om));
+          k.ix0v = frcp(k.x0v);
+          k.kyv = fmaf(c.ka, tis[j] + S.dTI, c.kb);
+        }
+        column_deficit(c, sc, k, dx, dy + c.off[j], lin, amp_on, e1[j], e0[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      esq[2 * j] = fmaf(e0[j], e0[j], esq[2 * j]);
+      esq[2 * j + 1] = fmaf(e1[j], e1[j], esq[2 * j + 1]);
+    }
+    // wake-added TI [A.3-8]: only within 15 D downstream and 2 D laterally (float64 decisions of the table)
+    if (!__any(in15 && (bits & 7))) return;
+    float cnt = 0.0f;
+    unsigned fbits = 0u;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float f0 = __builtin_amdgcn_fmed3f(fmaf(e0[j], ovs[0], ovc), 0.0f, 1.0f);
+      const float f1 = __builtin_amdgcn_fmed3f(fmaf(e1[j], ovs[1], ovc), 0.0f, 1.0f);
+      const float f2 = __builtin_amdgcn_fmed3f(fmaf(e0[j], ovs[2], ovc), 0.0f, 1.0f);
+      cnt += (f0 + f1) + f2;
+      fbits |= __float_as_uint(f0) | __float_as_uint(f1) | __float_as_uint(f2);
+    }
+    cnt = rintf(cnt);
+    if ((fbits & 0xc07fffffu) && in15 && (bits & 7)) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_OVERLAP);
+    const float ti = S.ch_pref * ex.z;
+    const float tia = in15 ? ti * (cnt * (1.0f / 9.0f)) : 0.0f;
+    const float cand = fsqrt(fmaf(tia, tia, c.amb2));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float cm = (bits & (1 << j)) ? cand : 0.0f;
+      TI[j] = __uint_as_float(max(__float_as_uint(TI[j]), __float_as_uint(cm)));
+    }
+  };
+
+  float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
+  int q = 0;                        // running chunk index (LDS buffer q & 1)
+  float* const logf = src_log + (size_t)slot * N * WF_LOG_STRIDE;
+  for (int J = 0; J < nblk; ++J) {
+    const int t = J * G + sub;
+    const bool tvalid = t < N;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { V[k] = 0.0f; W[k] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) esq[k] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) TI[j] = amb0;
+    const float yaw_t = yawL[tvalid ? t : 0];
+    float sg_t, cg_t;
+    sincos_yaw(yaw_t * kDeg2Rad, sg_t, cg_t);  // this lane's turbine: source constants (own block) and the power output
+
+    const int first_own = J * G;                  // sources [0, first_own) come from the log, [first_own, n_src) are this block's
+    const int n_src = min(N, first_own + G);
+    const int n_chunks = (n_src + CH - 1) / CH;
+    // the first logged source's record is fetched ahead; every later one while its predecessor is being applied
+    SrcLog nxt;
+    if (first_own > 0) {
+      const float4* lp = reinterpret_cast<const float4*>(logf);
+      float4* d = reinterpret_cast<float4*>(&nxt);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d[k] = lp[k];
+    }
+    for (int cq = 0; cq < n_chunks; ++cq, ++q) {
+      if (cq + 1 < n_chunks || J + 1 < nblk) stage_chunk(q + 1);  // lands in the other buffer while this chunk is consumed
+      const float* buf = &prow[q & 1][0];
+#pragma unroll 1
+      for (int k = 0; k < CH; ++k) {
+        const int i = cq * CH + k;
+        if (i >= n_src) break;
+        const float* rec = buf + (k * G + sub) * WF_PAIR_STRIDE;
+        const float4 ex = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
+        if (i < first_own) {
+          // ---- a source of an earlier block: replay it from the log on this block's targets ------------
+          const SrcLog S = nxt;
+          if (i + 1 < first_own) {
+            const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)(i + 1) * WF_LOG_STRIDE);
+            float4* d = reinterpret_cast<float4*>(&nxt);
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) d[kk] = lp[kk];
+          }
+          if (tvalid) apply_tab(reinterpret_cast<const float4*>(rec), S.Gy, S.Gwt);  // every real turbine here has dx >= 0
+          pass2(S, ex, tvalid);
+        } else {
+          // ---- a source of this block: the sequential recurrence, as wf_step_kernel's slot 0 --------------
+          const int li = i - first_own;
+          const int src = gbase + li;
+          // A. the source's state (lane li of the group)
+          float fe = 0.0f, fc = 0.0f, vsum = 0.0f;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float ue = 1.0f - fsqrt(esq[2 * j]), uc = 1.0f - fsqrt(esq[2 * j + 1]);
+            fe = fmaf(ue * ue, ue, fe);
+            fc = fmaf(uc * uc, uc, fc);
+          }
+#pragma unroll
+          for (int k2 = 0; k2 < 9; ++k2) vsum += V[k2];
+          const float m3 = __shfl(fmaf(U02c, fe, U1c * fc), src);
+          const float Vmean = __shfl(vsum, src) * (1.0f / 9.0f);
+          float TIs[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) TIs[j] = __shfl(TI[j], src);
+          const float yaw_i = __shfl(yaw_t, src);
+          const float cg = __shfl(cg_t, src), sg = __shfl(sg_t, src);
+          // B. circulations [A.3-1, A.3-4]
+          SrcLog S;
+          const float ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
+          const float ct = table_ct(c, T, ubar) * cg;
+          const float sq1 = fsqrt(1.0f - ct * cg);
+          const float a = 0.5f * ct * frcp(1.0f + sq1);
+          const float Gwr = c.gam_wr * (a - a * a) * ubar;
+          const float gt = c.gam_top * ws * ct, gb = c.gam_bot * ws * ct;
+          const float scg = sg * cg * c.sw_tv;
+          S.Gy = scg * ct * ws;
+          S.Gwt = Gwr * c.sw_tv;
+          // C. pass 1 on this block (upstream lanes of the block: dx < 0 in the record)
+          const float dx = ex.x;
+          if (dx >= 0.0f) apply_tab(reinterpret_cast<const float4*>(rec), S.Gy, S.Gwt);
+          float vbar = 0.0f, wbar = 0.0f;
+#pragma unroll
+          for (int k2 = 0; k2 < 9; ++k2) { vbar += V[k2]; wbar += W[k2]; }
+          vbar = __shfl(vbar, src) * (1.0f / 9.0f);
+          wbar = __shfl(wbar, src) * (1.0f / 9.0f);
+          // B2. steering + deflection constants [A.3-2, A.3-3]
+          float val = c.sw_steer * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
+          val = fminf(fmaxf(val, -1.0f), 1.0f);
+          const float asv = __any(fabsf(val) > 0.3f) ? asinf(val) : asin_small(val);
+          const float gd = -(yaw_i * kDeg2Rad + 0.5f * asv);
+          const float c2h = fsqrt(fmaxf(fmaf(-val, val, 1.0f), 0.0f));
+          const float ch = fsqrt(0.5f * (1.0f + c2h));
+          const float sh = 0.5f * val * frcp(ch);
+          const float cgd = fmaf(cg, ch, -sg * sh);
+          const float s_cc = fsqrt(1.0f - ct * cgd), s_c = fsqrt(1.0f - ct);
+          const float om_scc = ct * cgd * frcp(1.0f + s_cc);
+          const float om_sc = ct * frcp(1.0f + s_c);
+          S.sM = fsqrt(ct);
+          const float E0 = fmaf(om_sc, om_sc, fmaf(-c.e0c1, om_sc, c.e0c2));
+          S.sz0d = 0.5f * c.D * fsqrt((1.0f + s_cc) * frcp(2.0f * (1.0f + s_c)));
+          S.sy0d = S.sz0d * cgd;
+          const float th0 = c.dm03 * gd * frcp(cgd) * om_scc;
+          {
+            const float t2 = th0 * th0;
+            const float poly = th0 * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 0.0088632355f, 0.0218694885f), 0.0539682540f),
+                                                              0.1333333333f), 0.3333333333f), 1.0f);
+            S.tan_th0 = poly;
+            if (__any(fabsf(th0) > 0.35f)) {
+              const float rev = th0 * 0.15915494309189535f;
+              const float hw = __builtin_amdgcn_sinf(rev) * frcp(__builtin_amdgcn_cosf(rev));
+              S.tan_th0 = (fabsf(th0) > 0.35f) ? hw : poly;
+            }
+          }
+          S.inv_s0d = frcp(S.sy0d * S.sz0d);
+          const float pfac = th0 * E0 * (1.0f / 5.2f) * fsqrt(S.sy0d * S.sz0d * frcp(ct)) * kLn2;
+          S.lnA = 1.6f + S.sM;
+          S.lnB = 1.6f - S.sM;
+          const float x0num_d = c.D * cgd * (1.0f + s_cc) * (1.0f / 1.41421356237f);
+          // D. yaw-added recovery [A.3-5] and deficit constants [A.3-6]
+          const float I0 = TIs[0];
+          const float uI = ubar * I0;
+          const float mix2 = (vbar * vbar + wbar * wbar) * (1.0f / 3.0f);
+          const float inv_ubar = frcp(ubar);
+          const float Itot = fsqrt(fmaf(uI, uI, mix2)) * inv_ubar;
+          const float Imix = mix2 * inv_ubar * inv_ubar * frcp(Itot + I0);
+          S.dTI = c.gch_gain * Imix;
+          if (lane == src) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) TI[j] += S.dTI;
+          }
+          S.sy0v = c.sz0v * cg;
+          S.snw = c.near_c * fsqrt(0.5f * ct);
+          S.kdef = ct * cg * c.kdef;
+          S.ch_pref = c.ch_c * fexp2(c.ch_ai * flog2(a));
+          const float x0num_v = c.D * cg * (1.0f + s_c) * (1.0f / 1.41421356237f);
+          const float b2om = c.beta2 * om_sc, b2om_d = c.beta2_d * om_sc;
+          S.x0d = x0num_d * frcp(fmaf(c.alpha4_d, TIs[0], b2om_d));
+          S.kyd = fmaf(c.ka_d, TIs[0], c.kb_d);
+          S.d0 = S.tan_th0 * S.x0d;
+          S.pj = pfac * frcp(S.kyd);
+          S.x0v = x0num_v * frcp(fmaf(c.alpha4, TIs[0] + S.dTI, b2om));
+          S.ix0v = frcp(S.x0v);
+          S.kyv = fmaf(c.ka, TIs[0] + S.dTI, c.kb);
+          S.TI0 = TIs[0]; S.TI1 = TIs[1]; S.TI2 = TIs[2];
+          // the later blocks replay this source from the log
+          if (J + 1 < nblk && sub == 0) {
+            float4* lp = reinterpret_cast<float4*>(logf + (size_t)i * WF_LOG_STRIDE);
+            const float4* sp = reinterpret_cast<const float4*>(&S);
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) lp[kk] = sp[kk];
+          }
+          // E. pass 2 on this block (strictly downstream lanes)
+          pass2(S, ex, dx > 0.0f);
+        }
+      }
+      __syncthreads();  // the next chunk has landed; everyone is done with this one
+    }
+
+    // ---- outputs [A.4] of block J --------------------------------------------------------------
+    if (tvalid) {
+      const int o = gidx[gofs + t];
+      float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float ue = 1.0f - fsqrt(esq[2 * j]), uc = 1.0f - fsqrt(esq[2 * j + 1]);
+        U[3 * j] = Ui[0] * ue; U[3 * j + 1] = Ui[1] * uc; U[3 * j + 2] = Ui[2] * ue;
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        m3 = fmaf(U[k] * U[k], U[k], m3);
+        mu += U[k]; mv += V[k]; mw += W[k];
+      }
+      if (o_wd) {
+        bool small = true;
+        float rr[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          rr[k] = V[k] * frcp(U[k]);
+          small = small && (U[k] > 0.0f) && (fabsf(rr[k]) <= 0.25f);
+        }
+        if (__all(small)) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) adir += atan_small(rr[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) adir += atan2f(V[k], U[k]);
+        }
+      }
+      mu *= (1.0f / 9.0f); mv *= (1.0f / 9.0f); mw *= (1.0f / 9.0f);
+      float su = 0.0f, sv = 0.0f, sw = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float du = U[k] - mu, dv = V[k] - mv, dw = W[k] - mw;
+        su = fmaf(du, du, su); sv = fmaf(dv, dv, sv); sw = fmaf(dw, dw, sw);
+      }
+      const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
+      const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cg_t));
+      float pslope;
+      const float pwr = c.rho * table_pw(c, T, veff, pslope);
+      if (c.rho * fabsf(pslope) * veff > c.knee_kappa * fmaxf(pwr, 1.0e3f))
+        atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_POWER_KNEE);
+      float4 l;
+      l.x = (TI[0] + TI[1] + TI[2]) * (1.0f / 3.0f);
+      l.y = fsqrt(su * (1.0f / 9.0f));
+      l.z = fsqrt(sv * (1.0f / 9.0f));
+      l.w = fsqrt(sw * (1.0f / 9.0f));
+      psum += pwr;
+      lsum += (l.x + l.y) + (l.z + l.w);
+      if (env_ok) {
+        const size_t oo = yofs + o;
+        if (o_power) o_power[oo] = pwr;
+        if (o_ws) o_ws[oo] = wsp;
+        if (o_wd) o_wd[oo] = wd - adir * (kRad2Deg / 9.0f);
+        if (o_load) reinterpret_cast<float4*>(o_load)[oo] = l;
+      }
+    }
+  }  // J
+
+  if (ga.risk_flags && sub == 0 && env_ok) ga.risk_flags[env] = (int)risk_lds[wave][eiw];
+  if (ea.reward) {
+#pragma unroll
+    for (int w = G / 2; w >= 1; w >>= 1) {
+      psum += __shfl_xor(psum, w);
+      lsum += __shfl_xor(lsum, w);
+    }
+    if (sub == 0 && env_ok) {
+      const float invN = __fdiv_rn(1.0f, (float)N);
+      const float wr = ea.ws_prev ? (float)ea.ws_prev[env] : ws;
+      const float r = psum * invN * 1.0e-3f * frcp(wr * wr * wr) - ea.load_coef * lsum * invN * 0.25f;
+      ea.reward[env] = r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch
+// ---------------------------------------------------------------------------------------------
+constexpr int kLLWaves = 4;
+
+template <int G>
+static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws, const double* wd,
+                            int wind_stride, const float* yaw, float* power, float* o_ws, float* o_wd, float* load, int B,
+                            const WfEnvArgs* env, const float* ll_tab, const int* cross_tie, float* src_log,
+                            const WfGroupArgs* grp, hipStream_t s) {
+  constexpr int fpb = kLLWaves * (64 / G);
+  WfGroupArgs ga = *grp;
+  const int grid = ga.blk_group ? (ga.n_slots + fpb - 1) / fpb : (B + fpb - 1) / fpb;
+  WfConsts cc = *c;
+  WfEnvArgs ea;
+  if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
+  size_t group_floats = wfk_ll_table_floats(cc.N, G);
+  int n_pad = ((cc.N + G - 1) / G) * G;
+  const size_t dyn_lds = sizeof(float) * (size_t)fpb * n_pad;
+  void* args[] = {&cc, &tab, &gidx, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &ll_tab,
+                  &group_floats, &cross_tie, &src_log, &n_pad, &ga};
+  const void* fn = wind_stride == 0 ? (const void*)&wf_step_ll_kernel<G, true, kLLWaves> : (const void*)&wf_step_ll_kernel<G, false, kLLWaves>;
+  return hipLaunchKernel(fn, dim3(grid), dim3(64 * kLLWaves), args, dyn_lds, s);
+}
+
+extern "C" int wfk_ll_farms_per_block(int G) { return kLLWaves * (64 / G); }
+
+extern "C" hipError_t wfk_launch_step_ll(int G, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
+                                         const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
+                                         float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
+                                         const int* cross_tie, float* src_log, const WfGroupArgs* grp, hipStream_t s) {
+  switch (G) {
+    case 4: return launch_ll<4>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, grp, s);
+    case 8: return launch_ll<8>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, grp, s);
+    case 16: return launch_ll<16>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, grp, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+extern "C" hipError_t wfk_ll_func_attributes(int G, int shared_speed, hipFuncAttributes* a) {
+  const void* fn = nullptr;
+  switch (G) {
+    case 4: fn = shared_speed ? (const void*)&wf_step_ll_kernel<4, true, kLLWaves> : (const void*)&wf_step_ll_kernel<4, false, kLLWaves>; break;
+    case 8: fn = shared_speed ? (const void*)&wf_step_ll_kernel<8, true, kLLWaves> : (const void*)&wf_step_ll_kernel<8, false, kLLWaves>; break;
+    case 16: fn = shared_speed ? (const void*)&wf_step_ll_kernel<16, true, kLLWaves> : (const void*)&wf_step_ll_kernel<16, false, kLLWaves>; break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipFuncGetAttributes(a, fn);
+}
