@@ -152,6 +152,8 @@ struct wf_handle {
   int* d_ll_flag = nullptr;    // [groups] 1 = cross-block tie
   float* d_src_log = nullptr;  // [launch slots][N][WF_LOG_STRIDE]
   size_t ll_groups_cap = 0, log_slots_cap = 0;
+  bool wind_sync = true;       // the wind was set by a call that synchronises anyway (host arrays, series, binned sampling)
+  int ll_ties = 2;             // cross-block ties of the current directions: 0 none, 1 all of them, 2 some / not read back
 };
 
 namespace {
@@ -435,6 +437,18 @@ int pair_table(wf_handle* h, const float** out) {
         h->ll_groups_cap = ng;
       }
       WF_HIP(h, wfk_launch_pair_table_ll(&pc, h->ll_G, (int)ng, h->d_gx, h->d_gy, h->d_ll_tab, h->d_ll_flag, h->stream));
+      // which kernel serves which direction is decided on the device (no host round trip on the asynchronous path);
+      // where the wind came through a synchronising call anyway, the flags are read back once so that a launch nobody
+      // needs is not enqueued at all
+      h->ll_ties = 2;
+      if (h->wind_sync) {
+        std::vector<int> f(ng);
+        WF_HIP(h, hipMemcpyAsync(f.data(), h->d_ll_flag, sizeof(int) * ng, hipMemcpyDeviceToHost, h->stream));
+        WF_HIP(h, hipStreamSynchronize(h->stream));
+        size_t tied = 0;
+        for (int v : f) tied += v != 0;
+        h->ll_ties = tied == 0 ? 0 : (tied == ng ? 1 : 2);
+      }
     }
     h->pair_dirty = false;
   }
@@ -542,8 +556,10 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
       WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * h->N * WF_LOG_STRIDE));
       h->log_slots_cap = slots;
     }
-    WF_HIP(h, wfk_launch_step_ll(h->ll_G, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
-                                 load, h->B, ea, h->d_ll_tab, h->d_ll_flag, h->d_src_log, &ga, h->stream));
+    if (h->ll_ties != 1)
+      WF_HIP(h, wfk_launch_step_ll(h->ll_G, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
+                                   load, h->B, ea, h->d_ll_tab, h->d_ll_flag, h->d_src_log, &ga, h->stream));
+    if (h->ll_ties == 0) return WF_OK;
     ga.pred = h->d_ll_flag;
   }
   WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
@@ -765,6 +781,7 @@ int wf_set_wind_counts(wf_handle* h, const double* ws, int n_ws, const double* w
   WF_HIP(h, wfk_launch_geometry(same_dir ? 1 : count, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
   if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));  // caller's host arrays may go away
   h->shared_dir = same_dir;
+  h->wind_sync = !on_device;
   h->wind_count = count;
   h->series_T = 0;
   h->n_groups = 0;
@@ -821,6 +838,7 @@ int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* di
   WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
   h->wind_count = h->B;
   h->shared_dir = false;
+  h->wind_sync = false;
   h->series_T = 0;
   h->n_groups = 0;
   h->ws_prev_valid = false;
@@ -859,6 +877,7 @@ int wf_wind_sample_binned(wf_handle* h, unsigned long long seed, const wf_wind_d
   int rc = build_groups(h, bins.data(), K, h->d_group_wd, !cached);
   if (rc != WF_OK) return rc;
   h->grid_step = step_deg;
+  h->wind_sync = true;
   h->wind_count = h->B;
   h->shared_dir = false;
   h->series_T = 0;
@@ -905,6 +924,7 @@ int wf_wind_series(wf_handle* h, int T, const double* ws, const double* wd, cons
     int rc = build_groups(h, st.data(), T, h->d_series_wd, true);
     if (rc != WF_OK) return rc;
   }
+  h->wind_sync = true;
   return wf_wind_series_step(h);
 }
 

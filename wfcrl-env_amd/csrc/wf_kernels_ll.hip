@@ -98,7 +98,11 @@ extern "C" hipError_t wfk_launch_pair_table_ll(const WfPairConsts* pc, int G, in
 // G: lanes per farm = turbines per block.  UWS: one wind speed for the whole batch (its derived constants live in SGPRs).
 // WPB waves per block; all of them walk the same chunk sequence, one barrier per chunk.
 template <int G, bool UWS, int WPB>
-__global__ __launch_bounds__(64 * WPB, 3 * 4 / WPB) void wf_step_ll_kernel(
+#ifndef WF_LL_OCC
+#define WF_LL_OCC 3  // waves per SIMD the register allocator is asked to make room for (measured: 2 -> 1.87 ms, 3 -> 1.60 ms,
+                     // 4 -> 2.9 ms with 168 B of spills, HornsRev1 x 65536)
+#endif
+__global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const int* __restrict__ gidx, const double* __restrict__ ws_in,
     const double* __restrict__ wd_in, int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power,
     float* __restrict__ o_ws, float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea,
