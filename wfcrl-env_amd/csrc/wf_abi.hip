@@ -42,7 +42,8 @@ extern "C" hipError_t wfk_launch_pair_table_ll(const WfPairConsts* pc, int G, in
 extern "C" hipError_t wfk_launch_step_ll(int G, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
                                          const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
                                          float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
-                                         const int* cross_tie, float* src_log, const WfGroupArgs* grp, hipStream_t s);
+                                         const int* cross_tie, float* src_log, size_t log_side_offset,
+                                         const WfGroupArgs* grp, hipStream_t s);
 extern "C" hipError_t wfk_ll_func_attributes(int G, int shared_speed, hipFuncAttributes* a);
 extern "C" hipError_t wfk_launch_fill(int n, double* a, hipStream_t s);  // a[1..n) = a[0]
 extern "C" hipError_t wfk_launch_wind_sample_binned(int B, unsigned long long seed, const double* dist, double step, double* ws,
@@ -150,7 +151,7 @@ struct wf_handle {
   int ll_G = 0;                // 0: not used for this layout / batch
   float* d_ll_tab = nullptr;   // [groups][wfk_ll_table_floats]
   int* d_ll_flag = nullptr;    // [groups] 1 = cross-block tie
-  float* d_src_log = nullptr;  // [launch slots][N][WF_LOG_STRIDE]
+  float* d_src_log = nullptr;  // [launch slots][N][WF_LOG_FLOATS], then [launch slots][N][WF_LOG_SIDE_FLOATS]
   size_t ll_groups_cap = 0, log_slots_cap = 0;
   bool wind_sync = true;       // the wind was set by a call that synchronises anyway (host arrays, series, binned sampling)
   int ll_ties = 2;             // cross-block ties of the current directions: 0 none, 1 all of them, 2 some / not read back
@@ -456,6 +457,9 @@ int pair_table(wf_handle* h, const float** out) {
   return WF_OK;
 }
 
+// turbines per farm in the source log of the one-block kernel: whole lane-group blocks
+size_t ll_npad(const wf_handle* h) { return (size_t)((h->N + h->ll_G - 1) / h->ll_G) * h->ll_G; }
+
 // Farms per block of the table-path launch of the handle's kernel variant (wf_step_kernel), and of the
 // one-block-at-a-time kernel when it is in use.  A grouped launch pads every group to a multiple of the larger of the
 // two (both are powers of two), and its block -> group list has one entry per `group_unit` farms (the smaller).
@@ -553,12 +557,13 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
     if (slots > h->log_slots_cap) {
       WF_HIP(h, hipStreamSynchronize(h->stream));
       hipFree(h->d_src_log); h->d_src_log = nullptr; h->log_slots_cap = 0;
-      WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * h->N * WF_LOG_STRIDE));
+      WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * ll_npad(h) * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
       h->log_slots_cap = slots;
     }
     if (h->ll_ties != 1)
       WF_HIP(h, wfk_launch_step_ll(h->ll_G, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
-                                   load, h->B, ea, h->d_ll_tab, h->d_ll_flag, h->d_src_log, &ga, h->stream));
+                                   load, h->B, ea, h->d_ll_tab, h->d_ll_flag, h->d_src_log,
+                                   h->log_slots_cap * ll_npad(h) * WF_LOG_FLOATS, &ga, h->stream));
     if (h->ll_ties == 0) return WF_OK;
     ga.pred = h->d_ll_flag;
   }

@@ -143,10 +143,10 @@ inline size_t wf_ll_block_offset(int J, int N, int G) {
   }
   return off;
 }
-// Source log of wf_step_ll_kernel: WF_LOG_FLOATS floats per (farm, source), one 128-byte line each (no two records
-// share a cache line: a line is first touched by its writer).
-#define WF_LOG_FLOATS 24
-#define WF_LOG_STRIDE 32
+// Source log of wf_step_ll_kernel: WF_LOG_FLOATS floats (64 bytes) per (farm, source) + a 16-byte side record that only
+// split-TI sources write and read (wf_kernels_ll.hip: SrcLog, WfLogSide); the side array follows the main one.
+#define WF_LOG_FLOATS 16
+#define WF_LOG_SIDE_FLOATS 4
 
 struct WfPairConsts {
   int N;   // turbines

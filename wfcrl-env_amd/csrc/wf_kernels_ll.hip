@@ -45,16 +45,19 @@ __device__ __forceinline__ void sincos_yaw(float x, float& s, float& c) {
   }
 }
 
-// What a source leaves behind for the target blocks after its own (WF_LOG_FLOATS floats, six float4).
+// What a source leaves behind for the target blocks after its own: WF_LOG_FLOATS floats (four float4, one 64-byte
+// record: two per 128-byte line, and a block's G records are whole lines, so no line is shared between a block that is
+// still being written and one that is being read).  Whatever follows from these by one or two instructions (1.6 +- sM,
+// 1 / (sy0d sz0d), tan_th0 x0d, 1 / x0v) is re-derived by the reader.  The sign of ch_pref (> 0 by construction)
+// carries the split-TI flag; the three column TIs and dTI such a source needs live in a side array (WfLogSide).
 struct SrcLog {
   float Gy, Gwt, sy0d, sz0d;        // circulations of the transverse pass (table path), deflection sigma_0
-  float inv_s0d, lnA, lnB, sM;      // deflection far-wake constants
-  float tan_th0, sy0v, snw, kdef;   // deflection angle; deficit sigma_y0, near-wake sigma, amplitude factor
-  float x0d, kyd, d0, pj;           // column 0: deflection near-wake length, expansion rate, delta_0, log prefactor
-  float x0v, ix0v, kyv, ch_pref;    // column 0: deficit near-wake length, 1/, expansion rate; Crespo-Hernandez prefactor
-  float TI0, TI1, TI2, dTI;         // the source's column TIs before mixing and the yaw-added-recovery increment
+  float sM, tan_th0, sy0v, snw;     // sqrt(ct), deflection angle; deficit sigma_y0, near-wake sigma
+  float kdef, x0d, kyd, pj;         // deficit amplitude factor; column 0: deflection near-wake length, expansion rate, log prefactor
+  float x0v, kyv, ch_pref, spare;   // column 0: deficit near-wake length, expansion rate; +-Crespo-Hernandez prefactor
 };
 static_assert(sizeof(SrcLog) == WF_LOG_FLOATS * 4, "source log record");
+struct WfLogSide { float TI0, TI1, TI2, dTI; };  // the source's column TIs before mixing, the yaw-added-recovery increment
 
 }  // namespace
 
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
     const double* __restrict__ wd_in, int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power,
     float* __restrict__ o_ws, float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea,
     const float* __restrict__ ll_tab, size_t group_floats, const int* __restrict__ cross_tie, float* __restrict__ src_log,
-    int n_pad, const WfGroupArgs ga) {
+    size_t log_side_offset, int n_pad, const WfGroupArgs ga) {
   constexpr int EPW = 64 / G;   // farms per wave
   constexpr int CH = 64 / G;    // sources per staged chunk (64 records)
   constexpr int CHUNK_FLOATS = 64 * WF_PAIR_STRIDE;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
 
   // deflection + deficit + SOSFS + wake-added turbulence of one source on this lane's target [A.3-3, 6, 7, 8]
   // (the body of wf_step_kernel's pass 2 for one slot; S holds the source's constants, ex = {dx, dy, tipow, bits})
-  auto pass2 = [&](const SrcLog& S, const float4 ex, bool act) {
+  auto pass2 = [&](const SrcLog& S, const float* side, bool side_from_log, const float4 ex, bool act) {
     if (!act) return;
     const float dx = ex.x, dy = ex.y;
     const bool in15 = ex.z > 0.0f;
@@ -235,19 +238,20 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
     const float lin = fmaf(c.bd, dx, c.ad);
     const float amp_on = (bits & 8) ? 1.0f : 0.0f;
     SrcConsts sc;
-    sc.sy0d = S.sy0d; sc.sz0d = S.sz0d; sc.inv_s0d = S.inv_s0d; sc.lnA = S.lnA; sc.lnB = S.lnB; sc.sM = S.sM;
+    sc.sy0d = S.sy0d; sc.sz0d = S.sz0d; sc.inv_s0d = frcp(S.sy0d * S.sz0d); sc.lnA = 1.6f + S.sM; sc.lnB = 1.6f - S.sM; sc.sM = S.sM;
     sc.tan_th0 = S.tan_th0; sc.sy0v = S.sy0v; sc.snw = S.snw; sc.kdef = S.kdef;
+    const float d0 = S.tan_th0 * S.x0d, ix0v = frcp(S.x0v);
     float e1[3], e0[3];
-    const bool same = __all((S.TI0 == S.TI1) && (S.TI1 == S.TI2));
+    const bool same = !__any(S.ch_pref < 0.0f);  // the sign of ch_pref flags a split-TI source
     if (same) {
       const float xs = fmaxf(dx - S.x0d, 0.0f);
       const float syd = fmaf(S.kyd, xs, sc.sy0d), szd = fmaf(S.kyd, xs, sc.sz0d);
       const float s = fsqrt(syd * szd * sc.inv_s0d);
       const float arg = sc.lnA * fmaf(1.6f, s, -sc.sM) * frcp(sc.lnB * fmaf(1.6f, s, sc.sM));
-      const float d_far = fmaf(S.pj, flog2(arg), S.d0);
+      const float d_far = fmaf(S.pj, flog2(arg), d0);
       const float delta = ((dx > S.x0d) ? d_far : dx * sc.tan_th0) + lin;
       const bool far = dx >= S.x0v;
-      const float up = dx * S.ix0v;
+      const float up = dx * ix0v;
       const float xf = dx - S.x0v;
       const float sy = far ? fmaf(S.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
       const float sz = far ? fmaf(S.kyv, xf, c.sz0v) : fmaf(up, c.sz0v - sc.snw, sc.snw);
@@ -267,26 +271,39 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
     } else {
       // split-TI source (rare): the other two columns' constants are re-derived from the log — the numerators of the
       // near-wake lengths and the log prefactor follow from column 0's values
+      // (wave-uniform branch: SOME farm of the wave has a split-TI source; the lanes of the other farms keep column 0's
+      // constants for all three columns, and only the split farms have a side record)
+      const bool mine = S.ch_pref < 0.0f;
+      WfLogSide X = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (!mine) {
+      } else if (side_from_log) {  // agent-scope loads: served by L2, where the writer's store went
+        X.TI0 = __hip_atomic_load(side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        X.TI1 = __hip_atomic_load(side + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        X.TI2 = __hip_atomic_load(side + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        X.dTI = __hip_atomic_load(side + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        X.TI0 = side[0]; X.TI1 = side[1]; X.TI2 = side[2]; X.dTI = side[3];
+      }
       const float s_c = fsqrt(fmaxf(1.0f - S.sM * S.sM, 0.0f));       // sM^2 = ct
       const float om_sc = S.sM * S.sM * frcp(1.0f + s_c);
       const float b2om = c.beta2 * om_sc, b2om_d = c.beta2_d * om_sc;
-      const float x0num_d = S.x0d * fmaf(c.alpha4_d, S.TI0, b2om_d);
-      const float x0num_v = S.x0v * fmaf(c.alpha4, S.TI0 + S.dTI, b2om);
+      const float x0num_d = S.x0d * fmaf(c.alpha4_d, X.TI0, b2om_d);
+      const float x0num_v = S.x0v * fmaf(c.alpha4, X.TI0 + X.dTI, b2om);
       const float pfac = S.pj * S.kyd;
-      const float tis[3] = {S.TI0, S.TI1, S.TI2};
+      const float tis[3] = {X.TI0, X.TI1, X.TI2};
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         ColConsts k;
-        if (j == 0) {
-          k.x0d = S.x0d; k.kyd = S.kyd; k.d0 = S.d0; k.pj = S.pj; k.x0v = S.x0v; k.ix0v = S.ix0v; k.kyv = S.kyv;
+        if (j == 0 || !mine) {
+          k.x0d = S.x0d; k.kyd = S.kyd; k.d0 = d0; k.pj = S.pj; k.x0v = S.x0v; k.ix0v = ix0v; k.kyv = S.kyv;
         } else {
           k.x0d = x0num_d * frcp(fmaf(c.alpha4_d, tis[j], b2om_d));
           k.kyd = fmaf(c.ka_d, tis[j], c.kb_d);
           k.d0 = sc.tan_th0 * k.x0d;
           k.pj = pfac * frcp(k.kyd);
-          k.x0v = x0num_v * frcp(fmaf(c.alpha4, tis[j] + S.dTI, b2om));
+          k.x0v = x0num_v * frcp(fmaf(c.alpha4, tis[j] + X.dTI, b2om));
           k.ix0v = frcp(k.x0v);
-          k.kyv = fmaf(c.ka, tis[j] + S.dTI, c.kb);
+          k.kyv = fmaf(c.ka, tis[j] + X.dTI, c.kb);
         }
         column_deficit(c, sc, k, dx, dy + c.off[j], lin, amp_on, e1[j], e0[j]);
       }
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
     }
     cnt = rintf(cnt);
     if ((fbits & 0xc07fffffu) && in15 && (bits & 7)) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_OVERLAP);
-    const float ti = S.ch_pref * ex.z;
+    const float ti = fabsf(S.ch_pref) * ex.z;
     const float tia = in15 ? ti * (cnt * (1.0f / 9.0f)) : 0.0f;
     const float cand = fsqrt(fmaf(tia, tia, c.amb2));
 #pragma unroll
@@ -322,7 +339,11 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
 
   float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
   int q = 0;                        // running chunk index (LDS buffer q & 1)
-  float* const logf = src_log + (size_t)slot * N * WF_LOG_STRIDE;
+  // Cache-line discipline of the log (the vector L1 is not updated by this CU's own stores): a farm's records start on
+  // a 128-byte line (n_pad is a multiple of G, G is even), so a line belongs to ONE block and is never read before that
+  // block has written it.  The 16-byte side records do share lines across blocks; they are read past the L1.
+  float* const logf = src_log + (size_t)slot * n_pad * WF_LOG_FLOATS;
+  float* const logx = src_log + log_side_offset + (size_t)slot * n_pad * WF_LOG_SIDE_FLOATS;
   for (int J = 0; J < nblk; ++J) {
     const int t = J * G + sub;
     const bool tvalid = t < N;
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
       const float4* lp = reinterpret_cast<const float4*>(logf);
       float4* d = reinterpret_cast<float4*>(&nxt);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) d[k] = lp[k];
+      for (int k = 0; k < 4; ++k) d[k] = lp[k];
     }
     for (int cq = 0; cq < n_chunks; ++cq, ++q) {
       if (cq + 1 < n_chunks || J + 1 < nblk) stage_chunk(q + 1);  // lands in the other buffer while this chunk is consumed
@@ -360,13 +381,15 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
           // ---- a source of an earlier block: replay it from the log on this block's targets ------------
           const SrcLog S = nxt;
           if (i + 1 < first_own) {
-            const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)(i + 1) * WF_LOG_STRIDE);
+            const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)(i + 1) * WF_LOG_FLOATS);
             float4* d = reinterpret_cast<float4*>(&nxt);
 #pragma unroll
-            for (int kk = 0; kk < 6; ++kk) d[kk] = lp[kk];
+            for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
           }
-          if (tvalid) apply_tab(reinterpret_cast<const float4*>(rec), S.Gy, S.Gwt);  // every real turbine here has dx >= 0
-          pass2(S, ex, tvalid);
+          // no lane mask on the transverse pass: every real turbine of this block is at or downstream of an earlier
+          // block's source (dx >= 0), and the lanes beyond N (last block only) carry all-zero records
+          apply_tab(reinterpret_cast<const float4*>(rec), S.Gy, S.Gwt);
+          pass2(S, logx + (size_t)i * WF_LOG_SIDE_FLOATS, true, ex, tvalid);
         } else {
           // ---- a source of this block: the sequential recurrence, as wf_step_kernel's slot 0 --------------
           const int li = i - first_own;
@@ -435,10 +458,7 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
               S.tan_th0 = (fabsf(th0) > 0.35f) ? hw : poly;
             }
           }
-          S.inv_s0d = frcp(S.sy0d * S.sz0d);
           const float pfac = th0 * E0 * (1.0f / 5.2f) * fsqrt(S.sy0d * S.sz0d * frcp(ct)) * kLn2;
-          S.lnA = 1.6f + S.sM;
-          S.lnB = 1.6f - S.sM;
           const float x0num_d = c.D * cgd * (1.0f + s_cc) * (1.0f / 1.41421356237f);
           // D. yaw-added recovery [A.3-5] and deficit constants [A.3-6]
           const float I0 = TIs[0];
@@ -447,10 +467,11 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
           const float inv_ubar = frcp(ubar);
           const float Itot = fsqrt(fmaf(uI, uI, mix2)) * inv_ubar;
           const float Imix = mix2 * inv_ubar * inv_ubar * frcp(Itot + I0);
-          S.dTI = c.gch_gain * Imix;
+          WfLogSide X;
+          X.dTI = c.gch_gain * Imix;
           if (lane == src) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) TI[j] += S.dTI;
+            for (int j = 0; j < 3; ++j) TI[j] += X.dTI;
           }
           S.sy0v = c.sz0v * cg;
           S.snw = c.near_c * fsqrt(0.5f * ct);
@@ -460,21 +481,24 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
           const float b2om = c.beta2 * om_sc, b2om_d = c.beta2_d * om_sc;
           S.x0d = x0num_d * frcp(fmaf(c.alpha4_d, TIs[0], b2om_d));
           S.kyd = fmaf(c.ka_d, TIs[0], c.kb_d);
-          S.d0 = S.tan_th0 * S.x0d;
           S.pj = pfac * frcp(S.kyd);
-          S.x0v = x0num_v * frcp(fmaf(c.alpha4, TIs[0] + S.dTI, b2om));
-          S.ix0v = frcp(S.x0v);
-          S.kyv = fmaf(c.ka, TIs[0] + S.dTI, c.kb);
-          S.TI0 = TIs[0]; S.TI1 = TIs[1]; S.TI2 = TIs[2];
+          S.x0v = x0num_v * frcp(fmaf(c.alpha4, TIs[0] + X.dTI, b2om));
+          S.kyv = fmaf(c.ka, TIs[0] + X.dTI, c.kb);
+          X.TI0 = TIs[0]; X.TI1 = TIs[1]; X.TI2 = TIs[2];
+          const bool split = !((TIs[0] == TIs[1]) && (TIs[1] == TIs[2]));
+          S.ch_pref = split ? -S.ch_pref : S.ch_pref;  // the flag travels in the sign
+          S.spare = 0.0f;
           // the later blocks replay this source from the log
           if (J + 1 < nblk && sub == 0) {
-            float4* lp = reinterpret_cast<float4*>(logf + (size_t)i * WF_LOG_STRIDE);
+            float4* lp = reinterpret_cast<float4*>(logf + (size_t)i * WF_LOG_FLOATS);
             const float4* sp = reinterpret_cast<const float4*>(&S);
 #pragma unroll
-            for (int kk = 0; kk < 6; ++kk) lp[kk] = sp[kk];
+            for (int kk = 0; kk < 4; ++kk) lp[kk] = sp[kk];
+            if (split) *reinterpret_cast<float4*>(logx + (size_t)i * WF_LOG_SIDE_FLOATS) = make_float4(X.TI0, X.TI1, X.TI2, X.dTI);
           }
           // E. pass 2 on this block (strictly downstream lanes)
-          pass2(S, ex, dx > 0.0f);
+          const float xs_[4] = {X.TI0, X.TI1, X.TI2, X.dTI};
+          pass2(S, xs_, false, ex, dx > 0.0f);
         }
       }
       __syncthreads();  // the next chunk has landed; everyone is done with this one
@@ -564,7 +588,7 @@ constexpr int kLLWaves = 4;
 template <int G>
 static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws, const double* wd,
                             int wind_stride, const float* yaw, float* power, float* o_ws, float* o_wd, float* load, int B,
-                            const WfEnvArgs* env, const float* ll_tab, const int* cross_tie, float* src_log,
+                            const WfEnvArgs* env, const float* ll_tab, const int* cross_tie, float* src_log, size_t log_side_offset,
                             const WfGroupArgs* grp, hipStream_t s) {
   constexpr int fpb = kLLWaves * (64 / G);
   WfGroupArgs ga = *grp;
@@ -576,7 +600,7 @@ static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* g
   int n_pad = ((cc.N + G - 1) / G) * G;
   const size_t dyn_lds = sizeof(float) * (size_t)fpb * n_pad;
   void* args[] = {&cc, &tab, &gidx, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &ll_tab,
-                  &group_floats, &cross_tie, &src_log, &n_pad, &ga};
+                  &group_floats, &cross_tie, &src_log, &log_side_offset, &n_pad, &ga};
   const void* fn = wind_stride == 0 ? (const void*)&wf_step_ll_kernel<G, true, kLLWaves> : (const void*)&wf_step_ll_kernel<G, false, kLLWaves>;
   return hipLaunchKernel(fn, dim3(grid), dim3(64 * kLLWaves), args, dyn_lds, s);
 }
@@ -586,11 +610,12 @@ extern "C" int wfk_ll_farms_per_block(int G) { return kLLWaves * (64 / G); }
 extern "C" hipError_t wfk_launch_step_ll(int G, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
                                          const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
                                          float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
-                                         const int* cross_tie, float* src_log, const WfGroupArgs* grp, hipStream_t s) {
+                                         const int* cross_tie, float* src_log, size_t log_side_offset,
+                                         const WfGroupArgs* grp, hipStream_t s) {
   switch (G) {
-    case 4: return launch_ll<4>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, grp, s);
-    case 8: return launch_ll<8>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, grp, s);
-    case 16: return launch_ll<16>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, grp, s);
+    case 4: return launch_ll<4>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, s);
+    case 8: return launch_ll<8>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, s);
+    case 16: return launch_ll<16>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, s);
     default: return hipErrorInvalidValue;
   }
 }
