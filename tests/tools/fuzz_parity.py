@@ -75,6 +75,13 @@ def run(n_cases, seed, only=-1):
         fits = [v for v in VARIANTS if v[0] * v[1] >= N]
         G, S = fits[rng.integers(0, len(fits))]
         os.environ["WF_KERNEL_GS"] = f"{G}x{S}"
+        # every other case also forces the one-block-at-a-time kernel (csrc/wf_kernels_ll.hip) at a random lane-group
+        # width: it serves the table-path modes of farms with more than one block, wf_step_kernel the rest
+        llg = int(rng.choice([0, 0, 4, 8, 16]))
+        if llg and N > llg:
+            os.environ["WF_LL_G"] = str(llg)
+        else:
+            os.environ.pop("WF_LL_G", None)
         B = int(rng.integers(1, 9))
         yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
         wd0 = float(rng.choice([0.0, 90.0, 180.0, 270.0, 360.0, rng.uniform(0, 360), rng.uniform(250, 290)]))
@@ -114,7 +121,7 @@ def run(n_cases, seed, only=-1):
             nflip += k == "flip"
             if k != "ok":
                 nbad += k == "BAD"
-                print(k, dict(case=case, N=N, G=G, S=S, B=B, mode=mode, wd0=wd0, ws0=ws0, model=model,
+                print(k, dict(case=case, N=N, G=G, S=S, LL=w.kernel_info()["one_block_kernel"] and llg, B=B, mode=mode, wd0=wd0, ws0=ws0, model=model,
                               table=w.kernel_info()["pair_table"]), r, flush=True)
             if only >= 0:
                 np.set_printoptions(linewidth=220, precision=5, suppress=True)
@@ -126,6 +133,7 @@ def run(n_cases, seed, only=-1):
         if run:
             w.close()
     os.environ.pop("WF_KERNEL_GS", None)
+    os.environ.pop("WF_LL_G", None)
     print(f"fuzz: {n_cases} cases x 3 wind modes: {nflip} threshold flips, {nbad} violations")
     return nflip, nbad
 

@@ -371,26 +371,35 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
     for (int cq = 0; cq < n_chunks; ++cq, ++q) {
       if (cq + 1 < n_chunks || J + 1 < nblk) stage_chunk(q + 1);  // lands in the other buffer while this chunk is consumed
       const float* buf = &prow[q & 1][0];
+      const int i0 = cq * CH;
+      const int k_log = min(max(first_own - i0, 0), CH);  // records [0, k_log) of the chunk belong to earlier blocks
+      const int k_end = min(n_src - i0, CH);
+      // ---- sources of earlier blocks: replayed from the log on this block's targets ----------------------
+      // (a loop of its own: the two kinds of source step share no loop-carried copies)
 #pragma unroll 1
-      for (int k = 0; k < CH; ++k) {
-        const int i = cq * CH + k;
-        if (i >= n_src) break;
+      for (int k = 0; k < k_log; ++k) {
+        const int i = i0 + k;
         const float* rec = buf + (k * G + sub) * WF_PAIR_STRIDE;
         const float4 ex = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
-        if (i < first_own) {
-          // ---- a source of an earlier block: replay it from the log on this block's targets ------------
-          const SrcLog S = nxt;
-          if (i + 1 < first_own) {
-            const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)(i + 1) * WF_LOG_FLOATS);
-            float4* d = reinterpret_cast<float4*>(&nxt);
+        const SrcLog S = nxt;
+        if (i + 1 < first_own) {
+          const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)(i + 1) * WF_LOG_FLOATS);
+          float4* d = reinterpret_cast<float4*>(&nxt);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
-          }
-          // no lane mask on the transverse pass: every real turbine of this block is at or downstream of an earlier
-          // block's source (dx >= 0), and the lanes beyond N (last block only) carry all-zero records
-          apply_tab(reinterpret_cast<const float4*>(rec), S.Gy, S.Gwt);
-          pass2(S, logx + (size_t)i * WF_LOG_SIDE_FLOATS, true, ex, tvalid);
-        } else {
+          for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
+        }
+        // no lane mask on the transverse pass: every real turbine of this block is at or downstream of an earlier
+        // block's source (dx >= 0), and the lanes beyond N (last block only) carry all-zero records
+        apply_tab(reinterpret_cast<const float4*>(rec), S.Gy, S.Gwt);
+        pass2(S, logx + (size_t)i * WF_LOG_SIDE_FLOATS, true, ex, tvalid);
+      }
+      // ---- sources of this block: the sequential recurrence, as wf_step_kernel's slot 0 -----------------
+#pragma unroll 1
+      for (int k = k_log; k < k_end; ++k) {
+        const int i = i0 + k;
+        const float* rec = buf + (k * G + sub) * WF_PAIR_STRIDE;
+        const float4 ex = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
+        {
           // ---- a source of this block: the sequential recurrence, as wf_step_kernel's slot 0 --------------
           const int li = i - first_own;
           const int src = gbase + li;
