@@ -2,10 +2,10 @@
 usage: python tools/all_configs.py [steps]"""
 import json, os, subprocess, sys
 steps = sys.argv[1] if len(sys.argv) > 1 else "40"
-runs = [("cfg2", [], {}), ("cfg3", [], {}), ("cfg3b", [], {}), ("cfg4", [], {}),
-        ("cfg4", [], {"WF_NO_PAIR_TABLE": "1"}), ("cfg5", [], {}), ("cfg5", ["--per-env-wind"], {})]
+runs = [("cfg2", [], {}), ("cfg3", [], {}), ("cfg3b", [], {}), ("cfg4", [], {}), ("cfg4", [], {"WF_LL": "0"}),
+        ("cfg4", [], {"WF_NO_PAIR_TABLE": "1"}), ("cfg5", [], {}), ("cfg5", [], {"WF_LL": "0"}), ("cfg5", ["--per-env-wind"], {})]
 for cfg, extra, env in runs:
-    cmd = [sys.executable, "bench.py", "--config", cfg, "--steps", steps, "--cpu-seconds", "1"] + extra
+    cmd = [sys.executable, "bench.py", "--config", cfg, "--steps", steps, "--cpu-seconds", "1", "--no-env-leg"] + extra
     out = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True).stdout.strip().splitlines()
     try:
         d = json.loads(out[-1])
