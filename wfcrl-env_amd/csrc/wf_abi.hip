@@ -266,8 +266,11 @@ int pick_ll(int N, int B) {
     const int g = atoi(force);
     return ((g == 4 || g == 8 || g == 16) && N > g) ? g : 0;
   }
-  if (N <= 32 || B < 4096) return 0;
-  return 8;
+  // measured (profiles/r02_v20_one_block_kernel_sweep.txt, 65536 farms): N = 80: 1.58 ms at G = 8 or 4 against 2.05 ms of the
+  // register-slot kernel and 1.92 at G = 16; N = 91: 2.14 (G = 8) / 2.22 (4) / 2.51 (16) against 2.63; N = 32: 0.36 at G = 4
+  // against 0.43 (0.40 at G = 8)
+  if (N <= 16 || B < 4096) return 0;
+  return N <= 32 ? 4 : 8;
 }
 
 int build_consts(wf_handle* h) {
