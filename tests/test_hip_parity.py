@@ -730,7 +730,7 @@ def test_model_surface_of_the_case_yaml(layouts, model):
     w.close()
 
 
-@pytest.mark.parametrize("G", [4, 8, 16])
+@pytest.mark.parametrize("G", ["4", "8", "16", "4x2"])
 @pytest.mark.parametrize("name,wdir", [("HornsRev1_", 270.0), ("HornsRev2_", 243.0), ("Turb_TCRWP_", 281.0), ("Ormonde_", 200.0)])
 def test_one_block_at_a_time_kernel(layouts, name, wdir, G, monkeypatch):
     """wf_step_ll_kernel (csrc/wf_kernels_ll.hip: one target block in registers, earlier sources replayed from the source
@@ -740,16 +740,17 @@ def test_one_block_at_a_time_kernel(layouts, name, wdir, G, monkeypatch):
 
     l = layouts[name]
     N = l["num_turbines"]
-    if N <= G:
+    lanes, slots = (int(v) for v in (G + "x1").split("x")[:2])
+    if N <= lanes * slots:
         pytest.skip("single block")
-    rng = np.random.default_rng(N * 10 + G)
+    rng = np.random.default_rng(N * 10 + lanes + slots)
     B = 133  # not a multiple of the farms per block
     yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
-    monkeypatch.setenv("WF_LL_G", str(G))
+    monkeypatch.setenv("WF_LL_G", G)
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
     w.set_wind(8.5, wdir)
     info = w.kernel_info()
-    assert info["one_block_kernel"] == 1 and info["lanes_per_env"] == G and info["pair_table"] == 1
+    assert info["one_block_kernel"] == 1 and (info["lanes_per_env"], info["slots_per_lane"]) == (lanes, slots) and info["pair_table"] == 1
     a = _with_flags(w, w.step(yaw))
     _check(a, _oracle(l["xcoords"], l["ycoords"], 8.5, wdir, yaw))
     ws = rng.uniform(4, 16, B)
@@ -779,7 +780,7 @@ def test_one_block_at_a_time_kernel(layouts, name, wdir, G, monkeypatch):
     assert np.abs(a["wind_direction"] - a0["wind_direction"])[both].max() < 2e-4
 
 
-@pytest.mark.parametrize("G", [4, 8])
+@pytest.mark.parametrize("G", ["4", "8", "4x2"])
 def test_one_block_kernel_hands_cross_block_ties_back(layouts, G, monkeypatch):
     """Axis-aligned grids at wd = 270 have exact x' ties that straddle lane-group blocks: the device-side flag of the
     target-block table routes such a direction to wf_step_kernel (no host round trip); other directions of the same
@@ -787,10 +788,10 @@ def test_one_block_kernel_hands_cross_block_ties_back(layouts, G, monkeypatch):
     from wfcrl_env_amd.backend import WfStep
 
     l = layouts["Turb32_Row5_"]
-    rng = np.random.default_rng(G)
+    rng = np.random.default_rng(len(G))
     B = 64
     yaw = rng.uniform(-30, 30, (B, 32)).astype(np.float32)
-    monkeypatch.setenv("WF_LL_G", str(G))
+    monkeypatch.setenv("WF_LL_G", G)
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
     for wdir in (270.0, 263.0, 270.0):
         w.set_wind(8.0, wdir)

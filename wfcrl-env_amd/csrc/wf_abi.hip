@@ -39,12 +39,12 @@ extern "C" size_t wfk_ll_table_floats(int N, int G);
 extern "C" int wfk_ll_farms_per_block(int G);
 extern "C" hipError_t wfk_launch_pair_table_ll(const WfPairConsts* pc, int G, int n_groups, const double* gx, const double* gy,
                                                float* tab, int* cross_tie, hipStream_t s);
-extern "C" hipError_t wfk_launch_step_ll(int G, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
+extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
                                          const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
                                          float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
                                          const int* cross_tie, float* src_log, size_t log_side_offset,
                                          const WfGroupArgs* grp, hipStream_t s);
-extern "C" hipError_t wfk_ll_func_attributes(int G, int shared_speed, hipFuncAttributes* a);
+extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, hipFuncAttributes* a);
 extern "C" hipError_t wfk_launch_fill(int n, double* a, hipStream_t s);  // a[1..n) = a[0]
 extern "C" hipError_t wfk_launch_wind_sample_binned(int B, unsigned long long seed, const double* dist, double step, double* ws,
                                                     double* wd, int* bin, hipStream_t s);
@@ -148,7 +148,7 @@ struct wf_handle {
   // One-block-at-a-time kernel (wf_kernels_ll.hip) for the pair-table path of farms with several lane-group blocks:
   // its own table layout, the per-farm source log, and the per-direction flag that hands a direction with x' ties
   // across a block boundary back to wf_step_kernel
-  int ll_G = 0;                // 0: not used for this layout / batch
+  int ll_G = 0, ll_S = 1;      // lanes per farm and target slots per lane of that kernel; ll_G = 0: not used
   float* d_ll_tab = nullptr;   // [groups][wfk_ll_table_floats]
   int* d_ll_flag = nullptr;    // [groups] 1 = cross-block tie
   float* d_src_log = nullptr;  // [launch slots][N][WF_LOG_FLOATS], then [launch slots][N][WF_LOG_SIDE_FLOATS]
@@ -257,20 +257,23 @@ int pick_variant(int N, int B) {
 // Lane-group width of the one-block-at-a-time kernel for N turbines and B farms, 0 = keep wf_step_kernel.  It pays once
 // the farm spans several blocks (the register-slot kernel is then pinned at two waves per SIMD by its 27 S state
 // registers) and the batch fills the chip; WF_LL=0 disables it, WF_LL_G=<4|8|16> forces a width (A/B runs).
-int pick_ll(int N, int B) {
+int pick_ll(int N, int B) {  // returns (G << 4) | S, 0 = keep wf_step_kernel
   const char* off = getenv("WF_LL");
   if (off && off[0] == '0') return 0;
   if (N > WF_PAIR_MAX_N) return 0;
-  const char* force = getenv("WF_LL_G");
+  const char* force = getenv("WF_LL_G");  // "8" or "4x2"
   if (force) {
-    const int g = atoi(force);
-    return ((g == 4 || g == 8 || g == 16) && N > g) ? g : 0;
+    int g = 0, sl = 1;
+    if (sscanf(force, "%dx%d", &g, &sl) < 1) return 0;
+    const bool ok = ((g == 4 || g == 8 || g == 16) && sl == 1) || (g == 4 && sl == 2);
+    return (ok && N > g * sl) ? ((g << 4) | sl) : 0;
   }
-  // measured (profiles/r02_v20_one_block_kernel_sweep.txt, 65536 farms): N = 80: 1.58 ms at G = 8 or 4 against 2.05 ms of the
-  // register-slot kernel and 1.92 at G = 16; N = 91: 2.14 (G = 8) / 2.22 (4) / 2.51 (16) against 2.63; N = 32: 0.36 at G = 4
-  // against 0.43 (0.40 at G = 8)
+  // measured (profiles/r02_v21_one_block_kernel_sweep.txt, 65536 farms; register-slot kernel / G = 4 / 8 / 4x2, ms): N = 80:
+  // 2.04 / 1.64 / 1.62 / 1.45; N = 91: 2.62 / 2.29 / 2.19 / 2.00; N = 32: 0.43 / 0.37 / 0.41 / 0.34.  Two slots at G = 4 (eight
+  // turbines per block, sixteen farms per wave sharing the per-source phase, half the log re-reads of G = 4 alone) win
+  // although their 54 state registers leave two waves per SIMD.
   if (N <= 16 || B < 4096) return 0;
-  return N <= 32 ? 4 : 8;
+  return (4 << 4) | 2;
 }
 
 int build_consts(wf_handle* h) {
@@ -436,11 +439,11 @@ int pair_table(wf_handle* h, const float** out) {
       if (!h->d_ll_tab || h->ll_groups_cap < ng) {
         hipFree(h->d_ll_tab); hipFree(h->d_ll_flag);
         h->d_ll_tab = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = 0;
-        WF_HIP(h, hipMalloc(&h->d_ll_tab, sizeof(float) * ng * wfk_ll_table_floats(h->N, h->ll_G)));
+        WF_HIP(h, hipMalloc(&h->d_ll_tab, sizeof(float) * ng * wfk_ll_table_floats(h->N, h->ll_G * h->ll_S)));
         WF_HIP(h, hipMalloc(&h->d_ll_flag, sizeof(int) * ng));
         h->ll_groups_cap = ng;
       }
-      WF_HIP(h, wfk_launch_pair_table_ll(&pc, h->ll_G, (int)ng, h->d_gx, h->d_gy, h->d_ll_tab, h->d_ll_flag, h->stream));
+      WF_HIP(h, wfk_launch_pair_table_ll(&pc, h->ll_G * h->ll_S, (int)ng, h->d_gx, h->d_gy, h->d_ll_tab, h->d_ll_flag, h->stream));
       // which kernel serves which direction is decided on the device (no host round trip on the asynchronous path);
       // where the wind came through a synchronising call anyway, the flags are read back once so that a launch nobody
       // needs is not enqueued at all
@@ -461,7 +464,10 @@ int pair_table(wf_handle* h, const float** out) {
 }
 
 // turbines per farm in the source log of the one-block kernel: whole lane-group blocks
-size_t ll_npad(const wf_handle* h) { return (size_t)((h->N + h->ll_G - 1) / h->ll_G) * h->ll_G; }
+size_t ll_npad(const wf_handle* h) {
+  const int gs = h->ll_G * h->ll_S;
+  return (size_t)((h->N + gs - 1) / gs) * gs;
+}
 
 // Farms per block of the table-path launch of the handle's kernel variant (wf_step_kernel), and of the
 // one-block-at-a-time kernel when it is in use.  A grouped launch pads every group to a multiple of the larger of the
@@ -564,7 +570,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
       h->log_slots_cap = slots;
     }
     if (h->ll_ties != 1)
-      WF_HIP(h, wfk_launch_step_ll(h->ll_G, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
+      WF_HIP(h, wfk_launch_step_ll(h->ll_G, h->ll_S, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
                                    load, h->B, ea, h->d_ll_tab, h->d_ll_flag, h->d_src_log,
                                    h->log_slots_cap * ll_npad(h) * WF_LOG_FLOATS, &ga, h->stream));
     if (h->ll_ties == 0) return WF_OK;
@@ -700,10 +706,10 @@ int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
   const int v = pick_variant(n, h->B);
   if (v < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
   const int llg = pick_ll(n, h->B);
-  if (llg != h->ll_G || n != h->N) {  // the target-block table and the source log are laid out for (N, G)
+  if ((llg >> 4) != h->ll_G || (llg ? (llg & 15) : 1) != h->ll_S || n != h->N) {  // table and source log are laid out for (N, G, S)
     hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
     h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
-    h->ll_G = llg;
+    h->ll_G = llg >> 4; h->ll_S = llg ? (llg & 15) : 1;
   }
   h->lx.assign(x, x + n); h->ly.assign(y, y + n);
   double xmin = x[0], xmax = x[0], ymin = y[0], ymax = y[0];
@@ -733,10 +739,10 @@ int wf_set_batch(wf_handle* h, int B) {
     const int v = pick_variant(h->N, B);
     if (v < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
     const int llg = pick_ll(h->N, B);
-    if (llg != h->ll_G) {
+    if ((llg >> 4) != h->ll_G || (llg ? (llg & 15) : 1) != h->ll_S) {
       hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
       h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
-      h->ll_G = llg; h->pair_dirty = true;
+      h->ll_G = llg >> 4; h->ll_S = llg ? (llg & 15) : 1; h->pair_dirty = true;
     }
     if (v != h->variant) {  // the pair table is laid out for the variant's capacity
       hipFree(h->d_pair_tab); hipFree(h->d_pair_first);
@@ -1166,8 +1172,8 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   if (info->one_block_kernel) {
     // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
     // fields above would describe) is enqueued behind it for the directions that have one
-    WF_HIP(h, wfk_ll_func_attributes(h->ll_G, h->wind_count == 1 ? 1 : 0, &a));
-    info->lanes_per_env = h->ll_G; info->slots_per_lane = 1;
+    WF_HIP(h, wfk_ll_func_attributes(h->ll_G, h->ll_S, h->wind_count == 1 ? 1 : 0, &a));
+    info->lanes_per_env = h->ll_G; info->slots_per_lane = h->ll_S;
     info->envs_per_block = wfk_ll_farms_per_block(h->ll_G); info->threads_per_block = 256;
     info->grid_blocks = (int)(((h->n_groups > 0 ? (size_t)h->n_slots : (size_t)h->B) + info->envs_per_block - 1) / info->envs_per_block);
   }

@@ -26,10 +26,23 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
+#include <utility>
 
 #include "wf_kernel_common.h"
 
 namespace {
+
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): slot loops whose index is a
+// compile-time constant inside generic lambdas (register arrays must be indexed statically)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // sin / cos of the commanded yaw from the angle in radians: |yaw| <= 45 deg for every admissible command, where the
 // Taylor polynomials below are exact to < 3e-9; larger angles (never produced by the env) take libm, wave-uniformly.
@@ -98,21 +111,27 @@ extern "C" hipError_t wfk_launch_pair_table_ll(const WfPairConsts* pc, int G, in
 // ---------------------------------------------------------------------------------------------
 // The farm step, one target block at a time
 // ---------------------------------------------------------------------------------------------
-// G: lanes per farm = turbines per block.  UWS: one wind speed for the whole batch (its derived constants live in SGPRs).
-// WPB waves per block; all of them walk the same chunk sequence, one barrier per chunk.
-template <int G, bool UWS, int WPB>
+// G: lanes per farm; S: target slots per lane — a block is the G S consecutive (sorted) turbines  t = J G S + p G + sub
+// (S = 2 halves the re-reads of the source log per farm at the same lane-group width, i.e. with as many farms per wave
+// sharing the per-source phase, for 27 more state registers).  UWS: one wind speed for the whole batch (its derived
+// constants live in SGPRs).  WPB waves per block; all of them walk the same chunk sequence, one barrier per chunk.
+template <int G, int S, bool UWS, int WPB>
+#ifndef WF_LL_OCC2
+#define WF_LL_OCC2 2  // ... for the two-slot variants
+#endif
 #ifndef WF_LL_OCC
 #define WF_LL_OCC 3  // waves per SIMD the register allocator is asked to make room for (measured: 2 -> 1.87 ms, 3 -> 1.60 ms,
                      // 4 -> 2.9 ms with 168 B of spills, HornsRev1 x 65536)
 #endif
-__global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kernel(
+__global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / WPB) void wf_step_ll_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const int* __restrict__ gidx, const double* __restrict__ ws_in,
     const double* __restrict__ wd_in, int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power,
     float* __restrict__ o_ws, float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea,
     const float* __restrict__ ll_tab, size_t group_floats, const int* __restrict__ cross_tie, float* __restrict__ src_log,
     size_t log_side_offset, int n_pad, const WfGroupArgs ga) {
   constexpr int EPW = 64 / G;   // farms per wave
-  constexpr int CH = 64 / G;    // sources per staged chunk (64 records)
+  constexpr int GS = G * S;     // turbines per block
+  constexpr int CH = 64 / GS;   // sources per staged chunk (64 records)
   constexpr int CHUNK_FLOATS = 64 * WF_PAIR_STRIDE;
   __shared__ TableLds T;
   __shared__ __attribute__((aligned(16))) float prow[2][CHUNK_FLOATS];
@@ -160,7 +179,7 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
   const int env = env_ok ? env_raw : (B - 1);
   if (sub == 0) risk_lds[wave][eiw] = 0u;
   const int N = c.N;
-  const int nblk = (N + G - 1) / G;
+  const int nblk = (N + GS - 1) / GS;
 
   auto uni = [](float v) { return UWS ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))) : v; };
   const float ws = uni((float)ws_in[(size_t)env * wind_stride]);
@@ -180,8 +199,8 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
   const bool env_mode = ea.yaw_state != nullptr;
   int moves_new = 0;
   if (env_mode && ea.action) moves_new = ea.moves[env] + 1;
-  for (int J = 0; J < nblk; ++J) {
-    const int t = J * G + sub;
+  for (int kb = 0; kb < nblk * S; ++kb) {
+    const int t = kb * G + sub;
     const bool ok = t < N;
     const size_t oi = yofs + gidx[gofs + (ok ? t : 0)];
     float yw;
@@ -210,27 +229,29 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
   __syncthreads();
 
   // ---- per-turbine state of the ONE target block in registers (as Slots<1> of wf_step_kernel) ----
-  float esq[6], V[9], W[9], TI[3];
+  float esq[S][6], V[S][9], W[S][9], TI[S][3];
   const float amb0 = fsqrt(c.amb2);
 
   // transverse velocities of one source on this lane's target [A.3-4]: record = 9 float4 {aV, bV, aW, bW}
-  auto apply_tab = [&](const float4* pr, float Gy, float Gwt) {
+  auto apply_tab = [&](auto PP, const float4* pr, float Gy, float Gwt) {
+    constexpr int p = decltype(PP)::value;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float4 cf[3] = {pr[3 * j], pr[3 * j + 1], pr[3 * j + 2]};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int q = j * 3 + k;
-        V[q] = fmaf(Gwt, cf[k].y, fmaf(Gy, cf[k].x, V[q]));
+        V[p][q] = fmaf(Gwt, cf[k].y, fmaf(Gy, cf[k].x, V[p][q]));
         const float ww = fmaf(Gwt, cf[k].w, Gy * cf[k].z);
-        W[q] += fmaxf(ww, 0.0f);  // W[W<0] = 0, quirk (5)
+        W[p][q] += fmaxf(ww, 0.0f);  // W[W<0] = 0, quirk (5)
       }
     }
   };
 
   // deflection + deficit + SOSFS + wake-added turbulence of one source on this lane's target [A.3-3, 6, 7, 8]
-  // (the body of wf_step_kernel's pass 2 for one slot; S holds the source's constants, ex = {dx, dy, tipow, bits})
-  auto pass2 = [&](const SrcLog& S, const float* side, bool side_from_log, const float4 ex, bool act) {
+  // (the body of wf_step_kernel's pass 2 for one slot; R holds the source's constants, ex = {dx, dy, tipow, bits})
+  auto pass2 = [&](auto PP, const SrcLog& R, const float* side, bool side_from_log, const float4 ex, bool act) {
+    constexpr int p = decltype(PP)::value;
     if (!act) return;
     const float dx = ex.x, dy = ex.y;
     const bool in15 = ex.z > 0.0f;
@@ -238,23 +259,23 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
     const float lin = fmaf(c.bd, dx, c.ad);
     const float amp_on = (bits & 8) ? 1.0f : 0.0f;
     SrcConsts sc;
-    sc.sy0d = S.sy0d; sc.sz0d = S.sz0d; sc.inv_s0d = frcp(S.sy0d * S.sz0d); sc.lnA = 1.6f + S.sM; sc.lnB = 1.6f - S.sM; sc.sM = S.sM;
-    sc.tan_th0 = S.tan_th0; sc.sy0v = S.sy0v; sc.snw = S.snw; sc.kdef = S.kdef;
-    const float d0 = S.tan_th0 * S.x0d, ix0v = frcp(S.x0v);
+    sc.sy0d = R.sy0d; sc.sz0d = R.sz0d; sc.inv_s0d = frcp(R.sy0d * R.sz0d); sc.lnA = 1.6f + R.sM; sc.lnB = 1.6f - R.sM; sc.sM = R.sM;
+    sc.tan_th0 = R.tan_th0; sc.sy0v = R.sy0v; sc.snw = R.snw; sc.kdef = R.kdef;
+    const float d0 = R.tan_th0 * R.x0d, ix0v = frcp(R.x0v);
     float e1[3], e0[3];
-    const bool same = !__any(S.ch_pref < 0.0f);  // the sign of ch_pref flags a split-TI source
+    const bool same = !__any(R.ch_pref < 0.0f);  // the sign of ch_pref flags a split-TI source
     if (same) {
-      const float xs = fmaxf(dx - S.x0d, 0.0f);
-      const float syd = fmaf(S.kyd, xs, sc.sy0d), szd = fmaf(S.kyd, xs, sc.sz0d);
+      const float xs = fmaxf(dx - R.x0d, 0.0f);
+      const float syd = fmaf(R.kyd, xs, sc.sy0d), szd = fmaf(R.kyd, xs, sc.sz0d);
       const float s = fsqrt(syd * szd * sc.inv_s0d);
       const float arg = sc.lnA * fmaf(1.6f, s, -sc.sM) * frcp(sc.lnB * fmaf(1.6f, s, sc.sM));
-      const float d_far = fmaf(S.pj, flog2(arg), d0);
-      const float delta = ((dx > S.x0d) ? d_far : dx * sc.tan_th0) + lin;
-      const bool far = dx >= S.x0v;
+      const float d_far = fmaf(R.pj, flog2(arg), d0);
+      const float delta = ((dx > R.x0d) ? d_far : dx * sc.tan_th0) + lin;
+      const bool far = dx >= R.x0v;
       const float up = dx * ix0v;
-      const float xf = dx - S.x0v;
-      const float sy = far ? fmaf(S.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
-      const float sz = far ? fmaf(S.kyv, xf, c.sz0v) : fmaf(up, c.sz0v - sc.snw, sc.snw);
+      const float xf = dx - R.x0v;
+      const float sy = far ? fmaf(R.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
+      const float sz = far ? fmaf(R.kyv, xf, c.sz0v) : fmaf(up, c.sz0v - sc.snw, sc.snw);
       const float isy = frcp(sy), isz = frcp(sz);
       const float xarg = sc.kdef * isy * isz;
       const float C = (xarg >= 1.0f) ? 1.0f : xarg * frcp(1.0f + fsqrt(fmaxf(1.0f - xarg, 0.0f)));
@@ -273,7 +294,7 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
       // near-wake lengths and the log prefactor follow from column 0's values
       // (wave-uniform branch: SOME farm of the wave has a split-TI source; the lanes of the other farms keep column 0's
       // constants for all three columns, and only the split farms have a side record)
-      const bool mine = S.ch_pref < 0.0f;
+      const bool mine = R.ch_pref < 0.0f;
       WfLogSide X = {0.0f, 0.0f, 0.0f, 0.0f};
       if (!mine) {
       } else if (side_from_log) {  // agent-scope loads: served by L2, where the writer's store went
@@ -284,18 +305,18 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
       } else {
         X.TI0 = side[0]; X.TI1 = side[1]; X.TI2 = side[2]; X.dTI = side[3];
       }
-      const float s_c = fsqrt(fmaxf(1.0f - S.sM * S.sM, 0.0f));       // sM^2 = ct
-      const float om_sc = S.sM * S.sM * frcp(1.0f + s_c);
+      const float s_c = fsqrt(fmaxf(1.0f - R.sM * R.sM, 0.0f));       // sM^2 = ct
+      const float om_sc = R.sM * R.sM * frcp(1.0f + s_c);
       const float b2om = c.beta2 * om_sc, b2om_d = c.beta2_d * om_sc;
-      const float x0num_d = S.x0d * fmaf(c.alpha4_d, X.TI0, b2om_d);
-      const float x0num_v = S.x0v * fmaf(c.alpha4, X.TI0 + X.dTI, b2om);
-      const float pfac = S.pj * S.kyd;
+      const float x0num_d = R.x0d * fmaf(c.alpha4_d, X.TI0, b2om_d);
+      const float x0num_v = R.x0v * fmaf(c.alpha4, X.TI0 + X.dTI, b2om);
+      const float pfac = R.pj * R.kyd;
       const float tis[3] = {X.TI0, X.TI1, X.TI2};
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         ColConsts k;
         if (j == 0 || !mine) {
-          k.x0d = S.x0d; k.kyd = S.kyd; k.d0 = d0; k.pj = S.pj; k.x0v = S.x0v; k.ix0v = ix0v; k.kyv = S.kyv;
+          k.x0d = R.x0d; k.kyd = R.kyd; k.d0 = d0; k.pj = R.pj; k.x0v = R.x0v; k.ix0v = ix0v; k.kyv = R.kyv;
         } else {
           k.x0d = x0num_d * frcp(fmaf(c.alpha4_d, tis[j], b2om_d));
           k.kyd = fmaf(c.ka_d, tis[j], c.kb_d);
@@ -310,8 +331,8 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      esq[2 * j] = fmaf(e0[j], e0[j], esq[2 * j]);
-      esq[2 * j + 1] = fmaf(e1[j], e1[j], esq[2 * j + 1]);
+      esq[p][2 * j] = fmaf(e0[j], e0[j], esq[p][2 * j]);
+      esq[p][2 * j + 1] = fmaf(e1[j], e1[j], esq[p][2 * j + 1]);
     }
     // wake-added TI [A.3-8]: only within 15 D downstream and 2 D laterally (float64 decisions of the table)
     if (!__any(in15 && (bits & 7))) return;
@@ -327,13 +348,13 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
     }
     cnt = rintf(cnt);
     if ((fbits & 0xc07fffffu) && in15 && (bits & 7)) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_OVERLAP);
-    const float ti = fabsf(S.ch_pref) * ex.z;
+    const float ti = fabsf(R.ch_pref) * ex.z;
     const float tia = in15 ? ti * (cnt * (1.0f / 9.0f)) : 0.0f;
     const float cand = fsqrt(fmaf(tia, tia, c.amb2));
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float cm = (bits & (1 << j)) ? cand : 0.0f;
-      TI[j] = __uint_as_float(max(__float_as_uint(TI[j]), __float_as_uint(cm)));
+      TI[p][j] = __uint_as_float(max(__float_as_uint(TI[p][j]), __float_as_uint(cm)));
     }
   };
 
@@ -345,20 +366,25 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
   float* const logf = src_log + (size_t)slot * n_pad * WF_LOG_FLOATS;
   float* const logx = src_log + log_side_offset + (size_t)slot * n_pad * WF_LOG_SIDE_FLOATS;
   for (int J = 0; J < nblk; ++J) {
-    const int t = J * G + sub;
-    const bool tvalid = t < N;
+    int tt[S];
+    bool tvalid[S];
+    float yaw_t[S], sg_t[S], cg_t[S];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { V[k] = 0.0f; W[k] = 0.0f; }
+    for (int p = 0; p < S; ++p) {
+      tt[p] = J * GS + p * G + sub;
+      tvalid[p] = tt[p] < N;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) esq[k] = 0.0f;
+      for (int k = 0; k < 9; ++k) { V[p][k] = 0.0f; W[p][k] = 0.0f; }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) TI[j] = amb0;
-    const float yaw_t = yawL[tvalid ? t : 0];
-    float sg_t, cg_t;
-    sincos_yaw(yaw_t * kDeg2Rad, sg_t, cg_t);  // this lane's turbine: source constants (own block) and the power output
+      for (int k = 0; k < 6; ++k) esq[p][k] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) TI[p][j] = amb0;
+      yaw_t[p] = yawL[tvalid[p] ? tt[p] : 0];
+      sincos_yaw(yaw_t[p] * kDeg2Rad, sg_t[p], cg_t[p]);  // this lane's turbines: source constants (own block), power output
+    }
 
-    const int first_own = J * G;                  // sources [0, first_own) come from the log, [first_own, n_src) are this block's
-    const int n_src = min(N, first_own + G);
+    const int first_own = J * GS;                 // sources [0, first_own) come from the log, [first_own, n_src) are this block's
+    const int n_src = min(N, first_own + GS);
     const int n_chunks = (n_src + CH - 1) / CH;
     // the first logged source's record is fetched ahead; every later one while its predecessor is being applied
     SrcLog nxt;
@@ -368,6 +394,134 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] = lp[k];
     }
+
+    // ---- one source of THIS block: the sequential recurrence, as wf_step_kernel's slot 0.  PS: the slot the source lives
+    // in; recs: its G S records in the staged chunk ----------------------------------------------------------------
+    auto own_source = [&](auto PS, int i, const float* recs) {
+      constexpr int ps = decltype(PS)::value;
+      const int src = gbase + ((i - first_own) - ps * G);  // owner lane
+      // A. the source's state
+      float fe = 0.0f, fc = 0.0f, vsum = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float ue = 1.0f - fsqrt(esq[ps][2 * j]), uc = 1.0f - fsqrt(esq[ps][2 * j + 1]);
+        fe = fmaf(ue * ue, ue, fe);
+        fc = fmaf(uc * uc, uc, fc);
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 9; ++k2) vsum += V[ps][k2];
+      const float m3 = __shfl(fmaf(U02c, fe, U1c * fc), src);
+      const float Vmean = __shfl(vsum, src) * (1.0f / 9.0f);
+      float TIs[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) TIs[j] = __shfl(TI[ps][j], src);
+      const float yaw_i = __shfl(yaw_t[ps], src);
+      const float cg = __shfl(cg_t[ps], src), sg = __shfl(sg_t[ps], src);
+      // B. circulations [A.3-1, A.3-4]
+      SrcLog Sc;
+      const float ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
+      const float ct = table_ct(c, T, ubar) * cg;
+      const float sq1 = fsqrt(1.0f - ct * cg);
+      const float a = 0.5f * ct * frcp(1.0f + sq1);
+      const float Gwr = c.gam_wr * (a - a * a) * ubar;
+      const float gt = c.gam_top * ws * ct, gb = c.gam_bot * ws * ct;
+      const float scg = sg * cg * c.sw_tv;
+      Sc.Gy = scg * ct * ws;
+      Sc.Gwt = Gwr * c.sw_tv;
+      // C. pass 1: the source's own slot (lanes upstream of it carry dx < 0 in their record), every later slot of the
+      // block, and the lanes of EARLIER slots that tie with it in x' (dx = 0 counts as downstream here [A.3-4])
+      float4 ex[S];
+      auto pass1_slot = [&](auto PP) {
+        constexpr int p = decltype(PP)::value;
+        const float* rec = recs + (p * G + sub) * WF_PAIR_STRIDE;
+        ex[p] = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
+        const bool act1 = (p > ps) ? tvalid[p] : (ex[p].x >= 0.0f);
+        if (p >= ps || __any(act1)) {
+          if (act1) apply_tab(PP, reinterpret_cast<const float4*>(rec), Sc.Gy, Sc.Gwt);
+        }
+      };
+      static_for<S>(pass1_slot);
+      float vbar = 0.0f, wbar = 0.0f;
+#pragma unroll
+      for (int k2 = 0; k2 < 9; ++k2) { vbar += V[ps][k2]; wbar += W[ps][k2]; }
+      vbar = __shfl(vbar, src) * (1.0f / 9.0f);
+      wbar = __shfl(wbar, src) * (1.0f / 9.0f);
+      // B2. steering + deflection constants [A.3-2, A.3-3]
+      float val = c.sw_steer * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
+      val = fminf(fmaxf(val, -1.0f), 1.0f);
+      const float asv = __any(fabsf(val) > 0.3f) ? asinf(val) : asin_small(val);
+      const float gd = -(yaw_i * kDeg2Rad + 0.5f * asv);
+      const float c2h = fsqrt(fmaxf(fmaf(-val, val, 1.0f), 0.0f));
+      const float chh = fsqrt(0.5f * (1.0f + c2h));
+      const float shh = 0.5f * val * frcp(chh);
+      const float cgd = fmaf(cg, chh, -sg * shh);
+      const float s_cc = fsqrt(1.0f - ct * cgd), s_c = fsqrt(1.0f - ct);
+      const float om_scc = ct * cgd * frcp(1.0f + s_cc);
+      const float om_sc = ct * frcp(1.0f + s_c);
+      Sc.sM = fsqrt(ct);
+      const float E0 = fmaf(om_sc, om_sc, fmaf(-c.e0c1, om_sc, c.e0c2));
+      Sc.sz0d = 0.5f * c.D * fsqrt((1.0f + s_cc) * frcp(2.0f * (1.0f + s_c)));
+      Sc.sy0d = Sc.sz0d * cgd;
+      const float th0 = c.dm03 * gd * frcp(cgd) * om_scc;
+      {
+        const float t2 = th0 * th0;
+        const float poly = th0 * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 0.0088632355f, 0.0218694885f), 0.0539682540f),
+                                                          0.1333333333f), 0.3333333333f), 1.0f);
+        Sc.tan_th0 = poly;
+        if (__any(fabsf(th0) > 0.35f)) {
+          const float rev = th0 * 0.15915494309189535f;
+          const float hw = __builtin_amdgcn_sinf(rev) * frcp(__builtin_amdgcn_cosf(rev));
+          Sc.tan_th0 = (fabsf(th0) > 0.35f) ? hw : poly;
+        }
+      }
+      const float pfac = th0 * E0 * (1.0f / 5.2f) * fsqrt(Sc.sy0d * Sc.sz0d * frcp(ct)) * kLn2;
+      const float x0num_d = c.D * cgd * (1.0f + s_cc) * (1.0f / 1.41421356237f);
+      // D. yaw-added recovery [A.3-5] and deficit constants [A.3-6]
+      const float I0 = TIs[0];
+      const float uI = ubar * I0;
+      const float mix2 = (vbar * vbar + wbar * wbar) * (1.0f / 3.0f);
+      const float inv_ubar = frcp(ubar);
+      const float Itot = fsqrt(fmaf(uI, uI, mix2)) * inv_ubar;
+      const float Imix = mix2 * inv_ubar * inv_ubar * frcp(Itot + I0);
+      WfLogSide X;
+      X.dTI = c.gch_gain * Imix;
+      if (lane == src) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) TI[ps][j] += X.dTI;
+      }
+      Sc.sy0v = c.sz0v * cg;
+      Sc.snw = c.near_c * fsqrt(0.5f * ct);
+      Sc.kdef = ct * cg * c.kdef;
+      Sc.ch_pref = c.ch_c * fexp2(c.ch_ai * flog2(a));
+      const float x0num_v = c.D * cg * (1.0f + s_c) * (1.0f / 1.41421356237f);
+      const float b2om = c.beta2 * om_sc, b2om_d = c.beta2_d * om_sc;
+      Sc.x0d = x0num_d * frcp(fmaf(c.alpha4_d, TIs[0], b2om_d));
+      Sc.kyd = fmaf(c.ka_d, TIs[0], c.kb_d);
+      Sc.pj = pfac * frcp(Sc.kyd);
+      Sc.x0v = x0num_v * frcp(fmaf(c.alpha4, TIs[0] + X.dTI, b2om));
+      Sc.kyv = fmaf(c.ka, TIs[0] + X.dTI, c.kb);
+      X.TI0 = TIs[0]; X.TI1 = TIs[1]; X.TI2 = TIs[2];
+      const bool split = !((TIs[0] == TIs[1]) && (TIs[1] == TIs[2]));
+      Sc.ch_pref = split ? -Sc.ch_pref : Sc.ch_pref;  // the flag travels in the sign
+      Sc.spare = 0.0f;
+      // the later blocks replay this source from the log
+      if (J + 1 < nblk && sub == 0) {
+        float4* lp = reinterpret_cast<float4*>(logf + (size_t)i * WF_LOG_FLOATS);
+        const float4* sp = reinterpret_cast<const float4*>(&Sc);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) lp[kk] = sp[kk];
+        if (split) *reinterpret_cast<float4*>(logx + (size_t)i * WF_LOG_SIDE_FLOATS) = make_float4(X.TI0, X.TI1, X.TI2, X.dTI);
+      }
+      // E. pass 2: strictly downstream lanes of the source's own slot, every later slot (an earlier slot's turbines are at
+      // or upstream of the source: nothing to do, a tie leaves deficit and TI untouched)
+      const float xs_[4] = {X.TI0, X.TI1, X.TI2, X.dTI};
+      static_for<S>([&](auto PP) {
+        constexpr int p = decltype(PP)::value;
+        if constexpr (p == ps) pass2(PP, Sc, xs_, false, ex[p], ex[p].x > 0.0f);
+        else if constexpr (p > ps) pass2(PP, Sc, xs_, false, ex[p], tvalid[p]);
+      });
+    };
+
     for (int cq = 0; cq < n_chunks; ++cq, ++q) {
       if (cq + 1 < n_chunks || J + 1 < nblk) stage_chunk(q + 1);  // lands in the other buffer while this chunk is consumed
       const float* buf = &prow[q & 1][0];
@@ -379,160 +533,61 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
 #pragma unroll 1
       for (int k = 0; k < k_log; ++k) {
         const int i = i0 + k;
-        const float* rec = buf + (k * G + sub) * WF_PAIR_STRIDE;
-        const float4 ex = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
-        const SrcLog S = nxt;
+        const SrcLog Sl = nxt;
         if (i + 1 < first_own) {
           const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)(i + 1) * WF_LOG_FLOATS);
           float4* d = reinterpret_cast<float4*>(&nxt);
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
         }
+        const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
         // no lane mask on the transverse pass: every real turbine of this block is at or downstream of an earlier
         // block's source (dx >= 0), and the lanes beyond N (last block only) carry all-zero records
-        apply_tab(reinterpret_cast<const float4*>(rec), S.Gy, S.Gwt);
-        pass2(S, logx + (size_t)i * WF_LOG_SIDE_FLOATS, true, ex, tvalid);
+        auto replay_slot = [&](auto PP) {
+          constexpr int p = decltype(PP)::value;
+          const float* rec = buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE;
+          const float4 exr = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
+          apply_tab(PP, reinterpret_cast<const float4*>(rec), Sl.Gy, Sl.Gwt);
+          pass2(PP, Sl, side, true, exr, tvalid[p]);
+        };
+        static_for<S>(replay_slot);
       }
-      // ---- sources of this block: the sequential recurrence, as wf_step_kernel's slot 0 -----------------
+      // ---- sources of this block ------------------------------------------------------------------------
 #pragma unroll 1
       for (int k = k_log; k < k_end; ++k) {
         const int i = i0 + k;
-        const float* rec = buf + (k * G + sub) * WF_PAIR_STRIDE;
-        const float4 ex = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
-        {
-          // ---- a source of this block: the sequential recurrence, as wf_step_kernel's slot 0 --------------
-          const int li = i - first_own;
-          const int src = gbase + li;
-          // A. the source's state (lane li of the group)
-          float fe = 0.0f, fc = 0.0f, vsum = 0.0f;
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const float ue = 1.0f - fsqrt(esq[2 * j]), uc = 1.0f - fsqrt(esq[2 * j + 1]);
-            fe = fmaf(ue * ue, ue, fe);
-            fc = fmaf(uc * uc, uc, fc);
-          }
-#pragma unroll
-          for (int k2 = 0; k2 < 9; ++k2) vsum += V[k2];
-          const float m3 = __shfl(fmaf(U02c, fe, U1c * fc), src);
-          const float Vmean = __shfl(vsum, src) * (1.0f / 9.0f);
-          float TIs[3];
-#pragma unroll
-          for (int j = 0; j < 3; ++j) TIs[j] = __shfl(TI[j], src);
-          const float yaw_i = __shfl(yaw_t, src);
-          const float cg = __shfl(cg_t, src), sg = __shfl(sg_t, src);
-          // B. circulations [A.3-1, A.3-4]
-          SrcLog S;
-          const float ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
-          const float ct = table_ct(c, T, ubar) * cg;
-          const float sq1 = fsqrt(1.0f - ct * cg);
-          const float a = 0.5f * ct * frcp(1.0f + sq1);
-          const float Gwr = c.gam_wr * (a - a * a) * ubar;
-          const float gt = c.gam_top * ws * ct, gb = c.gam_bot * ws * ct;
-          const float scg = sg * cg * c.sw_tv;
-          S.Gy = scg * ct * ws;
-          S.Gwt = Gwr * c.sw_tv;
-          // C. pass 1 on this block (upstream lanes of the block: dx < 0 in the record)
-          const float dx = ex.x;
-          if (dx >= 0.0f) apply_tab(reinterpret_cast<const float4*>(rec), S.Gy, S.Gwt);
-          float vbar = 0.0f, wbar = 0.0f;
-#pragma unroll
-          for (int k2 = 0; k2 < 9; ++k2) { vbar += V[k2]; wbar += W[k2]; }
-          vbar = __shfl(vbar, src) * (1.0f / 9.0f);
-          wbar = __shfl(wbar, src) * (1.0f / 9.0f);
-          // B2. steering + deflection constants [A.3-2, A.3-3]
-          float val = c.sw_steer * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
-          val = fminf(fmaxf(val, -1.0f), 1.0f);
-          const float asv = __any(fabsf(val) > 0.3f) ? asinf(val) : asin_small(val);
-          const float gd = -(yaw_i * kDeg2Rad + 0.5f * asv);
-          const float c2h = fsqrt(fmaxf(fmaf(-val, val, 1.0f), 0.0f));
-          const float ch = fsqrt(0.5f * (1.0f + c2h));
-          const float sh = 0.5f * val * frcp(ch);
-          const float cgd = fmaf(cg, ch, -sg * sh);
-          const float s_cc = fsqrt(1.0f - ct * cgd), s_c = fsqrt(1.0f - ct);
-          const float om_scc = ct * cgd * frcp(1.0f + s_cc);
-          const float om_sc = ct * frcp(1.0f + s_c);
-          S.sM = fsqrt(ct);
-          const float E0 = fmaf(om_sc, om_sc, fmaf(-c.e0c1, om_sc, c.e0c2));
-          S.sz0d = 0.5f * c.D * fsqrt((1.0f + s_cc) * frcp(2.0f * (1.0f + s_c)));
-          S.sy0d = S.sz0d * cgd;
-          const float th0 = c.dm03 * gd * frcp(cgd) * om_scc;
-          {
-            const float t2 = th0 * th0;
-            const float poly = th0 * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 0.0088632355f, 0.0218694885f), 0.0539682540f),
-                                                              0.1333333333f), 0.3333333333f), 1.0f);
-            S.tan_th0 = poly;
-            if (__any(fabsf(th0) > 0.35f)) {
-              const float rev = th0 * 0.15915494309189535f;
-              const float hw = __builtin_amdgcn_sinf(rev) * frcp(__builtin_amdgcn_cosf(rev));
-              S.tan_th0 = (fabsf(th0) > 0.35f) ? hw : poly;
-            }
-          }
-          const float pfac = th0 * E0 * (1.0f / 5.2f) * fsqrt(S.sy0d * S.sz0d * frcp(ct)) * kLn2;
-          const float x0num_d = c.D * cgd * (1.0f + s_cc) * (1.0f / 1.41421356237f);
-          // D. yaw-added recovery [A.3-5] and deficit constants [A.3-6]
-          const float I0 = TIs[0];
-          const float uI = ubar * I0;
-          const float mix2 = (vbar * vbar + wbar * wbar) * (1.0f / 3.0f);
-          const float inv_ubar = frcp(ubar);
-          const float Itot = fsqrt(fmaf(uI, uI, mix2)) * inv_ubar;
-          const float Imix = mix2 * inv_ubar * inv_ubar * frcp(Itot + I0);
-          WfLogSide X;
-          X.dTI = c.gch_gain * Imix;
-          if (lane == src) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) TI[j] += X.dTI;
-          }
-          S.sy0v = c.sz0v * cg;
-          S.snw = c.near_c * fsqrt(0.5f * ct);
-          S.kdef = ct * cg * c.kdef;
-          S.ch_pref = c.ch_c * fexp2(c.ch_ai * flog2(a));
-          const float x0num_v = c.D * cg * (1.0f + s_c) * (1.0f / 1.41421356237f);
-          const float b2om = c.beta2 * om_sc, b2om_d = c.beta2_d * om_sc;
-          S.x0d = x0num_d * frcp(fmaf(c.alpha4_d, TIs[0], b2om_d));
-          S.kyd = fmaf(c.ka_d, TIs[0], c.kb_d);
-          S.pj = pfac * frcp(S.kyd);
-          S.x0v = x0num_v * frcp(fmaf(c.alpha4, TIs[0] + X.dTI, b2om));
-          S.kyv = fmaf(c.ka, TIs[0] + X.dTI, c.kb);
-          X.TI0 = TIs[0]; X.TI1 = TIs[1]; X.TI2 = TIs[2];
-          const bool split = !((TIs[0] == TIs[1]) && (TIs[1] == TIs[2]));
-          S.ch_pref = split ? -S.ch_pref : S.ch_pref;  // the flag travels in the sign
-          S.spare = 0.0f;
-          // the later blocks replay this source from the log
-          if (J + 1 < nblk && sub == 0) {
-            float4* lp = reinterpret_cast<float4*>(logf + (size_t)i * WF_LOG_FLOATS);
-            const float4* sp = reinterpret_cast<const float4*>(&S);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) lp[kk] = sp[kk];
-            if (split) *reinterpret_cast<float4*>(logx + (size_t)i * WF_LOG_SIDE_FLOATS) = make_float4(X.TI0, X.TI1, X.TI2, X.dTI);
-          }
-          // E. pass 2 on this block (strictly downstream lanes)
-          const float xs_[4] = {X.TI0, X.TI1, X.TI2, X.dTI};
-          pass2(S, xs_, false, ex, dx > 0.0f);
-        }
+        const float* recs = buf + (k * GS) * WF_PAIR_STRIDE;
+        const int slot_of_source = (i - first_own) / G;
+        static_for<S>([&](auto PS) {
+          if (slot_of_source == decltype(PS)::value) own_source(PS, i, recs);
+        });
       }
       __syncthreads();  // the next chunk has landed; everyone is done with this one
     }
 
     // ---- outputs [A.4] of block J --------------------------------------------------------------
-    if (tvalid) {
+#pragma unroll
+    for (int p = 0; p < S; ++p) {
+      if (!tvalid[p]) continue;
+      const int t = tt[p];
       const int o = gidx[gofs + t];
       float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const float ue = 1.0f - fsqrt(esq[2 * j]), uc = 1.0f - fsqrt(esq[2 * j + 1]);
+        const float ue = 1.0f - fsqrt(esq[p][2 * j]), uc = 1.0f - fsqrt(esq[p][2 * j + 1]);
         U[3 * j] = Ui[0] * ue; U[3 * j + 1] = Ui[1] * uc; U[3 * j + 2] = Ui[2] * ue;
       }
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         m3 = fmaf(U[k] * U[k], U[k], m3);
-        mu += U[k]; mv += V[k]; mw += W[k];
+        mu += U[k]; mv += V[p][k]; mw += W[p][k];
       }
       if (o_wd) {
         bool small = true;
         float rr[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          rr[k] = V[k] * frcp(U[k]);
+          rr[k] = V[p][k] * frcp(U[k]);
           small = small && (U[k] > 0.0f) && (fabsf(rr[k]) <= 0.25f);
         }
         if (__all(small)) {
@@ -540,24 +595,24 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
           for (int k = 0; k < 9; ++k) adir += atan_small(rr[k]);
         } else {
 #pragma unroll
-          for (int k = 0; k < 9; ++k) adir += atan2f(V[k], U[k]);
+          for (int k = 0; k < 9; ++k) adir += atan2f(V[p][k], U[k]);
         }
       }
       mu *= (1.0f / 9.0f); mv *= (1.0f / 9.0f); mw *= (1.0f / 9.0f);
       float su = 0.0f, sv = 0.0f, sw = 0.0f;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        const float du = U[k] - mu, dv = V[k] - mv, dw = W[k] - mw;
+        const float du = U[k] - mu, dv = V[p][k] - mv, dw = W[p][k] - mw;
         su = fmaf(du, du, su); sv = fmaf(dv, dv, sv); sw = fmaf(dw, dw, sw);
       }
       const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
-      const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cg_t));
+      const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cg_t[p]));
       float pslope;
       const float pwr = c.rho * table_pw(c, T, veff, pslope);
       if (c.rho * fabsf(pslope) * veff > c.knee_kappa * fmaxf(pwr, 1.0e3f))
         atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_POWER_KNEE);
       float4 l;
-      l.x = (TI[0] + TI[1] + TI[2]) * (1.0f / 3.0f);
+      l.x = (TI[p][0] + TI[p][1] + TI[p][2]) * (1.0f / 3.0f);
       l.y = fsqrt(su * (1.0f / 9.0f));
       l.z = fsqrt(sv * (1.0f / 9.0f));
       l.w = fsqrt(sw * (1.0f / 9.0f));
@@ -594,7 +649,7 @@ __global__ __launch_bounds__(64 * WPB, WF_LL_OCC * 4 / WPB) void wf_step_ll_kern
 // ---------------------------------------------------------------------------------------------
 constexpr int kLLWaves = 4;
 
-template <int G>
+template <int G, int S>
 static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws, const double* wd,
                             int wind_stride, const float* yaw, float* power, float* o_ws, float* o_wd, float* load, int B,
                             const WfEnvArgs* env, const float* ll_tab, const int* cross_tie, float* src_log, size_t log_side_offset,
@@ -605,37 +660,39 @@ static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* g
   WfConsts cc = *c;
   WfEnvArgs ea;
   if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
-  size_t group_floats = wfk_ll_table_floats(cc.N, G);
-  int n_pad = ((cc.N + G - 1) / G) * G;
+  size_t group_floats = wfk_ll_table_floats(cc.N, G * S);
+  int n_pad = ((cc.N + G * S - 1) / (G * S)) * (G * S);
   const size_t dyn_lds = sizeof(float) * (size_t)fpb * n_pad;
   void* args[] = {&cc, &tab, &gidx, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &ll_tab,
                   &group_floats, &cross_tie, &src_log, &log_side_offset, &n_pad, &ga};
-  const void* fn = wind_stride == 0 ? (const void*)&wf_step_ll_kernel<G, true, kLLWaves> : (const void*)&wf_step_ll_kernel<G, false, kLLWaves>;
+  const void* fn = wind_stride == 0 ? (const void*)&wf_step_ll_kernel<G, S, true, kLLWaves> : (const void*)&wf_step_ll_kernel<G, S, false, kLLWaves>;
   return hipLaunchKernel(fn, dim3(grid), dim3(64 * kLLWaves), args, dyn_lds, s);
 }
 
 extern "C" int wfk_ll_farms_per_block(int G) { return kLLWaves * (64 / G); }
 
-extern "C" hipError_t wfk_launch_step_ll(int G, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
+// (G, S) instantiations: one slot per lane at every width, two slots at G = 4 (eight turbines per block like G = 8, S = 1,
+// with sixteen instead of eight farms per wave sharing the per-source phase)
+#define WF_LL_DISPATCH(G_, S_, CALL)                       \
+  if (G == G_ && S == S_) return CALL(G_, S_)
+extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
                                          const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
                                          float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
                                          const int* cross_tie, float* src_log, size_t log_side_offset,
                                          const WfGroupArgs* grp, hipStream_t s) {
-  switch (G) {
-    case 4: return launch_ll<4>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, s);
-    case 8: return launch_ll<8>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, s);
-    case 16: return launch_ll<16>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, s);
-    default: return hipErrorInvalidValue;
-  }
+#define WF_LL_LAUNCH(G_, S_) launch_ll<G_, S_>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, s)
+  WF_LL_DISPATCH(4, 1, WF_LL_LAUNCH);
+  WF_LL_DISPATCH(8, 1, WF_LL_LAUNCH);
+  WF_LL_DISPATCH(16, 1, WF_LL_LAUNCH);
+  WF_LL_DISPATCH(4, 2, WF_LL_LAUNCH);
+  return hipErrorInvalidValue;
 }
 
-extern "C" hipError_t wfk_ll_func_attributes(int G, int shared_speed, hipFuncAttributes* a) {
-  const void* fn = nullptr;
-  switch (G) {
-    case 4: fn = shared_speed ? (const void*)&wf_step_ll_kernel<4, true, kLLWaves> : (const void*)&wf_step_ll_kernel<4, false, kLLWaves>; break;
-    case 8: fn = shared_speed ? (const void*)&wf_step_ll_kernel<8, true, kLLWaves> : (const void*)&wf_step_ll_kernel<8, false, kLLWaves>; break;
-    case 16: fn = shared_speed ? (const void*)&wf_step_ll_kernel<16, true, kLLWaves> : (const void*)&wf_step_ll_kernel<16, false, kLLWaves>; break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipFuncGetAttributes(a, fn);
+extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, hipFuncAttributes* a) {
+#define WF_LL_ATTR(G_, S_) hipFuncGetAttributes(a, shared_speed ? (const void*)&wf_step_ll_kernel<G_, S_, true, kLLWaves> : (const void*)&wf_step_ll_kernel<G_, S_, false, kLLWaves>)
+  WF_LL_DISPATCH(4, 1, WF_LL_ATTR);
+  WF_LL_DISPATCH(8, 1, WF_LL_ATTR);
+  WF_LL_DISPATCH(16, 1, WF_LL_ATTR);
+  WF_LL_DISPATCH(4, 2, WF_LL_ATTR);
+  return hipErrorInvalidValue;
 }
