@@ -325,7 +325,7 @@ def main():
                       "layout": layout_name.rstrip("_"),
                       "turbines": N, "env_batch_per_gpu": B, "env_batch_total": main_leg["total"],
                       "parallelism": f"env-shard x{world}" + (f" ({world} ranks sharing {ndev} GPU(s) over gloo: test mode)" if shared_devices else ""),
-                      "kernel": (f"wf_step_ll_kernel<G={info['lanes_per_env']}> (one target block at a time, source log)"
+                      "kernel": (f"wf_step_ll_kernel<G={info['lanes_per_env']},S={info['slots_per_lane']}> (one target block at a time, source log)"
                                  if info.get("one_block_kernel") else
                                  f"wf_step_kernel<G={info['lanes_per_env']},S={info['slots_per_lane']}>")
                                 + (" + shared-wind pair table" if info.get("pair_table") else ""),

@@ -12,7 +12,7 @@ python3 bench.py --gpus 2 --steps 20 --no-env-leg 2> $O/bench_n2.err | grep "^{"
 python3 tools/all_configs.py 40 > $O/all_configs.txt 2>&1
 (BP=4096 TIME=0 python3 tests/tools/gpu_check.py) > $O/parity_stats.txt 2>&1
 python3 tools/gs_sweep.py 2>&1 | grep ms/step > $O/variant_sweep.txt
-(LAYOUTS="HornsRev1_ HornsRev2_ Turb_TCRWP_" bash tools/time_ll.sh) > $O/one_block_kernel_sweep.txt 2>&1
+(LLGS="0 4 8 16 4x2" LAYOUTS="HornsRev1_ HornsRev2_ Turb_TCRWP_" bash tools/time_ll.sh) > $O/one_block_kernel_sweep.txt 2>&1
 python3 tools/time_wind_modes.py 2>&1 | grep ms/step > $O/wind_modes.txt
 python3 tools/time_series_mode.py 64 2.0 2>&1 | grep ms/step > $O/series_modes.txt
 python3 tools/latency_b1.py 2>&1 | grep update_command > $O/latency_b1.txt
