@@ -272,8 +272,15 @@ int pick_ll(int N, int B) {  // returns (G << 4) | S, 0 = keep wf_step_kernel
   // 2.04 / 1.64 / 1.62 / 1.45; N = 91: 2.62 / 2.29 / 2.19 / 2.00; N = 32: 0.43 / 0.37 / 0.41 / 0.34.  Two slots at G = 4 (eight
   // turbines per block, sixteen farms per wave sharing the per-source phase, half the log re-reads of G = 4 alone) win
   // although their 54 state registers leave two waves per SIMD.
-  if (N <= 16 || B < 4096) return 0;
-  return (4 << 4) | 2;
+  // A wave solves its 64 / G farms start to finish, so a launch runs in ROUNDS of (waves the chip holds) x (farms per
+  // wave) farms, and the fewer, fatter waves of these kernels only pay once a round is full (tools/series_group_sweep.py:
+  // 1025 blocks instead of 1024 cost 4x2 30 %).  Per round at N = 80: wf_step_kernel<16,5> 8192 farms in 0.25 ms, G = 8
+  // 24576 farms in 0.54 ms, 4x2 32768 farms in 0.72 ms; the ratios hold for other N.  Cheapest estimate wins.
+  if (N <= 16) return 0;
+  auto rounds = [](long farms, long cap) { return (double)((farms + cap - 1) / cap); };
+  const double t_old = rounds(B, 8192) * 0.254, t_g8 = rounds(B, 24576) * 0.54, t_4x2 = rounds(B, 32768) * 0.72;
+  if (t_old <= t_g8 && t_old <= t_4x2) return 0;
+  return (N > 32 && t_g8 < t_4x2) ? ((8 << 4) | 1) : ((4 << 4) | 2);
 }
 
 int build_consts(wf_handle* h) {

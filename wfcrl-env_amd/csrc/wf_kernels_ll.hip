@@ -5,19 +5,20 @@
 // visited, and with it what has to stay in registers:
 //   * wf_step_kernel ("right-looking") applies a source to ALL downstream targets at once: the state of S target slots
 //     (27 S floats) lives in VGPRs for the whole solve, which pins the S >= 4 variants at two waves per SIMD;
-//   * here ONE target block of G turbines (27 floats per lane) is in registers at a time.  Block J is first swept by all
-//     sources of the earlier blocks, whose constants (24 floats per source and farm: circulations, deflection / deficit /
-//     turbulence constants) are replayed from a per-farm SOURCE LOG in device memory, written when that source had its
-//     turn; then the block's own G sources run the sequential recurrence exactly as wf_step_kernel's slot 0 does
-//     (source phase, transverse pass, yaw-added recovery, deficit pass), appending to the log; then the block's outputs
-//     are written.  State no longer limits occupancy (three waves per SIMD at <= 168 VGPRs), the lane group can be
-//     narrower (G = 8: eight farms per wave share every per-source instruction, and 92 % instead of 84 % of the lanes
-//     are busy on the triangle at N = 80), and no register slots have to be shifted.
+//   * here ONE target block of G S turbines (27 S floats per lane, S = 1 or 2) is in registers at a time.  Block J is first
+//     swept by all sources of the earlier blocks, whose constants (16 floats per source and farm: circulations,
+//     deflection / deficit / turbulence constants) are replayed from a per-farm SOURCE LOG in device memory, written when
+//     that source had its turn; then the block's own sources run the sequential recurrence exactly as wf_step_kernel's
+//     slot 0 does (source phase, transverse pass, yaw-added recovery, deficit pass), appending to the log; then the
+//     block's outputs are written.  The lane group can be narrow — G = 4: sixteen farms per wave share every per-source
+//     instruction — because the block, not the farm, has to fit the registers; with S = 1 the kernel runs three waves
+//     per SIMD (168 VGPRs), with G = 4, S = 2 two (the pick: 24 % fewer instructions per farm than G = 8, S = 1, the
+//     same log traffic), and no register slots have to be shifted.
 //   * pair-table records are laid out per target block, [J][source i][target of J], so that the 64 records of a chunk
 //     (64 / G consecutive sources of one block) are one contiguous 11-KiB piece, staged into a double-buffered LDS slab
 //     with global_load_lds_dwordx4 one chunk ahead (one __syncthreads() per chunk);
-//   * the price is the log traffic: 96 B written per source and farm, re-read once per later block (L2 / MALL resident:
-//     it is consumed by the wave that wrote it, at most a few hundred microseconds later).
+//   * the price is the log traffic: 64 B written per source and farm, re-read once per later block (it does not fit the
+//     L2: DESIGN.md §4).
 // Precondition: no x' tie across a block boundary (a later block's source at dx = 0 from an earlier block's target owes
 // that target its transverse velocities [A.3-4], which this order cannot deliver).  wf_pair_table_ll_kernel detects it
 // per wind direction and raises a device flag; this kernel then leaves the launch to wf_step_kernel, which is always
