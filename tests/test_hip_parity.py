@@ -798,3 +798,54 @@ def test_one_block_kernel_hands_cross_block_ties_back(layouts, G, monkeypatch):
         assert w.kernel_info()["one_block_kernel"] == 1
         _check(_with_flags(w, w.step(yaw)), _oracle(l["xcoords"], l["ycoords"], 8.0, wdir, yaw))
     w.close()
+
+
+@pytest.mark.parametrize("G", ["4x2", "8"])
+@pytest.mark.parametrize("name", ["HornsRev1_", "Turb32_Row5_", "Ormonde_"])
+def test_one_block_kernel_on_the_fly_with_a_wind_per_farm(layouts, name, G, monkeypatch):
+    """A wind per farm on the one-block kernel (transverse pass on the fly from each farm's own sorted geometry), against
+    the oracle and against wf_step_kernel.  Some farms get wd = 270 exactly: on the grid layout their geometry has x' ties
+    across the kernel's blocks, and those farms — only those — are served by wf_step_kernel behind it (per-farm device
+    flags); the fused env step must advance every farm's state exactly once either way."""
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts[name]
+    N = l["num_turbines"]
+    rng = np.random.default_rng(N + len(G))
+    B = 150
+    yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
+    ws = rng.uniform(4, 16, B)
+    wd = rng.uniform(0, 360, B)
+    wd[::7] = 270.0
+    wd[3] = 90.0
+    monkeypatch.setenv("WF_LL_G", G)
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w.set_wind(ws, wd)
+    info = w.kernel_info()
+    assert info["one_block_kernel"] == 1 and info["pair_table"] == 0
+    ref = _oracle(l["xcoords"], l["ycoords"], ws, wd, yaw)
+    a = _with_flags(w, w.step(yaw))
+    _check(a, ref)
+    import torch
+
+    w.set_wind(torch.from_numpy(ws).cuda(), torch.from_numpy(wd).cuda())  # device arrays: nothing is read back
+    b = _with_flags(w, {k: v.cpu().numpy() for k, v in w.step(torch.from_numpy(yaw).cuda()).items()})
+    for k in ("power", "wind_speed", "wind_direction", "load"):
+        assert np.array_equal(a[k], b[k]), k
+    w.env_config(load_coef=0.2, budget=float("inf"))  # no actuation gate: the transition alone is under test here
+    w.env_reset()
+    act = rng.uniform(-5, 5, (B, N)).astype(np.float32)
+    e1 = w.env_step(act)
+    e2 = w.env_step(act)
+    assert np.array_equal(e1["yaw"], act) and np.array_equal(e2["yaw"], np.clip(2 * act, -40, 40).astype(np.float32))
+    st = w.env_get_state()
+    assert np.array_equal(st["moves"], np.full(B, 2)) and np.allclose(st["acc"], 2 * np.abs(act), rtol=1e-6)
+    w.close()
+    monkeypatch.setenv("WF_LL_FLY", "0")
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w.set_wind(ws, wd)
+    assert w.kernel_info()["one_block_kernel"] == 0
+    a0 = _with_flags(w, w.step(yaw))
+    w.close()
+    both = (a["flags"] == 0) & (a0["flags"] == 0)
+    assert np.abs(a["power"] / np.maximum(a0["power"], 1e3) - 1)[both].max() < 2e-5

@@ -24,7 +24,14 @@ extern "C" int wfk_variant_has_table(int i);
 extern "C" int wfk_tab_waves();
 extern "C" const void* wfk_variant_fn(int i, int kind);
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
-                                          const double* wd, double* gx, double* gy, int* gidx, hipStream_t s);
+                                          const double* wd, double* gx, double* gy, int* gidx, int tie_block, int* farm_tie,
+                                          int* any_tie, hipStream_t s);
+extern "C" int wfk_ll_has_fly(int G, int S);
+extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* gx,
+                                             const double* gy, const double* ws, const double* wd, const float* yaw,
+                                             float* power, float* o_ws, float* o_wd, float* load, int B, const WfEnvArgs* env,
+                                             const int* farm_tie, float* src_log, size_t log_side_offset,
+                                             const WfGroupArgs* grp, hipStream_t s);
 extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
                                       const double* gy, const int* gidx, int geom_stride, const double* ws,
                                       const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
@@ -44,7 +51,7 @@ extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const 
                                          float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
                                          const int* cross_tie, float* src_log, size_t log_side_offset,
                                          const WfGroupArgs* grp, hipStream_t s);
-extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, hipFuncAttributes* a);
+extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, hipFuncAttributes* a);
 extern "C" hipError_t wfk_launch_fill(int n, double* a, hipStream_t s);  // a[1..n) = a[0]
 extern "C" hipError_t wfk_launch_wind_sample_binned(int B, unsigned long long seed, const double* dist, double step, double* ws,
                                                     double* wd, int* bin, hipStream_t s);
@@ -131,6 +138,7 @@ struct wf_handle {
   int* d_pair_first = nullptr;  // per source: first sorted target index with dx >= 0
   bool pair_dirty = true;
   bool no_pair_table = false;  // WF_NO_PAIR_TABLE (A/B runs), read once at wf_create
+  bool no_ll_fly = false;      // WF_LL_FLY=0 (A/B runs): a wind per farm stays on wf_step_kernel
   bool ws_prev_valid = false;  // d_ws_prev holds the free wind of the state before the coming env step (one use)
   bool shared_dir = false;  // one wind per farm, but the same direction for all: shared geometry + pair table
   // Direction groups: farms partitioned by a small set of K distinct wind directions (series rows, binned reset
@@ -153,6 +161,8 @@ struct wf_handle {
   int* d_ll_flag = nullptr;    // [groups] 1 = cross-block tie
   float* d_src_log = nullptr;  // [launch slots][N][WF_LOG_FLOATS], then [launch slots][N][WF_LOG_SIDE_FLOATS]
   size_t ll_groups_cap = 0, log_slots_cap = 0;
+  int* d_farm_tie = nullptr;   // [B] + 1: per-farm cross-block-tie flag of the per-farm geometry, then the "any" flag
+  int farm_ties = 2;           // a wind per farm: 0 no farm has such a tie, 1 some have, 2 not read back
   bool wind_sync = true;       // the wind was set by a call that synchronises anyway (host arrays, series, binned sampling)
   int ll_ties = 2;             // cross-block ties of the current directions: 0 none, 1 all of them, 2 some / not read back
 };
@@ -192,7 +202,8 @@ int fail(wf_handle* h, int code, const std::string& msg) {
 
 void free_batch(wf_handle* h) {
   hipFree(h->d_ws); hipFree(h->d_wd); hipFree(h->d_gx); hipFree(h->d_gy); hipFree(h->d_gidx); hipFree(h->d_flags);
-  h->d_flags = nullptr;
+  hipFree(h->d_farm_tie);
+  h->d_flags = h->d_farm_tie = nullptr;
   hipFree(h->d_yaw); hipFree(h->d_out);
   hipFree(h->d_env_yaw); hipFree(h->d_env_acc); hipFree(h->d_env_act); hipFree(h->d_env_out); hipFree(h->d_env_moves);
   if (h->h_env_act) hipHostFree(h->h_env_act);
@@ -470,6 +481,24 @@ int pair_table(wf_handle* h, const float** out) {
   return WF_OK;
 }
 
+// Rotation + sort of `n_env` wind conditions on the handle's stream.  A geometry per farm (n_env == B) also yields the
+// per-farm cross-block-tie flags for the on-the-fly one-block kernel; sync_ok: the caller synchronises anyway, so the
+// "any farm tied" flag is read back and a launch nobody needs is never enqueued.
+int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
+  const bool per_farm = n_env == h->B && h->B > 1 && h->ll_G && wfk_ll_has_fly(h->ll_G, h->ll_S);
+  WF_HIP(h, wfk_launch_geometry(n_env, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd, h->d_gx, h->d_gy, h->d_gidx,
+                                per_farm ? h->ll_G * h->ll_S : 0, h->d_farm_tie, h->d_farm_tie ? h->d_farm_tie + h->B : nullptr,
+                                h->stream));
+  h->farm_ties = 2;
+  if (per_farm && sync_ok) {
+    int any = 0;
+    WF_HIP(h, hipMemcpyAsync(&any, h->d_farm_tie + h->B, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    WF_HIP(h, hipStreamSynchronize(h->stream));
+    h->farm_ties = any ? 1 : 0;
+  }
+  return WF_OK;
+}
+
 // turbines per farm in the source log of the one-block kernel: whole lane-group blocks
 size_t ll_npad(const wf_handle* h) {
   const int gs = h->ll_G * h->ll_S;
@@ -543,7 +572,7 @@ int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_
   h->n_groups = K;
   h->group_shift = 0;
   if (rebuild_geometry) {
-    WF_HIP(h, wfk_launch_geometry(K, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd_groups, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+    WF_HIP(h, wfk_launch_geometry(K, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd_groups, h->d_gx, h->d_gy, h->d_gidx, 0, nullptr, nullptr, h->stream));
     h->pair_dirty = true;
   }
   return WF_OK;
@@ -582,6 +611,23 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
                                    h->log_slots_cap * ll_npad(h) * WF_LOG_FLOATS, &ga, h->stream));
     if (h->ll_ties == 0) return WF_OK;
     ga.pred = h->d_ll_flag;
+  }
+  if (!ptab && gstride != 0 && h->B > 1 && h->ll_G && wfk_ll_has_fly(h->ll_G, h->ll_S) && !h->no_ll_fly) {
+    // a wind per farm: the one-block kernel on the fly; wf_step_kernel behind it for the farms whose own geometry has
+    // an x' tie across a block boundary (per-farm device flags from the geometry kernel)
+    const int fpb = wfk_ll_farms_per_block(h->ll_G);
+    const size_t slots = (size_t)((h->B + fpb - 1) / fpb) * fpb;
+    if (slots > h->log_slots_cap) {
+      WF_HIP(h, hipStreamSynchronize(h->stream));
+      hipFree(h->d_src_log); h->d_src_log = nullptr; h->log_slots_cap = 0;
+      WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * ll_npad(h) * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
+      h->log_slots_cap = slots;
+    }
+    WF_HIP(h, wfk_launch_step_ll_fly(h->ll_G, h->ll_S, &h->consts, h->d_tab, h->d_gidx, h->d_gx, h->d_gy, h->d_ws, h->d_wd, yaw,
+                                     power, wspd, wdir, load, h->B, ea, h->d_farm_tie, h->d_src_log,
+                                     h->log_slots_cap * ll_npad(h) * WF_LOG_FLOATS, &ga, h->stream));
+    if (h->farm_ties == 0) return WF_OK;
+    ga.farm_pred = h->d_farm_tie;
   }
   WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                             wstride, yaw, power, wspd, wdir, load, h->B, ea, ptab, h->d_pair_first, &ga, h->stream, &h->grid));
@@ -623,6 +669,7 @@ int wf_create(int device_id, wf_handle** out) {
   if (!h) return fail(nullptr, WF_E_NOMEM, "out of host memory");
   h->device = device_id;
   h->no_pair_table = getenv("WF_NO_PAIR_TABLE") != nullptr;
+  { const char* f = getenv("WF_LL_FLY"); h->no_ll_fly = f && f[0] == '0'; }
   DeviceGuard guard(device_id);
   if ((e = guard.err) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
@@ -768,6 +815,7 @@ int wf_set_batch(wf_handle* h, int B) {
     WF_HIP(h, hipMalloc(&h->d_gx, sizeof(double) * bn));
     WF_HIP(h, hipMalloc(&h->d_gy, sizeof(double) * bn));
     WF_HIP(h, hipMalloc(&h->d_flags, sizeof(int) * B));
+    WF_HIP(h, hipMalloc(&h->d_farm_tie, sizeof(int) * ((size_t)B + 1)));
     WF_HIP(h, hipMalloc(&h->d_gidx, sizeof(int) * bn));
     h->cap_env = B; h->cap_bn = bn;
   }
@@ -799,7 +847,10 @@ int wf_set_wind_counts(wf_handle* h, const double* ws, int n_ws, const double* w
   WF_HIP(h, hipMemcpyAsync(h->d_wd, wd, sizeof(double) * n_wd, kind, h->stream));
   if (n_wd == 1 && n_ws > 1)  // the step kernel reads a direction per farm next to the speed per farm
     WF_HIP(h, wfk_launch_fill(h->B, h->d_wd, h->stream));
-  WF_HIP(h, wfk_launch_geometry(same_dir ? 1 : count, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+  {
+    int rc = run_geometry(h, same_dir ? 1 : count, h->d_wd, !on_device);
+    if (rc != WF_OK) return rc;
+  }
   if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));  // caller's host arrays may go away
   h->shared_dir = same_dir;
   h->wind_sync = !on_device;
@@ -856,7 +907,10 @@ int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* di
     return fail(h, WF_E_INVALID, "invalid wind distribution parameters");
   const double dv[8] = {d.ws_scale, d.ws_shape, d.ws_lo, d.ws_hi, d.wd_mean, d.wd_std, d.wd_lo, d.wd_hi};
   WF_HIP(h, wfk_launch_wind_sample(h->B, seed, dv, h->d_ws, h->d_wd, h->stream));
-  WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+  {
+    int rc = run_geometry(h, h->B, h->d_wd, false);
+    if (rc != WF_OK) return rc;
+  }
   h->wind_count = h->B;
   h->shared_dir = false;
   h->wind_sync = false;
@@ -967,7 +1021,8 @@ int wf_wind_series_step(wf_handle* h) {
   if (h->n_groups > 0) {
     h->group_shift = h->series_t;  // group g (= start row g) is on row (g + t) % T now: geometry and tables are per row
   } else {
-    WF_HIP(h, wfk_launch_geometry(h->B, h->N, h->d_lx, h->d_ly, h->xc, h->yc, h->d_wd, h->d_gx, h->d_gy, h->d_gidx, h->stream));
+    int rc = run_geometry(h, h->B, h->d_wd, false);
+    if (rc != WF_OK) return rc;
     h->pair_dirty = true;  // see wf_wind_sample
   }
   return WF_OK;
@@ -1175,11 +1230,12 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   info->envs_per_block = wpb * (64 / G); info->threads_per_block = 64 * wpb;
   info->grid_blocks = h->n_groups > 0 ? (h->n_slots + info->envs_per_block - 1) / info->envs_per_block
                                       : (h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0);
-  info->one_block_kernel = (tab && h->ll_G) ? 1 : 0;
+  const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(h->ll_G, h->ll_S) && !h->no_ll_fly;
+  info->one_block_kernel = ((tab && h->ll_G) || ll_fly) ? 1 : 0;
   if (info->one_block_kernel) {
     // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
     // fields above would describe) is enqueued behind it for the directions that have one
-    WF_HIP(h, wfk_ll_func_attributes(h->ll_G, h->ll_S, h->wind_count == 1 ? 1 : 0, &a));
+    WF_HIP(h, wfk_ll_func_attributes(h->ll_G, h->ll_S, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, &a));
     info->lanes_per_env = h->ll_G; info->slots_per_lane = h->ll_S;
     info->envs_per_block = wfk_ll_farms_per_block(h->ll_G); info->threads_per_block = 256;
     info->grid_blocks = (int)(((h->n_groups > 0 ? (size_t)h->n_slots : (size_t)h->B) + info->envs_per_block - 1) / info->envs_per_block);

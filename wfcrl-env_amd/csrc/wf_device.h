@@ -99,6 +99,7 @@ struct WfGroupArgs {
   int n_slots;           // launch slots of the grouped launch (= entries of perm)
   const int* pred;       // [groups] when non-null, wf_step_kernel serves only the groups with pred[g] != 0 (the others
                          // are served by wf_step_ll_kernel, launched with the opposite predicate)
+  const int* farm_pred;  // [B] the same per farm (a wind per farm): wf_step_kernel serves the farms with farm_pred[b] != 0
   int* risk_flags;       // [B] out: WF_RISK_* bits of each farm; null = not written
 };
 #define WF_RISK_OVERLAP 1

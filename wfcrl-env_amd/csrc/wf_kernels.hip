@@ -59,10 +59,14 @@
 // Geometry: wd % 360, rotation about the layout's bounding-box centre, stable ascending sort [A.1]
 // One block per wind condition; float64 throughout.
 // ---------------------------------------------------------------------------------------------
+// tie_block > 0: also flag the farms whose sorted order has an exact x' tie across a boundary of blocks of tie_block
+// turbines (farm_tie[e] = 1, *any_tie = 1): the one-block-at-a-time kernel leaves those to wf_step_kernel.
 __global__ void wf_geometry_kernel(int N, const double* __restrict__ lx, const double* __restrict__ ly, double xc,
                                    double yc, const double* __restrict__ wd, double* __restrict__ gx,
-                                   double* __restrict__ gy, int* __restrict__ gidx) {
+                                   double* __restrict__ gy, int* __restrict__ gidx, int tie_block, int* __restrict__ farm_tie,
+                                   int* __restrict__ any_tie) {
   __shared__ double sx[WF_TABLE_PAD * 4];
+  __shared__ double sorted_x[WF_TABLE_PAD * 4];
   const int e = blockIdx.x;
   const int t = threadIdx.x;
   double w = fmod(wd[e], 360.0);
@@ -90,6 +94,15 @@ __global__ void wf_geometry_kernel(int N, const double* __restrict__ lx, const d
     gx[o] = xr;
     gy[o] = yr;  // absolute y' in float64: the lateral gate |y_i - y| < 2 D is decided on it [A.3-8]
     gidx[o] = t;
+    if (tie_block > 0) sorted_x[rank] = xr;
+  }
+  if (tie_block > 0) {  // uniform
+    if (t == 0) farm_tie[e] = 0;
+    __syncthreads();
+    if (t + 1 < N && (t + 1) % tie_block == 0 && sorted_x[t] == sorted_x[t + 1]) {
+      farm_tie[e] = 1;
+      *any_tie = 1;
+    }
   }
 }
 
@@ -340,8 +353,13 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   const int eiw = lane / G;  // env index inside the wave
   int env_raw = (blockIdx.x * (blockDim.x >> 6) + wave) * EPW + eiw;
   if (ga.perm) env_raw = ga.perm[env_raw];  // padded farm list of the grouped launch: -1 = no farm
-  const bool env_ok = env_raw >= 0 && env_raw < B;
+  bool env_ok = env_raw >= 0 && env_raw < B;
   const int env = env_ok ? env_raw : (B - 1);
+  if (ga.farm_pred) {  // a wind per farm, behind wf_step_ll_kernel: only the farms it left (x' tie across its blocks)
+    const int mine = env_ok ? ga.farm_pred[env] : 0;
+    env_ok = env_ok && mine;
+    if (!__syncthreads_or(mine)) return;  // nothing to do for this block (the usual case)
+  }
   if (sub == 0) risk_lds[wave][eiw] = 0u;
   const int N = c.N;
 
@@ -1066,9 +1084,15 @@ extern "C" const void* wfk_variant_fn(int i, int kind) {
 }
 
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
-                                          const double* wd, double* gx, double* gy, int* gidx, hipStream_t s) {
+                                          const double* wd, double* gx, double* gy, int* gidx, int tie_block, int* farm_tie,
+                                          int* any_tie, hipStream_t s) {
   const int threads = ((N + 63) / 64) * 64;
-  hipLaunchKernelGGL(wf_geometry_kernel, dim3(n_env), dim3(threads), 0, s, N, lx, ly, xc, yc, wd, gx, gy, gidx);
+  if (tie_block > 0) {
+    hipError_t e = hipMemsetAsync(any_tie, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(wf_geometry_kernel, dim3(n_env), dim3(threads), 0, s, N, lx, ly, xc, yc, wd, gx, gy, gidx, tie_block,
+                     farm_tie, any_tie);
   return hipGetLastError();
 }
 

@@ -116,7 +116,11 @@ extern "C" hipError_t wfk_launch_pair_table_ll(const WfPairConsts* pc, int G, in
 // (S = 2 halves the re-reads of the source log per farm at the same lane-group width, i.e. with as many farms per wave
 // sharing the per-source phase, for 27 more state registers).  UWS: one wind speed for the whole batch (its derived
 // constants live in SGPRs).  WPB waves per block; all of them walk the same chunk sequence, one barrier per chunk.
-template <int G, int S, bool UWS, int WPB>
+// TAB: pair-table path (one wind direction per launch group); false: a wind per farm — the transverse pass is evaluated
+// on the fly from the farm's own sorted geometry (source coordinates re-read from gx / gy, the targets' kept in
+// registers), nothing is staged and no barrier is needed after the start.  MC1 (on the fly only): compile-time skip of
+// the ground-mirror vortex cores that are exactly 1.0f in float32 (WfConsts::mirror_core_n <= 1).
+template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB>
 #ifndef WF_LL_OCC2
 #define WF_LL_OCC2 2  // ... for the two-slot variants
 #endif
@@ -129,11 +133,11 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     const double* __restrict__ wd_in, int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power,
     float* __restrict__ o_ws, float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea,
     const float* __restrict__ ll_tab, size_t group_floats, const int* __restrict__ cross_tie, float* __restrict__ src_log,
-    size_t log_side_offset, int n_pad, const WfGroupArgs ga) {
+    size_t log_side_offset, int n_pad, const WfGroupArgs ga, const double* __restrict__ gx, const double* __restrict__ gy) {
   constexpr int EPW = 64 / G;   // farms per wave
   constexpr int GS = G * S;     // turbines per block
   constexpr int CH = 64 / GS;   // sources per staged chunk (64 records)
-  constexpr int CHUNK_FLOATS = 64 * WF_PAIR_STRIDE;
+  constexpr int CHUNK_FLOATS = TAB ? 64 * WF_PAIR_STRIDE : 4;
   __shared__ TableLds T;
   __shared__ __attribute__((aligned(16))) float prow[2][CHUNK_FLOATS];
   __shared__ unsigned risk_lds[WPB][EPW];
@@ -145,8 +149,10 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     if (grp < 0) return;  // whole block, before any barrier
     grp = (grp + ga.shift) % ga.mod;
   }
-  if (cross_tie[grp]) return;  // this direction has an x' tie across a block boundary: wf_step_kernel serves it
-  ll_tab += (size_t)grp * group_floats;
+  if constexpr (TAB) {
+    if (cross_tie[grp]) return;  // this direction has an x' tie across a block boundary: wf_step_kernel serves it
+    ll_tab += (size_t)grp * group_floats;
+  }
 
   // chunk q of this direction's table -> LDS buffer q & 1 (the chunks of all target blocks are contiguous, in the order
   // they are consumed)
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
                                        (__attribute__((address_space(3))) void*)(l0 + ch * 1024), 16, 0, 0);
     }
   };
-  stage_chunk(0);
+  if constexpr (TAB) stage_chunk(0);
   for (int k = threadIdx.x; k < WF_TABLE_PAD; k += blockDim.x) {
     T.knot[k] = tab->knot[k];
     T.ct[k] = tab->ct[k];
@@ -176,8 +182,11 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
   const int slot = (blockIdx.x * WPB + wave) * EPW + eiw;  // launch slot of the farm: indexes the source log
   int env_raw = slot;
   if (ga.perm) env_raw = ga.perm[env_raw];
-  const bool env_ok = env_raw >= 0 && env_raw < B;
+  bool env_ok = env_raw >= 0 && env_raw < B;
   const int env = env_ok ? env_raw : (B - 1);
+  // a wind per farm: a farm whose own geometry has an x' tie across a block boundary is left to wf_step_kernel, which
+  // is enqueued behind this kernel for exactly those farms (its results here are computed and dropped)
+  if constexpr (!TAB) env_ok = env_ok && !cross_tie[env];
   if (sub == 0) risk_lds[wave][eiw] = 0u;
   const int N = c.N;
   const int nblk = (N + GS - 1) / GS;
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
   const float ovs[3] = {uni(ovh * Ui[0] * c.inv_overlap_thr), uni(ovh * Ui[1] * c.inv_overlap_thr), uni(ovh * Ui[2] * c.inv_overlap_thr)};
   const float ovc = 0.5f - ovh;
 
-  const size_t gofs = (size_t)grp * N;  // sorted geometry of the direction (group 0 for a shared wind)
+  const size_t gofs = TAB ? (size_t)grp * N : (size_t)env * N;  // sorted geometry of the direction (group 0 for a shared wind) / of the farm
   const size_t yofs = (size_t)env * N;
   float* yawL = yaw_lds + ((size_t)wave * EPW + eiw) * n_pad;
   // commanded yaw of every turbine, in sorted order; fused MDP transition as in wf_step_kernel
@@ -249,14 +258,59 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     }
   };
 
+  // the same on the fly (a wind per farm): wf_step_kernel's apply_fly — 7 + 7 distinct vortex offsets per grid column,
+  // circulations Gt = gam_top Gy, Gb = -gam_bot Gy (the tip vortices share their farm-dependent factor)
+  auto apply_fly = [&](auto PP, float dx, float dy, float Gy, float Gwt) {
+    constexpr int p = decltype(PP)::value;
+    const float Gt = c.gam_top * Gy, Gb = -c.gam_bot * Gy;
+    float dec[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dec[k] = frcp(fmaf(c.decay_a[k], dx, 1.0f));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float yL = dy + c.yoff[j];
+      const float yL2 = yL * yL;
+      const float Ey = fexp2(-yL2 * c.exp_c);
+      float A[3] = {0.0f, 0.0f, 0.0f}, Bw[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int mi = 0; mi < 7; ++mi) {
+        const float tr = fmaf(-Ey, c.ez[mi], 1.0f) * frcp(yL2 + c.zc2[mi]);
+        const float pr = c.zc[mi] * tr;
+        float tm = frcp(yL2 + c.zm2[mi]);
+        if (mi == 0 || !MC1) tm *= fmaf(-Ey, c.ezm[mi], 1.0f);  // compile-time: see mirror_core_n
+        const float pm = c.zm[mi] * tm;
+        if (mi <= 2) {
+          A[mi] = fmaf(Gt, pr, A[mi]);   Bw[mi] = fmaf(Gt, tr, Bw[mi]);      // real top
+          A[mi] = fmaf(-Gb, pm, A[mi]);  Bw[mi] = fmaf(-Gb, tm, Bw[mi]);     // mirror bottom
+        }
+        if (mi >= 4) {
+          A[mi - 4] = fmaf(Gb, pr, A[mi - 4]);   Bw[mi - 4] = fmaf(Gb, tr, Bw[mi - 4]);   // real bottom
+          A[mi - 4] = fmaf(-Gt, pm, A[mi - 4]);  Bw[mi - 4] = fmaf(-Gt, tm, Bw[mi - 4]);  // mirror top
+        }
+        if (mi >= 2 && mi <= 4) {
+          A[mi - 2] = fmaf(Gwt, pr - pm, A[mi - 2]);  // rotation, real - mirror
+          Bw[mi - 2] = fmaf(Gwt, tr - tm, Bw[mi - 2]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        V[p][j * 3 + k] = fmaf(A[k], dec[k], V[p][j * 3 + k]);
+        W[p][j * 3 + k] += fmaxf(-yL * Bw[k] * dec[k], 0.0f);  // W[W<0] = 0, quirk (5)
+      }
+    }
+  };
+
   // deflection + deficit + SOSFS + wake-added turbulence of one source on this lane's target [A.3-3, 6, 7, 8]
   // (the body of wf_step_kernel's pass 2 for one slot; R holds the source's constants, ex = {dx, dy, tipow, bits})
-  auto pass2 = [&](auto PP, const SrcLog& R, const float* side, bool side_from_log, const float4 ex, bool act) {
+  // (on the fly: ex.z is 1 / 0 for the 15 D reach and ex.w carries bit 3 only; the lateral gates and the
+  // Crespo-Hernandez distance factor are evaluated where they are needed, from the float64 y' of target and source)
+  auto pass2 = [&](auto PP, const SrcLog& R, const float* side, bool side_from_log, const float4 ex, bool act,
+                   double yt_d = 0.0, double yi_d = 0.0) {
     constexpr int p = decltype(PP)::value;
     if (!act) return;
     const float dx = ex.x, dy = ex.y;
     const bool in15 = ex.z > 0.0f;
-    const int bits = __float_as_int(ex.w);
+    int bits = __float_as_int(ex.w);
     const float lin = fmaf(c.bd, dx, c.ad);
     const float amp_on = (bits & 8) ? 1.0f : 0.0f;
     SrcConsts sc;
@@ -335,8 +389,19 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       esq[p][2 * j] = fmaf(e0[j], e0[j], esq[p][2 * j]);
       esq[p][2 * j + 1] = fmaf(e1[j], e1[j], esq[p][2 * j + 1]);
     }
-    // wake-added TI [A.3-8]: only within 15 D downstream and 2 D laterally (float64 decisions of the table)
-    if (!__any(in15 && (bits & 7))) return;
+    // wake-added TI [A.3-8]: only within 15 D downstream and 2 D laterally (float64 decisions)
+    float tipow = ex.z;
+    if constexpr (TAB) {
+      if (!__any(in15 && (bits & 7))) return;
+    } else {
+      if (!__any(in15 && (fabsf(dy) < c.twoD + c.off[2] + 1.0f))) return;  // float32 prefilter with a margin
+      const double twoD_d = 8.0 * c.q_d;
+      bits |= (fabs(yi_d - (yt_d - c.q_d)) < twoD_d) ? 1 : 0;
+      bits |= (fabs(yi_d - yt_d) < twoD_d) ? 2 : 0;
+      bits |= (fabs(yi_d - (yt_d + c.q_d)) < twoD_d) ? 4 : 0;
+      const float dxp = (bits & 8) ? dx : dx + 1.0f;
+      tipow = fexp2(c.ch_down * flog2(dxp * c.invD));
+    }
     float cnt = 0.0f;
     unsigned fbits = 0u;
 #pragma unroll
@@ -349,7 +414,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     }
     cnt = rintf(cnt);
     if ((fbits & 0xc07fffffu) && in15 && (bits & 7)) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_OVERLAP);
-    const float ti = fabsf(R.ch_pref) * ex.z;
+    const float ti = fabsf(R.ch_pref) * tipow;
     const float tia = in15 ? ti * (cnt * (1.0f / 9.0f)) : 0.0f;
     const float cand = fsqrt(fmaf(tia, tia, c.amb2));
 #pragma unroll
@@ -370,10 +435,17 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     int tt[S];
     bool tvalid[S];
     float yaw_t[S], sg_t[S], cg_t[S];
+    double xt_d[TAB ? 1 : S] = {}, yt_d[TAB ? 1 : S] = {};  // on the fly: this lane's targets' sorted coordinates (float64:
+    float yt_f[TAB ? 1 : S] = {};  // every geometric decision is taken on them), y' - yc in float32 for the distances
 #pragma unroll
     for (int p = 0; p < S; ++p) {
       tt[p] = J * GS + p * G + sub;
       tvalid[p] = tt[p] < N;
+      if constexpr (!TAB) {
+        xt_d[p] = tvalid[p] ? gx[gofs + tt[p]] : -1.0e300;  // padding is never downstream of anything
+        yt_d[p] = gy[gofs + (tvalid[p] ? tt[p] : 0)];
+        yt_f[p] = (float)(yt_d[p] - c.yc_d);
+      }
 #pragma unroll
       for (int k = 0; k < 9; ++k) { V[p][k] = 0.0f; W[p][k] = 0.0f; }
 #pragma unroll
@@ -395,6 +467,18 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] = lp[k];
     }
+
+    // on the fly: the {dx, dy, 15 D reach, bit 3} of (source at (xi, yi), this lane's target in slot p), decided in float64
+    auto fly_record = [&](auto PP, double xi, float yi_f) {
+      constexpr int p = decltype(PP)::value;
+      constexpr int q = TAB ? 0 : p;
+      float4 r;
+      r.x = (float)(xt_d[q] - xi);
+      r.y = yt_f[q] - yi_f;
+      r.z = (xt_d[q] <= xi + c.fifteenD_d) ? 1.0f : 0.0f;
+      r.w = __int_as_float((xt_d[q] > xi + 0.1) ? 8 : 0);
+      return r;
+    };
 
     // ---- one source of THIS block: the sequential recurrence, as wf_step_kernel's slot 0.  PS: the slot the source lives
     // in; recs: its G S records in the staged chunk ----------------------------------------------------------------
@@ -432,13 +516,28 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       // C. pass 1: the source's own slot (lanes upstream of it carry dx < 0 in their record), every later slot of the
       // block, and the lanes of EARLIER slots that tie with it in x' (dx = 0 counts as downstream here [A.3-4])
       float4 ex[S];
+      double xi_d = 0.0, yi_d = 0.0;
+      float yi_f = 0.0f;
+      if constexpr (!TAB) {  // the source's own coordinates (every lane of the group reads the same two words)
+        xi_d = gx[gofs + i];
+        yi_d = gy[gofs + i];
+        yi_f = (float)(yi_d - c.yc_d);
+      }
       auto pass1_slot = [&](auto PP) {
         constexpr int p = decltype(PP)::value;
-        const float* rec = recs + (p * G + sub) * WF_PAIR_STRIDE;
-        ex[p] = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
-        const bool act1 = (p > ps) ? tvalid[p] : (ex[p].x >= 0.0f);
-        if (p >= ps || __any(act1)) {
-          if (act1) apply_tab(PP, reinterpret_cast<const float4*>(rec), Sc.Gy, Sc.Gwt);
+        if constexpr (TAB) {
+          const float* rec = recs + (p * G + sub) * WF_PAIR_STRIDE;
+          ex[p] = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
+          const bool act1 = (p > ps) ? tvalid[p] : (ex[p].x >= 0.0f);
+          if (p >= ps || __any(act1)) {
+            if (act1) apply_tab(PP, reinterpret_cast<const float4*>(rec), Sc.Gy, Sc.Gwt);
+          }
+        } else {
+          ex[p] = fly_record(PP, xi_d, yi_f);
+          const bool act1 = (p > ps) ? tvalid[p] : (ex[p].x >= 0.0f);
+          if (p >= ps || __any(act1)) {
+            if (act1) apply_fly(PP, ex[p].x, ex[p].y, Sc.Gy, Sc.Gwt);
+          }
         }
       };
       static_for<S>(pass1_slot);
@@ -518,13 +617,15 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       const float xs_[4] = {X.TI0, X.TI1, X.TI2, X.dTI};
       static_for<S>([&](auto PP) {
         constexpr int p = decltype(PP)::value;
-        if constexpr (p == ps) pass2(PP, Sc, xs_, false, ex[p], ex[p].x > 0.0f);
-        else if constexpr (p > ps) pass2(PP, Sc, xs_, false, ex[p], tvalid[p]);
+        if constexpr (p == ps) pass2(PP, Sc, xs_, false, ex[p], ex[p].x > 0.0f, yt_d[TAB ? 0 : p], yi_d);
+        else if constexpr (p > ps) pass2(PP, Sc, xs_, false, ex[p], tvalid[p], yt_d[TAB ? 0 : p], yi_d);
       });
     };
 
     for (int cq = 0; cq < n_chunks; ++cq, ++q) {
-      if (cq + 1 < n_chunks || J + 1 < nblk) stage_chunk(q + 1);  // lands in the other buffer while this chunk is consumed
+      if constexpr (TAB) {
+        if (cq + 1 < n_chunks || J + 1 < nblk) stage_chunk(q + 1);  // lands in the other buffer while this chunk is consumed
+      }
       const float* buf = &prow[q & 1][0];
       const int i0 = cq * CH;
       const int k_log = min(max(first_own - i0, 0), CH);  // records [0, k_log) of the chunk belong to earlier blocks
@@ -544,12 +645,25 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
         // no lane mask on the transverse pass: every real turbine of this block is at or downstream of an earlier
         // block's source (dx >= 0), and the lanes beyond N (last block only) carry all-zero records
+        double xs_d = 0.0, ys_d = 0.0;
+        float ys_f = 0.0f;
+        if constexpr (!TAB) {
+          xs_d = gx[gofs + i];
+          ys_d = gy[gofs + i];
+          ys_f = (float)(ys_d - c.yc_d);
+        }
         auto replay_slot = [&](auto PP) {
           constexpr int p = decltype(PP)::value;
-          const float* rec = buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE;
-          const float4 exr = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
-          apply_tab(PP, reinterpret_cast<const float4*>(rec), Sl.Gy, Sl.Gwt);
-          pass2(PP, Sl, side, true, exr, tvalid[p]);
+          if constexpr (TAB) {
+            const float* rec = buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE;
+            const float4 exr = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
+            apply_tab(PP, reinterpret_cast<const float4*>(rec), Sl.Gy, Sl.Gwt);
+            pass2(PP, Sl, side, true, exr, tvalid[p]);
+          } else {
+            const float4 exr = fly_record(PP, xs_d, ys_f);
+            if (tvalid[p]) apply_fly(PP, exr.x, exr.y, Sl.Gy, Sl.Gwt);
+            pass2(PP, Sl, side, true, exr, tvalid[p], yt_d[TAB ? 0 : p], ys_d);
+          }
         };
         static_for<S>(replay_slot);
       }
@@ -563,7 +677,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
           if (slot_of_source == decltype(PS)::value) own_source(PS, i, recs);
         });
       }
-      __syncthreads();  // the next chunk has landed; everyone is done with this one
+      if constexpr (TAB) __syncthreads();  // the next chunk has landed; everyone is done with this one
     }
 
     // ---- outputs [A.4] of block J --------------------------------------------------------------
@@ -650,11 +764,11 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
 // ---------------------------------------------------------------------------------------------
 constexpr int kLLWaves = 4;
 
-template <int G, int S>
+template <int G, int S, bool TAB, bool MC1>
 static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws, const double* wd,
                             int wind_stride, const float* yaw, float* power, float* o_ws, float* o_wd, float* load, int B,
                             const WfEnvArgs* env, const float* ll_tab, const int* cross_tie, float* src_log, size_t log_side_offset,
-                            const WfGroupArgs* grp, hipStream_t s) {
+                            const WfGroupArgs* grp, const double* gx, const double* gy, hipStream_t s) {
   constexpr int fpb = kLLWaves * (64 / G);
   WfGroupArgs ga = *grp;
   const int grid = ga.blk_group ? (ga.n_slots + fpb - 1) / fpb : (B + fpb - 1) / fpb;
@@ -665,23 +779,27 @@ static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* g
   int n_pad = ((cc.N + G * S - 1) / (G * S)) * (G * S);
   const size_t dyn_lds = sizeof(float) * (size_t)fpb * n_pad;
   void* args[] = {&cc, &tab, &gidx, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &ll_tab,
-                  &group_floats, &cross_tie, &src_log, &log_side_offset, &n_pad, &ga};
-  const void* fn = wind_stride == 0 ? (const void*)&wf_step_ll_kernel<G, S, true, kLLWaves> : (const void*)&wf_step_ll_kernel<G, S, false, kLLWaves>;
+                  &group_floats, &cross_tie, &src_log, &log_side_offset, &n_pad, &ga, &gx, &gy};
+  const void* fn = (const void*)&wf_step_ll_kernel<G, S, false, TAB, MC1, kLLWaves>;
+  if constexpr (TAB) {
+    if (wind_stride == 0) fn = (const void*)&wf_step_ll_kernel<G, S, true, TAB, MC1, kLLWaves>;
+  }
   return hipLaunchKernel(fn, dim3(grid), dim3(64 * kLLWaves), args, dyn_lds, s);
 }
 
 extern "C" int wfk_ll_farms_per_block(int G) { return kLLWaves * (64 / G); }
 
-// (G, S) instantiations: one slot per lane at every width, two slots at G = 4 (eight turbines per block like G = 8, S = 1,
-// with sixteen instead of eight farms per wave sharing the per-source phase)
-#define WF_LL_DISPATCH(G_, S_, CALL)                       \
+// (G, S) instantiations of the table path: one slot per lane at every width, two slots at G = 4 (eight turbines per block
+// like G = 8, S = 1, with sixteen instead of eight farms per wave sharing the per-source phase).  On the fly (a wind
+// per farm): the two variants the rounds model ever picks, each with and without the mirror-core shortcut.
+#define WF_LL_DISPATCH(G_, S_, CALL) \
   if (G == G_ && S == S_) return CALL(G_, S_)
 extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
                                          const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
                                          float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
                                          const int* cross_tie, float* src_log, size_t log_side_offset,
                                          const WfGroupArgs* grp, hipStream_t s) {
-#define WF_LL_LAUNCH(G_, S_) launch_ll<G_, S_>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, s)
+#define WF_LL_LAUNCH(G_, S_) launch_ll<G_, S_, true, true>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, nullptr, nullptr, s)
   WF_LL_DISPATCH(4, 1, WF_LL_LAUNCH);
   WF_LL_DISPATCH(8, 1, WF_LL_LAUNCH);
   WF_LL_DISPATCH(16, 1, WF_LL_LAUNCH);
@@ -689,8 +807,33 @@ extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const 
   return hipErrorInvalidValue;
 }
 
-extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, hipFuncAttributes* a) {
-#define WF_LL_ATTR(G_, S_) hipFuncGetAttributes(a, shared_speed ? (const void*)&wf_step_ll_kernel<G_, S_, true, kLLWaves> : (const void*)&wf_step_ll_kernel<G_, S_, false, kLLWaves>)
+extern "C" int wfk_ll_has_fly(int G, int S) { return (G == 4 && S == 2) || (G == 8 && S == 1); }
+
+// a wind per farm: gx / gy [B][N] sorted coordinates of every farm, farm_tie [B] the per-farm cross-block-tie flags
+extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* gx,
+                                             const double* gy, const double* ws, const double* wd, const float* yaw,
+                                             float* power, float* o_ws, float* o_wd, float* load, int B, const WfEnvArgs* env,
+                                             const int* farm_tie, float* src_log, size_t log_side_offset,
+                                             const WfGroupArgs* grp, hipStream_t s) {
+#define WF_LL_LAUNCH_FLY(G_, S_)                                                                                              \
+  (c->mirror_core_n <= 1                                                                                                      \
+       ? launch_ll<G_, S_, false, true>(c, tab, gidx, ws, wd, 1, yaw, power, o_ws, o_wd, load, B, env, nullptr, farm_tie, src_log, \
+                                        log_side_offset, grp, gx, gy, s)                                                       \
+       : launch_ll<G_, S_, false, false>(c, tab, gidx, ws, wd, 1, yaw, power, o_ws, o_wd, load, B, env, nullptr, farm_tie,      \
+                                         src_log, log_side_offset, grp, gx, gy, s))
+  WF_LL_DISPATCH(4, 2, WF_LL_LAUNCH_FLY);
+  WF_LL_DISPATCH(8, 1, WF_LL_LAUNCH_FLY);
+  return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, hipFuncAttributes* a) {
+#define WF_LL_ATTR(G_, S_) hipFuncGetAttributes(a, shared_speed ? (const void*)&wf_step_ll_kernel<G_, S_, true, true, true, kLLWaves> : (const void*)&wf_step_ll_kernel<G_, S_, false, true, true, kLLWaves>)
+#define WF_LL_ATTR_FLY(G_, S_) hipFuncGetAttributes(a, (const void*)&wf_step_ll_kernel<G_, S_, false, false, true, kLLWaves>)
+  if (!table) {
+    WF_LL_DISPATCH(4, 2, WF_LL_ATTR_FLY);
+    WF_LL_DISPATCH(8, 1, WF_LL_ATTR_FLY);
+    return hipErrorInvalidValue;
+  }
   WF_LL_DISPATCH(4, 1, WF_LL_ATTR);
   WF_LL_DISPATCH(8, 1, WF_LL_ATTR);
   WF_LL_DISPATCH(16, 1, WF_LL_ATTR);
