@@ -39,6 +39,13 @@ def run(n_sessions, n_ops, seed):
     for sess in range(n_sessions):
         x, y = make_layout(rng)
         B = int(rng.integers(1, 20))
+        # every other session forces the one-block-at-a-time kernel (table path and on the fly) where the farm has more
+        # than one of its blocks; the batch sizes of this fuzzer would never pick it by themselves
+        llg = str(rng.choice(["", "", "8", "4x2"]))
+        if llg:
+            os.environ["WF_LL_G"] = llg
+        else:
+            os.environ.pop("WF_LL_G", None)
         w = WfStep(x, y, env_batch=B)
         mp, model = None, {}
         envp = dict(yaw_lo=-40.0, yaw_hi=40.0, yaw_step=5.0, actuator_rate=0.3, dt=60.0, budget=0.1, load_coef=0.1, discrete=False)
@@ -149,6 +156,7 @@ def run(n_sessions, n_ops, seed):
                     nbad += 1
                     print("BAD reward", dict(session=sess, seed=seed, N=N, B=B, envp=envp), float(np.abs(got["reward"] / r_ref - 1).max()), log[-12:], flush=True)
         w.close()
+    os.environ.pop("WF_LL_G", None)
     print(f"api fuzz: {n_sessions} sessions x {n_ops} ops, {nchecks} oracle checks: {nflip} threshold flips, {nbad} violations")
     return nflip, nbad
 
