@@ -2,7 +2,7 @@
 
 The contract is in tests/parity.py (fp32 device arithmetic vs float64 oracle; north_star: per-turbine power within
 1e-4): STRICT on every farm whose risk flags are 0 — power |dP| / max(P, 1 kW) <= 1e-4, wind speed 5e-5 relative, wind
-direction 2e-4 deg, TI 5e-6, std u/v/w 1e-4 m/s, on every turbine, no count allowance.  A farm is flagged by the
+direction 3e-4 deg, TI 5e-6, std u/v/w 1e-4 m/s, on every turbine, no count allowance.  A farm is flagged by the
 kernel itself (include/wfstep.h WF_RISK_*) when a deficit comes within the guard band of the overlap threshold
 `deficit * Uinit > 0.05` (the one state-dependent discontinuity of the model) or a turbine sits on a knee
 of the power table; flagged farms must stay inside the bounded signature of such an event, must be few, and the flag

@@ -149,7 +149,10 @@ def run(n_sessions, n_ops, seed):
                     print("BAD yaw transition", dict(session=sess, seed=seed, N=N, B=B, envp=envp), np.abs(got["yaw"] - yaw_new).max(), log[-12:], flush=True)
                 ref, ws = oracle(yaw_new.astype(np.float64))
                 check("env_step", got, ref)
+                # the wind of the state before the step: the one before the last series tick, ONCE (a second env step without
+                # a new tick starts from the current wind; include/wfstep.h: wf_env_set_prev_wind)
                 wsn = w._ws_prev if getattr(w, "_ws_prev", None) is not None else ws
+                w._ws_prev = None
                 r_ref = (ref["power"] / 1e6 * 1e3 / wsn[:, None] ** 3).mean(axis=1) - envp["load_coef"] * np.abs(ref["load"]).mean(axis=(1, 2))
                 bad_r = np.abs(got["reward"] - r_ref) > 5e-5 * np.abs(r_ref) + 1e-7
                 if (bad_r & (w.risk_flags() == 0)).any():  # a reward may only differ where the kernel flagged the farm
