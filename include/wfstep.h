@@ -141,7 +141,7 @@ int wf_sync(wf_handle* h);
  * wf_get_risk_flags copies the flags of the last wf_step / wf_env_step (env_batch ints). */
 #define WF_RISK_OVERLAP 1
 #define WF_RISK_POWER_KNEE 2
-int wf_set_risk_guard(wf_handle* h, double rel_band); /* default 2e-5; 0 disables WF_RISK_OVERLAP */
+int wf_set_risk_guard(wf_handle* h, double rel_band); /* default 5e-5; 0 disables WF_RISK_OVERLAP */
 int wf_get_risk_flags(wf_handle* h, int* flags, int on_device);
 
 /* ---- Fused env step (not in the reference, which does this in Python per farm) ----

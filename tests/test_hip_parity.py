@@ -137,7 +137,7 @@ def test_risk_flags_mark_exactly_the_farms_near_the_threshold(layouts):
     ref = _oracle(l["xcoords"], l["ycoords"], ws, wd, yaw)
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
     w.set_wind(ws, wd)
-    for band in (0.0, 2e-5, 1e-3, 1e-2):
+    for band in (0.0, 5e-5, 1e-3, 1e-2):
         w.set_risk_guard(band)
         out = w.step(yaw)
         fl = (w.risk_flags() & 1) != 0
@@ -145,11 +145,11 @@ def test_risk_flags_mark_exactly_the_farms_near_the_threshold(layouts):
             assert not fl.any()
             continue
         # float32 rounding of the deficit (<~ 1e-5 relative after the recurrence) and the +-5 % row dependence of the band
-        assert fl[ref["margin"] < 0.9 * band - 2e-5].all(), band
+        assert fl[ref["margin"] < 0.9 * band - 3e-5].all(), band
         assert not fl[ref["margin"] > 1.1 * band + 1e-4].any(), band
         if band >= 1e-3:
             assert fl.any()
-    w.set_risk_guard(2e-5)
+    w.set_risk_guard(5e-5)
     w.close()
 
 
