@@ -134,13 +134,19 @@ int wf_sync(wf_handle* h);
  *                       the count matters (inside the 15 D reach and the 2 D lateral gate);
  *   WF_RISK_POWER_KNEE  a turbine at a point of the power curve whose relative condition number v |P'| / max(P, 1 kW)
  *                       exceeds 30, where a float32-sized wind-speed error (~3e-6) is amplified past 1e-4 of
- *                       max(P, 1 kW): just above cut-in (P < ~7 kW) and on the cut-out drop of nrel_5MW.
+ *                       max(P, 1 kW): just above cut-in (P < ~7 kW) and on the cut-out drop of nrel_5MW;
+ *   WF_RISK_THRUST_RAMP a turbine on a segment of the thrust table with v |dCt/dv| > 5: the cut-in ramp of nrel_5MW
+ *                       (Ct 0 -> 0.99 between 2.5 and 3 m/s, 20x steeper than anywhere in the operating range) and its
+ *                       cut-out drop.  With a row of turbines on the ramp the float64 result itself moves by 7e-5 in
+ *                       power for 1e-5 deg of wind direction (tests/golden/README: case bad_512_56); float32 wind
+ *                       speeds (3e-7 relative each) are amplified the same way.
  * Farms with flag 0 match the float64 path within the parity tolerances; flagged farms may differ by a bounded amount
  * (tests/test_hip_parity.py).  All geometric discontinuities (upstream/downstream order, dx > 0.1, 15 D reach, 2 D
  * lateral gate) are decided in float64 on the device and need no flag.
  * wf_get_risk_flags copies the flags of the last wf_step / wf_env_step (env_batch ints). */
 #define WF_RISK_OVERLAP 1
 #define WF_RISK_POWER_KNEE 2
+#define WF_RISK_THRUST_RAMP 4
 int wf_set_risk_guard(wf_handle* h, double rel_band); /* default 5e-5; 0 disables WF_RISK_OVERLAP */
 int wf_get_risk_flags(wf_handle* h, int* flags, int on_device);
 

@@ -849,3 +849,42 @@ def test_one_block_kernel_on_the_fly_with_a_wind_per_farm(layouts, name, G, monk
     w.close()
     both = (a["flags"] == 0) & (a0["flags"] == 0)
     assert (np.abs(a["power"] - a0["power"]) / np.maximum(a0["power"], 1e3))[both].max() < 2e-5
+
+
+def _regime(name):
+    d = np.load(os.path.join(ROOT, "tests", "golden", "regime_cases.npz"))
+    inp = {k: d[f"{name}_{k}"] for k in ("x", "y", "ws", "wd", "yaw")}
+    ref = {k[len(name) + 5:]: d[k] for k in d.files if k.startswith(name + "_ref_")}
+    return inp, ref
+
+
+@pytest.mark.parametrize("kernel", ["", "8", "4x2"])
+def test_regime_cases_are_flagged_and_bounded(kernel, monkeypatch):
+    """The two fuzzer-found regime farms (tests/golden/make_regime_cases.py) on every kernel family: the farm on the
+    cut-in ramp of the thrust table raises WF_RISK_THRUST_RAMP, the farm 3.7e-7 from the overlap threshold raises
+    WF_RISK_OVERLAP, both stay inside the bounded signature; at 9 m/s neither flag is raised and parity is strict."""
+    import parity
+    from wfcrl_env_amd.backend import WfStep
+
+    if kernel:
+        monkeypatch.setenv("WF_LL_G", kernel)
+    for name, bit in (("thrust_ramp", parity.RISK_THRUST_RAMP), ("overlap_flip", parity.RISK_OVERLAP)):
+        i, ref = _regime(name)
+        B = 64
+        w = WfStep(i["x"], i["y"], env_batch=B)
+        for per_farm in (False, True):  # pair-table path / on-the-fly path
+            ws, wd = (np.repeat(i["ws"], B), np.repeat(i["wd"], B)) if per_farm else (float(i["ws"][0]), float(i["wd"][0]))
+            w.set_wind(ws, wd)
+            out = w.step(np.repeat(i["yaw"], B, axis=0).astype(np.float32))
+            fl = w.risk_flags()
+            assert (fl & bit).all(), (name, per_farm, fl[:4])
+            refB = {k: np.repeat(v, B, axis=0) for k, v in ref.items()}
+            s = parity.summarize(out, refB, fl)
+            assert s["n_bad_flagged"] == 0 and s["n_bad_unflagged"] == 0, s
+        w.set_wind(9.0, float(i["wd"][0]))
+        yaw = np.repeat(i["yaw"], B, axis=0).astype(np.float32)
+        out = _with_flags(w, w.step(yaw))
+        if name == "thrust_ramp":
+            assert not (out["flags"] & parity.RISK_THRUST_RAMP).any()
+        _check(out, _oracle(i["x"], i["y"], 9.0, float(i["wd"][0]), yaw), max_flagged_frac=1.0)
+        w.close()

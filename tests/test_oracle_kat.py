@@ -186,3 +186,45 @@ def test_oracle_margin_output():
     assert r["margin"].shape == (1,) and r["margin"][0] > 1.0  # full overlap: deficit * U far above 0.05
     r = c_oracle.farm_step_batch(x, [0.0, 5000.0], 8.0, 270.0, np.zeros((1, 2)), margin=True)
     assert r["margin"][0] > 1e100  # outside the 2 D lateral gate: no relevant pair at all
+
+
+REGIME = os.path.join(os.path.dirname(__file__), "golden", "regime_cases.npz")
+
+
+def _regime(name):
+    d = np.load(REGIME)
+    inp = {k: d[f"{name}_{k}"] for k in ("x", "y", "ws", "wd", "yaw")}
+    ref = {k[len(name) + 5:]: d[k] for k in d.files if k.startswith(name + "_ref_")}
+    return inp, ref
+
+
+@pytest.mark.parametrize("name", ["thrust_ramp", "overlap_flip"])
+def test_regime_cases_reproduce(name):
+    """The fuzzer-found regime farms (tests/golden/make_regime_cases.py): both oracles against the stored outputs."""
+    i, ref = _regime(name)
+    for o in (c_oracle.farm_step_batch(i["x"], i["y"], i["ws"], i["wd"], i["yaw"]),
+              onp.farm_step_batch(i["x"], i["y"], i["ws"], i["wd"], i["yaw"])):
+        for k in ("power", "wind_speed", "wind_direction", "load"):
+            np.testing.assert_allclose(o[k], ref[k], rtol=1e-9, atol=1e-9)
+
+
+def test_thrust_ramp_is_ill_conditioned_in_float64():
+    """Why WF_RISK_THRUST_RAMP exists: with 48 turbines on the cut-in ramp of the thrust table the float64 model itself
+    moves by more than half the 1e-4 power tolerance for 1e-5 deg of wind direction (1e-7 relative of the input); on an
+    same farm at 9 m/s the same perturbation moves it 30x less."""
+    i, ref = _regime("thrust_ramp")
+    on_ramp = (ref["wind_speed"] > 2.5) & (ref["wind_speed"] < 3.0)
+    assert on_ramp.sum() >= 20
+
+    def moved(ws):
+        a = c_oracle.farm_step_batch(i["x"], i["y"], ws, i["wd"], i["yaw"])["power"]
+        b = c_oracle.farm_step_batch(i["x"], i["y"], ws, i["wd"] + 1e-5, i["yaw"])["power"]
+        return (np.abs(a - b) / np.maximum(a, 1e3)).max()
+
+    assert moved(i["ws"]) > 5e-5
+    assert moved(np.array([9.0])) < 5e-6
+
+
+def test_overlap_flip_case_sits_on_the_threshold():
+    i, ref = _regime("overlap_flip")
+    assert ref["margin"][0] < 1e-6

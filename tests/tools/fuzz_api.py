@@ -58,6 +58,8 @@ def run(n_sessions, n_ops, seed):
             ws, wd = w.get_wind()
             return c_oracle.farm_step_batch(x, y, ws, wd, yaw64, mp, margin=True), ws
 
+        last_yaw = None
+
         def check(tag, got, ref):
             nonlocal nbad, nflip, nchecks
             nchecks += 1
@@ -68,6 +70,10 @@ def run(n_sessions, n_ops, seed):
             if k == "BAD":
                 nbad += 1
                 print("BAD", dict(session=sess, seed=seed, N=x.size, B=B, tag=tag, info=w.kernel_info()), r, "\n   ops:", log[-12:], flush=True)
+                if os.environ.get("WF_FUZZ_DUMP"):  # the whole case, for a post-mortem against the oracle on a CPU
+                    ws_, wd_ = w.get_wind()
+                    np.savez(os.path.join(os.environ["WF_FUZZ_DUMP"], f"bad_{seed}_{sess}_{nchecks}.npz"), x=x, y=y, ws=ws_, wd=wd_,
+                             yaw=last_yaw, flags=w.risk_flags(), model=np.array(repr(model)), **{"got_" + k: v for k, v in got.items()})
 
         for _ in range(n_ops):
             op = rng.choice(["step", "step", "step_torch", "wind_shared", "wind_per_farm", "wind_device", "wind_sample", "series",
@@ -136,6 +142,7 @@ def run(n_sessions, n_ops, seed):
                 yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
                 got = w.step(torch.from_numpy(yaw).cuda()) if op == "step_torch" else w.step(yaw)
                 ref, _ = oracle(yaw.astype(np.float64))
+                last_yaw = yaw
                 check(op, got, ref)
             elif op == "env_step":
                 st = w.env_get_state()
@@ -148,6 +155,7 @@ def run(n_sessions, n_ops, seed):
                     nbad += 1
                     print("BAD yaw transition", dict(session=sess, seed=seed, N=N, B=B, envp=envp), np.abs(got["yaw"] - yaw_new).max(), log[-12:], flush=True)
                 ref, ws = oracle(yaw_new.astype(np.float64))
+                last_yaw = yaw_new
                 check("env_step", got, ref)
                 # the wind of the state before the step: the one before the last series tick, ONCE (a second env step without
                 # a new tick starts from the current wind; include/wfstep.h: wf_env_set_prev_wind)

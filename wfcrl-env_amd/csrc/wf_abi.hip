@@ -374,6 +374,7 @@ int build_consts(wf_handle* h) {
   c.guard_inv = h->guard_rel > 0.0 ? (float)(1.0 / h->guard_rel) : 1125899906842624.0f;
   c.inv_overlap_thr = (float)(1.0 / m.overlap_thresh);
   c.yc_d = h->yc;
+  c.ct_kappa = 5.0f;     // nrel_5MW: 5.9 on the cut-in ramp (2.5-3 m/s), 143 on the cut-out drop, <= 4.0 everywhere else
   c.knee_kappa = 30.0f;  // 30 x (wind-speed error ~3e-6) ~ 1e-4 of max(P, 1 kW)
   c.rho = (float)m.ref_density; c.pw = (float)(m.pP / 3.0);
   c.dens_f = (float)std::cbrt(m.air_density / m.ref_density);

@@ -57,6 +57,7 @@ struct WfConsts {
   // risk flags (include/wfstep.h WF_RISK_*): relative half-width of the guard band around the overlap threshold
   // "deficit * Uinit > overlap_thr", and the relative condition number of the power curve v |P'| / max(P, 1 kW) above
   // which a turbine counts as sitting on a knee of the curve
+  float ct_kappa;  // v |dCt/dv| above which a turbine counts as sitting on a ramp of the thrust table
   float guard_inv, inv_overlap_thr, knee_kappa;  // 1 / guard band (2^50 when the band is 0), 1 / overlap_thr
   double yc_d;  // centre of rotation (y): the float32 lateral distances are taken on y' - yc
 };
@@ -104,6 +105,7 @@ struct WfGroupArgs {
 };
 #define WF_RISK_OVERLAP 1
 #define WF_RISK_POWER_KNEE 2
+#define WF_RISK_THRUST_RAMP 4
 
 // Pair-coefficient table (shared wind only): for source i and target t (sorted indices) the
 // transverse-velocity contribution is linear in the source's circulations.  The tip vortices' circulations share

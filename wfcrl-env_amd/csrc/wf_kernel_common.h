@@ -63,9 +63,12 @@ __device__ __forceinline__ int table_segment(const WfConsts& c, const TableLds& 
 }
 
 // scipy interp1d(linear, fill_value=(lo,hi)) on the LDS copy of the table
-__device__ __forceinline__ float table_ct(const WfConsts& c, const TableLds& T, float v) {
+// steep: the turbine sits on a segment of the thrust table with v |dCt/dv| > ct_kappa (WF_RISK_THRUST_RAMP)
+__device__ __forceinline__ float table_ct(const WfConsts& c, const TableLds& T, float v, bool& steep) {
   int j = table_segment(c, T, v);
   float r = fmaf(T.cts[j], v - T.knot[j], T.ct[j]);
+  const bool inside = v >= T.knot[0] && v <= T.knot[c.n_table - 1] && r > 0.0001f && r < 0.9999f;
+  steep = inside && fabsf(T.cts[j]) * v > c.ct_kappa;
   r = (v < T.knot[0]) ? 0.0001f : r;
   r = (v > T.knot[c.n_table - 1]) ? 0.9999f : r;
   return fminf(fmaxf(r, 0.0001f), 0.9999f);

@@ -515,7 +515,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
                           float& a, float& gt, float& gb) {
     ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
     const float cg = L.cg[eiw][i], sg = L.sg[eiw][i];
-    ct = table_ct(c, T, ubar) * cg;
+    bool steep;
+    ct = table_ct(c, T, ubar, steep) * cg;
+    if (steep) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_THRUST_RAMP);
     const float sq1 = fsqrt(1.0f - ct * cg);
     a = 0.5f * ct * frcp(1.0f + sq1);  // == 0.5/cg*(1 - sqrt(1 - ct*cg))
     Gwr = c.gam_wr * (a - a * a) * ubar;

@@ -505,7 +505,9 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       // B. circulations [A.3-1, A.3-4]
       SrcLog Sc;
       const float ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
-      const float ct = table_ct(c, T, ubar) * cg;
+      bool steep;
+      const float ct = table_ct(c, T, ubar, steep) * cg;
+      if (steep) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_THRUST_RAMP);
       const float sq1 = fsqrt(1.0f - ct * cg);
       const float a = 0.5f * ct * frcp(1.0f + sq1);
       const float Gwr = c.gam_wr * (a - a * a) * ubar;
