@@ -20,7 +20,7 @@ bash tools/run_pmc.sh $tag > /dev/null 2>&1
 python3 tools/parse_pmc.py $tag wf_step_ll_kernel > $O/pmc_cfg4.json
 rm -rf $R/gpurun_out/pmc_$tag
 WF_NO_PAIR_TABLE=1 bash tools/run_pmc.sh ${tag}_fly > /dev/null 2>&1
-python3 tools/parse_pmc.py ${tag}_fly wf_step_kernel > $O/pmc_cfg4_on_the_fly.json
+python3 tools/parse_pmc.py ${tag}_fly wf_step_ll_kernel > $O/pmc_cfg4_on_the_fly.json
 rm -rf $R/gpurun_out/pmc_${tag}_fly
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof -- python3 $R/bench.py --no-cpu-baseline --no-env-leg > $O/bench_under_rocprof.json 2> $O/rocprof.err

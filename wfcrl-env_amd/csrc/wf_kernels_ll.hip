@@ -62,13 +62,15 @@ __device__ __forceinline__ void sincos_yaw(float x, float& s, float& c) {
 // What a source leaves behind for the target blocks after its own: WF_LOG_FLOATS floats (four float4, one 64-byte
 // record: two per 128-byte line, and a block's G records are whole lines, so no line is shared between a block that is
 // still being written and one that is being read).  Whatever follows from these by one or two instructions (1.6 +- sM,
-// 1 / (sy0d sz0d), tan_th0 x0d, 1 / x0v) is re-derived by the reader.  The sign of ch_pref (> 0 by construction)
+// 1 / (sy0d sz0d), tan_th0 x0d) is re-derived by the reader; all sixteen floats are read by it — a dead component of
+// a record load that is still in flight gets reused as a scratch register, which makes the compiler wait for the load
+// (the prefetch of the next record) on the spot.  The sign of ch_pref (> 0 by construction)
 // carries the split-TI flag; the three column TIs and dTI such a source needs live in a side array (WfLogSide).
 struct SrcLog {
   float Gy, Gwt, sy0d, sz0d;        // circulations of the transverse pass (table path), deflection sigma_0
   float sM, tan_th0, sy0v, snw;     // sqrt(ct), deflection angle; deficit sigma_y0, near-wake sigma
   float kdef, x0d, kyd, pj;         // deficit amplitude factor; column 0: deflection near-wake length, expansion rate, log prefactor
-  float x0v, kyv, ch_pref, spare;   // column 0: deficit near-wake length, expansion rate; +-Crespo-Hernandez prefactor
+  float x0v, kyv, ch_pref, ix0v;    // column 0: deficit near-wake length, expansion rate; +-Crespo-Hernandez prefactor; 1 / x0v
 };
 static_assert(sizeof(SrcLog) == WF_LOG_FLOATS * 4, "source log record");
 struct WfLogSide { float TI0, TI1, TI2, dTI; };  // the source's column TIs before mixing, the yaw-added-recovery increment
@@ -120,6 +122,14 @@ extern "C" hipError_t wfk_launch_pair_table_ll(const WfPairConsts* pc, int G, in
 // on the fly from the farm's own sorted geometry (source coordinates re-read from gx / gy, the targets' kept in
 // registers), nothing is staged and no barrier is needed after the start.  MC1 (on the fly only): compile-time skip of
 // the ground-mirror vortex cores that are exactly 1.0f in float32 (WfConsts::mirror_core_n <= 1).
+#ifdef WF_LL_STAMP  // debug build (tools/ll_stamps.py): wave cycles per phase, summed over the launch
+__device__ unsigned long long wf_ll_stamp[8];
+#define WF_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define WF_ACC(k, a, b) st_acc[k] += (b) - (a)
+#else
+#define WF_T(v)
+#define WF_ACC(k, a, b)
+#endif
 template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB>
 #ifndef WF_LL_OCC2
 #define WF_LL_OCC2 2  // ... for the two-slot variants
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     SrcConsts sc;
     sc.sy0d = R.sy0d; sc.sz0d = R.sz0d; sc.inv_s0d = frcp(R.sy0d * R.sz0d); sc.lnA = 1.6f + R.sM; sc.lnB = 1.6f - R.sM; sc.sM = R.sM;
     sc.tan_th0 = R.tan_th0; sc.sy0v = R.sy0v; sc.snw = R.snw; sc.kdef = R.kdef;
-    const float d0 = R.tan_th0 * R.x0d, ix0v = frcp(R.x0v);
+    const float d0 = R.tan_th0 * R.x0d, ix0v = R.ix0v;
     float e1[3], e0[3];
     const bool same = !__any(R.ch_pref < 0.0f);  // the sign of ch_pref flags a split-TI source
     if (same) {
@@ -425,6 +435,10 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
   };
 
   float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
+#ifdef WF_LL_STAMP
+  unsigned long long st_acc[5] = {0, 0, 0, 0, 0};
+  WF_T(st_begin);
+#endif
   int q = 0;                        // running chunk index (LDS buffer q & 1)
   // Cache-line discipline of the log (the vector L1 is not updated by this CU's own stores): a farm's records start on
   // a 128-byte line (n_pad is a multiple of G, G is even), so a line belongs to ONE block and is never read before that
@@ -605,7 +619,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       X.TI0 = TIs[0]; X.TI1 = TIs[1]; X.TI2 = TIs[2];
       const bool split = !((TIs[0] == TIs[1]) && (TIs[1] == TIs[2]));
       Sc.ch_pref = split ? -Sc.ch_pref : Sc.ch_pref;  // the flag travels in the sign
-      Sc.spare = 0.0f;
+      Sc.ix0v = frcp(Sc.x0v);
       // the later blocks replay this source from the log
       if (J + 1 < nblk && sub == 0) {
         float4* lp = reinterpret_cast<float4*>(logf + (size_t)i * WF_LOG_FLOATS);
@@ -634,6 +648,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       const int k_end = min(n_src - i0, CH);
       // ---- sources of earlier blocks: replayed from the log on this block's targets ----------------------
       // (a loop of its own: the two kinds of source step share no loop-carried copies)
+      WF_T(st_a);
 #pragma unroll 1
       for (int k = 0; k < k_log; ++k) {
         const int i = i0 + k;
@@ -670,6 +685,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         static_for<S>(replay_slot);
       }
       // ---- sources of this block ------------------------------------------------------------------------
+      WF_T(st_b);
+      WF_ACC(0, st_a, st_b);
 #pragma unroll 1
       for (int k = k_log; k < k_end; ++k) {
         const int i = i0 + k;
@@ -679,8 +696,13 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
           if (slot_of_source == decltype(PS)::value) own_source(PS, i, recs);
         });
       }
+      WF_T(st_c);
+      WF_ACC(1, st_b, st_c);
       if constexpr (TAB) __syncthreads();  // the next chunk has landed; everyone is done with this one
+      WF_T(st_d);
+      WF_ACC(2, st_c, st_d);
     }
+    WF_T(st_e);
 
     // ---- outputs [A.4] of block J --------------------------------------------------------------
 #pragma unroll
@@ -743,7 +765,16 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         if (o_load) reinterpret_cast<float4*>(o_load)[oo] = l;
       }
     }
+    WF_T(st_f);
+    WF_ACC(3, st_e, st_f);
   }  // J
+#ifdef WF_LL_STAMP
+  if (lane == 0) {
+    st_acc[4] = __builtin_readcyclecounter() - st_begin;
+    for (int k = 0; k < 5; ++k) atomicAdd(&wf_ll_stamp[k], st_acc[k]);
+    atomicAdd(&wf_ll_stamp[5], 1ull);
+  }
+#endif
 
   if (ga.risk_flags && sub == 0 && env_ok) ga.risk_flags[env] = (int)risk_lds[wave][eiw];
   if (ea.reward) {
@@ -790,6 +821,16 @@ static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* g
 }
 
 extern "C" int wfk_ll_farms_per_block(int G) { return kLLWaves * (64 / G); }
+#ifdef WF_LL_STAMP
+extern "C" int wfk_ll_stamps(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_ll_stamp), sizeof(wf_ll_stamp));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(wf_ll_stamp), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
 
 // (G, S) instantiations of the table path: one slot per lane at every width, two slots at G = 4 (eight turbines per block
 // like G = 8, S = 1, with sixteen instead of eight farms per wave sharing the per-source phase).  On the fly (a wind
