@@ -653,12 +653,15 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       for (int k = 0; k < k_log; ++k) {
         const int i = i0 + k;
         const SrcLog Sl = nxt;
-        if (i + 1 < first_own) {
-          const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)(i + 1) * WF_LOG_FLOATS);
-          float4* d = reinterpret_cast<float4*>(&nxt);
+        auto prefetch_next = [&]() {
+          if (i + 1 < first_own) {
+            const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)(i + 1) * WF_LOG_FLOATS);
+            float4* d = reinterpret_cast<float4*>(&nxt);
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
-        }
+            for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
+          }
+        };
+        if constexpr (!TAB) prefetch_next();
         const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
         // no lane mask on the transverse pass: every real turbine of this block is at or downstream of an earlier
         // block's source (dx >= 0), and the lanes beyond N (last block only) carry all-zero records
@@ -669,13 +672,30 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
           ys_d = gy[gofs + i];
           ys_f = (float)(ys_d - c.yc_d);
         }
+        if constexpr (TAB) {
+          // deflection / deficit / TI of every slot first, on the {dx, dy, tipow, decision bits} float4 of the pair records
+          // alone; the 9 coefficient float4 per slot are read behind a compiler barrier, right before the transverse
+          // pass uses them — read at the top of the iteration (where the compiler hoists them by itself) they stay
+          // live across both pass2 bodies, 36 registers per slot, and all of them are waited for before the first one
+          float4 exs[S];
+#pragma unroll
+          for (int p = 0; p < S; ++p)
+            exs[p] = *reinterpret_cast<const float4*>(buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE + WF_PAIR_DX);
+          // the next record's loads are issued BEHIND the first LDS reads of the iteration: the compiler guards the first
+          // read of the staged chunk with s_waitcnt vmcnt(0) (the chunk arrives by LDS-DMA, counted in vmcnt), and a
+          // prefetch issued before that read would be waited for on the spot
+          asm volatile("" ::: "memory");
+          prefetch_next();
+          static_for<S>([&](auto PP) { pass2(PP, Sl, side, true, exs[decltype(PP)::value], tvalid[decltype(PP)::value]); });
+          asm volatile("" ::: "memory");
+          static_for<S>([&](auto PP) {
+            apply_tab(PP, reinterpret_cast<const float4*>(buf + (k * GS + decltype(PP)::value * G + sub) * WF_PAIR_STRIDE), Sl.Gy, Sl.Gwt);
+          });
+          continue;
+        }
         auto replay_slot = [&](auto PP) {
           constexpr int p = decltype(PP)::value;
           if constexpr (TAB) {
-            const float* rec = buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE;
-            const float4 exr = *reinterpret_cast<const float4*>(rec + WF_PAIR_DX);  // {dx, dy, tipow, decision bits}
-            apply_tab(PP, reinterpret_cast<const float4*>(rec), Sl.Gy, Sl.Gwt);
-            pass2(PP, Sl, side, true, exr, tvalid[p]);
           } else {
             const float4 exr = fly_record(PP, xs_d, ys_f);
             if (tvalid[p]) apply_fly(PP, exr.x, exr.y, Sl.Gy, Sl.Gwt);
