@@ -654,12 +654,12 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         const int i = i0 + k;
         const SrcLog Sl = nxt;
         auto prefetch_next = [&]() {
-          if (i + 1 < first_own) {
-            const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)(i + 1) * WF_LOG_FLOATS);
-            float4* d = reinterpret_cast<float4*>(&nxt);
+          // unconditional (the last logged source re-reads its own record): a conditional load leaves "nxt keeps its
+          // value" on the other path, which costs sixteen register copies per iteration
+          const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)min(i + 1, first_own - 1) * WF_LOG_FLOATS);
+          float4* d = reinterpret_cast<float4*>(&nxt);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
-          }
+          for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
         };
         if constexpr (!TAB) prefetch_next();
         const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
