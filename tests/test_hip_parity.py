@@ -800,7 +800,7 @@ def test_one_block_kernel_hands_cross_block_ties_back(layouts, G, monkeypatch):
     w.close()
 
 
-@pytest.mark.parametrize("G", ["4x2", "8"])
+@pytest.mark.parametrize("G", ["4x2", "8", "4"])
 @pytest.mark.parametrize("name", ["HornsRev1_", "Turb32_Row5_", "Ormonde_"])
 def test_one_block_kernel_on_the_fly_with_a_wind_per_farm(layouts, name, G, monkeypatch):
     """A wind per farm on the one-block kernel (transverse pass on the fly from each farm's own sorted geometry), against
@@ -840,6 +840,17 @@ def test_one_block_kernel_on_the_fly_with_a_wind_per_farm(layouts, name, G, monk
     assert np.array_equal(e1["yaw"], act) and np.array_equal(e2["yaw"], np.clip(2 * act, -40, 40).astype(np.float32))
     st = w.env_get_state()
     assert np.array_equal(st["moves"], np.full(B, 2)) and np.allclose(st["acc"], 2 * np.abs(act), rtol=1e-6)
+    # the table path and the on-the-fly path of one handle share the source log; at G = 4 they use different block
+    # sizes (one slot per lane on the table path, two on the fly): alternate them
+    lanes = int(G.split("x")[0])
+    assert w.kernel_info()["slots_per_lane"] == (2 if lanes == 4 else 1)
+    w.set_wind(9.0, 281.0)
+    assert w.kernel_info()["pair_table"] == 1 and w.kernel_info()["one_block_kernel"] == (1 if N > lanes * (2 if G == "4x2" else 1) else 0)
+    _check(_with_flags(w, w.step(yaw)), _oracle(l["xcoords"], l["ycoords"], 9.0, 281.0, yaw))
+    w.set_wind(ws, wd)
+    c2 = _with_flags(w, w.step(yaw))
+    for k in ("power", "wind_speed", "wind_direction", "load"):
+        assert np.array_equal(a[k], c2[k]), k
     w.close()
     monkeypatch.setenv("WF_LL_FLY", "0")
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
@@ -858,7 +869,7 @@ def _regime(name):
     return inp, ref
 
 
-@pytest.mark.parametrize("kernel", ["", "8", "4x2"])
+@pytest.mark.parametrize("kernel", ["", "8", "4x2", "4"])
 def test_regime_cases_are_flagged_and_bounded(kernel, monkeypatch):
     """The two fuzzer-found regime farms (tests/golden/make_regime_cases.py) on every kernel family: the farm on the
     cut-in ramp of the thrust table raises WF_RISK_THRUST_RAMP, the farm 3.7e-7 from the overlap threshold raises

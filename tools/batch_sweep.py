@@ -1,14 +1,15 @@
-"""GPU box: HornsRev1, shared wind, over env-batch sizes — which kernel `pick_ll` chooses and what it delivers, against the
+"""GPU box: HornsRev1 (or LAYOUT=...), shared wind, over env-batch sizes — which kernel `pick_ll` chooses and what it delivers, against the
 register-slot kernel (WF_LL=0) and the forced one-block variants.  usage: python tools/batch_sweep.py"""
 import json, os, subprocess, sys
 code = r'''
 import os, sys, json, torch
 sys.path.insert(0, os.getcwd())
 from wfcrl_env_amd.backend import WfStep
-L = json.load(open("wfcrl-env_amd/environments/layouts.json"))["HornsRev1_"]
+L = json.load(open("wfcrl-env_amd/environments/layouts.json"))[os.environ.get("LAYOUT", "HornsRev1_")]
+N = L["num_turbines"]
 for B in (4096, 8192, 16384, 24576, 32768, 40000, 49152, 65536, 73728, 98304, 131072):
     w = WfStep(L["xcoords"], L["ycoords"], env_batch=B); w.set_wind(8.0, 270.0)
-    yaw = (torch.rand((B, 80), device="cuda") * 60 - 30).float()
+    yaw = (torch.rand((B, N), device="cuda") * 60 - 30).float()
     out = w.step(yaw); w.sync()
     best = 1e9
     for r in range(3):
@@ -19,6 +20,9 @@ for B in (4096, 8192, 16384, 24576, 32768, 40000, 49152, 65536, 73728, 98304, 13
     print(f"B={B:7d} {best:.3f} ms {B / best * 1e3:.3e} farm-steps/s  one_block={k['one_block_kernel']} G={k['lanes_per_env']} S={k['slots_per_lane']}", flush=True)
     w.close()
 '''
-for label, env in (("pick_ll", {}), ("WF_LL=0", {"WF_LL": "0"}), ("WF_LL_G=8", {"WF_LL_G": "8"}), ("WF_LL_G=4x2", {"WF_LL_G": "4x2"})):
+for label, env in (("pick_ll", {}), ("WF_LL=0", {"WF_LL": "0"}), ("WF_LL_G=8", {"WF_LL_G": "8"}), ("WF_LL_G=4x2", {"WF_LL_G": "4x2"}),
+                   ("WF_LL_G=4", {"WF_LL_G": "4"})):
+    if label == "pick_ll" and os.environ.get("SKIP_PICK"):
+        continue
     print("#", label, flush=True)
     subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env))

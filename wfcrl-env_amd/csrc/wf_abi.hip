@@ -280,19 +280,34 @@ int pick_ll(int N, int B) {  // returns (G << 4) | S, 0 = keep wf_step_kernel
     const bool ok = ((g == 4 || g == 8 || g == 16) && sl == 1) || (g == 4 && sl == 2);
     return (ok && N > g * sl) ? ((g << 4) | sl) : 0;
   }
-  // measured (profiles/r02_v21_one_block_kernel_sweep.txt, 65536 farms; register-slot kernel / G = 4 / 8 / 4x2, ms): N = 80:
-  // 2.04 / 1.64 / 1.62 / 1.45; N = 91: 2.62 / 2.29 / 2.19 / 2.00; N = 32: 0.43 / 0.37 / 0.41 / 0.34.  Two slots at G = 4 (eight
-  // turbines per block, sixteen farms per wave sharing the per-source phase, half the log re-reads of G = 4 alone) win
-  // although their 54 state registers leave two waves per SIMD.
-  // A wave solves its 64 / G farms start to finish, so a launch runs in ROUNDS of (waves the chip holds) x (farms per
-  // wave) farms, and the fewer, fatter waves of these kernels only pay once a round is full (tools/series_group_sweep.py:
-  // 1025 blocks instead of 1024 cost 4x2 30 %).  Per round at N = 80: wf_step_kernel<16,5> 8192 farms in 0.25 ms, G = 8
-  // 24576 farms in 0.54 ms, 4x2 32768 farms in 0.72 ms; the ratios hold for other N.  Cheapest estimate wins.
+  // A wave solves its 64 / G farms start to finish, so a launch runs in ROUNDS of (blocks the chip holds) x (farms per
+  // block), and within a round the time depends on how many blocks share a CU (one wave per SIMD each).  Measured at
+  // N = 80 (profiles/r02_v24_batch_sweep_variants.txt; ms for 1, 2, 3 blocks per CU; the ratios hold at N = 91):
+  //   wf_step_kernel<16,5>  16 farms per block, 2 per CU: 0.235 0.298
+  //   G = 8                 32 farms per block, 3 per CU: 0.33  0.42  0.55
+  //   G = 4, two slots      64 farms per block, 2 per CU: 0.49  0.644
+  //   G = 4                 64 farms per block, 3 per CU: 0.53  0.67  0.89
+  // A partial round behind full ones overlaps with their tail (factor 0.8).  The estimates are within 6 % of the sweep
+  // (4096 ... 131072 farms); the cheapest wins: the register-slot kernel up to ~8192 farms, G = 8 up to ~24576, then
+  // the two G = 4 kernels depending on how the batch divides into rounds of 32768 / 49152.
   if (N <= 16) return 0;
-  auto rounds = [](long farms, long cap) { return (double)((farms + cap - 1) / cap); };
-  const double t_old = rounds(B, 8192) * 0.254, t_g8 = rounds(B, 24576) * 0.54, t_4x2 = rounds(B, 32768) * 0.72;
-  if (t_old <= t_g8 && t_old <= t_4x2) return 0;
-  return (N > 32 && t_g8 < t_4x2) ? ((8 << 4) | 1) : ((4 << 4) | 2);
+  struct Fam { int code, farms_per_block, per_cu; double t[3]; };
+  static const Fam fam[] = {{0, 16, 2, {0.235, 0.298, 0.0}},
+                            {(8 << 4) | 1, 32, 3, {0.33, 0.42, 0.55}},
+                            {(4 << 4) | 2, 64, 2, {0.49, 0.644, 0.0}},
+                            {(4 << 4) | 1, 64, 3, {0.53, 0.67, 0.89}}};
+  int best = 0;
+  double t_best = 1e300;
+  for (const Fam& f : fam) {
+    if (f.code && N <= (f.code >> 4) * (f.code & 15)) continue;  // needs more than one block
+    if (f.code == ((8 << 4) | 1) && N <= 32) continue;           // (not instantiated to pay below that)
+    const long blocks = ((long)B + f.farms_per_block - 1) / f.farms_per_block, per_round = 256L * f.per_cu;
+    const long full = blocks / per_round, rem = blocks % per_round;
+    double t = full * f.t[f.per_cu - 1];
+    if (rem) t += (full ? 0.8 : 1.0) * f.t[(rem + 255) / 256 - 1];
+    if (t < t_best) { t_best = t; best = f.code; }
+  }
+  return best;
 }
 
 int build_consts(wf_handle* h) {
@@ -486,10 +501,11 @@ int pair_table(wf_handle* h, const float** out) {
 // Rotation + sort of `n_env` wind conditions on the handle's stream.  A geometry per farm (n_env == B) also yields the
 // per-farm cross-block-tie flags for the on-the-fly one-block kernel; sync_ok: the caller synchronises anyway, so the
 // "any farm tied" flag is read back and a launch nobody needs is never enqueued.
+int ll_fly_S(const wf_handle* h);
 int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
-  const bool per_farm = n_env == h->B && h->B > 1 && h->ll_G && wfk_ll_has_fly(h->ll_G, h->ll_S);
+  const bool per_farm = n_env == h->B && h->B > 1 && h->ll_G && wfk_ll_has_fly(h->ll_G, ll_fly_S(h));
   WF_HIP(h, wfk_launch_geometry(n_env, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd, h->d_gx, h->d_gy, h->d_gidx,
-                                per_farm ? h->ll_G * h->ll_S : 0, h->d_farm_tie, h->d_farm_tie ? h->d_farm_tie + h->B : nullptr,
+                                per_farm ? h->ll_G * ll_fly_S(h) : 0, h->d_farm_tie, h->d_farm_tie ? h->d_farm_tie + h->B : nullptr,
                                 h->stream));
   h->farm_ties = 2;
   if (per_farm && sync_ok) {
@@ -501,9 +517,14 @@ int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
   return WF_OK;
 }
 
-// turbines per farm in the source log of the one-block kernel: whole lane-group blocks
+// Target slots per lane of the one-block kernel ON THE FLY (a wind per farm): two at G = 4 whatever the table path
+// uses — there the second slot halves the per-source geometry work as well (HornsRev1 x 65536: 3.48 ms against 4.14).
+int ll_fly_S(const wf_handle* h) { return h->ll_G == 4 ? 2 : h->ll_S; }
+
+// turbines per farm in the source log of the one-block kernel: whole lane-group blocks (of the larger of the two
+// block sizes: the table path and the on-the-fly path share the buffer)
 size_t ll_npad(const wf_handle* h) {
-  const int gs = h->ll_G * h->ll_S;
+  const int gs = h->ll_G * (h->ll_S > ll_fly_S(h) ? h->ll_S : ll_fly_S(h));
   return (size_t)((h->N + gs - 1) / gs) * gs;
 }
 
@@ -614,7 +635,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
     if (h->ll_ties == 0) return WF_OK;
     ga.pred = h->d_ll_flag;
   }
-  if (!ptab && gstride != 0 && h->B > 1 && h->ll_G && wfk_ll_has_fly(h->ll_G, h->ll_S) && !h->no_ll_fly) {
+  if (!ptab && gstride != 0 && h->B > 1 && h->ll_G && wfk_ll_has_fly(h->ll_G, ll_fly_S(h)) && !h->no_ll_fly) {
     // a wind per farm: the one-block kernel on the fly; wf_step_kernel behind it for the farms whose own geometry has
     // an x' tie across a block boundary (per-farm device flags from the geometry kernel)
     const int fpb = wfk_ll_farms_per_block(h->ll_G);
@@ -625,7 +646,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
       WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * ll_npad(h) * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
       h->log_slots_cap = slots;
     }
-    WF_HIP(h, wfk_launch_step_ll_fly(h->ll_G, h->ll_S, &h->consts, h->d_tab, h->d_gidx, h->d_gx, h->d_gy, h->d_ws, h->d_wd, yaw,
+    WF_HIP(h, wfk_launch_step_ll_fly(h->ll_G, ll_fly_S(h), &h->consts, h->d_tab, h->d_gidx, h->d_gx, h->d_gy, h->d_ws, h->d_wd, yaw,
                                      power, wspd, wdir, load, h->B, ea, h->d_farm_tie, h->d_src_log,
                                      h->log_slots_cap * ll_npad(h) * WF_LOG_FLOATS, &ga, h->stream));
     if (h->farm_ties == 0) return WF_OK;
@@ -1232,13 +1253,14 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   info->envs_per_block = wpb * (64 / G); info->threads_per_block = 64 * wpb;
   info->grid_blocks = h->n_groups > 0 ? (h->n_slots + info->envs_per_block - 1) / info->envs_per_block
                                       : (h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0);
-  const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(h->ll_G, h->ll_S) && !h->no_ll_fly;
+  const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(h->ll_G, ll_fly_S(h)) && !h->no_ll_fly;
   info->one_block_kernel = ((tab && h->ll_G) || ll_fly) ? 1 : 0;
   if (info->one_block_kernel) {
     // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
     // fields above would describe) is enqueued behind it for the directions that have one
-    WF_HIP(h, wfk_ll_func_attributes(h->ll_G, h->ll_S, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, &a));
-    info->lanes_per_env = h->ll_G; info->slots_per_lane = h->ll_S;
+    const int ll_s = tab ? h->ll_S : ll_fly_S(h);
+    WF_HIP(h, wfk_ll_func_attributes(h->ll_G, ll_s, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, &a));
+    info->lanes_per_env = h->ll_G; info->slots_per_lane = ll_s;
     info->envs_per_block = wfk_ll_farms_per_block(h->ll_G); info->threads_per_block = 256;
     info->grid_blocks = (int)(((h->n_groups > 0 ? (size_t)h->n_slots : (size_t)h->B) + info->envs_per_block - 1) / info->envs_per_block);
   }

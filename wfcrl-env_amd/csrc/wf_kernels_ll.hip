@@ -131,6 +131,9 @@ __device__ unsigned long long wf_ll_stamp[8];
 #define WF_ACC(k, a, b)
 #endif
 template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB>
+#ifndef WF_LL_PINGPONG
+#define WF_LL_PINGPONG 0  // 1: two record buffers used alternately (2x unrolled replay): 20-30 spilled registers, slower
+#endif
 #ifndef WF_LL_OCC2
 #define WF_LL_OCC2 2  // ... for the two-slot variants
 #endif
@@ -649,10 +652,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       // ---- sources of earlier blocks: replayed from the log on this block's targets ----------------------
       // (a loop of its own: the two kinds of source step share no loop-carried copies)
       WF_T(st_a);
-#pragma unroll 1
-      for (int k = 0; k < k_log; ++k) {
+      auto replay_one = [&](int k, const SrcLog& Sl, SrcLog& nxt) {
         const int i = i0 + k;
-        const SrcLog Sl = nxt;
         auto prefetch_next = [&]() {
           // unconditional (the last logged source re-reads its own record): a conditional load leaves "nxt keeps its
           // value" on the other path, which costs sixteen register copies per iteration
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
           static_for<S>([&](auto PP) {
             apply_tab(PP, reinterpret_cast<const float4*>(buf + (k * GS + decltype(PP)::value * G + sub) * WF_PAIR_STRIDE), Sl.Gy, Sl.Gwt);
           });
-          continue;
+          return;
         }
         auto replay_slot = [&](auto PP) {
           constexpr int p = decltype(PP)::value;
@@ -703,7 +704,26 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
           }
         };
         static_for<S>(replay_slot);
+      };
+#if WF_LL_PINGPONG
+      // two record buffers used alternately: no copy of the prefetched record into the current one per iteration
+      {
+        SrcLog nxt2;
+        int k = 0;
+#pragma unroll 1
+        for (; k + 1 < k_log; k += 2) {
+          replay_one(k, nxt, nxt2);
+          replay_one(k + 1, nxt2, nxt);
+        }
+        if (k < k_log) replay_one(k, nxt, nxt2);
       }
+#else
+#pragma unroll 1
+      for (int k = 0; k < k_log; ++k) {
+        const SrcLog Sl = nxt;
+        replay_one(k, Sl, nxt);
+      }
+#endif
       // ---- sources of this block ------------------------------------------------------------------------
       WF_T(st_b);
       WF_ACC(0, st_a, st_b);
@@ -870,7 +890,7 @@ extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const 
   return hipErrorInvalidValue;
 }
 
-extern "C" int wfk_ll_has_fly(int G, int S) { return (G == 4 && S == 2) || (G == 8 && S == 1); }
+extern "C" int wfk_ll_has_fly(int G, int S) { return (G == 4 && S <= 2) || (G == 8 && S == 1); }
 
 // a wind per farm: gx / gy [B][N] sorted coordinates of every farm, farm_tie [B] the per-farm cross-block-tie flags
 extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* gx,
@@ -885,6 +905,7 @@ extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, co
        : launch_ll<G_, S_, false, false>(c, tab, gidx, ws, wd, 1, yaw, power, o_ws, o_wd, load, B, env, nullptr, farm_tie,      \
                                          src_log, log_side_offset, grp, gx, gy, s))
   WF_LL_DISPATCH(4, 2, WF_LL_LAUNCH_FLY);
+  WF_LL_DISPATCH(4, 1, WF_LL_LAUNCH_FLY);
   WF_LL_DISPATCH(8, 1, WF_LL_LAUNCH_FLY);
   return hipErrorInvalidValue;
 }
@@ -894,6 +915,7 @@ extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int
 #define WF_LL_ATTR_FLY(G_, S_) hipFuncGetAttributes(a, (const void*)&wf_step_ll_kernel<G_, S_, false, false, true, kLLWaves>)
   if (!table) {
     WF_LL_DISPATCH(4, 2, WF_LL_ATTR_FLY);
+    WF_LL_DISPATCH(4, 1, WF_LL_ATTR_FLY);
     WF_LL_DISPATCH(8, 1, WF_LL_ATTR_FLY);
     return hipErrorInvalidValue;
   }
