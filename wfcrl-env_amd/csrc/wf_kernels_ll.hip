@@ -478,11 +478,16 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     const int n_chunks = (n_src + CH - 1) / CH;
     // the first logged source's record is fetched ahead; every later one while its predecessor is being applied
     SrcLog nxt;
+    double xs_nx = 0.0, ys_nx = 0.0;  // on the fly: the sorted coordinates of that source come with its record
     if (first_own > 0) {
       const float4* lp = reinterpret_cast<const float4*>(logf);
       float4* d = reinterpret_cast<float4*>(&nxt);
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] = lp[k];
+      if constexpr (!TAB) {
+        xs_nx = gx[gofs];
+        ys_nx = gy[gofs];
+      }
     }
 
     // on the fly: the {dx, dy, 15 D reach, bit 3} of (source at (xi, yi), this lane's target in slot p), decided in float64
@@ -661,7 +666,12 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
           float4* d = reinterpret_cast<float4*>(&nxt);
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
+          if constexpr (!TAB) {
+            xs_nx = gx[gofs + min(i + 1, first_own - 1)];
+            ys_nx = gy[gofs + min(i + 1, first_own - 1)];
+          }
         };
+        const double xs_cur = xs_nx, ys_cur = ys_nx;
         if constexpr (!TAB) prefetch_next();
         const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
         // no lane mask on the transverse pass: every real turbine of this block is at or downstream of an earlier
@@ -669,8 +679,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         double xs_d = 0.0, ys_d = 0.0;
         float ys_f = 0.0f;
         if constexpr (!TAB) {
-          xs_d = gx[gofs + i];
-          ys_d = gy[gofs + i];
+          xs_d = xs_cur;
+          ys_d = ys_cur;
           ys_f = (float)(ys_d - c.yc_d);
         }
         if constexpr (TAB) {
