@@ -899,3 +899,44 @@ def test_regime_cases_are_flagged_and_bounded(kernel, monkeypatch):
             assert not (out["flags"] & parity.RISK_THRUST_RAMP).any()
         _check(out, _oracle(i["x"], i["y"], 9.0, float(i["wd"][0]), yaw), max_flagged_frac=1.0)
         w.close()
+
+
+def test_grouped_launch_follows_the_padded_farm_count(layouts):
+    """HornsRev1 x 65536: the plain batch is two full rounds of the two-slot G = 4 kernel; grouped by 64 series rows the
+    launch has 1057 blocks of farm slots, a third round for that kernel, and the one-slot kernel (three blocks per CU)
+    is chosen instead; back on a shared wind the first choice returns.  Parity on a sample of farms in each state."""
+    import torch
+
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    B, N = 65536, 80
+    rng = np.random.default_rng(77)
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    yaw_t = (torch.rand((B, N), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 60 - 30).float()
+    yaw = yaw_t.cpu().numpy()
+    idx = rng.choice(B, 192, replace=False)
+
+    def check_sample():
+        out = {k: v.cpu().numpy()[idx] for k, v in w.step(yaw_t).items()}
+        ws, wd = w.get_wind()
+        out["flags"] = w.risk_flags()[idx]
+        _check(out, _oracle(l["xcoords"], l["ycoords"], ws[idx], wd[idx], yaw[idx]), max_flagged_frac=1.0)
+
+    w.set_wind(8.0, 270.0)
+    k = w.kernel_info()
+    assert (k["one_block_kernel"], k["lanes_per_env"], k["slots_per_lane"]) == (1, 4, 2)
+    check_sample()
+    series = np.stack([rng.uniform(6, 12, 64), rng.uniform(0, 360, 64)], axis=1)
+    w.set_wind_series(series, seed=3)
+    w.wind_series_step()
+    k = w.kernel_info()
+    assert k["direction_groups"] == 64 and (k["one_block_kernel"], k["lanes_per_env"], k["slots_per_lane"]) == (1, 4, 1), k
+    check_sample()
+    w.wind_series_step()
+    check_sample()
+    w.set_wind(9.0, 255.0)
+    k = w.kernel_info()
+    assert (k["one_block_kernel"], k["lanes_per_env"], k["slots_per_lane"]) == (1, 4, 2)
+    check_sample()
+    w.close()

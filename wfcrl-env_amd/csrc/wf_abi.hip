@@ -266,6 +266,20 @@ int pick_variant(int N, int B) {
   return find_variant(G, S);
 }
 
+struct LlFamily { int code, farms_per_block, per_cu; double t[3]; };  // code = (G << 4) | S, 0 = wf_step_kernel<16,5>
+const LlFamily kLlFamilies[] = {{0, 16, 2, {0.235, 0.298, 0.0}},
+                                {(8 << 4) | 1, 32, 3, {0.33, 0.42, 0.55}},
+                                {(4 << 4) | 2, 64, 2, {0.49, 0.644, 0.0}},
+                                {(4 << 4) | 1, 64, 3, {0.53, 0.67, 0.89}}};
+// rounds model of pick_ll below: ms (at N = 80) for `farms` farm slots
+double ll_estimate(const LlFamily& f, long farms) {
+  const long blocks = (farms + f.farms_per_block - 1) / f.farms_per_block, per_round = 256L * f.per_cu;
+  const long full = blocks / per_round, rem = blocks % per_round;
+  double t = full * f.t[f.per_cu - 1];
+  if (rem) t += (full ? 0.8 : 1.0) * f.t[(rem + 255) / 256 - 1];
+  return t;
+}
+
 // Lane-group width of the one-block-at-a-time kernel for N turbines and B farms, 0 = keep wf_step_kernel.  It pays once
 // the farm spans several blocks (the register-slot kernel is then pinned at two waves per SIMD by its 27 S state
 // registers) and the batch fills the chip; WF_LL=0 disables it, WF_LL_G=<4|8|16> forces a width (A/B runs).
@@ -291,23 +305,39 @@ int pick_ll(int N, int B) {  // returns (G << 4) | S, 0 = keep wf_step_kernel
   // (4096 ... 131072 farms); the cheapest wins: the register-slot kernel up to ~8192 farms, G = 8 up to ~24576, then
   // the two G = 4 kernels depending on how the batch divides into rounds of 32768 / 49152.
   if (N <= 16) return 0;
-  struct Fam { int code, farms_per_block, per_cu; double t[3]; };
-  static const Fam fam[] = {{0, 16, 2, {0.235, 0.298, 0.0}},
-                            {(8 << 4) | 1, 32, 3, {0.33, 0.42, 0.55}},
-                            {(4 << 4) | 2, 64, 2, {0.49, 0.644, 0.0}},
-                            {(4 << 4) | 1, 64, 3, {0.53, 0.67, 0.89}}};
   int best = 0;
   double t_best = 1e300;
-  for (const Fam& f : fam) {
+  for (const LlFamily& f : kLlFamilies) {
     if (f.code && N <= (f.code >> 4) * (f.code & 15)) continue;  // needs more than one block
     if (f.code == ((8 << 4) | 1) && N <= 32) continue;           // (not instantiated to pay below that)
-    const long blocks = ((long)B + f.farms_per_block - 1) / f.farms_per_block, per_round = 256L * f.per_cu;
-    const long full = blocks / per_round, rem = blocks % per_round;
-    double t = full * f.t[f.per_cu - 1];
-    if (rem) t += (full ? 0.8 : 1.0) * f.t[(rem + 255) / 256 - 1];
+    const double t = ll_estimate(f, B);
     if (t < t_best) { t_best = t; best = f.code; }
   }
   return best;
+}
+
+// A grouped launch (series rows / binned directions) pads every group to whole blocks: more farm slots than farms.  The
+// two G = 4 kernels have the same block size, so the choice between them can follow the padded count without touching
+// the group lists (HornsRev1 x 65536 in 104 groups = 1072 blocks: three rounds of the two-slot kernel, 1.65 ms, against
+// two of the one-slot kernel).
+int repick_ll_slots(int N, int ll_G, int ll_S, long farm_slots) {
+  if (ll_G != 4 || getenv("WF_LL_G") || N <= 8) return ll_S;
+  return ll_estimate(kLlFamilies[3], farm_slots) < ll_estimate(kLlFamilies[2], farm_slots) ? 1 : 2;
+}
+
+// leaving a grouped launch: back to the choice for the plain batch
+void ungroup(wf_handle* h) {
+  if (h->n_groups > 0 && h->ll_G) {
+    const int llg = pick_ll(h->N, h->B);
+    const int s_new = llg ? (llg & 15) : 1;
+    if ((llg >> 4) == h->ll_G && s_new != h->ll_S) {
+      hipStreamSynchronize(h->stream);
+      hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
+      h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
+      h->ll_S = s_new; h->pair_dirty = true;
+    }
+  }
+  h->n_groups = 0;
 }
 
 int build_consts(wf_handle* h) {
@@ -594,6 +624,14 @@ int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_
   h->n_slots = slots;
   h->n_groups = K;
   h->group_shift = 0;
+  {
+    const int s_new = repick_ll_slots(h->N, h->ll_G, h->ll_S, (long)slots);
+    if (s_new != h->ll_S) {  // table and source log are laid out for (N, G, S)
+      hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
+      h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
+      h->ll_S = s_new; h->pair_dirty = true;
+    }
+  }
   if (rebuild_geometry) {
     WF_HIP(h, wfk_launch_geometry(K, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd_groups, h->d_gx, h->d_gy, h->d_gidx, 0, nullptr, nullptr, h->stream));
     h->pair_dirty = true;
@@ -879,7 +917,7 @@ int wf_set_wind_counts(wf_handle* h, const double* ws, int n_ws, const double* w
   h->wind_sync = !on_device;
   h->wind_count = count;
   h->series_T = 0;
-  h->n_groups = 0;
+  ungroup(h);
   h->ws_prev_valid = false;
   h->pair_dirty = true;
   return WF_OK;
@@ -938,7 +976,7 @@ int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* di
   h->shared_dir = false;
   h->wind_sync = false;
   h->series_T = 0;
-  h->n_groups = 0;
+  ungroup(h);
   h->ws_prev_valid = false;
   h->pair_dirty = true;  // env_batch 1: "one wind per farm" is also "one wind for the batch" (table path)
   return WF_OK;
@@ -1008,7 +1046,7 @@ int wf_wind_series(wf_handle* h, int T, const double* ws, const double* wd, cons
   h->series_T = T;
   h->series_t = -1;
   h->ws_prev_valid = false;
-  h->n_groups = 0;
+  ungroup(h);
   h->grid_step = 0.0;
   // A shared series has only T distinct winds: farms are grouped by their start row (farms with the same start see the
   // same row at every tick), one sorted geometry + pair table per ROW, and the table path serves the whole playback.
