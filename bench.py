@@ -126,7 +126,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-leg", action="store_true", help="skip the fused-env-step and env-level legs (profiling runs)")
     ap.add_argument("--per-env-wind", action="store_true",
-                    help="cfg5 variant: wd_b(t) = wd(t) + U(-10,10) per farm (per-farm rotation + sort on the device)")
+                    help="a wind per farm: cfg5 wd_b(t) = wd(t) + U(-10,10) (per-farm rotation + sort on the device every step); "
+                         "other configs a fixed ws ~ U(6,12), wd ~ 270 + U(-10,10) per farm (the on-the-fly path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -214,6 +215,9 @@ def main():
             def set_wind_at(t):
                 return None
         w.set_wind(8.0, 270.0)
+        if args.per_env_wind and not sweep:  # a fixed wind per farm: the on-the-fly path (profiling runs)
+            w.set_wind(torch.rand(B, device="cuda", generator=gen, dtype=torch.float64) * 6 + 6,
+                       270.0 + torch.rand(B, device="cuda", generator=gen, dtype=torch.float64) * 20 - 10)
         out = w.step(ring[0])
         w.sync()
         for i in range(args.warmup):
@@ -309,13 +313,13 @@ def main():
     value = main_leg["total"] * args.steps / elapsed
     algo_bytes = (32 * N + 8) * B  # read 4N yaw + 8 wind, write 28N outputs, per farm-step
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    cp = counter_profile(args.config, B) if not sweep else None
+    cp = counter_profile(args.config, B) if not (sweep or args.per_env_wind) else None
     lops = lane_ops_per_farm_step(N, bool(info.get("pair_table")))
     lane_ops = lops * B
     valu_achieved = lane_ops / (kern_ms * 1e-3)
 
     wl_wind = ("ws 8 m/s, wd(t) = 270 + 30 sin(2 pi t/200)" + (" + U(-10,10) per farm" if args.per_env_wind else " shared")
-               if sweep else "ws 8 m/s, wd 270")
+               if sweep else ("ws ~ U(6,12) m/s, wd ~ 270 + U(-10,10) per farm (fixed)" if args.per_env_wind else "ws 8 m/s, wd 270"))
     res = {"metric": "farm_steps_per_sec", "value": value, "unit": "farm-steps/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
            "ms_per_step_host_synced": main_leg["sync_ms"],

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: everything profiles/ cites for one kernel version.  Usage: tools/record_profiles.sh <tag>
 #   bench line (with cpu_baseline), the same command under rocprofv3 --kernel-trace --stats, PMC counters in
-#   separate passes (tools/run_pmc.sh) for the headline kernel and for the on-the-fly kernel, every BASELINE config,
+#   separate passes (tools/run_pmc.sh) for the headline kernel and for the on-the-fly kernel (bench.py --per-env-wind: a wind per farm), every BASELINE config,
 #   parity statistics (tests/tools/gpu_check.py), wind / series modes, the two-rank bench line.
 tag=$1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag
@@ -19,7 +19,7 @@ python3 tools/latency_b1.py 2>&1 | grep update_command > $O/latency_b1.txt
 bash tools/run_pmc.sh $tag > /dev/null 2>&1
 python3 tools/parse_pmc.py $tag wf_step_ll_kernel > $O/pmc_cfg4.json
 rm -rf $R/gpurun_out/pmc_$tag
-WF_NO_PAIR_TABLE=1 bash tools/run_pmc.sh ${tag}_fly > /dev/null 2>&1
+bash tools/run_pmc.sh ${tag}_fly --per-env-wind > /dev/null 2>&1
 python3 tools/parse_pmc.py ${tag}_fly wf_step_ll_kernel > $O/pmc_cfg4_on_the_fly.json
 rm -rf $R/gpurun_out/pmc_${tag}_fly
 cd /tmp; export TMPDIR=/tmp
@@ -29,7 +29,7 @@ f=$(find $O/rocprof -name "*kernel_stats.csv" | head -1)
 python3 tools/summarize_rocprof.py $f $O/kernel_stats_bench_cfg4.csv > /dev/null
 rm -rf $O/rocprof
 cd /tmp
-WF_NO_PAIR_TABLE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof -- python3 $R/bench.py --no-cpu-baseline --no-env-leg > $O/bench_under_rocprof_on_the_fly.json 2> $O/rocprof_fly.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof -- python3 $R/bench.py --no-cpu-baseline --no-env-leg --per-env-wind > $O/bench_under_rocprof_on_the_fly.json 2> $O/rocprof_fly.err
 cd $R
 f=$(find $O/rocprof -name "*kernel_stats.csv" | head -1)
 python3 tools/summarize_rocprof.py $f $O/kernel_stats_bench_cfg4_on_the_fly.csv > /dev/null

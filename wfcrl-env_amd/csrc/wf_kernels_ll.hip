@@ -12,8 +12,12 @@
 //     slot 0 does (source phase, transverse pass, yaw-added recovery, deficit pass), appending to the log; then the
 //     block's outputs are written.  The lane group can be narrow — G = 4: sixteen farms per wave share every per-source
 //     instruction — because the block, not the farm, has to fit the registers; with S = 1 the kernel runs three waves
-//     per SIMD (168 VGPRs), with G = 4, S = 2 two (the pick: 24 % fewer instructions per farm than G = 8, S = 1, the
-//     same log traffic), and no register slots have to be shifted.
+//     per SIMD (168 VGPRs), with G = 4, S = 2 two (223 VGPRs; 24 % fewer instructions per farm than G = 8, S = 1, the
+//     same log traffic), and no register slots have to be shifted.  Which of them runs is decided per batch size by
+//     the rounds model in wf_abi.hip::pick_ll.
+//   * the replay loop's memory order is pinned by hand (compiler barriers; DESIGN.md §4 "what the replay loop was
+//     actually waiting for"): {dx, dy, tipow, bits} reads, the prefetch of the next log record, the deficit / TI bodies of
+//     all slots, and only then the 9 coefficient float4 per slot and the transverse pass.
 //   * pair-table records are laid out per target block, [J][source i][target of J], so that the 64 records of a chunk
 //     (64 / G consecutive sources of one block) are one contiguous 11-KiB piece, staged into a double-buffered LDS slab
 //     with global_load_lds_dwordx4 one chunk ahead (one __syncthreads() per chunk);
