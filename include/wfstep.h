@@ -232,7 +232,7 @@ typedef struct wf_kernel_info {
   int vgprs, lds_bytes, scratch_bytes; /* from hipFuncGetAttributes */
   int pair_table; /* 1: shared-wind pair-coefficient table path, 0: per-farm on-the-fly path */
   int direction_groups; /* > 0: farms grouped by that many distinct wind directions, one pair table each */
-  int one_block_kernel; /* 1: the figures describe wf_step_ll_kernel (one target block of lanes_per_env turbines in
+  int one_block_kernel; /* 1: the figures describe wf_step_ll_kernel (one target block of lanes_per_env x slots_per_lane turbines in
                            registers at a time, csrc/wf_kernels_ll.hip), which serves every wind direction without an
                            x' tie across a block boundary; the register-slot kernel is enqueued behind it for the rest */
 } wf_kernel_info;
