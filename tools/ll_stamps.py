@@ -31,7 +31,7 @@ yaw = (torch.rand((B, N), device="cuda", generator=g) * 80 - 40).float()
 out = w.step(yaw)
 w.sync()
 lib = ctypes.CDLL(str(_lib.LIB_PATH))
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 lib.wfk_ll_stamps(buf, 1)
 w.timing_begin()
 w.step(yaw, out)
@@ -44,3 +44,6 @@ print(f"{name} B={B} {w.kernel_info()}  {ms:.3f} ms with stamps; {nw} waves, {to
 for k in range(4):
     print(f"  {names[k]:14s} {buf[k] / nw:10.0f} cycles  {buf[k] / buf[4]:.3f}")
 print(f"  {'prologue/rest':14s} {(buf[4] - sum(buf[:4])) / nw:10.0f} cycles  {(buf[4] - sum(buf[:4])) / buf[4]:.3f}")
+print("  own-source step, cycles per source (the stamps themselves add ~10 %):")
+for k, nm in zip(range(6, 11), ["A state + broadcasts", "B cbrt, Ct lookup, induction", "C transverse pass in the block", "D steering, deflection/deficit constants, log store", "E deficit / TI pass in the block"]):
+    print(f"    {nm:52s} {buf[k] / nw / N:8.0f}")

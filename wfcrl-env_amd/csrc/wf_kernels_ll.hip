@@ -127,7 +127,7 @@ extern "C" hipError_t wfk_launch_pair_table_ll(const WfPairConsts* pc, int G, in
 // registers), nothing is staged and no barrier is needed after the start.  MC1 (on the fly only): compile-time skip of
 // the ground-mirror vortex cores that are exactly 1.0f in float32 (WfConsts::mirror_core_n <= 1).
 #ifdef WF_LL_STAMP  // debug build (tools/ll_stamps.py): wave cycles per phase, summed over the launch
-__device__ unsigned long long wf_ll_stamp[8];
+__device__ unsigned long long wf_ll_stamp[16];
 #define WF_T(v) const unsigned long long v = __builtin_readcyclecounter()
 #define WF_ACC(k, a, b) st_acc[k] += (b) - (a)
 #else
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
 
   float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
 #ifdef WF_LL_STAMP
-  unsigned long long st_acc[5] = {0, 0, 0, 0, 0};
+  unsigned long long st_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   WF_T(st_begin);
 #endif
   int q = 0;                        // running chunk index (LDS buffer q & 1)
@@ -511,6 +511,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     auto own_source = [&](auto PS, int i, const float* recs) {
       constexpr int ps = decltype(PS)::value;
       const int src = gbase + ((i - first_own) - ps * G);  // owner lane
+      WF_T(so_0);
       // A. the source's state
       float fe = 0.0f, fc = 0.0f, vsum = 0.0f;
 #pragma unroll
@@ -529,6 +530,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       const float yaw_i = __shfl(yaw_t[ps], src);
       const float cg = __shfl(cg_t[ps], src), sg = __shfl(sg_t[ps], src);
       // B. circulations [A.3-1, A.3-4]
+      WF_T(so_1);
+      WF_ACC(6, so_0, so_1);
       SrcLog Sc;
       const float ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
       bool steep;
@@ -541,6 +544,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       const float scg = sg * cg * c.sw_tv;
       Sc.Gy = scg * ct * ws;
       Sc.Gwt = Gwr * c.sw_tv;
+      WF_T(so_2);
+      WF_ACC(7, so_1, so_2);
       // C. pass 1: the source's own slot (lanes upstream of it carry dx < 0 in their record), every later slot of the
       // block, and the lanes of EARLIER slots that tie with it in x' (dx = 0 counts as downstream here [A.3-4])
       float4 ex[S];
@@ -569,6 +574,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         }
       };
       static_for<S>(pass1_slot);
+      WF_T(so_3);
+      WF_ACC(8, so_2, so_3);
       float vbar = 0.0f, wbar = 0.0f;
 #pragma unroll
       for (int k2 = 0; k2 < 9; ++k2) { vbar += V[ps][k2]; wbar += W[ps][k2]; }
@@ -640,6 +647,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         for (int kk = 0; kk < 4; ++kk) lp[kk] = sp[kk];
         if (split) *reinterpret_cast<float4*>(logx + (size_t)i * WF_LOG_SIDE_FLOATS) = make_float4(X.TI0, X.TI1, X.TI2, X.dTI);
       }
+      WF_T(so_4);
+      WF_ACC(9, so_3, so_4);
       // E. pass 2: strictly downstream lanes of the source's own slot, every later slot (an earlier slot's turbines are at
       // or upstream of the source: nothing to do, a tie leaves deficit and TI untouched)
       const float xs_[4] = {X.TI0, X.TI1, X.TI2, X.dTI};
@@ -648,6 +657,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         if constexpr (p == ps) pass2(PP, Sc, xs_, false, ex[p], ex[p].x > 0.0f, yt_d[TAB ? 0 : p], yi_d);
         else if constexpr (p > ps) pass2(PP, Sc, xs_, false, ex[p], tvalid[p], yt_d[TAB ? 0 : p], yi_d);
       });
+      WF_T(so_5);
+      WF_ACC(10, so_4, so_5);
     };
 
     for (int cq = 0; cq < n_chunks; ++cq, ++q) {
@@ -827,6 +838,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     st_acc[4] = __builtin_readcyclecounter() - st_begin;
     for (int k = 0; k < 5; ++k) atomicAdd(&wf_ll_stamp[k], st_acc[k]);
     atomicAdd(&wf_ll_stamp[5], 1ull);
+    for (int k = 6; k < 11; ++k) atomicAdd(&wf_ll_stamp[k], st_acc[k]);  // parts of an own-source step (tools/ll_stamps.py)
   }
 #endif
 
@@ -879,7 +891,7 @@ extern "C" int wfk_ll_farms_per_block(int G) { return kLLWaves * (64 / G); }
 extern "C" int wfk_ll_stamps(unsigned long long* out, int reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_ll_stamp), sizeof(wf_ll_stamp));
   if (e == hipSuccess && reset) {
-    unsigned long long z[8] = {};
+    unsigned long long z[16] = {};
     e = hipMemcpyToSymbol(HIP_SYMBOL(wf_ll_stamp), z, sizeof(z));
   }
   return (int)e;
