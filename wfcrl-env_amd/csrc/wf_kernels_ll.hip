@@ -142,8 +142,9 @@ template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB>
 #define WF_LL_OCC2 2  // ... for the two-slot variants
 #endif
 #ifndef WF_LL_OCC
-#define WF_LL_OCC 3  // waves per SIMD the register allocator is asked to make room for (measured: 2 -> 1.87 ms, 3 -> 1.60 ms,
-                     // 4 -> 2.9 ms with 168 B of spills, HornsRev1 x 65536)
+#define WF_LL_OCC 3  // waves per SIMD the register allocator is asked to make room for (first version of the kernel, G = 8:
+                     // 2 -> 1.87 ms, 3 -> 1.60 ms, 4 -> 2.9 ms with 168 B of spills; final version, G = 4: 3 -> 1.24 ms,
+                     // 4 -> 1.35 ms with 96 B of scratch; HornsRev1 x 65536)
 #endif
 __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / WPB) void wf_step_ll_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const int* __restrict__ gidx, const double* __restrict__ ws_in,
