@@ -730,7 +730,7 @@ def test_model_surface_of_the_case_yaml(layouts, model):
     w.close()
 
 
-@pytest.mark.parametrize("G", ["4", "8", "16", "4x2"])
+@pytest.mark.parametrize("G", ["4", "8", "16", "4x2", "2x2"])
 @pytest.mark.parametrize("name,wdir", [("HornsRev1_", 270.0), ("HornsRev2_", 243.0), ("Turb_TCRWP_", 281.0), ("Ormonde_", 200.0)])
 def test_one_block_at_a_time_kernel(layouts, name, wdir, G, monkeypatch):
     """wf_step_ll_kernel (csrc/wf_kernels_ll.hip: one target block in registers, earlier sources replayed from the source
@@ -780,7 +780,7 @@ def test_one_block_at_a_time_kernel(layouts, name, wdir, G, monkeypatch):
     assert np.abs(a["wind_direction"] - a0["wind_direction"])[both].max() < 2e-4
 
 
-@pytest.mark.parametrize("G", ["4", "8", "4x2"])
+@pytest.mark.parametrize("G", ["4", "8", "4x2", "2x2"])
 def test_one_block_kernel_hands_cross_block_ties_back(layouts, G, monkeypatch):
     """Axis-aligned grids at wd = 270 have exact x' ties that straddle lane-group blocks: the device-side flag of the
     target-block table routes such a direction to wf_step_kernel (no host round trip); other directions of the same
@@ -800,7 +800,7 @@ def test_one_block_kernel_hands_cross_block_ties_back(layouts, G, monkeypatch):
     w.close()
 
 
-@pytest.mark.parametrize("G", ["4x2", "8", "4"])
+@pytest.mark.parametrize("G", ["4x2", "8", "4", "2x2"])
 @pytest.mark.parametrize("name", ["HornsRev1_", "Turb32_Row5_", "Ormonde_"])
 def test_one_block_kernel_on_the_fly_with_a_wind_per_farm(layouts, name, G, monkeypatch):
     """A wind per farm on the one-block kernel (transverse pass on the fly from each farm's own sorted geometry), against
@@ -843,9 +843,10 @@ def test_one_block_kernel_on_the_fly_with_a_wind_per_farm(layouts, name, G, monk
     # the table path and the on-the-fly path of one handle share the source log; at G = 4 they use different block
     # sizes (one slot per lane on the table path, two on the fly): alternate them
     lanes = int(G.split("x")[0])
-    assert w.kernel_info()["slots_per_lane"] == (2 if lanes == 4 else 1)
+    k = w.kernel_info()  # on the fly: two slots at G = 4, and G = 4 x 2 stands in for G = 2
+    assert (k["lanes_per_env"], k["slots_per_lane"]) == ((4, 2) if lanes <= 4 else (lanes, 1))
     w.set_wind(9.0, 281.0)
-    assert w.kernel_info()["pair_table"] == 1 and w.kernel_info()["one_block_kernel"] == (1 if N > lanes * (2 if G == "4x2" else 1) else 0)
+    assert w.kernel_info()["pair_table"] == 1 and w.kernel_info()["one_block_kernel"] == (1 if N > lanes * (2 if "x2" in G else 1) else 0)
     _check(_with_flags(w, w.step(yaw)), _oracle(l["xcoords"], l["ycoords"], 9.0, 281.0, yaw))
     w.set_wind(ws, wd)
     c2 = _with_flags(w, w.step(yaw))
@@ -869,7 +870,7 @@ def _regime(name):
     return inp, ref
 
 
-@pytest.mark.parametrize("kernel", ["", "8", "4x2", "4"])
+@pytest.mark.parametrize("kernel", ["", "8", "4x2", "4", "2x2"])
 def test_regime_cases_are_flagged_and_bounded(kernel, monkeypatch):
     """The two fuzzer-found regime farms (tests/golden/make_regime_cases.py) on every kernel family: the farm on the
     cut-in ramp of the thrust table raises WF_RISK_THRUST_RAMP, the farm 3.7e-7 from the overlap threshold raises
@@ -902,9 +903,11 @@ def test_regime_cases_are_flagged_and_bounded(kernel, monkeypatch):
 
 
 def test_grouped_launch_follows_the_padded_farm_count(layouts):
-    """HornsRev1 x 65536: the plain batch is two full rounds of the two-slot G = 4 kernel; grouped by 64 series rows the
-    launch has 1057 blocks of farm slots, a third round for that kernel, and the one-slot kernel (three blocks per CU)
-    is chosen instead; back on a shared wind the first choice returns.  Parity on a sample of farms in each state."""
+    """HornsRev1 x 65536: the plain batch is exactly one full round of the G = 2 x 2 kernel (128 farms per block, two
+    blocks per CU); grouped by 64 series rows the launch is padded per group, which that kernel's blocks would double:
+    grouped launches use G = 4, with 1057 blocks of farm slots the one-slot kernel (three blocks per CU) rather than the
+    two-slot one (a third round); back on a shared wind the first choice returns.  Parity on a sample of farms in each
+    state."""
     import torch
 
     from wfcrl_env_amd.backend import WfStep
@@ -925,7 +928,7 @@ def test_grouped_launch_follows_the_padded_farm_count(layouts):
 
     w.set_wind(8.0, 270.0)
     k = w.kernel_info()
-    assert (k["one_block_kernel"], k["lanes_per_env"], k["slots_per_lane"]) == (1, 4, 2)
+    assert (k["one_block_kernel"], k["lanes_per_env"], k["slots_per_lane"]) == (1, 2, 2)
     check_sample()
     series = np.stack([rng.uniform(6, 12, 64), rng.uniform(0, 360, 64)], axis=1)
     w.set_wind_series(series, seed=3)
@@ -937,6 +940,6 @@ def test_grouped_launch_follows_the_padded_farm_count(layouts):
     check_sample()
     w.set_wind(9.0, 255.0)
     k = w.kernel_info()
-    assert (k["one_block_kernel"], k["lanes_per_env"], k["slots_per_lane"]) == (1, 4, 2)
+    assert (k["one_block_kernel"], k["lanes_per_env"], k["slots_per_lane"]) == (1, 2, 2)
     check_sample()
     w.close()

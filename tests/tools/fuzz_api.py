@@ -41,7 +41,7 @@ def run(n_sessions, n_ops, seed):
         B = int(rng.integers(1, 20))
         # every other session forces the one-block-at-a-time kernel (table path and on the fly) where the farm has more
         # than one of its blocks; the batch sizes of this fuzzer would never pick it by themselves
-        llg = str(rng.choice(["", "", "8", "4x2", "4"]))
+        llg = str(rng.choice(["", "", "8", "4x2", "4", "2x2"]))
         if llg:
             os.environ["WF_LL_G"] = llg
         else:

@@ -77,7 +77,7 @@ def run(n_cases, seed, only=-1):
         os.environ["WF_KERNEL_GS"] = f"{G}x{S}"
         # every other case also forces the one-block-at-a-time kernel (csrc/wf_kernels_ll.hip) at a random lane-group
         # width: it serves the table-path modes of farms with more than one block, wf_step_kernel the rest
-        llg = str(rng.choice(["0", "0", "4", "8", "16", "4x2", "4x2"]))
+        llg = str(rng.choice(["0", "0", "4", "8", "16", "4x2", "4x2", "2x2"]))
         if llg != "0" and N > eval(llg.replace("x", "*")):
             os.environ["WF_LL_G"] = llg
         else:

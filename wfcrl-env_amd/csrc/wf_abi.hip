@@ -270,7 +270,8 @@ struct LlFamily { int code, farms_per_block, per_cu; double t[3]; };  // code = 
 const LlFamily kLlFamilies[] = {{0, 16, 2, {0.235, 0.298, 0.0}},
                                 {(8 << 4) | 1, 32, 3, {0.33, 0.42, 0.55}},
                                 {(4 << 4) | 2, 64, 2, {0.49, 0.644, 0.0}},
-                                {(4 << 4) | 1, 64, 3, {0.53, 0.67, 0.89}}};
+                                {(4 << 4) | 1, 64, 3, {0.53, 0.67, 0.89}},
+                                {(2 << 4) | 2, 128, 2, {0.855, 1.178, 0.0}}};
 // rounds model of pick_ll below: ms (at N = 80) for `farms` farm slots
 double ll_estimate(const LlFamily& f, long farms) {
   const long blocks = (farms + f.farms_per_block - 1) / f.farms_per_block, per_round = 256L * f.per_cu;
@@ -291,7 +292,7 @@ int pick_ll(int N, int B) {  // returns (G << 4) | S, 0 = keep wf_step_kernel
   if (force) {
     int g = 0, sl = 1;
     if (sscanf(force, "%dx%d", &g, &sl) < 1) return 0;
-    const bool ok = ((g == 4 || g == 8 || g == 16) && sl == 1) || (g == 4 && sl == 2);
+    const bool ok = ((g == 4 || g == 8 || g == 16) && sl == 1) || ((g == 4 || g == 2) && sl == 2);
     return (ok && N > g * sl) ? ((g << 4) | sl) : 0;
   }
   // A wave solves its 64 / G farms start to finish, so a launch runs in ROUNDS of (blocks the chip holds) x (farms per
@@ -301,6 +302,8 @@ int pick_ll(int N, int B) {  // returns (G << 4) | S, 0 = keep wf_step_kernel
   //   G = 8                 32 farms per block, 3 per CU: 0.33  0.42  0.55
   //   G = 4, two slots      64 farms per block, 2 per CU: 0.49  0.644
   //   G = 4                 64 farms per block, 3 per CU: 0.53  0.67  0.89
+  //   G = 2, two slots     128 farms per block, 2 per CU: 0.855 1.178   (thirty-two farms per wave share the per-source
+  //                         phase; twice the log re-reads of G = 4 x 2: pays only on full rounds of 65536 farms)
   // A partial round behind full ones overlaps with their tail (factor 0.8).  The estimates are within 6 % of the sweep
   // (4096 ... 131072 farms); the cheapest wins: the register-slot kernel up to ~8192 farms, G = 8 up to ~24576, then
   // the two G = 4 kernels depending on how the batch divides into rounds of 32768 / 49152.
@@ -310,6 +313,7 @@ int pick_ll(int N, int B) {  // returns (G << 4) | S, 0 = keep wf_step_kernel
   for (const LlFamily& f : kLlFamilies) {
     if (f.code && N <= (f.code >> 4) * (f.code & 15)) continue;  // needs more than one block
     if (f.code == ((8 << 4) | 1) && N <= 32) continue;           // (not instantiated to pay below that)
+    if (f.code == ((2 << 4) | 2) && N < 48) continue;            // (measured at N = 80 and 91 only)
     const double t = ll_estimate(f, B);
     if (t < t_best) { t_best = t; best = f.code; }
   }
@@ -325,16 +329,22 @@ int repick_ll_slots(int N, int ll_G, int ll_S, long farm_slots) {
   return ll_estimate(kLlFamilies[3], farm_slots) < ll_estimate(kLlFamilies[2], farm_slots) ? 1 : 2;
 }
 
+// The one-block kernel's (G, S) of a handle: its pair table and source log are laid out for (N, G, S).  The caller has
+// made sure no launch is in flight.
+void set_ll_shape(wf_handle* h, int G, int S) {
+  if (G == h->ll_G && S == h->ll_S) return;
+  hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
+  h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
+  h->ll_G = G; h->ll_S = S; h->pair_dirty = true;
+}
+
 // leaving a grouped launch: back to the choice for the plain batch
 void ungroup(wf_handle* h) {
   if (h->n_groups > 0 && h->ll_G) {
     const int llg = pick_ll(h->N, h->B);
-    const int s_new = llg ? (llg & 15) : 1;
-    if ((llg >> 4) == h->ll_G && s_new != h->ll_S) {
+    if (llg && ((llg >> 4) != h->ll_G || (llg & 15) != h->ll_S)) {
       hipStreamSynchronize(h->stream);
-      hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
-      h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
-      h->ll_S = s_new; h->pair_dirty = true;
+      set_ll_shape(h, llg >> 4, llg & 15);
     }
   }
   h->n_groups = 0;
@@ -532,10 +542,11 @@ int pair_table(wf_handle* h, const float** out) {
 // per-farm cross-block-tie flags for the on-the-fly one-block kernel; sync_ok: the caller synchronises anyway, so the
 // "any farm tied" flag is read back and a launch nobody needs is never enqueued.
 int ll_fly_S(const wf_handle* h);
+int ll_fly_G(const wf_handle* h);
 int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
-  const bool per_farm = n_env == h->B && h->B > 1 && h->ll_G && wfk_ll_has_fly(h->ll_G, ll_fly_S(h));
+  const bool per_farm = n_env == h->B && h->B > 1 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h));
   WF_HIP(h, wfk_launch_geometry(n_env, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd, h->d_gx, h->d_gy, h->d_gidx,
-                                per_farm ? h->ll_G * ll_fly_S(h) : 0, h->d_farm_tie, h->d_farm_tie ? h->d_farm_tie + h->B : nullptr,
+                                per_farm ? ll_fly_G(h) * ll_fly_S(h) : 0, h->d_farm_tie, h->d_farm_tie ? h->d_farm_tie + h->B : nullptr,
                                 h->stream));
   h->farm_ties = 2;
   if (per_farm && sync_ok) {
@@ -549,13 +560,20 @@ int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
 
 // Target slots per lane of the one-block kernel ON THE FLY (a wind per farm): two at G = 4 whatever the table path
 // uses — there the second slot halves the per-source geometry work as well (HornsRev1 x 65536: 3.48 ms against 4.14).
-int ll_fly_S(const wf_handle* h) { return h->ll_G == 4 ? 2 : h->ll_S; }
+int ll_fly_S(const wf_handle* h) { return h->ll_G <= 4 ? 2 : h->ll_S; }
+// ... and its lane-group width: the table path's, except that G = 2 has no on-the-fly instantiation (G = 4 x 2 serves)
+int ll_fly_G(const wf_handle* h) { return h->ll_G == 2 ? 4 : h->ll_G; }
 
 // turbines per farm in the source log of the one-block kernel: whole lane-group blocks (of the larger of the two
 // block sizes: the table path and the on-the-fly path share the buffer)
 size_t ll_npad(const wf_handle* h) {
-  const int gs = h->ll_G * (h->ll_S > ll_fly_S(h) ? h->ll_S : ll_fly_S(h));
+  const int a = h->ll_G * h->ll_S, b = ll_fly_G(h) * ll_fly_S(h), gs = a > b ? a : b;  // (powers of two)
   return (size_t)((h->N + gs - 1) / gs) * gs;
+}
+
+int ll_log_fpb(const wf_handle* h) {
+  const int a = wfk_ll_farms_per_block(h->ll_G), b = wfk_ll_farms_per_block(ll_fly_G(h));
+  return a > b ? a : b;
 }
 
 // Farms per block of the table-path launch of the handle's kernel variant (wf_step_kernel), and of the
@@ -567,11 +585,12 @@ int farms_per_block(const wf_handle* h) {
   return wfk_tab_waves() * (64 / vG);
 }
 int group_pad(const wf_handle* h) {
-  const int a = farms_per_block(h), b = h->ll_G ? wfk_ll_farms_per_block(h->ll_G) : 0;
+  // (a grouped launch never runs the G = 2 kernel: build_groups)
+  const int a = farms_per_block(h), b = h->ll_G ? wfk_ll_farms_per_block(h->ll_G == 2 ? 4 : h->ll_G) : 0;
   return a > b ? a : b;
 }
 int group_unit(const wf_handle* h) {
-  const int a = farms_per_block(h), b = h->ll_G ? wfk_ll_farms_per_block(h->ll_G) : a;
+  const int a = farms_per_block(h), b = h->ll_G ? wfk_ll_farms_per_block(h->ll_G == 2 ? 4 : h->ll_G) : a;
   return a < b ? a : b;
 }
 
@@ -591,6 +610,12 @@ bool groups_pay_off(const wf_handle* h, int K) {
 // whole blocks (d_perm, -1 = padding), group of each block (d_blk_group).  Then the sorted geometry of the K
 // directions `d_wd_groups` (device) is built into the geometry buffers; the pair tables follow lazily (pair_table()).
 int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_wd_groups, bool rebuild_geometry) {
+  // the 128-farm blocks of the G = 2 kernel would double the padding of every group: grouped launches use G = 4
+  // (the choice between its two kernels follows the padded count, below)
+  if (h->ll_G == 2 && !getenv("WF_LL_G")) {
+    WF_HIP(h, hipStreamSynchronize(h->stream));
+    set_ll_shape(h, 4, 2);
+  }
   const int epb = group_pad(h), unit = group_unit(h);
   std::vector<int> count(K, 0);
   for (int b = 0; b < h->B; ++b) {
@@ -626,11 +651,7 @@ int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_
   h->group_shift = 0;
   {
     const int s_new = repick_ll_slots(h->N, h->ll_G, h->ll_S, (long)slots);
-    if (s_new != h->ll_S) {  // table and source log are laid out for (N, G, S)
-      hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
-      h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
-      h->ll_S = s_new; h->pair_dirty = true;
-    }
+    if (s_new != h->ll_S) set_ll_shape(h, h->ll_G, s_new);
   }
   if (rebuild_geometry) {
     WF_HIP(h, wfk_launch_geometry(K, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd_groups, h->d_gx, h->d_gy, h->d_gidx, 0, nullptr, nullptr, h->stream));
@@ -658,7 +679,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   if (ptab && h->ll_G) {
     // the one-block-at-a-time kernel serves every direction without a cross-block tie; wf_step_kernel, enqueued right
     // behind it, serves the others (device-side predicate, no host round trip)
-    const int fpb = wfk_ll_farms_per_block(h->ll_G);
+    const int fpb = ll_log_fpb(h);  // (farm slots of the log: whole blocks of the wider of the two paths' blocks)
     const size_t slots = h->n_groups > 0 ? (size_t)h->n_slots : (size_t)((h->B + fpb - 1) / fpb) * fpb;
     if (slots > h->log_slots_cap) {
       WF_HIP(h, hipStreamSynchronize(h->stream));
@@ -673,10 +694,10 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
     if (h->ll_ties == 0) return WF_OK;
     ga.pred = h->d_ll_flag;
   }
-  if (!ptab && gstride != 0 && h->B > 1 && h->ll_G && wfk_ll_has_fly(h->ll_G, ll_fly_S(h)) && !h->no_ll_fly) {
+  if (!ptab && gstride != 0 && h->B > 1 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && !h->no_ll_fly) {
     // a wind per farm: the one-block kernel on the fly; wf_step_kernel behind it for the farms whose own geometry has
     // an x' tie across a block boundary (per-farm device flags from the geometry kernel)
-    const int fpb = wfk_ll_farms_per_block(h->ll_G);
+    const int fpb = ll_log_fpb(h);
     const size_t slots = (size_t)((h->B + fpb - 1) / fpb) * fpb;
     if (slots > h->log_slots_cap) {
       WF_HIP(h, hipStreamSynchronize(h->stream));
@@ -684,7 +705,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
       WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * ll_npad(h) * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
       h->log_slots_cap = slots;
     }
-    WF_HIP(h, wfk_launch_step_ll_fly(h->ll_G, ll_fly_S(h), &h->consts, h->d_tab, h->d_gidx, h->d_gx, h->d_gy, h->d_ws, h->d_wd, yaw,
+    WF_HIP(h, wfk_launch_step_ll_fly(ll_fly_G(h), ll_fly_S(h), &h->consts, h->d_tab, h->d_gidx, h->d_gx, h->d_gy, h->d_ws, h->d_wd, yaw,
                                      power, wspd, wdir, load, h->B, ea, h->d_farm_tie, h->d_src_log,
                                      h->log_slots_cap * ll_npad(h) * WF_LOG_FLOATS, &ga, h->stream));
     if (h->farm_ties == 0) return WF_OK;
@@ -1291,15 +1312,15 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   info->envs_per_block = wpb * (64 / G); info->threads_per_block = 64 * wpb;
   info->grid_blocks = h->n_groups > 0 ? (h->n_slots + info->envs_per_block - 1) / info->envs_per_block
                                       : (h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0);
-  const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(h->ll_G, ll_fly_S(h)) && !h->no_ll_fly;
+  const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && !h->no_ll_fly;
   info->one_block_kernel = ((tab && h->ll_G) || ll_fly) ? 1 : 0;
   if (info->one_block_kernel) {
     // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
     // fields above would describe) is enqueued behind it for the directions that have one
-    const int ll_s = tab ? h->ll_S : ll_fly_S(h);
-    WF_HIP(h, wfk_ll_func_attributes(h->ll_G, ll_s, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, &a));
-    info->lanes_per_env = h->ll_G; info->slots_per_lane = ll_s;
-    info->envs_per_block = wfk_ll_farms_per_block(h->ll_G); info->threads_per_block = 256;
+    const int ll_s = tab ? h->ll_S : ll_fly_S(h), ll_g = tab ? h->ll_G : ll_fly_G(h);
+    WF_HIP(h, wfk_ll_func_attributes(ll_g, ll_s, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, &a));
+    info->lanes_per_env = ll_g; info->slots_per_lane = ll_s;
+    info->envs_per_block = wfk_ll_farms_per_block(ll_g); info->threads_per_block = 256;
     info->grid_blocks = (int)(((h->n_groups > 0 ? (size_t)h->n_slots : (size_t)h->B) + info->envs_per_block - 1) / info->envs_per_block);
   }
   info->vgprs = a.numRegs;

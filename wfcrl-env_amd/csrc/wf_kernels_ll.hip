@@ -914,6 +914,7 @@ extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const 
   WF_LL_DISPATCH(8, 1, WF_LL_LAUNCH);
   WF_LL_DISPATCH(16, 1, WF_LL_LAUNCH);
   WF_LL_DISPATCH(4, 2, WF_LL_LAUNCH);
+  WF_LL_DISPATCH(2, 2, WF_LL_LAUNCH);
   return hipErrorInvalidValue;
 }
 
@@ -950,5 +951,6 @@ extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int
   WF_LL_DISPATCH(8, 1, WF_LL_ATTR);
   WF_LL_DISPATCH(16, 1, WF_LL_ATTR);
   WF_LL_DISPATCH(4, 2, WF_LL_ATTR);
+  WF_LL_DISPATCH(2, 2, WF_LL_ATTR);
   return hipErrorInvalidValue;
 }
