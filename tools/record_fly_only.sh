@@ -1,4 +1,4 @@
-tag=r02_v25
+tag=${1:-r02_fly}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag
 cd $R
 bash tools/run_pmc.sh ${tag}_fly --per-env-wind > /dev/null 2>&1
