@@ -606,8 +606,12 @@ def test_integration_md_stub_runs_as_printed():
     assert r.returncode == 0 and "stub: ok" in r.stdout, r.stdout + r.stderr
 
 
-def test_direction_groups_series_binned_and_explicit_shared_direction(layouts):
-    """Per-farm wind that is not really per-farm stays on the pair-table path:
+@pytest.mark.parametrize("forced", ["", "2x2", "4x2", "8", "4"])
+def test_direction_groups_series_binned_and_explicit_shared_direction(layouts, forced, monkeypatch):
+    """(every one-block kernel family forced in turn: a grouped launch lays its farm lists out in blocks of the kernel that
+    will run them — the G = 2 kernel's 128-farm blocks are never used for it, also when WF_LL_G forces that kernel for
+    the plain batch: found by the API fuzzer)
+    Per-farm wind that is not really per-farm stays on the pair-table path:
     (a) a shared wind SERIES has only T distinct winds: farms are grouped by start row, one geometry + table per row
         (reference wfcrl/interface.py:503-524 playback), checked at every tick against the oracle and against the
         on-the-fly path of the same handle state;
@@ -617,6 +621,8 @@ def test_direction_groups_series_binned_and_explicit_shared_direction(layouts):
 
     from wfcrl_env_amd.backend import WfStep
 
+    if forced:
+        monkeypatch.setenv("WF_LL_G", forced)
     l = layouts["HornsRev1_"]
     N, B, T = 80, 700, 7
     rng = np.random.default_rng(2025)
@@ -676,6 +682,10 @@ def test_direction_groups_series_binned_and_explicit_shared_direction(layouts):
     # (c) binned reset directions
     w.sample_wind(17, direction_step=5.0)
     info = w.kernel_info()
+    if forced in ("8", "4", "4x2", "2x2"):  # 72 groups padded to blocks of 32 / 64 farms at 700 farms: does not pay,
+        assert info["direction_groups"] == 0 and info["pair_table"] == 0  # the on-the-fly path serves (by design)
+        w.close()
+        return
     assert info["direction_groups"] == 72 and info["pair_table"] == 1
     ws, wd = w.get_wind()
     assert np.all(np.abs(wd / 5.0 - np.round(wd / 5.0)) < 1e-12) and len(np.unique(wd)) > 10 and ws.std() > 0.5

@@ -612,7 +612,7 @@ bool groups_pay_off(const wf_handle* h, int K) {
 int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_wd_groups, bool rebuild_geometry) {
   // the 128-farm blocks of the G = 2 kernel would double the padding of every group: grouped launches use G = 4
   // (the choice between its two kernels follows the padded count, below)
-  if (h->ll_G == 2 && !getenv("WF_LL_G")) {
+  if (h->ll_G == 2) {  // (also when WF_LL_G forces it for the plain batch: the group lists are laid out in 64-farm blocks)
     WF_HIP(h, hipStreamSynchronize(h->stream));
     set_ll_shape(h, 4, 2);
   }
