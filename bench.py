@@ -338,6 +338,9 @@ def main():
                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                         "traffic": cp["hbm_bytes"] if cp else None,
                         "traffic_source": cp["source"] if cp else None,
+                        # what the kernel actually moves (the source log of the one-block kernel on top of the
+                        # algorithmic bytes), as a fraction of the HBM peak at this run's kernel time
+                        "traffic_frac_of_peak": (cp["hbm_bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if cp else None,
                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
                         "note": "path is VALU-bound (arithmetic intensity ~2 kFLOP/B): see valu_roofline"},
            "valu_roofline": {"bound": "valu_fp32", "achieved": valu_achieved, "peak": VALU_PEAK_LANEOPS,
