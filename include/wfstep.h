@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 2
+#define WF_ABI_VERSION 3
 
 /* status codes (0 = ok, negative = error; text via wf_last_error) */
 #define WF_OK 0
@@ -46,7 +46,7 @@ typedef struct wf_handle wf_handle;
  * DATA: pass any FLORIS `power_thrust_table` (wind_speed, thrust=Ct, power=Cp). */
 typedef struct wf_model_params {
   /* flow field — case.yaml:30-39 */
-  double air_density, ambient_ti, shear, veer; /* veer must be 0 */
+  double air_density, ambient_ti, shear, veer; /* veer != 0: every farm is solved by the float64 kernel (wf_set_risk_resolve) */
   /* turbine — FLORIS turbine_library/nrel_5MW */
   double rotor_diameter, hub_height, tsr, pP, pT, gen_eff, ref_density;
   /* gauss velocity model — case.yaml:76-80 (alpha, beta, ka, kb); gauss deflection model — case.yaml:52-59 (ad, bd,
@@ -149,6 +149,20 @@ int wf_sync(wf_handle* h);
 #define WF_RISK_THRUST_RAMP 4
 int wf_set_risk_guard(wf_handle* h, double rel_band); /* default 5e-5; 0 disables WF_RISK_OVERLAP */
 int wf_get_risk_flags(wf_handle* h, int* flags, int on_device);
+
+/* ---- Float64 re-solve: the 1e-4 contract without exemptions ------------------------------------------------
+ * The reference evaluates this path in float64 (interface.py:564 -> FLORIS `calculate_wake`).  With mode 1, every
+ * wf_step / wf_env_step is followed, on the same stream and without a host round trip, by a compaction of the farms
+ * whose risk flags are nonzero and a float64 solve of exactly those farms (csrc/wf_resolve.hip: the same recurrence with
+ * double arithmetic and FLORIS' own comparisons), which overwrites their outputs (and reward) and clears their flags:
+ * afterwards EVERY farm of the batch matches the float64 path within the parity tolerances.  Cost: nothing measurable
+ * when no farm is flagged (two tiny launches); about 1 ms per 1000 flagged HornsRev1 farms otherwise.
+ * mode 2 solves every farm in float64 (validation; also what a model with wind_veer != 0 gets, whatever the mode).
+ * mode 0 (default): float32 results with flags, as before.
+ * wf_get_resolve_stats: number of farms the last step solved in float64, and (raw_flags != NULL, env_batch ints) the
+ * flags as the float32 kernels raised them before they were cleared. */
+int wf_set_risk_resolve(wf_handle* h, int mode);
+int wf_get_resolve_stats(wf_handle* h, int* n_resolved, int* raw_flags, int on_device);
 
 /* ---- Fused env step (not in the reference, which does this in Python per farm) ----
  * Device-resident env state per farm instance: absolute yaw [B*N], actuation accumulator [B*N], move

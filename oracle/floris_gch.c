@@ -315,7 +315,16 @@ static void farm_step_one(const wfo_params* p, int N, const double* x, const dou
               }
               if (on) {
                 const double yy = Y - y_i - delta, zz = Zk - HH;
-                const double r = yy * yy / (2.0 * sy * sy) + zz * zz / (2.0 * sz * sz);
+                double r;
+                if (p->veer == 0.0) {
+                  r = yy * yy / (2.0 * sy * sy) + zz * zz / (2.0 * sz * sz);
+                } else { /* FLORIS 3.5 wake_velocity/gauss.py rCalt: the Gaussian rotated by the veer angle */
+                  const double vr = p->veer * DEG2RAD;
+                  const double ca = cos(vr) * cos(vr) / (2.0 * sy * sy) + sin(vr) * sin(vr) / (2.0 * sz * sz);
+                  const double cb = -sin(2.0 * vr) / (4.0 * sy * sy) + sin(2.0 * vr) / (4.0 * sz * sz);
+                  const double cc = sin(vr) * sin(vr) / (2.0 * sy * sy) + cos(vr) * cos(vr) / (2.0 * sz * sz);
+                  r = ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz;
+                }
                 double dd = 1.0 - ct * cgv / (8.0 * sy * sz / (D * D));
                 if (dd < 0.0) dd = 0.0;
                 if (dd > 1.0) dd = 1.0;

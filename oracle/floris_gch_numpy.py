@@ -340,7 +340,14 @@ def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=Fal
         far = X >= x0
 
         def r_and_C(sy, sz):
-            r = (Y - y_i - delta) ** 2 / (2.0 * sy**2) + (Z - HH) ** 2 / (2.0 * sz**2)
+            if p.veer == 0.0:
+                r = (Y - y_i - delta) ** 2 / (2.0 * sy**2) + (Z - HH) ** 2 / (2.0 * sz**2)
+            else:  # FLORIS 3.5 wake_velocity/gauss.py rCalt: the Gaussian rotated by the veer angle (reference case.yaml:36)
+                vr = np.radians(p.veer)
+                ca = np.cos(vr) ** 2 / (2.0 * sy**2) + np.sin(vr) ** 2 / (2.0 * sz**2)
+                cb = -np.sin(2.0 * vr) / (4.0 * sy**2) + np.sin(2.0 * vr) / (4.0 * sz**2)
+                cc = np.sin(vr) ** 2 / (2.0 * sy**2) + np.cos(vr) ** 2 / (2.0 * sz**2)
+                r = ca * (Y - y_i - delta) ** 2 - 2.0 * cb * (Y - y_i - delta) * (Z - HH) + cc * (Z - HH) ** 2
             dd = np.clip(1.0 - ct * cgv / (8.0 * sy * sz / (D * D)), 0.0, 1.0)
             return r, 1.0 - np.sqrt(dd)
 

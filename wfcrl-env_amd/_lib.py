@@ -80,6 +80,8 @@ ABI = {
     "wf_sync": (C.c_int, [_P]),
     "wf_set_risk_guard": (C.c_int, [_P, C.c_double]),
     "wf_get_risk_flags": (C.c_int, [_P, _P, C.c_int]),
+    "wf_set_risk_resolve": (C.c_int, [_P, C.c_int]),
+    "wf_get_resolve_stats": (C.c_int, [_P, C.POINTER(C.c_int), _P, C.c_int]),
     "wf_wind_sample": (C.c_int, [_P, C.c_ulonglong, C.POINTER(WindDist)]),
     "wf_wind_series": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_ulonglong]),
     "wf_wind_series_step": (C.c_int, [_P]),
@@ -100,7 +102,8 @@ _lib = None
 
 def build(force: bool = False) -> Path:
     """Compile csrc/ into libwfstep.so with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [PKG_DIR / "csrc" / n for n in ("wf_kernels.hip", "wf_kernels_ll.hip", "wf_abi.hip", "wf_device.h", "wf_kernel_common.h")]
+    srcs = [PKG_DIR / "csrc" / n for n in ("wf_kernels.hip", "wf_kernels_ll.hip", "wf_resolve.hip", "wf_abi.hip", "wf_device.h",
+                                            "wf_kernel_common.h", "wf_resolve.h")]
     srcs.append(PKG_DIR.parent / "include" / "wfstep.h")
     stale = (not LIB_PATH.exists()) or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
     if force or stale:

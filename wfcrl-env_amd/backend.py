@@ -267,6 +267,18 @@ class WfStep:
         """Relative half-width of the guard band around the overlap threshold (include/wfstep.h, WF_RISK_OVERLAP)."""
         check(self._lib.wf_set_risk_guard(self._h, float(rel_band)), self._h)
 
+    def set_risk_resolve(self, mode: int | bool = 1):
+        """Float64 re-solve of the farms the float32 kernels flag (include/wfstep.h: wf_set_risk_resolve): 0 / False off,
+        1 / True the flagged farms, 2 every farm.  Afterwards every farm meets the parity tolerances and its flag is 0."""
+        check(self._lib.wf_set_risk_resolve(self._h, int(mode)), self._h)
+
+    def resolve_stats(self) -> dict:
+        """{"n_resolved": farms the last step solved in float64, "raw_flags": int32 (B,) flags before they were cleared}."""
+        n = C.c_int(0)
+        raw = np.empty(self.env_batch, np.int32)
+        check(self._lib.wf_get_resolve_stats(self._h, C.byref(n), raw.ctypes.data, 0), self._h)
+        return {"n_resolved": int(n.value), "raw_flags": raw}
+
     def risk_flags(self, as_torch: bool = False):
         """WF_RISK_* bits of every farm for the last step: int32 (B,).  0 = every float64 decision of the reference
         was reproduced with a margin; see include/wfstep.h."""

@@ -17,7 +17,10 @@
 
 #include "../../include/wfstep.h"
 #include "wf_device.h"
+#include "wf_resolve.h"
 
+extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags,
+                                         hipStream_t s);
 extern "C" int wfk_num_variants();
 extern "C" void wfk_variant(int i, int* G, int* S, const void** fn);
 extern "C" int wfk_variant_has_table(int i);
@@ -166,6 +169,11 @@ struct wf_handle {
   int farm_ties = 2;           // a wind per farm: 0 no farm has such a tie, 1 some have, 2 not read back
   bool wind_sync = true;       // the wind was set by a call that synchronises anyway (host arrays, series, binned sampling)
   int ll_ties = 2;             // cross-block ties of the current directions: 0 none, 1 all of them, 2 some / not read back
+  // float64 re-solve of the farms the float32 kernels flag (wf_resolve.hip)
+  int resolve_mode = 0;        // 0 off, 1 flagged farms, 2 every farm (forced when the model has wind_veer != 0)
+  WfResolveConsts rconsts{};
+  double* d_tab64 = nullptr;   // [3][WF_TABLE_PAD] wind speed, Ct, power in float64
+  int *d_res_list = nullptr, *d_res_count = nullptr, *d_flags_raw = nullptr;  // [B], [1], [B]
 };
 
 namespace {
@@ -204,6 +212,8 @@ int fail(wf_handle* h, int code, const std::string& msg) {
 void free_batch(wf_handle* h) {
   hipFree(h->d_ws); hipFree(h->d_wd); hipFree(h->d_gx); hipFree(h->d_gy); hipFree(h->d_gidx); hipFree(h->d_flags);
   hipFree(h->d_farm_tie);
+  hipFree(h->d_res_list); hipFree(h->d_res_count); hipFree(h->d_flags_raw);
+  h->d_res_list = h->d_res_count = h->d_flags_raw = nullptr;
   h->d_flags = h->d_farm_tie = nullptr;
   hipFree(h->d_yaw); hipFree(h->d_out);
   hipFree(h->d_env_yaw); hipFree(h->d_env_acc); hipFree(h->d_env_act); hipFree(h->d_env_out); hipFree(h->d_env_moves);
@@ -352,7 +362,6 @@ void ungroup(wf_handle* h) {
 
 int build_consts(wf_handle* h) {
   const wf_model_params& m = h->model;
-  if (m.veer != 0.0) return fail(h, WF_E_UNSUPPORTED, "wind_veer != 0 is not implemented");
   const int n = (int)h->tws.size();
   if (n < 2 || n > WF_MAX_TABLE - 1) return fail(h, WF_E_INVALID, "power_thrust_table needs 2..63 entries");
   for (int i = 1; i < n; ++i)
@@ -464,6 +473,57 @@ int build_consts(wf_handle* h) {
     if (k - j > max_probe) max_probe = k - j;
   }
   c.max_probe = max_probe;
+  // the float64 solve (wf_resolve.hip): the same model in double
+  {
+    WfResolveConsts& r = h->rconsts;
+    r.N = h->N; r.n_table = n;
+    r.sw_steer = m.enable_secondary_steering ? 1 : 0; r.sw_yar = m.enable_yaw_added_recovery ? 1 : 0;
+    r.sw_tv = m.enable_transverse_velocities ? 1 : 0;
+    r.D = D; r.HH = HH; r.TSR = m.tsr; r.amb = m.ambient_ti; r.eps2 = eps2; r.num_eps = m.num_eps; r.sqrt2 = std::sqrt(2.0);
+    r.uinf1 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      r.off[k] = off[k];
+      r.shearf[k] = shearf[k];
+      r.uinf1 += shearf[k];
+      const double z = HH + off[k];
+      const double dudz1 = m.shear * std::pow(1.0 / HH, m.shear) * std::pow(z, m.shear - 1.0);
+      const double lm = m.kappa * z / (1.0 + m.kappa * z / (D / 8.0));
+      r.nu1[k] = lm * lm * std::fabs(dudz1);
+    }
+    r.uinf1 /= 3.0;
+    r.vel_top = vel_top; r.vel_bot = vel_bot;
+    double kk[3] = {0, 0, 0};
+    for (int v = 0; v < 3; ++v)
+      for (int k = 0; k < 3; ++k) {
+        const double zc = HH + off[k] - hs[v] + m_eps, zm = HH + off[k] + hs[v] + m_eps;
+        r.zr[k][v] = zc; r.ezr[k][v] = std::exp(-zc * zc / eps2);
+        r.zm[k][v] = zm; r.ezm[k][v] = std::exp(-zm * zm / eps2);
+        for (int j = 0; j < 3; ++j) {
+          const double yL = off[j] + m_eps;
+          const double rr = yL * yL + zc * zc;
+          kk[v] += zc / (2.0 * M_PI * rr) * (1.0 - std::exp(-rr / eps2)) / 9.0;
+        }
+      }
+    r.k_top = kk[0]; r.k_bot = kk[1]; r.k_core = kk[2];
+    r.alpha = m.alpha; r.beta = m.beta; r.ka = m.ka; r.kb = m.kb; r.ad = m.ad; r.bd = m.bd; r.dm = m.dm;
+    r.defl_alpha = m.defl_alpha; r.defl_beta = m.defl_beta; r.defl_ka = m.defl_ka; r.defl_kb = m.defl_kb;
+    r.e0c1 = 3.0 * std::exp(1.0 / 12.0); r.e0c2 = 3.0 * std::exp(1.0 / 3.0);
+    r.near_c = m.near_wake_c * D;
+    r.ch_constant = m.ch_constant; r.ch_ai = m.ch_ai; r.ch_amb_pow = std::pow(m.ambient_ti, m.ch_initial); r.ch_down = m.ch_downstream;
+    r.gch_gain = m.gch_gain; r.overlap_thr = m.overlap_thresh;
+    const double vr = m.veer * M_PI / 180.0;
+    r.cos_veer = std::cos(vr); r.cos2_veer = std::cos(vr) * std::cos(vr); r.sin2_veer = std::sin(vr) * std::sin(vr);
+    r.sin_2veer = std::sin(2.0 * vr);
+    r.rho_ref = m.ref_density; r.dens_cbrt = std::pow(m.air_density / m.ref_density, 1.0 / 3.0); r.pP3 = m.pP / 3.0;
+    std::vector<double> t64(3 * WF_TABLE_PAD, 0.0);
+    for (int i = 0; i < n; ++i) { t64[i] = h->tws[i]; t64[WF_TABLE_PAD + i] = h->tct[i]; t64[2 * WF_TABLE_PAD + i] = pwv[i]; }
+    if (!h->d_tab64) {
+      hipError_t e64 = hipMalloc(&h->d_tab64, sizeof(double) * 3 * WF_TABLE_PAD);
+      if (e64 != hipSuccess) return fail(h, WF_E_HIP, std::string("table64 alloc: ") + hipGetErrorString(e64));
+    }
+    hipError_t e64 = hipMemcpy(h->d_tab64, t64.data(), sizeof(double) * t64.size(), hipMemcpyHostToDevice);
+    if (e64 != hipSuccess) return fail(h, WF_E_HIP, std::string("table64 upload: ") + hipGetErrorString(e64));
+  }
   hipError_t e = hipMemcpyAsync(h->d_tab, &t, sizeof(WfTables), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) return fail(h, WF_E_HIP, std::string("table upload: ") + hipGetErrorString(e));
@@ -661,7 +721,7 @@ int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_
 }
 
 // One launch of the step kernel on the handle's stream with the handle's current geometry / wind / table state.
-int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
+int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
   const int gstride = (h->wind_count == 1 || h->shared_dir) ? 0 : h->N;
   const int wstride = (h->wind_count == 1) ? 0 : 1;
   const float* ptab = nullptr;
@@ -713,6 +773,38 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   }
   WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                             wstride, yaw, power, wspd, wdir, load, h->B, ea, ptab, h->d_pair_first, &ga, h->stream, &h->grid));
+  return WF_OK;
+}
+
+// The step as the ABI sees it: the float32 kernels, then — when asked for (wf_set_risk_resolve) or when the model needs
+// it (wind_veer != 0) — the float64 solve of the flagged (or all) farms on the same stream, overwriting their outputs.
+int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
+  int rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
+  if (rc != WF_OK) return rc;
+  const int mode = h->model.veer != 0.0 ? 2 : h->resolve_mode;
+  if (mode == 0) return WF_OK;
+  if (!h->d_res_list) {
+    WF_HIP(h, hipMalloc(&h->d_res_list, sizeof(int) * h->cap_env));
+    WF_HIP(h, hipMalloc(&h->d_res_count, sizeof(int)));
+    WF_HIP(h, hipMalloc(&h->d_flags_raw, sizeof(int) * h->cap_env));
+  }
+  WfResolveArgs ra{};
+  ra.tab64 = h->d_tab64; ra.list = h->d_res_list; ra.count = h->d_res_count; ra.flags = h->d_flags;
+  ra.gx = h->d_gx; ra.gy = h->d_gy; ra.gidx = h->d_gidx;
+  ra.geom_stride = (h->wind_count == 1 || h->shared_dir) ? 0 : (size_t)h->N;
+  ra.mod = 1;
+  if (h->n_groups > 0) {
+    ra.farm_group = h->series_T > 0 ? h->d_series_start : h->d_bins;
+    ra.shift = h->group_shift; ra.mod = h->n_groups;
+  }
+  ra.ws = h->d_ws; ra.wd = h->d_wd; ra.wind_stride = h->wind_count == 1 ? 0 : 1;
+  ra.yaw_in = yaw;
+  ra.o_power = power; ra.o_ws = wspd; ra.o_wd = wdir; ra.o_load = load;
+  if (ea) {
+    ra.yaw_state = ea->yaw_state; ra.reward = ea->reward; ra.ws_prev = ea->ws_prev; ra.load_coef = ea->load_coef;
+  }
+  h->rconsts.N = h->N;
+  WF_HIP(h, wfk_launch_resolve(&h->rconsts, &ra, h->B, mode == 2 ? 1 : 0, h->d_flags_raw, h->stream));
   return WF_OK;
 }
 
@@ -776,7 +868,7 @@ int wf_destroy(wf_handle* h) {
   DeviceGuard guard(h->device);
   hipStreamSynchronize(h->stream);
   free_batch(h);
-  hipFree(h->d_tab); hipFree(h->d_lx); hipFree(h->d_ly);
+  hipFree(h->d_tab); hipFree(h->d_tab64); hipFree(h->d_lx); hipFree(h->d_ly);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
   hipStreamDestroy(h->own_stream);
   delete h;
@@ -799,7 +891,7 @@ int wf_set_model(wf_handle* h, const wf_model_params* p) {
   if (!h || !p) return WF_E_INVALID;
   if (p->n_table < 2 || p->n_table > WF_MAX_TABLE - 1 || !p->table_ws || !p->table_ct || !p->table_cp)
     return fail(h, WF_E_INVALID, "power_thrust_table needs 2..63 entries");
-  if (p->veer != 0.0) return fail(h, WF_E_UNSUPPORTED, "wind_veer != 0 is not implemented");
+  if (!std::isfinite(p->veer)) return fail(h, WF_E_INVALID, "wind_veer must be finite");
   {
     const struct { double v; const char* name; } positive[] = {
         {p->air_density, "air_density"}, {p->ambient_ti, "turbulence_intensity"}, {p->rotor_diameter, "rotor_diameter"},
@@ -1257,6 +1349,30 @@ int wf_set_risk_guard(wf_handle* h, double rel_band) {
   if (!(rel_band >= 0.0) || !(rel_band < 0.5)) return fail(h, WF_E_INVALID, "risk guard band must be in [0, 0.5)");
   h->guard_rel = rel_band;
   h->consts.guard_inv = rel_band > 0.0 ? (float)(1.0 / rel_band) : 1125899906842624.0f;
+  return WF_OK;
+}
+
+int wf_set_risk_resolve(wf_handle* h, int mode) {
+  if (!h) return WF_E_INVALID;
+  if (mode < 0 || mode > 2) return fail(h, WF_E_INVALID, "risk resolve mode must be 0 (off), 1 (flagged farms) or 2 (every farm)");
+  h->resolve_mode = mode;
+  return WF_OK;
+}
+
+int wf_get_resolve_stats(wf_handle* h, int* n_resolved, int* raw_flags, int on_device) {
+  if (!h) return WF_E_INVALID;
+  if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called first");
+  WF_ON_DEVICE(h);
+  if (!h->d_res_list || (h->resolve_mode == 0 && h->model.veer == 0.0)) {  // nothing is being resolved on this batch
+    if (n_resolved) *n_resolved = 0;
+    if (raw_flags) return wf_get_risk_flags(h, raw_flags, on_device);
+    return WF_OK;
+  }
+  if (raw_flags)
+    WF_HIP(h, hipMemcpyAsync(raw_flags, h->d_flags_raw, sizeof(int) * h->B, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                             h->stream));
+  if (n_resolved) WF_HIP(h, hipMemcpyAsync(n_resolved, h->d_res_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (n_resolved || (raw_flags && !on_device)) WF_HIP(h, hipStreamSynchronize(h->stream));
   return WF_OK;
 }
 

@@ -1,0 +1,46 @@
+// wf_resolve.h — arguments of the float64 farm solve (wf_resolve.hip), shared with the host side (wf_abi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+// Model constants in float64 (from wf_model_params, include/wfstep.h; nothing depends on the wind speed)
+struct WfResolveConsts {
+  int N, n_table;
+  int sw_steer, sw_yar, sw_tv;  // solver switches of case.yaml:46-50
+  double D, HH, TSR, amb, eps2, num_eps, sqrt2;
+  double off[3];       // rotor-grid offsets -D/4, 0, +D/4 (lateral and vertical) [A.1-3]
+  double shearf[3];    // (z_k / HH)^shear [A.2]
+  double uinf1;        // mean shearf: Uinf = ws * uinf1
+  double nu1[3];       // eddy viscosity of the vortex decay per unit wind speed: lm_k^2 |dU/dz_k| / ws [A.3-4]
+  double vel_top, vel_bot;
+  double zr[3][3], ezr[3][3];  // [k][v]: z_k - h_v + num_eps of the three vortices (top, bottom, rotation); exp(-zr^2/eps^2)
+  double zm[3][3], ezm[3][3];  // ground mirrors: z_k + h_v + num_eps
+  double k_top, k_bot, k_core;  // secondary steering: mean_9(z / (2 pi r) core) on the source's own grid [A.3-2]
+  double alpha, beta, ka, kb, ad, bd, dm;
+  double defl_alpha, defl_beta, defl_ka, defl_kb;
+  double e0c1, e0c2;   // 3 e^(1/12), 3 e^(1/3)
+  double near_c;       // near_wake_c * D
+  double ch_constant, ch_ai, ch_amb_pow, ch_down;  // ch_amb_pow = ambient_ti ^ ch_initial
+  double gch_gain, overlap_thr;
+  double cos_veer, cos2_veer, sin2_veer, sin_2veer;  // wind_veer [gauss.py rCalt]
+  double rho_ref, dens_cbrt, pP3;  // outputs [A.4]
+};
+
+struct WfResolveArgs {
+  const double* tab64;  // [3][WF_TABLE_PAD]: wind speed, Ct, power (1/2 A Cp eta ws^3)
+  int* list;            // [B] compacted farm indices
+  int* count;           // [1]
+  int* flags;           // [B] WF_RISK_* of the float32 step; cleared for every farm solved here
+  const double *gx, *gy;  // sorted geometry (float64)
+  const int* gidx;
+  size_t geom_stride;   // N for a geometry per farm, 0 for a shared one (ignored when farm_group is set)
+  const int* farm_group;  // [B] direction group of each farm (grouped launches), or null
+  int shift, mod;       // geometry index of group g = (g + shift) % mod
+  const double *ws, *wd;
+  int wind_stride;
+  const float* yaw_in;     // [B][N] commanded yaw (plain step)
+  const float* yaw_state;  // [B][N] env state after the transition (fused env step), or null
+  float *o_power, *o_ws, *o_wd, *o_load;  // caller's outputs, each may be null
+  float* reward;           // [B] or null
+  const double* ws_prev;   // [B] or null
+  float load_coef;
+};
