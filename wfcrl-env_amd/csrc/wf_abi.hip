@@ -495,15 +495,20 @@ int build_consts(wf_handle* h) {
     double kk[3] = {0, 0, 0};
     for (int v = 0; v < 3; ++v)
       for (int k = 0; k < 3; ++k) {
-        const double zc = HH + off[k] - hs[v] + m_eps, zm = HH + off[k] + hs[v] + m_eps;
-        r.zr[k][v] = zc; r.ezr[k][v] = std::exp(-zc * zc / eps2);
-        r.zm[k][v] = zm; r.ezm[k][v] = std::exp(-zm * zm / eps2);
+        const double zc = HH + off[k] - hs[v] + m_eps;
         for (int j = 0; j < 3; ++j) {
           const double yL = off[j] + m_eps;
           const double rr = yL * yL + zc * zc;
           kk[v] += zc / (2.0 * M_PI * rr) * (1.0 - std::exp(-rr / eps2)) / 9.0;
         }
       }
+    r.mirror_core = 0;
+    for (int mm = -3; mm <= 3; ++mm) {
+      const double zc = mm * q + m_eps, zm = 2.0 * HH + mm * q + m_eps;
+      r.zc[mm + 3] = zc; r.zc2[mm + 3] = zc * zc; r.ezc[mm + 3] = std::exp(-zc * zc / eps2);
+      r.zm7[mm + 3] = zm; r.zm2[mm + 3] = zm * zm; r.ezm7[mm + 3] = std::exp(-zm * zm / eps2);
+      if (r.ezm7[mm + 3] >= 1.0e-17) r.mirror_core = 1;
+    }
     r.k_top = kk[0]; r.k_bot = kk[1]; r.k_core = kk[2];
     r.alpha = m.alpha; r.beta = m.beta; r.ka = m.ka; r.kb = m.kb; r.ad = m.ad; r.bd = m.bd; r.dm = m.dm;
     r.defl_alpha = m.defl_alpha; r.defl_beta = m.defl_beta; r.defl_ka = m.defl_ka; r.defl_kb = m.defl_kb;

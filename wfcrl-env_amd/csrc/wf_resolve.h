@@ -6,14 +6,17 @@
 struct WfResolveConsts {
   int N, n_table;
   int sw_steer, sw_yar, sw_tv;  // solver switches of case.yaml:46-50
+  int mirror_core;              // some exp(-zm^2 / eps^2) >= 1e-17: the ground mirrors' core factors differ from 1.0 in float64
   double D, HH, TSR, amb, eps2, num_eps, sqrt2;
   double off[3];       // rotor-grid offsets -D/4, 0, +D/4 (lateral and vertical) [A.1-3]
   double shearf[3];    // (z_k / HH)^shear [A.2]
   double uinf1;        // mean shearf: Uinf = ws * uinf1
   double nu1[3];       // eddy viscosity of the vortex decay per unit wind speed: lm_k^2 |dU/dz_k| / ws [A.3-4]
   double vel_top, vel_bot;
-  double zr[3][3], ezr[3][3];  // [k][v]: z_k - h_v + num_eps of the three vortices (top, bottom, rotation); exp(-zr^2/eps^2)
-  double zm[3][3], ezm[3][3];  // ground mirrors: z_k + h_v + num_eps
+  // vertical offsets of the three vortices (and their ground mirrors) from the three grid rows: 7 + 7 distinct values
+  // (wf_device.h: class m + 3, zc = m q + num_eps, zm = 2 HH + m q + num_eps, q = D / 4)
+  double zc[7], zc2[7], ezc[7];    // ezc = exp(-zc^2 / eps^2)
+  double zm7[7], zm2[7], ezm7[7];
   double k_top, k_bot, k_core;  // secondary steering: mean_9(z / (2 pi r) core) on the source's own grid [A.3-2]
   double alpha, beta, ka, kb, ad, bd, dm;
   double defl_alpha, defl_beta, defl_ka, defl_kb;

@@ -33,8 +33,11 @@ __device__ inline double interp_fill(double xq, int n, const double* xs, const d
   if (xq < xs[0]) return lo;
   if (xq > xs[n - 1]) return hi;
   if (xq == xs[n - 1]) return ys[n - 1];
-  int j = 0;
-  while (j < n - 2 && xq >= xs[j + 1]) ++j;
+  int j = 0;  // last knot <= xq, at most n - 2: bisection (the dependent LDS probes of a linear scan cost 5 k cycles per call)
+  for (int step = 32; step >= 1; step >>= 1) {
+    const int k = j + step;
+    if (k <= n - 2 && xq >= xs[k]) j = k;
+  }
   const double slope = (ys[j + 1] - ys[j]) / (xs[j + 1] - xs[j]);
   return slope * (xq - xs[j]) + ys[j];
 }
@@ -51,22 +54,46 @@ __global__ void wf_compact_flagged_kernel(const int* __restrict__ flags, int B, 
   if (f != 0 || all) list[atomicAdd(count, 1)] = b;
 }
 
+// 1 / x to float64 accuracy from the hardware estimate and two Newton steps (6 instructions; the compiler's IEEE division
+// sequence is 11): the quotients here are all between normal, finite, nonzero operands
+__device__ __forceinline__ double rcp64(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
+// Source-side constants of the deflection + deficit models for one grid column (TI of that column) [A.3-3, A.3-6]
+struct ColD {
+  double x0d, ix0d_rel, kyd, d0, pfar;  // deflection: near-wake end (absolute x), 1 / (x0 - x_i), expansion rate, delta0, far-wake log prefactor
+  double x0v, ix0v_rel, kyv;            // deficit: near-wake end (absolute x), 1 / (x0 - x_i), expansion rate
+};
+
+#ifndef WF_RES_OCC
+#define WF_RES_OCC 1  // waves per SIMD the register allocator is asked to make room for (HornsRev1, 1394 flagged farms: 1 -> 1.95 ms, 2 -> 2.3, 3 -> 2.6, 4 -> 3.7 with 300 spilled registers: tools/res_occ_sweep.sh)
+#endif
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void wf_resolve_kernel(const WfResolveConsts c, const WfResolveArgs a) {
+__global__ __launch_bounds__(THREADS, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a) {
   __shared__ double tws[WF_TABLE_PAD], tct[WF_TABLE_PAD], tpw[WF_TABLE_PAD];
   __shared__ double xsL[THREADS], ysL[THREADS], yawL[THREADS];
   __shared__ double bc[5], bc2[2];
   __shared__ double red[2][THREADS / 64];
+  // the model constants are read from LDS where they are used (by value in the kernel arguments the compiler keeps all
+  // ~130 of them in SGPRs across the source loop and spills: 1700 v_readlane / v_writelane in the first version)
+  __shared__ WfResolveConsts c;
   const int t = threadIdx.x;
-  const int N = c.N;
-  for (int k = t; k < c.n_table; k += THREADS) {
+  if (t == 0) c = c_arg;
+  const int N = c_arg.N;
+  for (int k = t; k < c_arg.n_table; k += THREADS) {
     tws[k] = a.tab64[k];
     tct[k] = a.tab64[WF_TABLE_PAD + k];
     tpw[k] = a.tab64[2 * WF_TABLE_PAD + k];
   }
   const int n_list = *a.count;
   const bool live = t < N;
-  const double D = c.D, eps2 = c.eps2;
+  const bool veer_on = c_arg.sin2_veer != 0.0;
+  const bool mcore = c_arg.mirror_core != 0;
 
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
     const int b = a.list[li];
@@ -79,7 +106,7 @@ __global__ __launch_bounds__(THREADS) void wf_resolve_kernel(const WfResolveCons
     const float* yaw_b = (a.yaw_state ? a.yaw_state : a.yaw_in) + (size_t)b * N;
     int o = 0;
     double x_t = 0.0, y_t = 0.0, yaw_t = 0.0;
-    __syncthreads();  // the previous farm's last readers of xsL / bc are done
+    __syncthreads();  // the previous farm's last readers of xsL / bc are done; c is in place
     if (live) {
       o = a.gidx[gofs + t];
       x_t = a.gx[gofs + t];
@@ -87,23 +114,27 @@ __global__ __launch_bounds__(THREADS) void wf_resolve_kernel(const WfResolveCons
       yaw_t = (double)yaw_b[o];
       xsL[t] = x_t; ysL[t] = y_t; yawL[t] = yaw_t;
     }
+    const double D = c.D, eps2 = c.eps2, ieps2 = 1.0 / c.eps2;
     // inflow [A.2]
     double Uinit[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) Uinit[k] = ws * c.shearf[k];
     const double Uinf = ws * c.uinf1;
-    double wake[9], V[9], W[9], TI[3];
+    // SOSFS [A.3-7]: FLORIS chains hypot(wake, deficit * Uinit); the sum of squares is kept and the root taken where the
+    // velocity is needed (the source's own rotor mean, the outputs)
+    double wake2[9], V[9], W[9], TI[3];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) { wake[q] = 0.0; V[q] = 0.0; W[q] = 0.0; }
+    for (int q = 0; q < 9; ++q) { wake2[q] = 0.0; V[q] = 0.0; W[q] = 0.0; }
 #pragma unroll
     for (int j = 0; j < 3; ++j) TI[j] = c.amb;
 
     for (int i = 0; i < N; ++i) {
+      asm volatile("" ::: "memory");  // the constants in LDS are re-read per source, not hoisted into registers for all of them
       if (t == i) {  // the source's state [A.3-1, A.3-2]
         double m3 = 0.0, vs = 0.0;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
-          const double u = Uinit[q % 3] - wake[q];
+          const double u = Uinit[q % 3] - sqrt(wake2[q]);
           m3 += u * u * u;
           vs += V[q];
         }
@@ -111,52 +142,64 @@ __global__ __launch_bounds__(THREADS) void wf_resolve_kernel(const WfResolveCons
       }
       __syncthreads();
       const double x_i = xsL[i], y_i = ysL[i], g = yawL[i];
-      const double ubar = cbrt(bc[0]), Vmean = bc[1];
-      const double TIs[3] = {bc[2], bc[3], bc[4]};
-      const double cg = cosd(g);
-      double ct_tab = interp_fill(ubar, c.n_table, tws, tct, 0.0001, 0.9999);
-      ct_tab = fmin(fmax(ct_tab, 0.0001), 0.9999);
-      const double ct = ct_tab * cg;
-      const double ai = 0.5 / cg * (1.0 - sqrt(1.0 - ct * cg));
-      const double G_wr = 0.25 * kTwoPi * D * (ai - ai * ai) * ubar / c.TSR;
-      const double gam_top = (kTwoPi / 16.0) * D * c.vel_top * Uinf * ct;
-      const double gam_bot = (kTwoPi / 16.0) * D * c.vel_bot * Uinf * ct;
       const double dx = x_t - x_i;
       const bool down = live && dx >= 0.0;  // ties (dx = 0) count as downstream for the transverse velocities [A.3-4]
+      const bool wave_on = __any(down);     // (the source's own wave always is)
+      double ct = 0.0, ai = 0.0, G_wr = 0.0, gam_top = 0.0, gam_bot = 0.0, cg = 1.0, sg = 0.0, ubar = 1.0;
+      if (wave_on) {
+        ubar = cbrt(bc[0]);
+        sincos(g * kDeg, &sg, &cg);
+        double ct_tab = interp_fill(ubar, c.n_table, tws, tct, 0.0001, 0.9999);
+        ct_tab = fmin(fmax(ct_tab, 0.0001), 0.9999);
+        ct = ct_tab * cg;
+        ai = 0.5 / cg * (1.0 - sqrt(1.0 - ct * cg));
+        G_wr = 0.25 * kTwoPi * D * (ai - ai * ai) * ubar / c.TSR;
+        gam_top = (kTwoPi / 16.0) * D * c.vel_top * Uinf * ct;
+        gam_bot = (kTwoPi / 16.0) * D * c.vel_bot * Uinf * ct;
+      }
 
-      // 4. transverse velocities (commanded yaw) on this thread's turbine
-      if (c.sw_tv && __any(down)) {
-        if (down) {
-          const double sc = sind(g) * cg;
-          const double Gs[3] = {sc * gam_top, -sc * gam_bot, G_wr};
+      // 4. transverse velocities (commanded yaw) on this thread's turbine: per grid column the 7 + 7 distinct vertical
+      // offsets of the three vortices and their ground mirrors on the 3 x 3 grid (wf_device.h: zc / zm classes)
+      if (c.sw_tv && wave_on && down) {
+        const double sc = sg * cg;
+        const double qd = c_arg.off[2], neps = c_arg.num_eps, twoHH = 2.0 * c_arg.HH;
+        const double Gt = sc * gam_top / kTwoPi, Gb = -sc * gam_bot / kTwoPi, Gw = G_wr / kTwoPi;
+        double dec[3];
 #pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const double yL = (y_t + c.off[j] - y_i) + c.num_eps;
-            const double yL2 = yL * yL;
-            const double Ey = exp(-yL2 / eps2);
+        for (int k = 0; k < 3; ++k) dec[k] = eps2 * rcp64(4.0 * (c.nu1[k] * ws) * dx / Uinf + eps2);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const double decay = eps2 / (4.0 * (c.nu1[k] * ws) * dx / Uinf + eps2);
-              double v = 0.0, w = 0.0;
+        for (int j = 0; j < 3; ++j) {
+          const double yL = (y_t + c.off[j] - y_i) + c.num_eps;
+          const double yL2 = yL * yL;
+          const double Ey = exp(-yL2 * ieps2);
+          double Av[3] = {0.0, 0.0, 0.0}, Bw[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-              for (int vv = 0; vv < 3; ++vv) {
-                {
-                  const double zc = c.zr[k][vv];
-                  const double r = yL2 + zc * zc;
-                  const double kk = Gs[vv] / (kTwoPi * r) * (1.0 - Ey * c.ezr[k][vv]) * decay;
-                  v += kk * zc; w -= kk * yL;
-                }
-                {
-                  const double zc = c.zm[k][vv];  // ground mirror
-                  const double r = yL2 + zc * zc;
-                  const double kk = Gs[vv] / (kTwoPi * r) * (1.0 - Ey * c.ezm[k][vv]) * decay;
-                  v -= kk * zc; w += kk * yL;
-                }
-              }
-              if (w < 0.0) w = 0.0;  // quirk (5) [A.6]
-              V[j * 3 + k] += v;
-              W[j * 3 + k] += w;
+          for (int m = 0; m < 7; ++m) {
+            // (offsets from the class index and three scalars; only the 7 core factors of the real vortices are tabulated:
+            // 42 tabulated constants cost 84 registers across this loop)
+            const double zc = (double)(m - 3) * qd + neps, zm = zc + twoHH;
+            const double tr = (1.0 - Ey * c_arg.ezc[m]) * rcp64(yL2 + zc * zc);   // core / r of a real vortex at offset zc
+            double tm = rcp64(yL2 + zm * zm);                                       // ... of a mirror vortex at zm
+            if (mcore) tm *= 1.0 - Ey * c.ezm7[m];  // (1 - Ey ezm == 1.0 exactly unless the hub is very low)
+            const double pr = zc * tr, pm = zm * tm;
+            if (m <= 2) {  // real top (k = m), mirror bottom (k = m)
+              Av[m] += Gt * pr - Gb * pm;
+              Bw[m] += Gt * tr - Gb * tm;
             }
+            if (m >= 4) {  // real bottom (k = m - 4), mirror top (k = m - 4)
+              Av[m - 4] += Gb * pr - Gt * pm;
+              Bw[m - 4] += Gb * tr - Gt * tm;
+            }
+            if (m >= 2 && m <= 4) {  // wake rotation, real - mirror (k = m - 2)
+              Av[m - 2] += Gw * (pr - pm);
+              Bw[m - 2] += Gw * (tr - tm);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            V[j * 3 + k] += Av[k] * dec[k];
+            const double w = -yL * Bw[k] * dec[k];
+            W[j * 3 + k] += (w < 0.0) ? 0.0 : w;  // quirk (5) [A.6]
           }
         }
       }
@@ -167,9 +210,11 @@ __global__ __launch_bounds__(THREADS) void wf_resolve_kernel(const WfResolveCons
         bc2[0] = vs / 9.0; bc2[1] = wsum / 9.0;
       }
       __syncthreads();
+      if (!wave_on) continue;
+      const double TIs[3] = {bc[2], bc[3], bc[4]};
       // 2. secondary steering [A.3-2]: the three means on the source's own grid are geometry constants
       const double v_top = gam_top * c.k_top, v_bot = -gam_bot * c.k_bot, v_core = G_wr * c.k_core;
-      double val = 2.0 * (Vmean - v_core) / (v_top + v_bot);
+      double val = 2.0 * (bc[1] - v_core) / (v_top + v_bot);
       val = fmin(fmax(val, -1.0), 1.0);
       const double g_eff = c.sw_steer ? g + (0.5 * asin(val)) / kDeg : g;
       // 5. yaw-added recovery [A.3-5]
@@ -185,102 +230,127 @@ __global__ __launch_bounds__(THREADS) void wf_resolve_kernel(const WfResolveCons
 #pragma unroll
         for (int j = 0; j < 3; ++j) TI[j] += dTI;
       }
-      if (!__any(down)) continue;
-      if (!down) continue;
-      // 3 + 6. deflection (TI before mixing, effective yaw) and deficit (TI after mixing, commanded yaw) [A.3-3, A.3-6]
-      const double gd = -g_eff, cgd = cosd(gd);
+      // 3 + 6. deflection (TI before mixing, effective yaw) and deficit (TI after mixing, commanded yaw) [A.3-3, A.3-6]:
+      // everything that depends on the source (and the column's TI) only
+      // cosd(-g_eff) = cos(g + d), d = asin(val) / 2: half-angle formulas instead of a second cosine
+      const double c2d = sqrt(fmax(1.0 - val * val, 0.0)), cd = sqrt(0.5 * (1.0 + c2d)), sd = 0.5 * val / cd;
+      const double cgd = c.sw_steer ? cg * cd - sg * sd : cg;
+      const double gd = -g_eff;
       const double s_cc = sqrt(1.0 - ct * cgd), s_c = sqrt(1.0 - ct);
       const double th0 = c.dm * (0.3 * (gd * kDeg) / cgd) * (1.0 - s_cc);
       const double tan_th0 = tan(th0);
-      const double gv = -g, cgv = cosd(gv);
+      const double cgv = cg;  // cosd(-g)
       const double C0 = 1.0 - s_c;
       const double M0 = C0 * (2.0 - C0);
       const double E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
       const double sM = sqrt(M0);
       const double sz0d = D * 0.5 * sqrt((ct * cgd / (2.0 * (1.0 - s_cc))) / (1.0 + s_c));
       const double sy0d = sz0d * cgd * c.cos_veer;
+      const double is0d = 1.0 / (sy0d * sz0d);
+      const double lnAB = (1.6 + sM) / (1.6 - sM);
       const double sz0v = D * 0.5 * sqrt((ct / (2.0 * (1.0 - s_c))) / (1.0 + s_c));
       const double sy0v = sz0v * cgv * c.cos_veer;
       const double snw = c.near_c * sqrt(ct / 2.0);
+      const double kdef = ct * cgv * D * D / 8.0;
+      const double ch_pref = c.ch_constant * exp(c.ch_ai * log(ai)) * c.ch_amb_pow;
+      auto column = [&](double TIpre) {
+        ColD k;
+        const double x0r = D * cgd * (1.0 + s_cc) / (c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - s_c)));
+        k.x0d = x0r + x_i;
+        k.ix0d_rel = 1.0 / (k.x0d - x_i);
+        k.kyd = c.defl_ka * TIpre + c.defl_kb;
+        k.d0 = tan_th0 * (k.x0d - x_i);
+        k.pfar = th0 * E0 / 5.2 * sqrt(sy0d * sz0d / (k.kyd * k.kyd * M0));
+        const double TIq = TIpre + dTI;
+        const double x0v = D * cgv * (1.0 + s_c) / (c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - s_c)));
+        k.x0v = x0v + x_i;
+        k.ix0v_rel = 1.0 / (k.x0v - x_i);
+        k.kyv = c.ka * TIq + c.kb;
+        return k;
+      };
+      const bool same = (TIs[0] == TIs[1]) && (TIs[1] == TIs[2]);  // (uniform: a property of the source)
+      if (!down) continue;
       const double lin = c.ad + c.bd * dx;
-      double defU[9];
+      // one target column: deflection -> delta; deficit -> amplitude and the Gaussian's 1 / (2 sigma^2)
+      struct ColT { double delta, amp, isy2, isz2; };
+      auto target_col = [&](const ColD& k) {
+        ColT r;
+        double d_near = (dx * k.ix0d_rel) * k.d0 + lin;
+        if (!(x_t <= k.x0d)) d_near = 0.0;  // [x >= x_i] holds here
+        double d_far = 0.0;
+        if (x_t > k.x0d) {
+          const double sy = k.kyd * (x_t - k.x0d) + sy0d, sz = k.kyd * (x_t - k.x0d) + sz0d;
+          const double s = sqrt(sy * sz * is0d);
+          const double ln_arg = lnAB * (1.6 * s - sM) * rcp64(1.6 * s + sM);
+          d_far = k.d0 + k.pfar * log(ln_arg) + lin;
+        }
+        r.delta = d_near + d_far;
+        r.amp = 0.0; r.isy2 = 0.0; r.isz2 = 0.0;
+        double sy = 0.0, sz = 0.0;
+        bool on = false;
+        if (x_t > x_i + 0.1 && x_t < k.x0v) {  // the masks as FLORIS takes them on the coordinates
+          const double up = dx * k.ix0v_rel, dn = (k.x0v - x_t) * k.ix0v_rel;
+          sy = dn * snw + up * sy0v;
+          sz = dn * snw + up * sz0v;
+          on = true;
+        } else if (x_t >= k.x0v) {
+          sy = k.kyv * (x_t - k.x0v) + sy0v;
+          sz = k.kyv * (x_t - k.x0v) + sz0v;
+          on = true;
+        }
+        if (on) {
+          const double isy = rcp64(sy), isz = rcp64(sz);
+          double dd = 1.0 - kdef * isy * isz;
+          dd = fmin(fmax(dd, 0.0), 1.0);
+          r.amp = 1.0 - sqrt(dd);
+          r.isy2 = 0.5 * isy * isy;
+          r.isz2 = 0.5 * isz * isz;
+        }
+        return r;
+      };
       int cnt = 0;
+      const double q2 = c.off[2] * c.off[2];
+      ColT Tc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        double delta;
-        {
-          const double TIq = TIs[j];
-          const double x0 = D * cgd * (1.0 + s_cc) / (c.sqrt2 * (4.0 * c.defl_alpha * TIq + 2.0 * c.defl_beta * (1.0 - s_c))) + x_i;
-          const double ky = c.defl_ka * TIq + c.defl_kb;
-          const double d0 = tan_th0 * (x0 - x_i);
-          double d_near = (dx / (x0 - x_i)) * d0 + lin;
-          if (!(x_t <= x0)) d_near = 0.0;  // [x >= x_i] holds here
-          double d_far = 0.0;
-          if (x_t > x0) {
-            const double sy = ky * (x_t - x0) + sy0d, sz = ky * (x_t - x0) + sz0d;
-            const double s = sqrt(sy * sz / (sy0d * sz0d));
-            const double ln_arg = ((1.6 + sM) * (1.6 * s - sM)) / ((1.6 - sM) * (1.6 * s + sM));
-            d_far = d0 + th0 * E0 / 5.2 * sqrt(sy0d * sz0d / (ky * ky * M0)) * log(ln_arg) + lin;
-          }
-          delta = d_near + d_far;
-        }
-        double amp = 0.0, ca = 0.0, cb = 0.0, cc = 0.0;
-        bool on = false;
-        {
-          const double TIq = TIs[j] + dTI;
-          const double x0 = D * cgv * (1.0 + s_c) / (c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - s_c))) + x_i;
-          double sy = 0.0, sz = 0.0;
-          if (x_t > x_i + 0.1 && x_t < x0) {  // the masks as FLORIS takes them on the coordinates
-            const double up = dx / (x0 - x_i), dn = (x0 - x_t) / (x0 - x_i);
-            sy = dn * snw + up * sy0v;
-            sz = dn * snw + up * sz0v;
-            on = true;
-          } else if (x_t >= x0) {
-            const double ky = c.ka * TIq + c.kb;
-            sy = ky * (x_t - x0) + sy0v;
-            sz = ky * (x_t - x0) + sz0v;
-            on = true;
-          }
-          if (on) {
-            double dd = 1.0 - ct * cgv / (8.0 * sy * sz / (D * D));
-            dd = fmin(fmax(dd, 0.0), 1.0);
-            amp = 1.0 - sqrt(dd);
-            // FLORIS rCalt with veer [gauss.py]: a, b, c of the rotated Gaussian (veer = 0: 1/(2 sy^2), 0, 1/(2 sz^2))
-            const double isy2 = 1.0 / (2.0 * sy * sy), isz2 = 1.0 / (2.0 * sz * sz);
-            ca = c.cos2_veer * isy2 + c.sin2_veer * isz2;
-            cb = 0.5 * c.sin_2veer * (isz2 - isy2);
-            cc = c.sin2_veer * isy2 + c.cos2_veer * isz2;
+        if (j == 0 || !same) Tc = target_col(column(TIs[j]));  // (one column serves all three when the source's TIs agree)
+        const double yy = (y_t + c.off[j]) - y_i - Tc.delta;
+        double def[3];
+        if (!veer_on) {  // r = yy^2 / (2 sy^2) + zz^2 / (2 sz^2), zz = -q, 0, +q
+          const double e1 = Tc.amp * exp(-(yy * yy) * Tc.isy2);
+          const double e0 = e1 * exp(-q2 * Tc.isz2);
+          def[0] = e0; def[1] = e1; def[2] = e0;
+        } else {  // FLORIS rCalt [gauss.py]: the Gaussian rotated by the veer angle
+          const double ca = c.cos2_veer * Tc.isy2 + c.sin2_veer * Tc.isz2;
+          const double cb = 0.5 * c.sin_2veer * (Tc.isz2 - Tc.isy2);
+          const double cc = c.sin2_veer * Tc.isy2 + c.cos2_veer * Tc.isz2;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double zz = c.off[k];
+            def[k] = Tc.amp * exp(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
           }
         }
-        const double yy = (y_t + c.off[j]) - y_i - delta;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          const double zz = c.off[k];
-          const double r = ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz;
-          const double deficit = on ? amp * exp(-r) : 0.0;
-          defU[j * 3 + k] = deficit * Uinit[k];
-          if (defU[j * 3 + k] > c.overlap_thr) ++cnt;
+          const double dU = def[k] * Uinit[k];
+          if (dU > c.overlap_thr) ++cnt;  // the comparison as FLORIS takes it [A.3-8]
+          wake2[j * 3 + k] = fma(dU, dU, wake2[j * 3 + k]);
         }
       }
-      // 7. SOSFS [A.3-7]
-#pragma unroll
-      for (int q = 0; q < 9; ++q) wake[q] = hypot(wake[q], defU[q]);
       // 8. Crespo-Hernandez + overlap gating [A.3-8]
-      {
-        const double upm = (dx <= 0.1) ? 1.0 : 0.0;  // dx > -0.1 holds for every downstream turbine
-        const double dxp = dx + upm;
-        const double ch_pref = c.ch_constant * pow(ai, c.ch_ai) * c.ch_amb_pow;
-        double ti = ch_pref * pow(dxp / D, c.ch_down);
-        if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
-        const double overlap = (double)cnt / 9.0;
-        const bool reach = (x_t > x_i) && (x_t <= x_i + 15.0 * D);
+      const bool reach = (x_t > x_i) && (x_t <= x_i + 15.0 * D);
+      bool gate[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const bool gate = reach && (fabs(y_i - (y_t + c.off[j])) < 2.0 * D);
-          const double ti_added = gate ? overlap * ti : 0.0;
-          const double cand = sqrt(ti_added * ti_added + c.amb * c.amb);
-          if (cand > TI[j]) TI[j] = cand;
-        }
+      for (int j = 0; j < 3; ++j) gate[j] = reach && (fabs(y_i - (y_t + c.off[j])) < 2.0 * D);
+      if (gate[0] || gate[1] || gate[2]) {
+        const double dxp = (dx <= 0.1) ? dx + 1.0 : dx;  // dx > -0.1 holds for every downstream turbine
+        double ti = ch_pref * exp(c.ch_down * log(dxp / D));
+        if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
+        const double ti_added = ((double)cnt / 9.0) * ti;
+        const double cand = sqrt(ti_added * ti_added + c.amb * c.amb);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (gate[j] && cand > TI[j]) TI[j] = cand;
       }
     }  // sources
 
@@ -290,7 +360,7 @@ __global__ __launch_bounds__(THREADS) void wf_resolve_kernel(const WfResolveCons
       double m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0, dir = 0.0, U[9];
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        U[q] = Uinit[q % 3] - wake[q];
+        U[q] = Uinit[q % 3] - sqrt(wake2[q]);
         m3 += U[q] * U[q] * U[q];
         mu += U[q]; mv += V[q]; mw += W[q];
         dir += wd - atan2(V[q], U[q]) / kDeg;
