@@ -74,6 +74,15 @@ int wf_version(void);
 /* Fill *p with the reference defaults; table pointers reference static storage inside the library. */
 int wf_default_model(wf_model_params* p);
 
+/* Named power / thrust tables shipped as data (pointers into static storage; *n entries each):
+ *   "nrel_5MW_floris3" (alias "nrel_5MW", the default of wf_default_model): the turbine the reference's case.yaml:27-28
+ *       selects, with the six-decimal Cp column of FLORIS 3.x' turbine_library/nrel_5MW.yaml as recollected — a 5.000 MW
+ *       plateau from 11.5 m/s up.  Not reference-held (FLORIS is not vendored): DESIGN.md §2 gives the evidence;
+ *   "nrel_5MW_survey_a5": the 8-decimal Cp column of SURVEY.md Appendix A.5 (FLORIS v2's example input: 4.969 MW at
+ *       12 m/s, 5.116 MW at 25 m/s), the default of rounds 1-2.  Thrust is the same in both.
+ * Unknown name: WF_E_INVALID. */
+int wf_turbine_table(const char* name, int* n, const double** ws, const double** ct, const double** cp);
+
 /* Replaces `tools.FlorisInterface(simul_file)` (interface.py:479): create a handle bound to HIP
  * device `device_id`, with the default model.  Fails with WF_E_NODEVICE when no GPU is visible —
  * there is no CPU fallback. */

@@ -104,6 +104,9 @@ def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None, nthreads: i
     )
     if rc != 0:
         raise RuntimeError(f"wfo_step_batch failed: {rc}")
+    if margin:  # what the parity contract needs to judge the kernel's knee / ramp flags (tests/parity.py)
+        out["yaw"] = yaw
+        out["model"] = p
     return out
 
 

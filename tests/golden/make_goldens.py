@@ -5,6 +5,9 @@ known-answer vector (kat1_demo_notebook.json) the goldens are produced by the fl
 (oracle/floris_gch_numpy.py) once it has passed that KAT.  They freeze the oracle's behaviour for
 yaw != 0, powers and load proxies so that regressions in either oracle or in the HIP path show up.
 Run from the repo root:  python tests/golden/make_goldens.py
+Round 3: regenerated with the default turbine table nrel_5MW_floris3 (six-decimal Cp, 5 MW plateau; the evidence is in
+oracle/floris_gch_numpy.py and DESIGN.md §2 — "recollection, not reference-held"); powers move by <= 1e-6 relative below
+rated, the wake solution (thrust table unchanged) does not move at all.
 """
 import json
 import os

@@ -7,7 +7,9 @@ that pin down a regime of the model, with the C oracle's float64 outputs.
                 evaluation may count one grid point the other way.  fuzz_api seed 513, session 62, farm 1626.
 
 usage: python tests/golden/make_regime_cases.py <dump_512_56.npz> <dump_513_62.npz>
-Inputs are stored next to the outputs, so the fixture is self-contained; this script only documents how it was made.
+       python tests/golden/make_regime_cases.py            (re-evaluate the stored inputs: after an oracle / table change)
+Inputs are stored next to the outputs, so the fixture is self-contained.
+Round 3: re-evaluated with the default turbine table nrel_5MW_floris3 (oracle/floris_gch_numpy.py).
 """
 import os, sys
 
@@ -17,6 +19,17 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from oracle import c_oracle  # noqa: E402
 
 out = {}
+HERE = os.path.join(os.path.dirname(__file__), "regime_cases.npz")
+if len(sys.argv) < 3:
+    d = np.load(HERE)
+    for name in ("thrust_ramp", "overlap_flip"):
+        inp = {k: d[f"{name}_{k}"] for k in ("x", "y", "ws", "wd", "yaw")}
+        ref = c_oracle.farm_step_batch(inp["x"], inp["y"], inp["ws"], inp["wd"], inp["yaw"], None, margin=True)
+        out.update({f"{name}_{k}": v for k, v in inp.items()})
+        out.update({f"{name}_ref_{k}": v for k, v in ref.items()})
+    np.savez_compressed(HERE, **out)
+    print({k: v.shape for k, v in out.items()})
+    sys.exit(0)
 for name, path, b in (("thrust_ramp", sys.argv[1], 1107), ("overlap_flip", sys.argv[2], 1626)):
     d = np.load(path)
     assert str(d["model"]) == "{}"  # default model

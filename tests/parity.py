@@ -64,6 +64,36 @@ def within(e, tol, n_turbines=0):
     return ok
 
 
+def table_flag_conditions(ref, slack=0.05, near=2e-4):
+    """What the oracle says about the two table flags, per farm (needs ref["yaw"], ref["model"]: c_oracle with
+    margin=True): (knee, ramp) bool (B,) — True where SOME turbine of the farm sits, in float64, on (or within `near`
+    relative of a knot next to) a segment whose condition number is within `slack` of the kernel's thresholds:
+      WF_RISK_POWER_KNEE   rho v |dP/dv| > 30 max(P, 1 kW) at v = (rho/rho_ref)^(1/3) wind_speed cos(yaw)^(pP/3)
+      WF_RISK_THRUST_RAMP  v |dCt/dv| > 5 at the turbine's rotor wind speed, Ct strictly inside (0.0001, 0.9999)
+    (csrc/wf_kernel_common.h: table_pw / table_ct; wf_abi.hip: knee_kappa, ct_kappa).  A raised flag without it is spurious."""
+    p = ref["model"]
+    tws = np.asarray(p.table_ws, float)
+    tct = np.asarray(p.table_ct, float)
+    tpw = np.asarray(p.power_table(), float)
+    wsd = np.asarray(ref["wind_speed"], float)
+    veff = (p.air_density / p.ref_density) ** (1.0 / 3.0) * wsd * np.cos(np.radians(ref["yaw"])) ** (p.pP / 3.0)
+
+    def cond(v, tab, kind):
+        out = np.zeros(v.shape, bool)
+        for vv in (v * (1 - near), v, v * (1 + near)):  # a float32 speed may sit on the other side of a knot
+            j = np.clip(np.searchsorted(tws, vv, side="right") - 1, 0, len(tws) - 2)
+            slope = (tab[j + 1] - tab[j]) / (tws[j + 1] - tws[j])
+            val = tab[j] + slope * (vv - tws[j])
+            inside = (vv >= tws[0]) & (vv <= tws[-1])
+            if kind == "knee":
+                out |= inside & (p.ref_density * np.abs(slope) * vv > 30.0 * (1 - slack) * np.maximum(p.ref_density * val, 1e3))
+            else:
+                out |= inside & (val > 0.0001 * (1 - slack)) & (val < 0.9999 * (1 + slack)) & (np.abs(slope) * vv > 5.0 * (1 - slack))
+        return out.reshape(out.shape[0], -1).any(axis=1)
+
+    return cond(veff, tpw, "knee"), cond(wsd, tct, "ramp")
+
+
 def summarize(got, ref, flags, guard_rel=5e-5):
     """Classification of a batch: dict with
       n, n_flagged, n_bad_unflagged (must be 0), n_bad_flagged (beyond FLAGGED_BOUND: must be 0),
@@ -84,6 +114,11 @@ def summarize(got, ref, flags, guard_rel=5e-5):
         # the device's deficit differs from the oracle's by float32 rounding accumulated over the recurrence (<~ 1e-5
         # relative): a raised flag means the oracle's margin is inside the band widened by that much
         out["n_spurious"] = int((ref["margin"][ov] > 10 * guard_rel + 1e-4).sum())
+        if "model" in ref:  # the two table flags against the oracle's own rotor speeds (a kernel that raises
+            knee, ramp = table_flag_conditions(ref)  # them anywhere would hide real errors behind FLAGGED_BOUND)
+            out["n_spurious_knee"] = int((((flags & RISK_POWER_KNEE) != 0) & ~knee).sum())
+            out["n_spurious_ramp"] = int((((flags & RISK_THRUST_RAMP) != 0) & ~ramp).sum())
+            out["n_spurious"] += out["n_spurious_knee"] + out["n_spurious_ramp"]
         badf = ~bounded & fl
         if badf.any():
             out["bad_flagged_flags"] = [int(f) for f in flags[badf][:8]]

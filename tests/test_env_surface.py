@@ -252,10 +252,11 @@ def test_case_yaml_round_trip_and_rejections(tmp_path):
     m = load_case_yaml(cfg)["model"]
     assert (m["ka"], m["defl_ka"], m["alpha"], m["defl_alpha"]) == (0.5, 0.38, 0.58, 0.4)
     assert (m["enable_secondary_steering"], m["enable_yaw_added_recovery"], m["enable_transverse_velocities"]) == (False, True, True)
+    cfg["flow_field"]["wind_veer"] = 2.0  # (served by the float64 kernel: tests/test_resolve_gpu.py)
+    assert load_case_yaml(cfg)["model"]["veer"] == 2.0
     for mutate, msg in [
         (lambda c: c["wake"]["model_strings"].__setitem__("velocity_model", "jensen"), "velocity_model"),
         (lambda c: c["solver"].__setitem__("turbine_grid_points", 5), "turbine_grid_points"),
-        (lambda c: c["flow_field"].__setitem__("wind_veer", 2.0), "veer"),
         (lambda c: c["farm"].__setitem__("turbine_type", ["iea_10MW"]), "nrel_5MW"),
     ]:
         bad = yaml.safe_load(yaml.safe_dump(case_config(case.dict())))

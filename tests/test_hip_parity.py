@@ -99,6 +99,39 @@ def test_parity_random_yaw_and_wind(layouts, name, B, mode):
     _check(out, ref)
 
 
+@pytest.mark.parametrize("table", ["nrel_5MW_floris3", "nrel_5MW_survey_a5"])
+def test_above_rated_wind_speeds(layouts, table):
+    """The above-rated branch of the power table (rotor-effective speeds >= 11.5 m/s: `options={"wind_speed": 13}`, any
+    time series), on both nrel_5MW Cp columns shipped as data: 12 and 18 m/s shared, and a speed per farm from rated to
+    past cut-out (the cut-out drop raises WF_RISK_POWER_KNEE).  With the default column the front row makes 5.000 MW at
+    18 m/s; with SURVEY A.5's it makes 5.011 MW — the difference VERDICT r2 asked to be written down."""
+    from oracle.floris_gch_numpy import ModelParams, turbine_table
+    from wfcrl_env_amd.backend import WfStep
+    from wfcrl_env_amd.backend import turbine_table as product_table
+
+    l = layouts["Ormonde_"]
+    x, y, N, B = l["xcoords"], l["ycoords"], l["num_turbines"], 256
+    rng = np.random.default_rng(1218)
+    yaw = rng.uniform(-25, 25, (B, N)).astype(np.float32)
+    yaw[0] = 0.0
+    mp = ModelParams(**turbine_table(table))
+    w = WfStep(x, y, env_batch=B, model=product_table(table))
+    for ws in (12.0, 18.0):
+        w.set_wind(ws, 270.0)
+        out = _with_flags(w, w.step(yaw))
+        _check(out, _oracle(x, y, ws, 270.0, yaw, mp))
+        if ws == 18.0:
+            want = 5.0e6 if table == "nrel_5MW_floris3" else 5.0113e6
+            assert abs(out["power"][0].max() / want - 1) < 1e-4
+    ws = rng.uniform(11.0, 26.0, B)
+    wd = rng.normal(270, 20, B) % 360
+    w.set_wind(ws, wd)
+    out = _with_flags(w, w.step(yaw))
+    s = _check(out, _oracle(x, y, ws, wd, yaw, mp), max_flagged_frac=0.2)
+    assert (out["power"][ws > 25.1] == 0).all() and s["n_flagged"] > 0
+    w.close()
+
+
 def test_baseline_config2_named_turb16_tcrwp(layouts):
     """BASELINE.json configs[2] as named: `Turb16_TCRWP_Floris` = the first 16 turbines of the TCRWP layout (the
     reference's README spelling; its registry only has Turb16_Row5 and Turb_TCRWP — SURVEY Appendix C2), random yaw
@@ -290,7 +323,7 @@ def test_error_behaviour(layouts):
     with pytest.raises(ValueError):
         w.set_wind(-1.0, 270.0)
     with pytest.raises(ValueError, match="veer"):
-        w.set_model({"veer": 3.0})
+        w.set_model({"veer": float("inf")})  # (a finite veer is served by the float64 kernel: tests/test_resolve_gpu.py)
     for bad, msg in [({"num_eps": 0.0}, "num_eps"), ({"ambient_ti": -0.1}, "turbulence_intensity"), ({"tsr": float("nan")}, "TSR"),
                      ({"hub_height": 60.0}, "hub_height"), ({"table_ws": [0.0, 5.0, 4.0], "table_ct": [0, 0.8, 0.5], "table_cp": [0, 0.4, 0.3]}, "ascending"),
                      ({"table_ws": [0.0, 5.0, 9.0], "table_ct": [0, -0.8, 0.5], "table_cp": [0, 0.4, 0.3]}, "non-negative")]:

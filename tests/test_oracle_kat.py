@@ -31,11 +31,14 @@ def test_c_oracle_reproduces_reference_kat(kat1):
 
 
 def test_kat_oracle_derived_intermediates(kat1):
-    """SURVEY Appendix B (oracle-derived, not reference-pinned): powers, load proxies, reward."""
+    """SURVEY Appendix B (oracle-derived, not reference-pinned): powers, load proxies, reward.  The survey's powers were
+    taken with the 8-decimal Cp column (nrel_5MW_survey_a5); the default column (six decimals) moves them by < 1e-6."""
     r = onp.farm_step(kat1["xcoords"], kat1["ycoords"], kat1["wind_speed_free"], kat1["wind_direction_free"],
-                      np.zeros(7))
+                      np.zeros(7), onp.ModelParams(**onp.turbine_table("nrel_5MW_survey_a5")))
     p = np.array([897109.26, 289160.86, 896636.25, 793482.19, 788737.41, 752001.51, 626876.67])
     assert np.allclose(r["power"], p, rtol=0, atol=0.006)
+    r3 = onp.farm_step(kat1["xcoords"], kat1["ycoords"], kat1["wind_speed_free"], kat1["wind_direction_free"], np.zeros(7))
+    assert np.abs(r3["power"] / p - 1).max() < 1e-6 and np.array_equal(r3["load"], r["load"])
     assert np.allclose(r["load"][:, 0], [0.0602306076, 0.1204899426, 0.0604958592, 0.0908289244, 0.0918397491,
                                          0.0918914198, 0.1202582964], rtol=0, atol=1e-10)
     assert np.allclose(r["load"][:, 1], [0.23158, 1.15882, 0.23153, 0.36036, 0.36488, 0.43621, 0.70063], atol=6e-6)
@@ -104,16 +107,49 @@ def test_layout_counts(layouts):
 def test_turbine_table_corroboration_point():
     """a row recollected from FLORIS v3's gauss regression baseline for the unwaked NREL 5MW
     turbine — rotor-averaged speed 7.9803783 m/s -> Ct 0.7634300, power 1 695 368.8 W, axial induction 0.2568077.
-    NOT a fixture of the reference repository (hence only a corroboration of the table of Appendix A.5, which the
-    reference's own KAT pins at 4.5-6.5 m/s only)."""
-    p = onp.ModelParams()
+    NOT a fixture of the reference repository (hence only a corroboration of the tables, which the reference's own KAT
+    pins at 4.5-6.5 m/s only) — but it discriminates between the two Cp columns: the six-decimal column (default,
+    nrel_5MW_floris3) gives 1 695 368.81 W, inside what the seven-decimal speed allows (dP/dv = 6.4e5 W per m/s:
+    +-0.03 W); the 8-decimal column of SURVEY A.5 gives 1 695 368.66 W, outside it."""
     v = 7.9803783
-    ct = float(onp._interp_fill(v, p.table_ws, p.table_ct, 0.0001, 0.9999))
-    power = p.ref_density * float(onp._interp_fill(v, p.table_ws, p.power_table(), 0.0, 0.0))
-    a = 0.5 * (1.0 - np.sqrt(1.0 - ct))
-    assert abs(ct - 0.7634300) < 5e-8
-    assert abs(power - 1695368.8) < 0.5
-    assert abs(a - 0.2568077) < 5e-8
+    got = {}
+    for name in ("nrel_5MW_floris3", "nrel_5MW_survey_a5"):
+        p = onp.ModelParams(**onp.turbine_table(name))
+        ct = float(onp._interp_fill(v, p.table_ws, p.table_ct, 0.0001, 0.9999))
+        got[name] = p.ref_density * float(onp._interp_fill(v, p.table_ws, p.power_table(), 0.0, 0.0))
+        a = 0.5 * (1.0 - np.sqrt(1.0 - ct))
+        assert abs(ct - 0.7634300) < 5e-8
+        assert abs(a - 0.2568077) < 5e-8
+    assert abs(got["nrel_5MW_floris3"] - 1695368.8) < 0.05
+    assert 0.1 < abs(got["nrel_5MW_survey_a5"] - 1695368.8) < 0.5
+    assert onp.ModelParams().table_cp == onp.turbine_table("nrel_5MW_floris3")["table_cp"]  # the default
+
+
+def test_rated_power_plateau():
+    """The two nrel_5MW Cp columns shipped as data (oracle/floris_gch_numpy.py, include/wfstep.h: wf_turbine_table),
+    above rated: FLORIS 3.x' six-decimal column is Cp = 5 MW / (1/2 rho A v^3) — a flat plateau — while the 8-decimal
+    column of SURVEY A.5 (the default of rounds 1-2; FLORIS v2's example input) sags to 4.969 MW at 12 m/s and drifts up
+    to 5.116 MW at 25 m/s.  Recollection, not reference-held: the reference selects the turbine by name
+    (wfcrl/simulators/floris/inputs/template/case.yaml:27-28) and reads powers from FLORIS (wfcrl/interface.py:622-623)."""
+    rho, A = 1.225, np.pi * 63.0**2
+    v = np.arange(11.5, 25.01, 0.5)
+    rated = {}
+    for name in ("nrel_5MW_floris3", "nrel_5MW_survey_a5"):
+        p = onp.ModelParams(**onp.turbine_table(name))
+        rated[name] = np.array([p.ref_density * float(onp._interp_fill(x, p.table_ws, p.power_table(), 0.0, 0.0)) for x in v])
+        assert np.allclose(p.ref_density * 0.5 * A * np.interp(v, p.table_ws, p.table_cp) * v**3, rated[name], rtol=1e-12)
+    f3, a5 = rated["nrel_5MW_floris3"], rated["nrel_5MW_survey_a5"]
+    assert np.abs(f3 / 5.0e6 - 1).max() < 2e-5          # 4.99993 ... 5.00007 MW at every knot
+    assert abs(a5[1] / 1e6 - 4.969) < 1e-3 and abs(a5[-1] / 1e6 - 5.116) < 1e-3  # 12 m/s, 25 m/s
+    assert (a5 / f3 - 1).min() < -6e-3 and (a5 / f3 - 1).max() > 2.3e-2
+    # six decimals of 5e6 / (1/2 rho A v^3); a handful of knots differ in the last digit (as recollected from the file)
+    cp = np.array(onp.turbine_table("nrel_5MW_floris3")["table_cp"])[20:48]
+    assert np.abs(cp - 5.0e6 / (0.5 * rho * A * v**3)).max() < 1.6e-6
+    # below rated the two columns agree to the rounding of the sixth decimal
+    lo = slice(3, 20)
+    t3, t5 = onp.turbine_table("nrel_5MW_floris3"), onp.turbine_table("nrel_5MW_survey_a5")
+    assert np.abs(np.array(t3["table_cp"])[lo] - np.array(t5["table_cp"])[lo]).max() <= 5e-7
+    assert t3["table_ct"] == t5["table_ct"] and t3["table_ws"] == t5["table_ws"]
 
 
 def test_c_and_numpy_oracles_agree_on_tie_and_threshold_layouts():

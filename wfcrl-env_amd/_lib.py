@@ -66,6 +66,8 @@ _P = C.c_void_p
 ABI = {
     "wf_version": (C.c_int, []),
     "wf_default_model": (C.c_int, [C.POINTER(ModelParams)]),
+    "wf_turbine_table": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_double)),
+                                   C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double))]),
     "wf_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "wf_destroy": (C.c_int, [_P]),
     "wf_set_stream": (C.c_int, [_P, _P, C.c_int]),

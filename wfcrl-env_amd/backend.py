@@ -30,6 +30,17 @@ def default_model() -> dict:
     return d
 
 
+def turbine_table(name: str = "nrel_5MW_floris3") -> dict:
+    """A named power/thrust table shipped with the library (include/wfstep.h: wf_turbine_table) as the three model keys
+    `table_ws`, `table_ct`, `table_cp` — e.g. WfStep(..., model=turbine_table("nrel_5MW_survey_a5"))."""
+    n = C.c_int(0)
+    dp = C.POINTER(C.c_double)
+    ws, ct, cp = dp(), dp(), dp()
+    check(_lib.load().wf_turbine_table(name.encode(), C.byref(n), C.byref(ws), C.byref(ct), C.byref(cp)))
+    return {"table_ws": [ws[i] for i in range(n.value)], "table_ct": [ct[i] for i in range(n.value)],
+            "table_cp": [cp[i] for i in range(n.value)]}
+
+
 class WfStep:
     def __init__(self, xcoords, ycoords, env_batch: int = 1, device_id: int = 0, model: dict | None = None):
         self._lib = _lib.load()

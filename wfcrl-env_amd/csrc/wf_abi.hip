@@ -72,21 +72,31 @@ const double kCtFrom3[45] = {
     0.54054532, 0.45509459, 0.39343381, 0.34250785, 0.30487242, 0.27164979, 0.24361964, 0.21973831, 0.19918151,
     0.18131868, 0.16537679, 0.15103727, 0.13998636, 0.1289037,  0.11970413, 0.11087113, 0.10339901, 0.09617888,
     0.09009926, 0.08395078, 0.0791188,  0.07448356, 0.07050731, 0.06684119, 0.06345518, 0.06032267, 0.05741999};
-const double kCpFrom3[45] = {
+const double kCpFrom3SurveyA5[45] = {  // "nrel_5MW_survey_a5": the 8-decimal column (FLORIS v2 example input; 4.969 MW at 12 m/s, 5.116 MW at 25 m/s)
     0.1780851,  0.28907459, 0.34902166, 0.3847278,  0.40605878, 0.4202279,  0.42882274, 0.43387274, 0.43622267,
     0.43684468, 0.43657497, 0.43651053, 0.4365612,  0.43651728, 0.43590309, 0.43467276, 0.43322955, 0.43003137,
     0.37655587, 0.33328466, 0.29700574, 0.26420779, 0.23839379, 0.21459275, 0.19382354, 0.1756635,  0.15970926,
     0.14561785, 0.13287856, 0.12130194, 0.11219941, 0.10311631, 0.09545392, 0.08813781, 0.08186763, 0.07585005,
     0.07071926, 0.06557558, 0.06148104, 0.05755207, 0.05413366, 0.05097969, 0.04806545, 0.04536883, 0.04287006};
-double g_tab_ws[51], g_tab_ct[51], g_tab_cp[51];
+// "nrel_5MW_floris3", the default: the six-decimal column of FLORIS 3.x' turbine_library/nrel_5MW.yaml as recollected
+// (not reference-held): below rated the values above rounded, from 11.5 m/s the rated-power plateau
+// Cp = 5 MW / (1/2 rho A v^3)
+const double kCpFrom3Floris3[45] = {
+    0.178085, 0.289075, 0.349022, 0.384728, 0.406059, 0.420228, 0.428823, 0.433873, 0.436223,
+    0.436845, 0.436575, 0.436511, 0.436561, 0.436517, 0.435903, 0.434673, 0.433230, 0.430466,
+    0.378869, 0.335199, 0.297991, 0.266092, 0.238588, 0.214748, 0.193981, 0.175808, 0.159835,
+    0.145741, 0.133256, 0.122157, 0.112257, 0.103399, 0.095449, 0.088294, 0.081836, 0.075993,
+    0.070692, 0.065875, 0.061484, 0.057476, 0.053809, 0.050447, 0.047358, 0.044518, 0.041900,
+};
+double g_tab_ws[51], g_tab_ct[51], g_tab_cp[51], g_tab_cp_a5[51];
 std::once_flag g_tab_once;
 void fill_default_table() {
   int n = 0;
   const double head[3] = {0.0, 2.0, 2.5};
-  for (int i = 0; i < 3; ++i) { g_tab_ws[n] = head[i]; g_tab_ct[n] = 0.0; g_tab_cp[n] = 0.0; ++n; }
-  for (int i = 0; i < 45; ++i) { g_tab_ws[n] = 3.0 + 0.5 * i; g_tab_ct[n] = kCtFrom3[i]; g_tab_cp[n] = kCpFrom3[i]; ++n; }
+  for (int i = 0; i < 3; ++i) { g_tab_ws[n] = head[i]; g_tab_ct[n] = 0.0; g_tab_cp[n] = g_tab_cp_a5[n] = 0.0; ++n; }
+  for (int i = 0; i < 45; ++i) { g_tab_ws[n] = 3.0 + 0.5 * i; g_tab_ct[n] = kCtFrom3[i]; g_tab_cp[n] = kCpFrom3Floris3[i]; g_tab_cp_a5[n] = kCpFrom3SurveyA5[i]; ++n; }
   const double tail[3] = {25.01, 25.02, 50.0};
-  for (int i = 0; i < 3; ++i) { g_tab_ws[n] = tail[i]; g_tab_ct[n] = 0.0; g_tab_cp[n] = 0.0; ++n; }
+  for (int i = 0; i < 3; ++i) { g_tab_ws[n] = tail[i]; g_tab_ct[n] = 0.0; g_tab_cp[n] = g_tab_cp_a5[n] = 0.0; ++n; }
 }
 void init_default_table() { std::call_once(g_tab_once, fill_default_table); }  // concurrent wf_create calls
 
@@ -832,6 +842,15 @@ int wf_default_model(wf_model_params* p) {
   p->defl_alpha = p->alpha; p->defl_beta = p->beta; p->defl_ka = p->ka; p->defl_kb = p->kb;
   p->enable_secondary_steering = p->enable_yaw_added_recovery = p->enable_transverse_velocities = 1;
   p->n_table = 51; p->table_ws = g_tab_ws; p->table_ct = g_tab_ct; p->table_cp = g_tab_cp;
+  return WF_OK;
+}
+
+int wf_turbine_table(const char* name, int* n, const double** ws, const double** ct, const double** cp) {
+  if (!name || !n || !ws || !ct || !cp) return WF_E_INVALID;
+  init_default_table();
+  const bool f3 = std::strcmp(name, "nrel_5MW_floris3") == 0 || std::strcmp(name, "nrel_5MW") == 0;
+  if (!f3 && std::strcmp(name, "nrel_5MW_survey_a5") != 0) return WF_E_INVALID;
+  *n = 51; *ws = g_tab_ws; *ct = g_tab_ct; *cp = f3 ? g_tab_cp : g_tab_cp_a5;
   return WF_OK;
 }
 

@@ -107,8 +107,6 @@ def load_case_yaml(path_or_dict) -> dict:
             raise UnsupportedCaseError(f"wake.model_strings.{key} = {got!r} is not implemented (only {want!r})")
     if len(flow.get("wind_speeds", [0])) != 1 or len(flow.get("wind_directions", [0])) != 1:
         raise UnsupportedCaseError("exactly one wind speed and one wind direction per case (as the reference uses)")
-    if float(flow.get("wind_veer", 0.0)) != 0.0:
-        raise UnsupportedCaseError("wind_veer != 0 is not implemented")
     if flow.get("heterogenous_inflow_config") or flow.get("heterogeneous_inflow_config"):
         raise UnsupportedCaseError("heterogeneous inflow is not implemented")
     ttypes = farm.get("turbine_type", ["nrel_5MW"])
@@ -120,7 +118,7 @@ def load_case_yaml(path_or_dict) -> dict:
     if ref_h != -1 and ref_h != hub:
         raise UnsupportedCaseError("reference_wind_height must be -1 (hub height) or equal to the hub height")
     model.update(air_density=float(flow["air_density"]), ambient_ti=float(flow["turbulence_intensity"]),
-                 shear=float(flow["wind_shear"]), veer=0.0)
+                 shear=float(flow["wind_shear"]), veer=float(flow.get("wind_veer", 0.0)))
     gd = wake["wake_deflection_parameters"]["gauss"]
     gv = wake["wake_velocity_parameters"]["gauss"]
     for k in ("alpha", "beta", "ka", "kb"):  # each model has its own set (case.yaml:55-59 and 76-80)
