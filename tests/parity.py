@@ -37,6 +37,28 @@ LARGE_FARM_FACTOR = 3.0  # N > 128, see above
 # genuine flip, float64 margin 9.8e-6 — fuzz_api seed 802, session 15
 FLAGGED_BOUND = dict(power=1e-1, ws=2e-2, wd=0.1, ti=2e-2, std=5e-2)
 RISK_OVERLAP, RISK_POWER_KNEE, RISK_THRUST_RAMP = 1, 2, 4
+# A flag only excuses what its event can move (round 3; tests/tools/flag_stats.py on 10 x 4096 farms,
+# profiles/r03_flag_stats.txt): a farm flagged for the power knee ALONE has a wind field as good as an unflagged farm's —
+# only the power read off the steep segment moves (1.3e-2 measured on the cut-out drop, condition number 2500) — and
+# a farm on the thrust ramp without an overlap flag stays within a few TOL (power 7.7e-4, ws 6.9e-5, wd 8.9e-4 deg
+# measured; TI 1.3e-5 on the fixture farm with 48 turbines on the ramp).
+KNEE_ONLY_BOUND = dict(power=5e-2, ws=TOL["ws"], wd=TOL["wd"], ti=TOL["ti"], std=TOL["std"])
+RAMP_BOUND = dict(power=1e-2, ws=1e-3, wd=1e-2, ti=2e-4, std=1e-2)
+
+
+def flagged_within(e, flags, n_turbines):
+    """(B,) bool: farm inside the bound its flag combination allows (FLAGGED_BOUND with the overlap flag, RAMP_BOUND with
+    the thrust-ramp flag and no overlap flag, KNEE_ONLY_BOUND for the power knee alone)."""
+    flags = np.asarray(flags)
+    ok = within(e, FLAGGED_BOUND, n_turbines)
+    f = LARGE_FARM_FACTOR if n_turbines > 128 else 1.0
+    ramp_no_overlap = ((flags & RISK_OVERLAP) == 0) & ((flags & RISK_THRUST_RAMP) != 0)
+    for mask, bound in ((ramp_no_overlap, RAMP_BOUND), (flags == RISK_POWER_KNEE, KNEE_ONLY_BOUND)):
+        inside = np.ones_like(ok)
+        for k, t in bound.items():
+            inside &= e[k] <= t * f
+        ok &= inside | ~mask
+    return ok
 
 
 def errors(got, ref):
@@ -104,7 +126,7 @@ def summarize(got, ref, flags, guard_rel=5e-5):
     fl = flags != 0
     n_turbines = np.asarray(ref["power"]).shape[-1]
     strict = within(e, TOL, n_turbines)
-    bounded = within(e, FLAGGED_BOUND, n_turbines)  # a flip deep inside a 256-turbine farm moves more behind it: 3x there too
+    bounded = flagged_within(e, flags, n_turbines)  # a flip deep inside a 256-turbine farm moves more behind it: 3x there too
     out = dict(n=int(fl.size), n_flagged=int(fl.sum()), n_bad_unflagged=int((~strict & ~fl).sum()),
                n_bad_flagged=int((~bounded & fl).sum()), n_mismatch_flagged=int((~strict & fl).sum()),
                worst_unflagged={k: float(v[~fl].max()) if (~fl).any() else 0.0 for k, v in e.items()},
@@ -160,8 +182,8 @@ def check(got, ref, flags, max_flagged_frac=0.05, guard_rel=5e-5):
     assert s["n_bad_unflagged"] == 0, ("unflagged farm outside the parity tolerances", s)
     assert s["n_bad_flagged"] == 0, ("flagged farm outside the bounded signature of a flip", s)
     assert s.get("n_spurious", 0) == 0, ("risk flag raised far from the threshold", s)
-    if s["n"] >= 200:  # a rate is only meaningful on a batch of some size
-        assert s["n_flagged"] <= max_flagged_frac * s["n"], ("too many flagged farms", s)
+    # (a rate needs a batch of some size; small batches are capped too — ADVICE r2 — with room for the odd farm)
+    assert s["n_flagged"] <= max(max_flagged_frac * s["n"], 4 if s["n"] < 200 else 0) or max_flagged_frac >= 1.0, ("too many flagged farms", s)
     p = (np.abs(np.asarray(got["power"].cpu().numpy() if hasattr(got["power"], "cpu") else got["power"], dtype=np.float64)
                 - ref["power"]) / np.maximum(ref["power"], 1e3))
     assert np.median(p) <= 1e-6, np.median(p)
