@@ -407,9 +407,12 @@ def test_batched_aec_env_matches_B_reference_aec_envs(layouts, name, discrete):
     rng = np.random.default_rng(3)
     blocked_seen = 0
     n_calls = 0
+    snaps = []  # (agent, history index, copies of what last() returned): history entries must stay what they were
     for agent in venv.agent_iter():
         assert all(e.agent_selection == agent for e in refs)
         obs, rew, term, trunc, info = venv.last()
+        if len(snaps) < 4 * N:
+            snaps.append((agent, len(venv.history[agent]["reward"]) - 1, {k: obs[k].clone() for k in obs}))
         for b, e in enumerate(refs):
             o, r, t, tr, i = e.last()
             assert tr == trunc and t == term
@@ -441,4 +444,8 @@ def test_batched_aec_env_matches_B_reference_aec_envs(layouts, name, discrete):
     assert blocked_seen > 0  # the budget gate must have acted, or the comparison is vacuous
     h = venv.history["turbine_2"]
     assert len(h["reward"]) == len(refs[0].history["turbine_2"]["reward"]) if hasattr(refs[0], "history") else len(h["reward"]) > 0
+    # the history holds independent values — an entry recorded at joint step t is unchanged many steps later
+    for agent, idx, o in snaps:
+        for k in o:
+            assert torch.equal(venv.history[agent]["observation"][idx][k], o[k]), (agent, idx, k)
     venv.close()

@@ -86,6 +86,13 @@ def make(env_id: str, controls: Union[dict, list] = ["yaw"], log=True, **env_kwa
         if decentralised:  # "Dec_<layout>_Floris" with env_batch: the batched AEC flavour (one launch per agent cycle)
             from ..vec_adapters import VecAECLogWrapper, VecAECWindFarmEnv
 
+            # the per-agent budget of the AEC env replaces the joint one (multiagent_env.py:196-207); a logged env keeps
+            # what it returned, so its inner env never reuses output buffers
+            if env_kwargs.pop("actuation_budget", None) is not None:
+                raise ValueError("actuation_budget is fixed by the AEC flavour (per-agent budget, reference "
+                                 "wfcrl/multiagent_env.py:196-207)")
+            if log:
+                env_kwargs["reuse_buffers"] = False
             inner = VecWindFarmEnv(case, controls, env_batch=batch, start_iter=first_control_iter,
                                    actuation_budget=float("inf"), **env_kwargs)
             env = VecAECWindFarmEnv(inner)

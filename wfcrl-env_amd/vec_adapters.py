@@ -243,6 +243,12 @@ class VecAECWindFarmEnv(AECEnv):
         self.env.close()
 
 
+def _copy(v):
+    if hasattr(v, "clone"):
+        return v.clone()
+    return np.array(v, copy=True) if isinstance(v, np.ndarray) else v
+
+
 class VecAECLogWrapper(BaseWrapper):
     """Per-agent history recorded on `last()` (reference wfcrl/wrappers.py:24-58), entries batched over the B farms."""
 
@@ -254,11 +260,13 @@ class VecAECLogWrapper(BaseWrapper):
         agent = self.env.agent_selection
         result = self.env.last()
         h = self.history[agent]
-        h["observation"].append(result[0])
-        h["reward"].append(result[1])
+        # independent copies, as the reference's AECLogWrapper stores independent values: the env may hand out views of
+        # buffers it reuses (VecWindFarmEnv(reuse_buffers=True)) or of the joint step's tensors
+        h["observation"].append({k: _copy(v) for k, v in result[0].items()} if isinstance(result[0], dict) else _copy(result[0]))
+        h["reward"].append(_copy(result[1]))
         for key in ("power", "load"):
             if key in result[4]:
-                h[key].append(result[4][key])
+                h[key].append(_copy(result[4][key]))
         return result
 
     def reset(self, seed=None, options=None):

@@ -30,7 +30,7 @@ class VecWindFarmEnv:
     def __init__(self, farm_case, controls: dict = None, env_batch: int = 1, continuous_control: bool = True,
                  reward_shaper=None, start_iter: int = 0, max_num_steps: int = 500, load_coef: float = 0.1,
                  device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None,
-                 wind_sampling: str = "host", reuse_buffers: bool = True, wind_direction_step: float = None,
+                 wind_sampling: str = "host", reuse_buffers: bool = False, wind_direction_step: float = None,
                  actuation_budget: float = 0.1):
         controls = {"yaw": (-40, 40, 5)} if controls is None else dict(controls)
         if list(controls) != ["yaw"]:
@@ -94,9 +94,10 @@ class VecWindFarmEnv:
         self._num_iter = 0
         self._freewind = None
         self._shaper_ref = None
-        # Output tensors are preallocated and used alternately (torch path): what step t returned stays valid until step
-        # t + 2 overwrites it — enough for (obs, next_obs) pairs, copy what must live longer.  reuse_buffers=False
-        # allocates fresh tensors every step, as B reference envs would.
+        # reuse_buffers=True (opt-in, throughput loops): output tensors are preallocated and used alternately (torch path) —
+        # what step t returned stays valid until step t + 2 overwrites it: enough for (obs, next_obs) pairs, copy what must
+        # live longer (rollout storage, loggers).  The default allocates fresh tensors every step, as B reference envs
+        # would: nothing a caller keeps is ever overwritten.
         self.reuse_buffers = bool(reuse_buffers) and return_torch
         self._bufs = [{}, {}]
         self._flip = 0
