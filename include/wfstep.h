@@ -261,6 +261,22 @@ typedef struct wf_kernel_info {
 } wf_kernel_info;
 int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info);
 
+/* Which kernels may serve a handle.  Per handle (two handles in two threads may be steered differently); the
+ * environment variables of earlier builds (WF_KERNEL_GS, WF_LL, WF_LL_G, WF_NO_PAIR_TABLE, WF_LL_FLY) only seed this
+ * structure once, at wf_create.  Setting a choice drops the current wind (geometry, groups and tables were laid out
+ * for the previous kernels): call wf_set_wind / wf_wind_* again before the next step.
+ * wf_get_kernel_choice returns the request as set; what actually runs is reported by wf_get_kernel_info. */
+typedef struct wf_kernel_choice {
+  int slot_G, slot_S;   /* wf_step_kernel<G,S> (register-slot kernel): lanes per farm x target slots per lane; 0, 0 = by N
+                           and batch.  Ignored when G x S cannot hold the layout's turbines. */
+  int one_block;        /* wf_step_ll_kernel: -1 by the rounds model, 0 never, 1 always with (ll_G, ll_S) */
+  int ll_G, ll_S;       /* one of 4x1, 8x1, 16x1, 4x2, 2x2 (used when one_block == 1) */
+  int pair_table;       /* -1 whenever the batch shares a wind direction, 0 never (everything on the fly) */
+  int fly_one_block;    /* -1: a wind per farm runs wf_step_ll_kernel on the fly where it pays; 0: stays on wf_step_kernel */
+} wf_kernel_choice;
+int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c);
+int wf_get_kernel_choice(wf_handle* h, wf_kernel_choice* c);
+
 const char* wf_last_error(wf_handle* h); /* h may be NULL: last error of a failed wf_create */
 
 #ifdef __cplusplus

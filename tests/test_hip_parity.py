@@ -496,7 +496,11 @@ def test_shared_wind_pair_table_path_and_its_fallbacks(layouts, monkeypatch):
     both = (a["flags"] == 0) & (b["flags"] == 0)  # the two paths round differently: compare where neither is at risk
     assert np.abs(a["power"] / np.maximum(b["power"], 1e3) - 1)[both][b["power"][both] > 1e3].max() < 2e-5
     assert np.abs(a["load"] - b["load"])[both].max() < 2e-5
-    # env switch for A/B runs
+    # per-handle switch for A/B runs (wf_set_kernel_choice); the environment variable of earlier builds seeds it at wf_create
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, kernel_choice=dict(pair_table=False))
+    w.set_wind(9.0, 281.0)
+    assert w.kernel_info()["pair_table"] == 0 and w.kernel_choice()["pair_table"] == 0
+    w.close()
     monkeypatch.setenv("WF_NO_PAIR_TABLE", "1")
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
     w.set_wind(9.0, 281.0)
@@ -547,8 +551,7 @@ def test_every_kernel_variant_matches_the_oracle(G, S, monkeypatch):
     y = (np.arange(N) % cols) * 560.0 + rng.uniform(-60, 60, N)
     B = 6
     yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
-    monkeypatch.setenv("WF_KERNEL_GS", f"{G}x{S}")
-    w = WfStep(x, y, env_batch=B)
+    w = WfStep(x, y, env_batch=B, kernel_choice=dict(slot=(G, S)))
     info = w.kernel_info()
     assert (info["lanes_per_env"], info["slots_per_lane"]) == (G, S)
     w.set_wind(9.5, 263.0)
@@ -586,8 +589,7 @@ def test_exact_x_ties_across_kernel_blocks(gs, shape, wdir, monkeypatch):
     rng = np.random.default_rng(N * 131 + ncol)
     B = 5
     yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
-    monkeypatch.setenv("WF_KERNEL_GS", gs)
-    w = WfStep(x, y, env_batch=B)
+    w = WfStep(x, y, env_batch=B, kernel_choice=dict(slot=gs))
     info = w.kernel_info()
     assert f'{info["lanes_per_env"]}x{info["slots_per_lane"]}' == gs
     w.set_wind(8.0, wdir)
@@ -657,8 +659,7 @@ def test_direction_groups_series_binned_and_explicit_shared_direction(layouts, f
 
     from wfcrl_env_amd.backend import WfStep
 
-    if forced:
-        monkeypatch.setenv("WF_LL_G", forced)
+    choice = dict(one_block=forced) if forced else None
     l = layouts["HornsRev1_"]
     N, B, T = 80, 700, 7
     rng = np.random.default_rng(2025)
@@ -667,7 +668,7 @@ def test_direction_groups_series_binned_and_explicit_shared_direction(layouts, f
     series = np.stack([rng.uniform(5, 14, T), rng.uniform(200, 340, T)], axis=1)
     start = rng.integers(0, T, B).astype(np.int32)
     start[:3] = [0, T - 1, T - 1]
-    w = WfStep(x, y, env_batch=B)
+    w = WfStep(x, y, env_batch=B, kernel_choice=choice)
     w.set_wind_series(series, start=start)
     info = w.kernel_info()
     assert info["pair_table"] == 1 and info["direction_groups"] == T and info["grid_blocks"] >= B // info["envs_per_block"]
@@ -792,8 +793,7 @@ def test_one_block_at_a_time_kernel(layouts, name, wdir, G, monkeypatch):
     rng = np.random.default_rng(N * 10 + lanes + slots)
     B = 133  # not a multiple of the farms per block
     yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
-    monkeypatch.setenv("WF_LL_G", G)
-    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, kernel_choice=dict(one_block=G))
     w.set_wind(8.5, wdir)
     info = w.kernel_info()
     assert info["one_block_kernel"] == 1 and (info["lanes_per_env"], info["slots_per_lane"]) == (lanes, slots) and info["pair_table"] == 1
@@ -815,8 +815,7 @@ def test_one_block_at_a_time_kernel(layouts, name, wdir, G, monkeypatch):
     assert np.abs(e["reward"] - r_ref)[ok].max() < 5e-5 * np.abs(r_ref).max()
     w.close()
     # the register-slot kernel on the same inputs
-    monkeypatch.setenv("WF_LL", "0")
-    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, kernel_choice=dict(one_block=False))
     w.set_wind(8.5, wdir)
     assert w.kernel_info()["one_block_kernel"] == 0
     a0 = _with_flags(w, w.step(yaw))
@@ -837,8 +836,7 @@ def test_one_block_kernel_hands_cross_block_ties_back(layouts, G, monkeypatch):
     rng = np.random.default_rng(len(G))
     B = 64
     yaw = rng.uniform(-30, 30, (B, 32)).astype(np.float32)
-    monkeypatch.setenv("WF_LL_G", G)
-    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, kernel_choice=dict(one_block=G))
     for wdir in (270.0, 263.0, 270.0):
         w.set_wind(8.0, wdir)
         assert w.kernel_info()["one_block_kernel"] == 1
@@ -864,8 +862,7 @@ def test_one_block_kernel_on_the_fly_with_a_wind_per_farm(layouts, name, G, monk
     wd = rng.uniform(0, 360, B)
     wd[::7] = 270.0
     wd[3] = 90.0
-    monkeypatch.setenv("WF_LL_G", G)
-    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, kernel_choice=dict(one_block=G))
     w.set_wind(ws, wd)
     info = w.kernel_info()
     assert info["one_block_kernel"] == 1 and info["pair_table"] == 0
@@ -899,8 +896,7 @@ def test_one_block_kernel_on_the_fly_with_a_wind_per_farm(layouts, name, G, monk
     for k in ("power", "wind_speed", "wind_direction", "load"):
         assert np.array_equal(a[k], c2[k]), k
     w.close()
-    monkeypatch.setenv("WF_LL_FLY", "0")
-    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, kernel_choice=dict(one_block=G, fly_one_block=False))
     w.set_wind(ws, wd)
     assert w.kernel_info()["one_block_kernel"] == 0
     a0 = _with_flags(w, w.step(yaw))
@@ -924,12 +920,10 @@ def test_regime_cases_are_flagged_and_bounded(kernel, monkeypatch):
     import parity
     from wfcrl_env_amd.backend import WfStep
 
-    if kernel:
-        monkeypatch.setenv("WF_LL_G", kernel)
     for name, bit in (("thrust_ramp", parity.RISK_THRUST_RAMP), ("overlap_flip", parity.RISK_OVERLAP)):
         i, ref = _regime(name)
         B = 64
-        w = WfStep(i["x"], i["y"], env_batch=B)
+        w = WfStep(i["x"], i["y"], env_batch=B, kernel_choice=dict(one_block=kernel) if kernel else None)
         for per_farm in (False, True):  # pair-table path / on-the-fly path
             ws, wd = (np.repeat(i["ws"], B), np.repeat(i["wd"], B)) if per_farm else (float(i["ws"][0]), float(i["wd"][0]))
             w.set_wind(ws, wd)
@@ -989,3 +983,46 @@ def test_grouped_launch_follows_the_padded_farm_count(layouts):
     assert (k["one_block_kernel"], k["lanes_per_env"], k["slots_per_lane"]) == (1, 2, 2)
     check_sample()
     w.close()
+
+
+def test_two_threads_force_different_kernel_families_on_two_handles(layouts):
+    """SURVEY §8(b) "Threading": the kernel choice is per handle (wf_set_kernel_choice), not process-global — two threads
+    drive two handles concurrently, one forced onto the register-slot kernel and one onto wf_step_ll_kernel<4,2>, for
+    many steps; each keeps its own kernel and both match the oracle (and each other)."""
+    import threading
+
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    x, y, N, B = l["xcoords"], l["ycoords"], 80, 192
+    rng = np.random.default_rng(31)
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    ref = _oracle(x, y, 8.0, 263.0, yaw)
+    choices = [dict(one_block=False), dict(one_block="4x2"), dict(one_block="8")]
+    want = [(0, 16, 5), (1, 4, 2), (1, 8, 1)]
+    results, errors = [None] * len(choices), []
+
+    def work(k):
+        try:
+            w = WfStep(x, y, env_batch=B, kernel_choice=choices[k])
+            w.set_wind(8.0, 263.0)
+            info = w.kernel_info()
+            assert (info["one_block_kernel"], info["lanes_per_env"], info["slots_per_lane"]) == want[k], info
+            out = None
+            for _ in range(40):
+                out = w.step(yaw)
+            assert w.kernel_info()["one_block_kernel"] == want[k][0]
+            results[k] = _with_flags(w, out)
+            w.close()
+        except Exception as e:  # pragma: no cover
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(choices))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for r in results:
+        _check(r, ref)
+    assert np.abs(results[0]["power"] / results[1]["power"] - 1).max() < 2e-5

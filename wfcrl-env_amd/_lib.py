@@ -61,6 +61,12 @@ class KernelInfo(C.Structure):
         "vgprs", "lds_bytes", "scratch_bytes", "pair_table", "direction_groups", "one_block_kernel")]
 
 
+class KernelChoice(C.Structure):
+    """Mirror of `struct wf_kernel_choice`."""
+
+    _fields_ = [(n, C.c_int) for n in ("slot_G", "slot_S", "one_block", "ll_G", "ll_S", "pair_table", "fly_one_block")]
+
+
 # every symbol include/wfstep.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 ABI = {
@@ -96,6 +102,8 @@ ABI = {
     "wf_timing_begin": (C.c_int, [_P]),
     "wf_timing_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "wf_get_kernel_info": (C.c_int, [_P, C.POINTER(KernelInfo)]),
+    "wf_set_kernel_choice": (C.c_int, [_P, C.POINTER(KernelChoice)]),
+    "wf_get_kernel_choice": (C.c_int, [_P, C.POINTER(KernelChoice)]),
     "wf_last_error": (C.c_char_p, [_P]),
 }
 
@@ -104,8 +112,7 @@ _lib = None
 
 def build(force: bool = False) -> Path:
     """Compile csrc/ into libwfstep.so with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [PKG_DIR / "csrc" / n for n in ("wf_kernels.hip", "wf_kernels_ll.hip", "wf_resolve.hip", "wf_abi.hip", "wf_device.h",
-                                            "wf_kernel_common.h", "wf_resolve.h")]
+    srcs = sorted((PKG_DIR / "csrc").glob("*.hip")) + sorted((PKG_DIR / "csrc").glob("*.h"))
     srcs.append(PKG_DIR.parent / "include" / "wfstep.h")
     stale = (not LIB_PATH.exists()) or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
     if force or stale:

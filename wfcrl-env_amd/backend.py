@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import EnvParams, KernelInfo, ModelParams, WindDist, check
+from ._lib import EnvParams, KernelChoice, KernelInfo, ModelParams, WindDist, check
 
 
 def _is_torch(a) -> bool:
@@ -42,7 +42,8 @@ def turbine_table(name: str = "nrel_5MW_floris3") -> dict:
 
 
 class WfStep:
-    def __init__(self, xcoords, ycoords, env_batch: int = 1, device_id: int = 0, model: dict | None = None):
+    def __init__(self, xcoords, ycoords, env_batch: int = 1, device_id: int = 0, model: dict | None = None,
+                 kernel_choice: dict | None = None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         check(self._lib.wf_create(int(device_id), C.byref(self._h)))
@@ -53,6 +54,8 @@ class WfStep:
             self.set_model(model)
         self.set_layout(xcoords, ycoords)
         self.set_batch(env_batch)
+        if kernel_choice:  # keyword arguments of set_kernel_choice: which kernels may serve this handle
+            self.set_kernel_choice(**kernel_choice)
 
     # -- configuration ---------------------------------------------------------------------------
     def set_model(self, model: dict):
@@ -312,6 +315,41 @@ class WfStep:
         ms = C.c_float()
         check(self._lib.wf_timing_end(self._h, C.byref(ms)), self._h)
         return float(ms.value)
+
+    def set_kernel_choice(self, slot=None, one_block=None, pair_table=None, fly_one_block=None):
+        """Which kernels may serve THIS handle (include/wfstep.h: wf_set_kernel_choice); None = automatic.
+          slot=(G, S) or "16x5"      wf_step_kernel<G,S>
+          one_block=False            never wf_step_ll_kernel;  one_block=(G, S) / "4x2" / "8": always, with that shape
+          pair_table=False           everything on the fly
+          fly_one_block=False        a wind per farm stays on wf_step_kernel
+        Drops the current wind: set it again before the next step."""
+        def gs(v, default_s=1):
+            if isinstance(v, str):
+                parts = v.lower().split("x")
+                return int(parts[0]), (int(parts[1]) if len(parts) > 1 else default_s)
+            if isinstance(v, int):
+                return v, default_s
+            return int(v[0]), int(v[1])
+
+        c = KernelChoice(0, 0, -1, 0, 0, -1, -1)
+        if slot:
+            c.slot_G, c.slot_S = gs(slot)
+        if one_block is not None:
+            if one_block is False or one_block == 0:
+                c.one_block = 0
+            else:
+                c.one_block = 1
+                c.ll_G, c.ll_S = gs(one_block)
+        if pair_table is not None:
+            c.pair_table = int(bool(pair_table)) if pair_table is False else -1
+        if fly_one_block is not None:
+            c.fly_one_block = 0 if fly_one_block is False else -1
+        check(self._lib.wf_set_kernel_choice(self._h, C.byref(c)), self._h)
+
+    def kernel_choice(self) -> dict:
+        c = KernelChoice()
+        check(self._lib.wf_get_kernel_choice(self._h, C.byref(c)), self._h)
+        return {n: getattr(c, n) for n, _ in KernelChoice._fields_}
 
     def kernel_info(self) -> dict:
         k = KernelInfo()

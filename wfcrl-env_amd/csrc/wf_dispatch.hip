@@ -1,0 +1,416 @@
+// wf_dispatch.hip — which kernel serves a handle and how it is launched: the per-handle kernel choice
+// (wf_set_kernel_choice), the rounds model, the pair tables, the step launch with the float64 re-solve behind it,
+// kernel introspection.
+#include "wf_handle.h"
+
+namespace wfi {
+
+// Kernel variant for N turbines and B farms: G lanes per farm, S target slots per lane, G*S >= N.
+// Throughput regime (the grid fills the chip): smaller G wastes fewer lanes on the triangular
+// (upstream->downstream) structure and amortises the per-source work over more farms per wave; S is bounded by
+// the 256-VGPR budget that keeps two waves per SIMD resident.
+// Latency regime (few farms, e.g. the reference's single-farm env): the chip is not full anyway, so G is widened
+// as long as all waves still fit in one residency round — fewer slot passes per source step.
+int find_variant(int G, int S) {
+  for (int i = 0; i < wfk_num_variants(); ++i) {
+    int g, s; const void* fn;
+    wfk_variant(i, &g, &s, &fn);
+    if (g == G && s == S) return i;
+  }
+  return -1;
+}
+
+int pick_variant(const wf_handle* h, int N, int B) {
+  if (h->choice.slot_G > 0 && h->choice.slot_G * h->choice.slot_S >= N) {  // forced (wf_set_kernel_choice), e.g. 16 x 5
+    const int v = find_variant(h->choice.slot_G, h->choice.slot_S);
+    if (v >= 0) return v;
+  }
+  static const int pref[][3] = {  // {max N, G, S}
+      {4, 4, 1}, {8, 4, 2}, {12, 4, 3}, {16, 4, 4}, {24, 8, 3}, {32, 8, 4}, {48, 16, 3}, {64, 16, 4},
+      {80, 16, 5}, {96, 16, 6}, {128, 32, 4}, {192, 64, 3}, {256, 64, 4}};
+  int G = 0, S = 0;
+  for (auto& r : pref)
+    if (N <= r[0]) { G = r[1]; S = r[2]; break; }
+  if (!G) return -1;
+  if (B > 0) {
+    const long resident = (long)h->n_cu * 4 * 2;  // waves the chip holds at two per SIMD
+    while (G < 64) {
+      const int g2 = G * 2, s2 = (N + g2 - 1) / g2;
+      if ((long)B * g2 / 64 > resident / 2 || find_variant(g2, s2) < 0) break;
+      G = g2; S = s2;
+    }
+  }
+  return find_variant(G, S);
+}
+
+// Rounds model.  A wave solves its 64 / G farms start to finish, so a launch runs in ROUNDS of (blocks the chip holds) x
+// (farms per block), and within a round the time depends on how many blocks share a CU (one wave per SIMD each).
+// Measured per family at 1, 2, 3 blocks per CU on one MI355X (256 CUs) for several farm sizes (tools/rounds_table.py ->
+// profiles/r03_rounds_table.txt), ms; between the measured N the times are interpolated linearly in N (N + 1) / 2, the
+// number of (source, target) pairs, beyond them extrapolated the same way.  The number of CUs comes from the device
+// (a partitioned or smaller part has shorter rounds, the same time per round).
+//   code = (G << 4) | S of wf_step_ll_kernel, 0 = the register-slot kernel wf_step_kernel (its variant for N: pick_variant)
+struct LlFamily { int code, farms_per_block, per_cu; };
+const LlFamily kLlFamilies[] = {{0, 16, 2}, {(8 << 4) | 1, 32, 3}, {(4 << 4) | 2, 64, 2}, {(4 << 4) | 1, 64, 3}, {(2 << 4) | 2, 128, 2}};
+constexpr int kNumFamilies = 5, kNumRoundsN = 5;
+const int kRoundsN[kNumRoundsN] = {32, 48, 64, 80, 91};
+// [family][N index][blocks per CU - 1]
+const double kRoundsMs[kNumFamilies][kNumRoundsN][3] = {
+    {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.235, 0.298, 0.0}, {0.0, 0.0, 0.0}},
+    {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.33, 0.42, 0.55}, {0.0, 0.0, 0.0}},
+    {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.49, 0.644, 0.0}, {0.0, 0.0, 0.0}},
+    {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.53, 0.67, 0.89}, {0.0, 0.0, 0.0}},
+    {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.855, 1.178, 0.0}, {0.0, 0.0, 0.0}}};
+
+// ms of one round of family `fi` at `per_cu` blocks per CU for N turbines
+double round_ms(int fi, int N, int per_cu) {
+  auto pairs = [](int n) { return 0.5 * n * (n + 1); };
+  auto at = [&](int k) { return kRoundsMs[fi][k][per_cu - 1]; };
+  int lo = -1, hi = -1;  // measured neighbours (entries that are 0 were not measured: skipped)
+  for (int k = 0; k < kNumRoundsN; ++k) {
+    if (at(k) <= 0.0) continue;
+    if (kRoundsN[k] <= N) lo = k;
+    if (kRoundsN[k] >= N && hi < 0) hi = k;
+  }
+  if (lo < 0 && hi < 0) return 1e300;
+  if (lo < 0) return at(hi) * pairs(N) / pairs(kRoundsN[hi]);
+  if (hi < 0) return at(lo) * pairs(N) / pairs(kRoundsN[lo]);
+  if (lo == hi) return at(lo);
+  const double w = (pairs(N) - pairs(kRoundsN[lo])) / (pairs(kRoundsN[hi]) - pairs(kRoundsN[lo]));
+  return at(lo) + w * (at(hi) - at(lo));
+}
+
+// ms for `farms` farm slots on family fi: whole rounds at full occupancy, then the partial round at the occupancy it
+// reaches; a partial round behind full ones overlaps with their tail (factor 0.8, measured)
+double ll_estimate(const wf_handle* h, int fi, int N, long farms) {
+  const LlFamily& f = kLlFamilies[fi];
+  const long blocks = (farms + f.farms_per_block - 1) / f.farms_per_block, per_round = (long)h->n_cu * f.per_cu;
+  const long full = blocks / per_round, rem = blocks % per_round;
+  double t = full * round_ms(fi, N, f.per_cu);
+  if (rem) t += (full ? 0.8 : 1.0) * round_ms(fi, N, (int)((rem + h->n_cu - 1) / h->n_cu));
+  return t;
+}
+
+// Lane-group width of the one-block-at-a-time kernel for N turbines and B farms, 0 = keep wf_step_kernel.  It pays once
+// the farm spans several blocks (the register-slot kernel is then pinned at two waves per SIMD by its 27 S state
+// registers) and the batch fills the chip.  wf_set_kernel_choice: one_block = 0 disables it, 1 forces (ll_G, ll_S).
+int pick_ll(const wf_handle* h, int N, int B) {  // returns (G << 4) | S, 0 = keep wf_step_kernel
+  if (h->choice.one_block == 0) return 0;
+  if (N > WF_PAIR_MAX_N) return 0;
+  if (h->choice.one_block == 1) {
+    const int g = h->choice.ll_G, sl = h->choice.ll_S > 0 ? h->choice.ll_S : 1;
+    const bool ok = ((g == 4 || g == 8 || g == 16) && sl == 1) || ((g == 4 || g == 2) && sl == 2);
+    return (ok && N > g * sl) ? ((g << 4) | sl) : 0;
+  }
+  // the cheapest estimate wins: at N = 80 the register-slot kernel up to ~8192 farms, G = 8 up to ~24576, then the two
+  // G = 4 kernels depending on how the batch divides into rounds of 32768 / 49152, G = 2 x 2 on whole rounds of 65536
+  if (N <= 16) return 0;
+  int best = 0;
+  double t_best = 1e300;
+  for (int fi = 0; fi < kNumFamilies; ++fi) {
+    const LlFamily& f = kLlFamilies[fi];
+    if (f.code && N <= (f.code >> 4) * (f.code & 15)) continue;  // needs more than one block
+    if (f.code == ((8 << 4) | 1) && N <= 32) continue;           // (not instantiated to pay below that)
+    if (f.code == ((2 << 4) | 2) && N < 48) continue;            // (two slots of two lanes: needs a farm of some depth)
+    const double t = ll_estimate(h, fi, N, B);
+    if (t < t_best) { t_best = t; best = f.code; }
+  }
+  return best;
+}
+
+// A grouped launch (series rows / binned directions) pads every group to whole blocks: more farm slots than farms.  The
+// two G = 4 kernels have the same block size, so the choice between them can follow the padded count without touching
+// the group lists (HornsRev1 x 65536 in 104 groups = 1072 blocks: three rounds of the two-slot kernel, 1.65 ms, against
+// two of the one-slot kernel).
+int repick_ll_slots(const wf_handle* h, int N, int ll_G, int ll_S, long farm_slots) {
+  if (ll_G != 4 || h->choice.one_block == 1 || N <= 8) return ll_S;
+  return ll_estimate(h, 3, N, farm_slots) < ll_estimate(h, 2, N, farm_slots) ? 1 : 2;
+}
+
+// (Re)pick the kernels of a handle for N turbines and B farms under its choice: the register-slot variant and the
+// one-block kernel's shape; frees what was laid out for another shape.  The caller has drained the stream.
+void apply_kernel_pick(wf_handle* h, int N, int B, bool* variant_changed) {
+  const int v = pick_variant(h, N, B);
+  const int llg = pick_ll(h, N, B);
+  set_ll_shape(h, llg >> 4, llg ? (llg & 15) : 1);
+  if (variant_changed) *variant_changed = v != h->variant;
+  if (v != h->variant) {  // the pair table is laid out for the variant's capacity
+    hipFree(h->d_pair_tab); hipFree(h->d_pair_first);
+    h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_dirty = true; h->pair_groups_cap = 0;
+    h->variant = v;
+  }
+}
+
+// The one-block kernel's (G, S) of a handle: its pair table and source log are laid out for (N, G, S).  The caller has
+// made sure no launch is in flight.
+void set_ll_shape(wf_handle* h, int G, int S) {
+  if (G == h->ll_G && S == h->ll_S) return;
+  hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
+  h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
+  h->ll_G = G; h->ll_S = S; h->pair_dirty = true;
+}
+// Shared wind: (re)build the geometry-only pair table after the geometry kernel (same stream).  Returns the table
+// pointer to hand to the step kernel, or nullptr when the on-the-fly path applies (per-farm wind, N too large,
+// or WF_NO_PAIR_TABLE set for A/B runs).
+int pair_table(wf_handle* h, const float** out) {
+  *out = nullptr;
+  if ((h->wind_count != 1 && !h->shared_dir && h->n_groups == 0) || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->choice.pair_table == 0)
+    return WF_OK;
+  int vG, vS; const void* vfn;
+  wfk_variant(h->variant, &vG, &vS, &vfn);
+  const int NP = vG * vS;
+  const size_t ng = h->n_groups > 0 ? (size_t)h->n_groups : 1;
+  if (!h->d_pair_tab || h->pair_groups_cap < ng) {
+    hipFree(h->d_pair_tab); hipFree(h->d_pair_first);
+    h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_groups_cap = 0;
+    WF_HIP(h, hipMalloc(&h->d_pair_tab, sizeof(float) * ng * h->N * WF_PAIR_ROW_FLOATS(NP)));
+    WF_HIP(h, hipMalloc(&h->d_pair_first, sizeof(int) * ng * h->N));
+    h->pair_groups_cap = ng;
+    h->pair_dirty = true;
+  }
+  if (h->pair_dirty) {
+    const wf_model_params& m = h->model;
+    WfPairConsts pc{};
+    const double D = m.rotor_diameter, HH = m.hub_height, eps = m.eps_gain * D;
+    pc.N = h->N; pc.NP = NP; pc.D = D; pc.HH = HH; pc.eps2 = eps * eps; pc.num_eps = m.num_eps; pc.ch_down = m.ch_downstream;
+    const double off[3] = {-D / 4, 0.0, D / 4};
+    double uinf = 0;
+    for (int k = 0; k < 3; ++k) uinf += std::pow((HH + off[k]) / HH, m.shear) / 3.0;
+    pc.fifteenD = 15.0 * D;
+    pc.twoD = 2.0 * D;
+    pc.gam_top = (1.0 / 16.0) * D * std::pow((HH + D / 2) / HH, m.shear) * uinf;  // (1/2pi)(pi/8) D vel_top uinf
+    pc.gam_bot = (1.0 / 16.0) * D * std::pow((HH - D / 2) / HH, m.shear) * uinf;
+    for (int k = 0; k < 3; ++k) {
+      pc.off[k] = off[k];
+      const double z = HH + off[k];
+      const double dudz = m.shear * std::pow(1.0 / HH, m.shear) * std::pow(z, m.shear - 1.0);
+      const double lm = m.kappa * z / (1.0 + m.kappa * z / (D / 8.0));
+      pc.decay_a[k] = 4.0 * lm * lm * std::fabs(dudz) / uinf / pc.eps2;
+    }
+    WF_HIP(h, wfk_launch_pair_table(&pc, (int)ng, h->d_gx, h->d_gy, h->d_pair_tab, h->d_pair_first, h->stream));
+    if (h->ll_G) {  // the same records in target-block order, and the per-direction cross-block-tie flag
+      if (!h->d_ll_tab || h->ll_groups_cap < ng) {
+        hipFree(h->d_ll_tab); hipFree(h->d_ll_flag);
+        h->d_ll_tab = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = 0;
+        WF_HIP(h, hipMalloc(&h->d_ll_tab, sizeof(float) * ng * wfk_ll_table_floats(h->N, h->ll_G * h->ll_S)));
+        WF_HIP(h, hipMalloc(&h->d_ll_flag, sizeof(int) * ng));
+        h->ll_groups_cap = ng;
+      }
+      WF_HIP(h, wfk_launch_pair_table_ll(&pc, h->ll_G * h->ll_S, (int)ng, h->d_gx, h->d_gy, h->d_ll_tab, h->d_ll_flag, h->stream));
+      // which kernel serves which direction is decided on the device (no host round trip on the asynchronous path);
+      // where the wind came through a synchronising call anyway, the flags are read back once so that a launch nobody
+      // needs is not enqueued at all
+      h->ll_ties = 2;
+      if (h->wind_sync) {
+        std::vector<int> f(ng);
+        WF_HIP(h, hipMemcpyAsync(f.data(), h->d_ll_flag, sizeof(int) * ng, hipMemcpyDeviceToHost, h->stream));
+        WF_HIP(h, hipStreamSynchronize(h->stream));
+        size_t tied = 0;
+        for (int v : f) tied += v != 0;
+        h->ll_ties = tied == 0 ? 0 : (tied == ng ? 1 : 2);
+      }
+    }
+    h->pair_dirty = false;
+  }
+  *out = h->d_pair_tab;
+  return WF_OK;
+}
+
+// Rotation + sort of `n_env` wind conditions on the handle's stream.  A geometry per farm (n_env == B) also yields the
+// per-farm cross-block-tie flags for the on-the-fly one-block kernel; sync_ok: the caller synchronises anyway, so the
+// "any farm tied" flag is read back and a launch nobody needs is never enqueued.
+int ll_fly_S(const wf_handle* h);
+int ll_fly_G(const wf_handle* h);
+int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
+  const bool per_farm = n_env == h->B && h->B > 1 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h));
+  WF_HIP(h, wfk_launch_geometry(n_env, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd, h->d_gx, h->d_gy, h->d_gidx,
+                                per_farm ? ll_fly_G(h) * ll_fly_S(h) : 0, h->d_farm_tie, h->d_farm_tie ? h->d_farm_tie + h->B : nullptr,
+                                h->stream));
+  h->farm_ties = 2;
+  if (per_farm && sync_ok) {
+    int any = 0;
+    WF_HIP(h, hipMemcpyAsync(&any, h->d_farm_tie + h->B, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    WF_HIP(h, hipStreamSynchronize(h->stream));
+    h->farm_ties = any ? 1 : 0;
+  }
+  return WF_OK;
+}
+
+// Target slots per lane of the one-block kernel ON THE FLY (a wind per farm): two at G = 4 whatever the table path
+// uses — there the second slot halves the per-source geometry work as well (HornsRev1 x 65536: 3.48 ms against 4.14).
+int ll_fly_S(const wf_handle* h) { return h->ll_G <= 4 ? 2 : h->ll_S; }
+// ... and its lane-group width: the table path's, except that G = 2 has no on-the-fly instantiation (G = 4 x 2 serves)
+int ll_fly_G(const wf_handle* h) { return h->ll_G == 2 ? 4 : h->ll_G; }
+
+// turbines per farm in the source log of the one-block kernel: whole lane-group blocks (of the larger of the two
+// block sizes: the table path and the on-the-fly path share the buffer)
+size_t ll_npad(const wf_handle* h) {
+  const int a = h->ll_G * h->ll_S, b = ll_fly_G(h) * ll_fly_S(h), gs = a > b ? a : b;  // (powers of two)
+  return (size_t)((h->N + gs - 1) / gs) * gs;
+}
+
+int ll_log_fpb(const wf_handle* h) {
+  const int a = wfk_ll_farms_per_block(h->ll_G), b = wfk_ll_farms_per_block(ll_fly_G(h));
+  return a > b ? a : b;
+}
+// One launch of the step kernel on the handle's stream with the handle's current geometry / wind / table state.
+int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
+  const int gstride = (h->wind_count == 1 || h->shared_dir) ? 0 : h->N;
+  const int wstride = (h->wind_count == 1) ? 0 : 1;
+  const float* ptab = nullptr;
+  int rc = pair_table(h, &ptab);
+  if (rc != WF_OK) return rc;
+  WfGroupArgs ga{};
+  ga.mod = 1;
+  ga.risk_flags = h->d_flags;
+  ga.blk_unit = 1;
+  if (h->n_groups > 0) {
+    ga.perm = h->d_perm; ga.blk_group = h->d_blk_group; ga.n_blocks = h->n_blocks;
+    ga.shift = h->group_shift; ga.mod = h->n_groups;
+    ga.blk_unit = group_unit(h); ga.n_slots = h->n_slots;
+  }
+  if (ptab && h->ll_G) {
+    // the one-block-at-a-time kernel serves every direction without a cross-block tie; wf_step_kernel, enqueued right
+    // behind it, serves the others (device-side predicate, no host round trip)
+    const int fpb = ll_log_fpb(h);  // (farm slots of the log: whole blocks of the wider of the two paths' blocks)
+    const size_t slots = h->n_groups > 0 ? (size_t)h->n_slots : (size_t)((h->B + fpb - 1) / fpb) * fpb;
+    if (slots > h->log_slots_cap) {
+      WF_HIP(h, hipStreamSynchronize(h->stream));
+      hipFree(h->d_src_log); h->d_src_log = nullptr; h->log_slots_cap = 0;
+      WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * ll_npad(h) * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
+      h->log_slots_cap = slots;
+    }
+    if (h->ll_ties != 1)
+      WF_HIP(h, wfk_launch_step_ll(h->ll_G, h->ll_S, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
+                                   load, h->B, ea, h->d_ll_tab, h->d_ll_flag, h->d_src_log,
+                                   h->log_slots_cap * ll_npad(h) * WF_LOG_FLOATS, &ga, h->stream));
+    if (h->ll_ties == 0) return WF_OK;
+    ga.pred = h->d_ll_flag;
+  }
+  if (!ptab && gstride != 0 && h->B > 1 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && h->choice.fly_one_block != 0) {
+    // a wind per farm: the one-block kernel on the fly; wf_step_kernel behind it for the farms whose own geometry has
+    // an x' tie across a block boundary (per-farm device flags from the geometry kernel)
+    const int fpb = ll_log_fpb(h);
+    const size_t slots = (size_t)((h->B + fpb - 1) / fpb) * fpb;
+    if (slots > h->log_slots_cap) {
+      WF_HIP(h, hipStreamSynchronize(h->stream));
+      hipFree(h->d_src_log); h->d_src_log = nullptr; h->log_slots_cap = 0;
+      WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * ll_npad(h) * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
+      h->log_slots_cap = slots;
+    }
+    WF_HIP(h, wfk_launch_step_ll_fly(ll_fly_G(h), ll_fly_S(h), &h->consts, h->d_tab, h->d_gidx, h->d_gx, h->d_gy, h->d_ws, h->d_wd, yaw,
+                                     power, wspd, wdir, load, h->B, ea, h->d_farm_tie, h->d_src_log,
+                                     h->log_slots_cap * ll_npad(h) * WF_LOG_FLOATS, &ga, h->stream));
+    if (h->farm_ties == 0) return WF_OK;
+    ga.farm_pred = h->d_farm_tie;
+  }
+  WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
+                            wstride, yaw, power, wspd, wdir, load, h->B, ea, ptab, h->d_pair_first, &ga, h->stream, &h->grid));
+  return WF_OK;
+}
+
+// The step as the ABI sees it: the float32 kernels, then — when asked for (wf_set_risk_resolve) or when the model needs
+// it (wind_veer != 0) — the float64 solve of the flagged (or all) farms on the same stream, overwriting their outputs.
+int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
+  int rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
+  if (rc != WF_OK) return rc;
+  const int mode = h->model.veer != 0.0 ? 2 : h->resolve_mode;
+  if (mode == 0) return WF_OK;
+  if (!h->d_res_list) {
+    WF_HIP(h, hipMalloc(&h->d_res_list, sizeof(int) * h->cap_env));
+    WF_HIP(h, hipMalloc(&h->d_res_count, sizeof(int)));
+    WF_HIP(h, hipMalloc(&h->d_flags_raw, sizeof(int) * h->cap_env));
+  }
+  WfResolveArgs ra{};
+  ra.tab64 = h->d_tab64; ra.list = h->d_res_list; ra.count = h->d_res_count; ra.flags = h->d_flags;
+  ra.gx = h->d_gx; ra.gy = h->d_gy; ra.gidx = h->d_gidx;
+  ra.geom_stride = (h->wind_count == 1 || h->shared_dir) ? 0 : (size_t)h->N;
+  ra.mod = 1;
+  if (h->n_groups > 0) {
+    ra.farm_group = h->series_T > 0 ? h->d_series_start : h->d_bins;
+    ra.shift = h->group_shift; ra.mod = h->n_groups;
+  }
+  ra.ws = h->d_ws; ra.wd = h->d_wd; ra.wind_stride = h->wind_count == 1 ? 0 : 1;
+  ra.yaw_in = yaw;
+  ra.o_power = power; ra.o_ws = wspd; ra.o_wd = wdir; ra.o_load = load;
+  if (ea) {
+    ra.yaw_state = ea->yaw_state; ra.reward = ea->reward; ra.ws_prev = ea->ws_prev; ra.load_coef = ea->load_coef;
+  }
+  h->rconsts.N = h->N;
+  WF_HIP(h, wfk_launch_resolve(&h->rconsts, &ra, h->B, mode == 2 ? 1 : 0, h->d_flags_raw, h->stream));
+  return WF_OK;
+}
+
+}  // namespace wfi
+
+using namespace wfi;
+
+extern "C" {
+
+int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
+  if (!h || !info) return WF_E_INVALID;
+  if (h->variant < 0) return fail(h, WF_E_INVALID, "wf_set_layout must be called first");
+  int G, S; const void* fn;
+  wfk_variant(h->variant, &G, &S, &fn);
+  // the instantiation the next step would launch: pair table (shared wind), general mirror cores, or default
+  if (h->model_dirty && h->N > 0) { int rc = build_consts(h); if (rc != WF_OK) return rc; }
+  const bool tab = (h->wind_count == 1 || h->shared_dir || h->n_groups > 0) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && h->choice.pair_table != 0;
+  fn = wfk_variant_fn(h->variant, tab ? (h->wind_count == 1 ? 2 : 3) : (h->consts.mirror_core_n <= 1 ? 0 : 1));
+  info->pair_table = tab ? 1 : 0;
+  info->direction_groups = h->n_groups;
+  hipFuncAttributes a;
+  WF_ON_DEVICE(h);
+  WF_HIP(h, hipFuncGetAttributes(&a, fn));
+  info->lanes_per_env = G; info->slots_per_lane = S;
+  const int wpb = tab ? wfk_tab_waves() : 4;
+  info->envs_per_block = wpb * (64 / G); info->threads_per_block = 64 * wpb;
+  info->grid_blocks = h->n_groups > 0 ? (h->n_slots + info->envs_per_block - 1) / info->envs_per_block
+                                      : (h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0);
+  const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && h->choice.fly_one_block != 0;
+  info->one_block_kernel = ((tab && h->ll_G) || ll_fly) ? 1 : 0;
+  if (info->one_block_kernel) {
+    // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
+    // fields above would describe) is enqueued behind it for the directions that have one
+    const int ll_s = tab ? h->ll_S : ll_fly_S(h), ll_g = tab ? h->ll_G : ll_fly_G(h);
+    WF_HIP(h, wfk_ll_func_attributes(ll_g, ll_s, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, &a));
+    info->lanes_per_env = ll_g; info->slots_per_lane = ll_s;
+    info->envs_per_block = wfk_ll_farms_per_block(ll_g); info->threads_per_block = 256;
+    info->grid_blocks = (int)(((h->n_groups > 0 ? (size_t)h->n_slots : (size_t)h->B) + info->envs_per_block - 1) / info->envs_per_block);
+  }
+  info->vgprs = a.numRegs;
+  info->lds_bytes = (int)a.sharedSizeBytes; info->scratch_bytes = (int)a.localSizeBytes;
+  return WF_OK;
+}
+
+
+int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c) {
+  if (!h || !c) return WF_E_INVALID;
+  if ((c->slot_G > 0) != (c->slot_S > 0) || (c->slot_G > 0 && find_variant(c->slot_G, c->slot_S) < 0))
+    return fail(h, WF_E_INVALID, "no wf_step_kernel variant with these lanes per farm x slots per lane");
+  if (c->one_block < -1 || c->one_block > 1 || c->pair_table < -1 || c->pair_table > 1 || c->fly_one_block < -1 || c->fly_one_block > 1)
+    return fail(h, WF_E_INVALID, "kernel choice switches must be -1 (automatic), 0 or 1");
+  if (c->one_block == 1) {
+    const int g = c->ll_G, sl = c->ll_S > 0 ? c->ll_S : 1;
+    if (!(((g == 4 || g == 8 || g == 16) && sl == 1) || ((g == 4 || g == 2) && sl == 2)))
+      return fail(h, WF_E_INVALID, "wf_step_ll_kernel is instantiated for G x S in {4x1, 8x1, 16x1, 4x2, 2x2}");
+  }
+  WF_ON_DEVICE(h);
+  WF_HIP(h, hipStreamSynchronize(h->stream));
+  h->choice = *c;
+  if (h->N > 0) {
+    const int v = pick_variant(h, h->N, h->B);
+    if (v < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
+    apply_kernel_pick(h, h->N, h->B, nullptr);
+  }
+  // geometry, groups and tables of the current wind were laid out for the previous choice: the wind has to be set again
+  h->wind_count = 0; h->shared_dir = false; h->n_groups = 0; h->grid_step = 0.0; h->series_T = 0; h->pair_dirty = true;
+  return WF_OK;
+}
+
+int wf_get_kernel_choice(wf_handle* h, wf_kernel_choice* c) {
+  if (!h || !c) return WF_E_INVALID;
+  *c = h->choice;
+  return WF_OK;
+}
+
+}  // extern "C"

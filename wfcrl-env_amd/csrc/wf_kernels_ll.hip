@@ -14,7 +14,7 @@
 //     instruction — because the block, not the farm, has to fit the registers; with S = 1 the kernel runs three waves
 //     per SIMD (168 VGPRs), with G = 4, S = 2 two (223 VGPRs; 24 % fewer instructions per farm than G = 8, S = 1, the
 //     same log traffic), and no register slots have to be shifted.  Which of them runs is decided per batch size by
-//     the rounds model in wf_abi.hip::pick_ll.
+//     the rounds model in wf_dispatch.hip::pick_ll.
 //   * the replay loop's memory order is pinned by hand (compiler barriers; DESIGN.md §4 "what the replay loop was
 //     actually waiting for"): {dx, dy, tipow, bits} reads, the prefetch of the next log record, the deficit / TI bodies of
 //     all slots, and only then the 9 coefficient float4 per slot and the transverse pass.
