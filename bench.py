@@ -148,9 +148,11 @@ def main():
     # one rank per GPU (the driver's launch); BENCH_DIST_BACKEND=gloo + fewer GPUs than ranks is a test mode that
     # exercises the multi-rank flow on a single-GPU box (ranks then share devices)
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    from wfcrl_env_amd.sharding import device_for_rank
+
     ndev = max(1, torch.cuda.device_count())
     shared_devices = backend != "nccl" and ndev < world
-    local_rank = local_rank % ndev if backend != "nccl" else local_rank
+    local_rank = device_for_rank(local_rank, ndev, backend)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -243,11 +245,18 @@ def main():
             w.step(ring[i % len(ring)], out)
             w.sync()
         sync_ms = (time.perf_counter() - t1) / nsync * 1e3
+        shards = [[rank, local_rank, lo, hi]]
         if dist is not None:
-            t = torch.tensor([elapsed, kern_ms], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            dev = "cuda" if backend == "nccl" else "cpu"
+            t = torch.tensor([elapsed, kern_ms], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, kern_ms = float(t[0]), float(t[1])
-        return dict(mode=mode, B=B, total=total, elapsed=elapsed, kern_ms=kern_ms, sync_ms=sync_ms, w=w, ring=ring, out=out)
+            mine = torch.tensor([rank, local_rank, lo, hi], device=dev, dtype=torch.int64)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)  # (bookkeeping for the JSON line, outside the timed region: not a data-path collective)
+            shards = [[int(v) for v in p_] for p_ in parts]
+        return dict(mode=mode, B=B, total=total, elapsed=elapsed, kern_ms=kern_ms, sync_ms=sync_ms, w=w, ring=ring, out=out,
+                    shards=shards)
 
     main_leg = run_leg(args.scaling)
     other_leg = None
@@ -365,6 +374,9 @@ def main():
                                   + wl_wind + (", yaw ~ U(-40,40)" if cfg_id == 2 else ", random-walk yaw"),
                       "layout": layout_name.rstrip("_"),
                       "turbines": N, "env_batch_per_gpu": B, "env_batch_total": main_leg["total"],
+                      # which farms each rank stepped: [rank, device, first farm, one past the last] (contiguous blocks,
+                      # wfcrl_env_amd/sharding.py: shard_bounds)
+                      "shards": main_leg["shards"],
                       "parallelism": f"env-shard x{world}" + (f" ({world} ranks sharing {ndev} GPU(s) over gloo: test mode)" if shared_devices else ""),
                       "kernel": (f"wf_step_ll_kernel<G={info['lanes_per_env']},S={info['slots_per_lane']}> (one target block at a time, source log)"
                                  if info.get("one_block_kernel") else

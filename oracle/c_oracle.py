@@ -57,6 +57,13 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+class OracleResult(dict):
+    """Output arrays of a batch, plus the inputs they belong to as attributes (`yaw` (B, N) float64, `model`)."""
+
+    yaw = None
+    model = None
+
+
 def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None, nthreads: int = 0, margin: bool = False,
                     tie_reverse: bool = False):
     """Same contract as floris_gch_numpy.farm_step_batch, evaluated by the C restatement.
@@ -104,9 +111,9 @@ def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None, nthreads: i
     )
     if rc != 0:
         raise RuntimeError(f"wfo_step_batch failed: {rc}")
-    if margin:  # what the parity contract needs to judge the kernel's knee / ramp flags (tests/parity.py)
-        out["yaw"] = yaw
-        out["model"] = p
+    if margin:  # what the parity contract needs to judge the kernel's knee / ramp flags (tests/parity.py): attributes,
+        out = OracleResult(out)  # not items — the dict holds output arrays only
+        out.yaw, out.model = yaw, p
     return out
 
 

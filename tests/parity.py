@@ -87,18 +87,18 @@ def within(e, tol, n_turbines=0):
 
 
 def table_flag_conditions(ref, slack=0.05, near=2e-4):
-    """What the oracle says about the two table flags, per farm (needs ref["yaw"], ref["model"]: c_oracle with
+    """What the oracle says about the two table flags, per farm (needs ref.yaw, ref.model: c_oracle with
     margin=True): (knee, ramp) bool (B,) — True where SOME turbine of the farm sits, in float64, on (or within `near`
     relative of a knot next to) a segment whose condition number is within `slack` of the kernel's thresholds:
       WF_RISK_POWER_KNEE   rho v |dP/dv| > 30 max(P, 1 kW) at v = (rho/rho_ref)^(1/3) wind_speed cos(yaw)^(pP/3)
       WF_RISK_THRUST_RAMP  v |dCt/dv| > 5 at the turbine's rotor wind speed, Ct strictly inside (0.0001, 0.9999)
     (csrc/wf_kernel_common.h: table_pw / table_ct; wf_abi.hip: knee_kappa, ct_kappa).  A raised flag without it is spurious."""
-    p = ref["model"]
+    p = ref.model
     tws = np.asarray(p.table_ws, float)
     tct = np.asarray(p.table_ct, float)
     tpw = np.asarray(p.power_table(), float)
     wsd = np.asarray(ref["wind_speed"], float)
-    veff = (p.air_density / p.ref_density) ** (1.0 / 3.0) * wsd * np.cos(np.radians(ref["yaw"])) ** (p.pP / 3.0)
+    veff = (p.air_density / p.ref_density) ** (1.0 / 3.0) * wsd * np.cos(np.radians(ref.yaw)) ** (p.pP / 3.0)
 
     def cond(v, tab, kind):
         out = np.zeros(v.shape, bool)
@@ -136,7 +136,7 @@ def summarize(got, ref, flags, guard_rel=5e-5):
         # the device's deficit differs from the oracle's by float32 rounding accumulated over the recurrence (<~ 1e-5
         # relative): a raised flag means the oracle's margin is inside the band widened by that much
         out["n_spurious"] = int((ref["margin"][ov] > 10 * guard_rel + 1e-4).sum())
-        if "model" in ref:  # the two table flags against the oracle's own rotor speeds (a kernel that raises
+        if getattr(ref, "model", None) is not None and np.asarray(ref["wind_speed"]).shape == np.shape(ref.yaw):  # the two table flags against the oracle's own rotor speeds (a kernel that raises
             knee, ramp = table_flag_conditions(ref)  # them anywhere would hide real errors behind FLAGGED_BOUND)
             out["n_spurious_knee"] = int((((flags & RISK_POWER_KNEE) != 0) & ~knee).sum())
             out["n_spurious_ramp"] = int((((flags & RISK_THRUST_RAMP) != 0) & ~ramp).sum())
@@ -183,7 +183,8 @@ def check(got, ref, flags, max_flagged_frac=0.05, guard_rel=5e-5):
     assert s["n_bad_flagged"] == 0, ("flagged farm outside the bounded signature of a flip", s)
     assert s.get("n_spurious", 0) == 0, ("risk flag raised far from the threshold", s)
     # (a rate needs a batch of some size; small batches are capped too — ADVICE r2 — with room for the odd farm)
-    assert s["n_flagged"] <= max(max_flagged_frac * s["n"], 4 if s["n"] < 200 else 0) or max_flagged_frac >= 1.0, ("too many flagged farms", s)
+    cap = max_flagged_frac * s["n"] + (4 + 0.05 * s["n"] if s["n"] < 200 else 0)
+    assert s["n_flagged"] <= cap or max_flagged_frac >= 1.0, ("too many flagged farms", s)
     p = (np.abs(np.asarray(got["power"].cpu().numpy() if hasattr(got["power"], "cpu") else got["power"], dtype=np.float64)
                 - ref["power"]) / np.maximum(ref["power"], 1e3))
     assert np.median(p) <= 1e-6, np.median(p)

@@ -47,3 +47,20 @@ def test_two_ranks_self_launched_strong_and_weak():
     d = _run("--gpus", "2", "--config", "cfg2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-env-leg",
              "--scaling", "weak")
     assert d["scaling"] == "weak" and d["config"]["env_batch_total"] == 8192 and d["strong_scaling"]["env_batch_total"] == 4096
+
+
+def test_eight_rank_dry_run_of_baseline_config4():
+    """BASELINE.json configs[3] at its real world size: `bench.py --gpus 8 --config cfg4` (HornsRev1 x 65536 farms sharded
+    over 8 ranks).  No 8-GPU node is available to the build, so the ranks share this box's GPU(s) over gloo (bench.py
+    selects that itself) — what is proven is the code path: every rank steps its own contiguous 8192-farm block, the
+    blocks tile the batch, the kernel is the one the rounds model picks for an 8192-farm shard, and ONE line comes out."""
+    from wfcrl_env_amd.sharding import shard_bounds
+
+    d = _run("--gpus", "8", "--config", "cfg4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-env-leg", timeout=1500)
+    c = d["config"]
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and c["env_batch_per_gpu"] == 8192 and c["env_batch_total"] == 65536
+    assert sorted(s[0] for s in c["shards"]) == list(range(8))
+    for r, dev, lo, hi in c["shards"]:
+        assert (lo, hi) == shard_bounds(65536, r, 8) and hi - lo == 8192
+    assert "wf_step_kernel<G=16,S=5>" in c["kernel"]  # the latency-bound choice for a chip a quarter full (DESIGN.md §6)
+    assert d["value"] > 1e6 and d["weak_scaling"]["env_batch_per_gpu"] == 65536

@@ -998,7 +998,7 @@ def test_two_threads_force_different_kernel_families_on_two_handles(layouts):
     rng = np.random.default_rng(31)
     yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
     ref = _oracle(x, y, 8.0, 263.0, yaw)
-    choices = [dict(one_block=False), dict(one_block="4x2"), dict(one_block="8")]
+    choices = [dict(one_block=False, slot="16x5"), dict(one_block="4x2"), dict(one_block="8")]
     want = [(0, 16, 5), (1, 4, 2), (1, 8, 1)]
     results, errors = [None] * len(choices), []
 

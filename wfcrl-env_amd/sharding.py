@@ -17,6 +17,19 @@ def shard_bounds(total_envs: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def device_for_rank(local_rank: int, n_devices: int, backend: str = "nccl") -> int:
+    """HIP device of a rank on this node.  One process per GPU over RCCL ("nccl"): the identity — rank r drives GPU r, and
+    a node with fewer GPUs than ranks is an error.  Any other backend (gloo) is the test mode of a box with fewer GPUs
+    than ranks: the ranks share the devices round-robin."""
+    if local_rank < 0 or n_devices < 1:
+        raise ValueError("need local_rank >= 0 and at least one device")
+    if backend == "nccl":
+        if local_rank >= n_devices:
+            raise ValueError(f"local rank {local_rank} has no GPU of its own ({n_devices} visible): one process per GPU")
+        return local_rank
+    return local_rank % n_devices
+
+
 def gather_results(local, total_envs: int, group=None):
     """all_gather a per-env tensor (first dim = local env count) into the full [total_envs, ...] tensor
     on every rank.  Handles ragged shards by padding to the largest shard."""
