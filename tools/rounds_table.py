@@ -16,9 +16,12 @@ FAMILIES = [("slot", dict(one_block=False)), ("8x1", dict(one_block="8")), ("4x2
 n_cu = torch.cuda.get_device_properties(0).multi_processor_count
 print(f"# device: {torch.cuda.get_device_name(0)}, {n_cu} CUs")
 table = {}
+SLOT = {32: "8x4", 48: "16x3", 64: "16x4", 80: "16x5", 91: "16x6"}  # pick_variant's throughput choice per N
 for fam, choice in FAMILIES:
     for N in NS:
         x, y = L["xcoords"][:N], L["ycoords"][:N]
+        if fam == "slot":
+            choice = dict(one_block=False, slot=SLOT[N])
         row = []
         for per_cu in (1, 2, 3):
             w = WfStep(x, y, env_batch=64, kernel_choice=choice)

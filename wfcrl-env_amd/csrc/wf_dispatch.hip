@@ -45,8 +45,8 @@ int pick_variant(const wf_handle* h, int N, int B) {
 
 // Rounds model.  A wave solves its 64 / G farms start to finish, so a launch runs in ROUNDS of (blocks the chip holds) x
 // (farms per block), and within a round the time depends on how many blocks share a CU (one wave per SIMD each).
-// Measured per family at 1, 2, 3 blocks per CU on one MI355X (256 CUs) for several farm sizes (tools/rounds_table.py ->
-// profiles/r03_rounds_table.txt), ms; between the measured N the times are interpolated linearly in N (N + 1) / 2, the
+// Measured per family at 1, 2, 3 blocks per CU on one MI355X (256 CUs) for farms of 32, 48, 64, 80, 91 turbines
+// (tools/rounds_table.py -> profiles/r03_rounds_table.txt), ms; between the measured N the times are interpolated linearly in N (N + 1) / 2, the
 // number of (source, target) pairs, beyond them extrapolated the same way.  The number of CUs comes from the device
 // (a partitioned or smaller part has shorter rounds, the same time per round).
 //   code = (G << 4) | S of wf_step_ll_kernel, 0 = the register-slot kernel wf_step_kernel (its variant for N: pick_variant)
@@ -56,11 +56,27 @@ constexpr int kNumFamilies = 5, kNumRoundsN = 5;
 const int kRoundsN[kNumRoundsN] = {32, 48, 64, 80, 91};
 // [family][N index][blocks per CU - 1]
 const double kRoundsMs[kNumFamilies][kNumRoundsN][3] = {
-    {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.235, 0.298, 0.0}, {0.0, 0.0, 0.0}},
-    {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.33, 0.42, 0.55}, {0.0, 0.0, 0.0}},
-    {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.49, 0.644, 0.0}, {0.0, 0.0, 0.0}},
-    {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.53, 0.67, 0.89}, {0.0, 0.0, 0.0}},
-    {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.855, 1.178, 0.0}, {0.0, 0.0, 0.0}}};
+    {{0.093, 0.116, 0.0}, {0.123, 0.149, 0.187}, {0.166, 0.213, 0.0}, {0.225, 0.285, 0.0}, {0.303, 0.366, 0.0}},            // slot (8x4, 16x3, 16x4, 16x5, 16x6)
+    {{0.086, 0.112, 0.144}, {0.152, 0.197, 0.254}, {0.230, 0.300, 0.386}, {0.327, 0.417, 0.543}, {0.432, 0.552, 0.720}},  // 8x1
+    {{0.118, 0.159, 0.0}, {0.220, 0.291, 0.0}, {0.349, 0.458, 0.0}, {0.506, 0.670, 0.0}, {0.661, 0.876, 0.0}},            // 4x2
+    {{0.127, 0.170, 0.226}, {0.241, 0.309, 0.418}, {0.377, 0.489, 0.657}, {0.546, 0.700, 0.946}, {0.690, 0.904, 1.215}},  // 4x1
+    {{0.190, 0.274, 0.0}, {0.377, 0.532, 0.0}, {0.607, 0.842, 0.0}, {0.934, 1.279, 0.0}, {1.168, 1.615, 0.0}}};           // 2x2
+
+// farms per block and resident blocks per CU of family fi for N turbines (the register-slot kernel's follow from its
+// variant for N: three waves per SIMD where S <= 3, two otherwise — wf_kernels.hip)
+void family_shape(const wf_handle* h, int fi, int N, int* fpb, int* per_cu) {
+  *fpb = kLlFamilies[fi].farms_per_block;
+  *per_cu = kLlFamilies[fi].per_cu;
+  if (kLlFamilies[fi].code == 0) {
+    const int v = pick_variant(h, N, 1 << 30);
+    if (v >= 0) {
+      int G, S; const void* fn;
+      wfk_variant(v, &G, &S, &fn);
+      *fpb = wfk_tab_waves() * (64 / G);
+      *per_cu = S <= 3 ? 3 : 2;
+    }
+  }
+}
 
 // ms of one round of family `fi` at `per_cu` blocks per CU for N turbines
 double round_ms(int fi, int N, int per_cu) {
@@ -83,10 +99,11 @@ double round_ms(int fi, int N, int per_cu) {
 // ms for `farms` farm slots on family fi: whole rounds at full occupancy, then the partial round at the occupancy it
 // reaches; a partial round behind full ones overlaps with their tail (factor 0.8, measured)
 double ll_estimate(const wf_handle* h, int fi, int N, long farms) {
-  const LlFamily& f = kLlFamilies[fi];
-  const long blocks = (farms + f.farms_per_block - 1) / f.farms_per_block, per_round = (long)h->n_cu * f.per_cu;
+  int fpb, per_cu;
+  family_shape(h, fi, N, &fpb, &per_cu);
+  const long blocks = (farms + fpb - 1) / fpb, per_round = (long)h->n_cu * per_cu;
   const long full = blocks / per_round, rem = blocks % per_round;
-  double t = full * round_ms(fi, N, f.per_cu);
+  double t = full * round_ms(fi, N, per_cu);
   if (rem) t += (full ? 0.8 : 1.0) * round_ms(fi, N, (int)((rem + h->n_cu - 1) / h->n_cu));
   return t;
 }
@@ -111,7 +128,6 @@ int pick_ll(const wf_handle* h, int N, int B) {  // returns (G << 4) | S, 0 = ke
     const LlFamily& f = kLlFamilies[fi];
     if (f.code && N <= (f.code >> 4) * (f.code & 15)) continue;  // needs more than one block
     if (f.code == ((8 << 4) | 1) && N <= 32) continue;           // (not instantiated to pay below that)
-    if (f.code == ((2 << 4) | 2) && N < 48) continue;            // (two slots of two lanes: needs a farm of some depth)
     const double t = ll_estimate(h, fi, N, B);
     if (t < t_best) { t_best = t; best = f.code; }
   }
