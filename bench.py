@@ -127,7 +127,7 @@ def main():
                          "weak = the full config batch on every GPU.  The other one is timed too and reported beside it.")
     ap.add_argument("--env-batch", type=int, default=0, help="total env batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-env-leg", action="store_true", help="skip the fused-env-step and env-level legs (profiling runs)")
+    ap.add_argument("--no-env-leg", action="store_true", help="skip the fused-env-step, env-level and per-farm-wind legs (profiling runs: only the headline kernel is launched)")
     ap.add_argument("--per-env-wind", action="store_true",
                     help="a wind per farm: cfg5 wd_b(t) = wd(t) + U(-10,10) (per-farm rotation + sort on the device every step); "
                          "other configs a fixed ws ~ U(6,12), wd ~ 270 + U(-10,10) per farm (the on-the-fly path)")
@@ -327,7 +327,7 @@ def main():
     # N(270, 20) mod 360).  The same farms under that distribution — the on-the-fly kernel, about 2 % of the farms
     # flagged — without and with the float64 re-solve (wf_set_risk_resolve): reported under `extra`, never as `value`.
     per_farm = None
-    if not sweep and not args.per_env_wind:
+    if not sweep and not args.per_env_wind and not args.no_env_leg:
         try:
             rngw = np.random.default_rng(1234 + cfg_id)
             ws_pf = np.clip(8 * rngw.weibull(8, B), 3, 28)

@@ -138,6 +138,12 @@ template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB>
 #ifndef WF_LL_PINGPONG
 #define WF_LL_PINGPONG 0  // 1: two record buffers used alternately (2x unrolled replay): 20-30 spilled registers, slower
 #endif
+#ifndef WF_LL_LOGT
+#define WF_LL_LOGT 1  // 1: wave-major source log [source][float4 q][farm of the wave] — a record of the wave is one contiguous
+                      // piece (2 KiB at G = 2), fetched by one or two fully coalesced loads per lane and handed to the farms'
+                      // lanes through a wave-private LDS slab; 0: farm-major log [farm][source][16 floats] (round 2: four
+                      // 16-byte gathers per record over 64 / G lines 5 KB apart)
+#endif
 #ifndef WF_LL_OCC2
 #define WF_LL_OCC2 2  // ... for the two-slot variants
 #endif
@@ -160,6 +166,11 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
   __shared__ __attribute__((aligned(16))) float prow[2][CHUNK_FLOATS];
   __shared__ unsigned risk_lds[WPB][EPW];
   extern __shared__ float yaw_lds[];  // [WPB][EPW][n_pad] commanded yaw in sorted order, degrees
+#if WF_LL_LOGT
+  constexpr int PIECES = 4 * EPW;              // 16-byte pieces of a wave's record: piece q * EPW + f = float4 q of farm f
+  constexpr int PPL = (PIECES + 63) / 64;      // pieces a lane fetches: 2 at G = 2, else 1
+  __shared__ float4 recslab[WPB][PIECES];      // the current record of each wave, transposed through LDS
+#endif
 
   int grp = 0;
   if (ga.blk_group) {
@@ -452,6 +463,14 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
   // a 128-byte line (n_pad is a multiple of G, G is even), so a line belongs to ONE block and is never read before that
   // block has written it.  The 16-byte side records do share lines across blocks; they are read past the L1.
   float* const logf = src_log + (size_t)slot * n_pad * WF_LOG_FLOATS;
+#if WF_LL_LOGT
+  // the wave's part of the log (its EPW farm slots x n_pad records x 64 bytes, as before), record i at i * EPW * 64 bytes
+  float* const logw = src_log + (size_t)(slot - eiw) * n_pad * WF_LOG_FLOATS;
+  constexpr int RECF = EPW * WF_LOG_FLOATS;
+  int piece[PPL];
+#pragma unroll
+  for (int kk = 0; kk < PPL; ++kk) piece[kk] = (lane + 64 * kk) % PIECES;  // (fewer pieces than lanes at G >= 8: fetched twice)
+#endif
   float* const logx = src_log + log_side_offset + (size_t)slot * n_pad * WF_LOG_SIDE_FLOATS;
   for (int J = 0; J < nblk; ++J) {
     int tt[S];
@@ -482,13 +501,24 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     const int n_src = min(N, first_own + GS);
     const int n_chunks = (n_src + CH - 1) / CH;
     // the first logged source's record is fetched ahead; every later one while its predecessor is being applied
+#if WF_LL_LOGT
+    struct RecPieces { float4 v[PPL]; };
+    RecPieces nxt;
+#else
     SrcLog nxt;
+#endif
     double xs_nx = 0.0, ys_nx = 0.0;  // on the fly: the sorted coordinates of that source come with its record
     if (first_own > 0) {
+#if WF_LL_LOGT
+      const float4* lp = reinterpret_cast<const float4*>(logw);
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) nxt.v[k] = lp[piece[k]];
+#else
       const float4* lp = reinterpret_cast<const float4*>(logf);
       float4* d = reinterpret_cast<float4*>(&nxt);
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] = lp[k];
+#endif
       if constexpr (!TAB) {
         xs_nx = gx[gofs];
         ys_nx = gy[gofs];
@@ -642,10 +672,16 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       Sc.ix0v = frcp(Sc.x0v);
       // the later blocks replay this source from the log
       if (J + 1 < nblk && sub == 0) {
-        float4* lp = reinterpret_cast<float4*>(logf + (size_t)i * WF_LOG_FLOATS);
         const float4* sp = reinterpret_cast<const float4*>(&Sc);
+#if WF_LL_LOGT
+        float4* lp = reinterpret_cast<float4*>(logw + (size_t)i * RECF);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) lp[kk * EPW + eiw] = sp[kk];  // EPW * 16 contiguous bytes per store instruction
+#else
+        float4* lp = reinterpret_cast<float4*>(logf + (size_t)i * WF_LOG_FLOATS);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) lp[kk] = sp[kk];
+#endif
         if (split) *reinterpret_cast<float4*>(logx + (size_t)i * WF_LOG_SIDE_FLOATS) = make_float4(X.TI0, X.TI1, X.TI2, X.dTI);
       }
       WF_T(so_4);
@@ -673,21 +709,44 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       // ---- sources of earlier blocks: replayed from the log on this block's targets ----------------------
       // (a loop of its own: the two kinds of source step share no loop-carried copies)
       WF_T(st_a);
+#if WF_LL_LOGT
+      auto replay_one = [&](int k, const RecPieces& cur, RecPieces& nxt) {
+#else
       auto replay_one = [&](int k, const SrcLog& Sl, SrcLog& nxt) {
+#endif
         const int i = i0 + k;
         auto prefetch_next = [&]() {
           // unconditional (the last logged source re-reads its own record): a conditional load leaves "nxt keeps its
           // value" on the other path, which costs sixteen register copies per iteration
+#if WF_LL_LOGT
+          const float4* lp = reinterpret_cast<const float4*>(logw + (size_t)min(i + 1, first_own - 1) * RECF);
+#pragma unroll
+          for (int kk = 0; kk < PPL; ++kk) nxt.v[kk] = lp[piece[kk]];
+#else
           const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)min(i + 1, first_own - 1) * WF_LOG_FLOATS);
           float4* d = reinterpret_cast<float4*>(&nxt);
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
+#endif
           if constexpr (!TAB) {
             xs_nx = gx[gofs + min(i + 1, first_own - 1)];
             ys_nx = gy[gofs + min(i + 1, first_own - 1)];
           }
         };
         const double xs_cur = xs_nx, ys_cur = ys_nx;
+#if WF_LL_LOGT
+        // the record fetched during the previous iteration: through the wave's LDS slab to the lanes of its farms
+        // (LDS operations of a wave execute in order: the slab is free again once these reads have returned)
+        SrcLog Sl;
+        auto slab_exchange = [&]() {
+#pragma unroll
+          for (int kk = 0; kk < PPL; ++kk) recslab[wave][piece[kk]] = cur.v[kk];
+          float4* d = reinterpret_cast<float4*>(&Sl);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) d[kk] = recslab[wave][kk * EPW + eiw];
+        };
+        if constexpr (!TAB) slab_exchange();
+#endif
         if constexpr (!TAB) prefetch_next();
         const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
         // no lane mask on the transverse pass: every real turbine of this block is at or downstream of an earlier
@@ -712,6 +771,9 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
           // read of the staged chunk with s_waitcnt vmcnt(0) (the chunk arrives by LDS-DMA, counted in vmcnt), and a
           // prefetch issued before that read would be waited for on the spot
           asm volatile("" ::: "memory");
+#if WF_LL_LOGT
+          slab_exchange();
+#endif
           prefetch_next();
           static_for<S>([&](auto PP) { pass2(PP, Sl, side, true, exs[decltype(PP)::value], tvalid[decltype(PP)::value]); });
           asm volatile("" ::: "memory");
@@ -731,7 +793,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         };
         static_for<S>(replay_slot);
       };
-#if WF_LL_PINGPONG
+#if WF_LL_PINGPONG && !WF_LL_LOGT
       // two record buffers used alternately: no copy of the prefetched record into the current one per iteration
       {
         SrcLog nxt2;
@@ -746,8 +808,13 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
 #else
 #pragma unroll 1
       for (int k = 0; k < k_log; ++k) {
+#if WF_LL_LOGT
+        const RecPieces cur = nxt;
+        replay_one(k, cur, nxt);
+#else
         const SrcLog Sl = nxt;
         replay_one(k, Sl, nxt);
+#endif
       }
 #endif
       // ---- sources of this block ------------------------------------------------------------------------
