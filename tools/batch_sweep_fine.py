@@ -1,0 +1,48 @@
+"""GPU box: throughput over the env batch in steps of 4096: what the rounds model picks, what every
+forced family delivers, and where the pick stands against the best family at that batch and against the running best
+(the "envelope": the highest farm-steps/s of any family at any batch up to this one).
+  python tools/batch_sweep_fine.py [layout ...] > gpurun_out/r03_batch_sweep_fine.txt"""
+import json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wfcrl_env_amd.backend import WfStep
+
+L = json.load(open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")))
+FAMS = [("slot", dict(one_block=False)), ("8x1", dict(one_block="8")), ("4x2", dict(one_block="4x2")), ("4x1", dict(one_block="4")),
+        ("2x2", dict(one_block="2x2"))]
+
+
+def time_it(lay, B, choice):
+    N = lay["num_turbines"]
+    w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B, kernel_choice=choice)
+    w.set_wind(8.0, 270.0)
+    yaw = (torch.rand((B, N), device="cuda") * 60 - 30).float()
+    out = w.step(yaw); w.sync()
+    best = 1e9
+    for r in range(3):
+        w.timing_begin()
+        for _ in range(6):
+            w.step(yaw, out)
+        best = min(best, w.timing_end() / 6)
+    k = w.kernel_info()
+    w.close()
+    return best, ("slot" if not k["one_block_kernel"] else f"{k['lanes_per_env']}x{k['slots_per_lane']}")
+
+
+for name in (sys.argv[1:] or ["HornsRev1_", "HornsRev2_"]):
+    lay = L[name]
+    print(f"# {name} N={lay['num_turbines']}  (ms per step; farm-steps/s of the pick; pick / best family at this batch; pick / envelope)")
+    env_best = 0.0
+    worst_fam, worst_env = 1.0, 1.0
+    for B in range(4096, 131072 + 1, 4096):
+        t_pick, fam_pick = time_it(lay, B, None)
+        ts = {f: time_it(lay, B, c)[0] for f, c in FAMS}
+        t_best = min(ts.values())
+        thr = B / t_pick * 1e3
+        env_best = max(env_best, B / min(t_best, t_pick) * 1e3)
+        r_fam, r_env = min(t_best / t_pick, 1.0), thr / env_best
+        worst_fam, worst_env = min(worst_fam, r_fam), min(worst_env, r_env)
+        print(f"B={B:7d} pick {fam_pick:4s} {t_pick:.3f} ms {thr:.3e}  " + " ".join(f"{f}={t:.3f}" for f, t in ts.items())
+              + f"  pick/best {r_fam:.3f}  pick/envelope {r_env:.3f}", flush=True)
+    print(f"# {name}: worst pick / best family {worst_fam:.3f}, worst pick / envelope {worst_env:.3f}")

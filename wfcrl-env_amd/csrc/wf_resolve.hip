@@ -42,6 +42,20 @@ __device__ inline double interp_fill(double xq, int n, const double* xs, const d
   return slope * (xq - xs[j]) + ys[j];
 }
 
+// the same for a query that is uniform over the wave (the source's rotor wind speed): every lane tests one knot, the
+// segment index is the population count of the ballot — one LDS read instead of six dependent ones
+__device__ inline double interp_fill_uniform(double xq, int n, const double* xs, const double* ys, double lo, double hi) {
+  const int l = threadIdx.x & 63;
+  const unsigned long long m = __ballot(l < n && xq >= xs[l < n ? l : 0]);
+  if (xq < xs[0]) return lo;
+  if (xq > xs[n - 1]) return hi;
+  if (xq == xs[n - 1]) return ys[n - 1];
+  int j = __popcll(m) - 1;
+  j = j < 0 ? 0 : (j > n - 2 ? n - 2 : j);
+  const double slope = (ys[j + 1] - ys[j]) / (xs[j + 1] - xs[j]);
+  return slope * (xq - xs[j]) + ys[j];
+}
+
 }  // namespace
 
 // farms with a nonzero risk flag -> list (any order), count; raw = copy of the flags as the float32 kernels raised them
@@ -64,344 +78,497 @@ __device__ __forceinline__ double rcp64(double x) {
   return fma(r, e, r);
 }
 
-// Source-side constants of the deflection + deficit models for one grid column (TI of that column) [A.3-3, A.3-6]
-struct ColD {
-  double x0d, ix0d_rel, kyd, d0, pfar;  // deflection: near-wake end (absolute x), 1 / (x0 - x_i), expansion rate, delta0, far-wake log prefactor
-  double x0v, ix0v_rel, kyv;            // deficit: near-wake end (absolute x), 1 / (x0 - x_i), expansion rate
-};
+// The transcendental functions of the per-source chain on the argument ranges this model produces, as short branch-free
+// polynomials (the device library's general-range tan / asin / atan2 / cbrt each keep 60-90 registers live: they set the
+// kernel's register count); callers fall back to the library outside the range, wave-uniformly.
+// tan(x), |x| <= 0.5: sin and cos by Taylor series (terms below 1e-19), one division
+__device__ __forceinline__ double tan_small(double x) {
+  const double x2 = x * x;
+  double sn = 1.0 / 51090942171709440000.0, cs = 1.0 / 2432902008176640000.0;  // 1/21!, 1/20!
+  const double fs[10] = {1.0 / 121645100408832000.0, 1.0 / 355687428096000.0, 1.0 / 1307674368000.0, 1.0 / 6227020800.0,
+                         1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0, 1.0};
+  const double fc[10] = {1.0 / 6402373705728000.0, 1.0 / 20922789888000.0, 1.0 / 87178291200.0, 1.0 / 479001600.0,
+                         1.0 / 3628800.0, 1.0 / 40320.0, 1.0 / 720.0, 1.0 / 24.0, 1.0 / 2.0, 1.0};
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    sn = fma(-x2, sn, fs[k]);
+    cs = fma(-x2, cs, fc[k]);
+  }
+  return x * sn * rcp64(cs);
+}
+// asin(x), |x| <= 0.3: odd series, coefficients (2k)! / (4^k (k!)^2 (2k + 1)), 17 terms (0.3^36 / 37 = 4e-21)
+__device__ __forceinline__ double asin_small(double x) {
+  const double x2 = x * x;
+  double cf[18];
+  cf[0] = 1.0;
+  double b = 1.0;
+#pragma unroll
+  for (int k = 1; k < 18; ++k) {
+    b *= (2.0 * k - 1.0) / (2.0 * k);
+    cf[k] = b / (2.0 * k + 1.0);
+  }
+  double p = cf[17];
+#pragma unroll
+  for (int k = 16; k >= 0; --k) p = fma(p, x2, cf[k]);
+  return x * p;
+}
+// atan(r), |r| <= 0.1: odd series, 10 terms (0.1^20 / 21 = 5e-22)
+__device__ __forceinline__ double atan_small(double r) {
+  const double r2 = r * r;
+  double p = -1.0 / 19.0;
+#pragma unroll
+  for (int k = 8; k >= 0; --k) p = fma(p, r2, ((k & 1) ? -1.0 : 1.0) / (2.0 * k + 1.0));
+  return r * p;
+}
+// cbrt(x), x > 0: float estimate, two Newton steps in float64
+__device__ __forceinline__ double cbrt_pos(double x) {
+  double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (1.0f / 3.0f));
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double y2 = y * y;
+    y = y - (y2 * y - x) * rcp64(3.0 * y2);
+  }
+  return y;
+}
 
+
+// One farm per WAVE (64-thread blocks).  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column
+// TIs, float64 — lives in LDS, structure-of-arrays over the sorted turbine index; a lane is not tied to a turbine:
+// for source i the lanes take the turbines the source can reach, t = first + lane (first = the start of the source's x'
+// tie group for the transverse velocities [A.3-4], i + 1 for deficit and wake-added turbulence), 64 at a time, so the
+// triangle of the recurrence costs 96 instead of 160 wave passes at N = 80 and nothing is done twice: the per-source
+// constants are derived once per farm (by every lane of the one wave).  No block-level barrier inside the solve: the
+// LDS operations of a wave execute in order.
+// The phases of a source step talk through LDS only (the per-source constants too), with a compiler barrier at every
+// phase boundary: written as one body with the constants in registers the allocator kept ~370 values live (the
+// per-source constants across both passes, the device library's temporaries) and spilled inside the source loop at any
+// occupancy above one wave per SIMD; as real (non-inlined) functions the calling convention's register saves cost 180
+// scratch accesses per source.
+// (First version, in the history: a thread per turbine, state in registers, two __syncthreads per source, every wave
+// re-deriving the source constants: 1.95 ms for 1394 HornsRev1 farms; the inlined one-wave version 1.42 ms.)
 #ifndef WF_RES_OCC
-#define WF_RES_OCC 1  // waves per SIMD the register allocator is asked to make room for (HornsRev1, 1394 flagged farms: 1 -> 1.95 ms, 2 -> 2.3, 3 -> 2.6, 4 -> 3.7 with 300 spilled registers: tools/res_occ_sweep.sh)
+#define WF_RES_OCC 2  // waves per SIMD the register allocator is asked to make room for (tools/res_occ_sweep.sh)
 #endif
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a) {
-  __shared__ double tws[WF_TABLE_PAD], tct[WF_TABLE_PAD], tpw[WF_TABLE_PAD];
-  __shared__ double xsL[THREADS], ysL[THREADS], yawL[THREADS];
-  __shared__ double bc[5], bc2[2];
-  __shared__ double red[2][THREADS / 64];
-  // the model constants are read from LDS where they are used (by value in the kernel arguments the compiler keeps all
-  // ~130 of them in SGPRs across the source loop and spills: 1700 v_readlane / v_writelane in the first version)
-  __shared__ WfResolveConsts c;
-  const int t = threadIdx.x;
-  if (t == 0) c = c_arg;
+struct SrcShared {  // what a source leaves for the two passes over its targets
+  double x_i, y_i, ct, ai, ubar, Vmean, TIs[3], dTI;
+  double Gt, Gb, Gw;  // circulations / (2 pi): top, bottom, wake rotation (commanded yaw)
+  double cgd, s_cc, s_c, th0, tan_th0, M0, E0, sM, sz0d, sy0d, is0d, lnAB, sz0v, sy0v, snw, kdef, ch_pref, cgv;
+  int same, first_tv;
+};
+struct ResShared {
+  WfResolveConsts c;
+  double tws[WF_TABLE_PAD], tct[WF_TABLE_PAD], tpw[WF_TABLE_PAD];
+  double ws, wd, Uinf, Uinit[3];
+  int N, n_pad, veer_on, mcore;
+  SrcShared s;
+};
+__shared__ ResShared R;
+extern __shared__ double res_dyn[];  // per sorted turbine: x', y', cos / sin / radians of the commanded yaw, the 30 state values, tie start
+
+#define RES_XS(t) res_dyn[(t)]
+#define RES_YS(t) res_dyn[R.n_pad + (t)]
+#define RES_CG(t) res_dyn[2 * R.n_pad + (t)]
+#define RES_SG(t) res_dyn[3 * R.n_pad + (t)]
+#define RES_GR(t) res_dyn[4 * R.n_pad + (t)]
+#define RES_ST(q, t) res_dyn[(5 + (q)) * R.n_pad + (t)]  // wake2 q = 0..8, V 9..17, W 18..26, TI 27..29
+#define RES_TIE(t) (reinterpret_cast<int*>(res_dyn + 35 * R.n_pad)[(t)])
+
+// ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
+__device__ __noinline__ void res_source_begin(int i) {
+  const WfResolveConsts& c = R.c;
+  const double cg = RES_CG(i), sg = RES_SG(i);
+  double m3 = 0.0, vs = 0.0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const double u = R.Uinit[q % 3] - sqrt(RES_ST(q, i));
+    m3 += u * u * u;
+    vs += RES_ST(9 + q, i);
+  }
+  const double m3m = m3 / 9.0;
+  const double ubar = __any(!(m3m > 1.0e-6)) ? cbrt(m3m) : cbrt_pos(m3m);
+  double ct_tab = interp_fill_uniform(ubar, c.n_table, R.tws, R.tct, 0.0001, 0.9999);
+  ct_tab = fmin(fmax(ct_tab, 0.0001), 0.9999);
+  const double ct = ct_tab * cg;
+  const double ai = 0.5 / cg * (1.0 - sqrt(1.0 - ct * cg));
+  const double G_wr = 0.25 * kTwoPi * c.D * (ai - ai * ai) * ubar / c.TSR;
+  const double gam_top = (kTwoPi / 16.0) * c.D * c.vel_top * R.Uinf * ct;
+  const double gam_bot = (kTwoPi / 16.0) * c.D * c.vel_bot * R.Uinf * ct;
+  const double sc = sg * cg;
+  if (threadIdx.x == 0) {
+    SrcShared& s = R.s;
+    s.x_i = RES_XS(i); s.y_i = RES_YS(i); s.ct = ct; s.ai = ai; s.ubar = ubar; s.Vmean = vs / 9.0;
+    s.TIs[0] = RES_ST(27, i); s.TIs[1] = RES_ST(28, i); s.TIs[2] = RES_ST(29, i);
+    s.Gt = sc * gam_top / kTwoPi; s.Gb = -sc * gam_bot / kTwoPi; s.Gw = G_wr / kTwoPi;
+    s.first_tv = RES_TIE(i);
+    // secondary steering [A.3-2]: the three means on the source's own grid are geometry constants
+    const double v_top = gam_top * c.k_top, v_bot = -gam_bot * c.k_bot, v_core = G_wr * c.k_core;
+    s.cgv = 2.0 * (s.Vmean - v_core) / (v_top + v_bot);  // (val: parked here until res_source_finish overwrites it)
+  }
+}
+
+// ---- 4. transverse velocities (commanded yaw) on every turbine at or downstream of the source, ties included; per grid
+// column the 7 + 7 distinct vertical offsets of the three vortices and their ground mirrors ----
+__device__ __noinline__ void res_transverse_pass() {
+  const WfResolveConsts& c = R.c;
+  const int lane = threadIdx.x, N = R.N;
+  const double x_i = R.s.x_i, y_i = R.s.y_i, Gt = R.s.Gt, Gb = R.s.Gb, Gw = R.s.Gw;
+  const double qd = c.off[2], neps = c.num_eps, twoHH = 2.0 * c.HH, eps2 = c.eps2, ieps2 = 1.0 / c.eps2;
+  const bool mcore = R.mcore != 0;
+  for (int base = R.s.first_tv; base < N; base += 64) {
+    const int t = base + lane;
+    if (t >= N) continue;
+    const double dx = RES_XS(t) - x_i, y_t = RES_YS(t);
+    double dec[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dec[k] = eps2 * rcp64(4.0 * (c.nu1[k] * R.ws) * dx / R.Uinf + eps2);
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {  // (a real loop: the state is addressed in LDS, nothing needs a static index)
+      double Vj[3], Wj[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { Vj[k] = RES_ST(9 + j * 3 + k, t); Wj[k] = RES_ST(18 + j * 3 + k, t); }
+      const double yL = (y_t + c.off[j] - y_i) + neps;
+      const double yL2 = yL * yL;
+      const double Ey = exp(-yL2 * ieps2);
+      double Av[3] = {0.0, 0.0, 0.0}, Bw[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int m = 0; m < 7; ++m) {
+        const double zc = (double)(m - 3) * qd + neps, zm = zc + twoHH;
+        const double tr = (1.0 - Ey * c.ezc[m]) * rcp64(yL2 + zc * zc);   // core / r of a real vortex at offset zc
+        double tm = rcp64(yL2 + zm * zm);                                   // ... of a mirror vortex at zm
+        if (mcore) tm *= 1.0 - Ey * c.ezm7[m];  // (1 - Ey ezm == 1.0 exactly unless the hub is very low)
+        const double pr = zc * tr, pm = zm * tm;
+        if (m <= 2) {  // real top (k = m), mirror bottom (k = m)
+          Av[m] += Gt * pr - Gb * pm;
+          Bw[m] += Gt * tr - Gb * tm;
+        }
+        if (m >= 4) {  // real bottom (k = m - 4), mirror top (k = m - 4)
+          Av[m - 4] += Gb * pr - Gt * pm;
+          Bw[m - 4] += Gb * tr - Gt * tm;
+        }
+        if (m >= 2 && m <= 4) {  // wake rotation, real - mirror (k = m - 2)
+          Av[m - 2] += Gw * (pr - pm);
+          Bw[m - 2] += Gw * (tr - tm);
+        }
+        // (the scheduler interleaves all 14 reciprocal chains of a column otherwise: 250 registers; the other waves of
+        // the SIMD hide the latency of one chain at a time)
+        if (WF_RES_OCC > 2 && (m & 1)) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double w = -yL * Bw[k] * dec[k];
+        RES_ST(9 + j * 3 + k, t) = Vj[k] + Av[k] * dec[k];
+        RES_ST(18 + j * 3 + k, t) = Wj[k] + ((w < 0.0) ? 0.0 : w);  // quirk (5) [A.6]
+      }
+    }
+  }
+}
+
+// ---- 2, 5 and the source-only part of 3 + 6: steering, yaw-added recovery, deflection / deficit constants ----
+__device__ __noinline__ void res_source_finish(int i) {
+  const WfResolveConsts& c = R.c;
+  const SrcShared& s0 = R.s;
+  const double cg = RES_CG(i), sg = RES_SG(i), ct = s0.ct, ubar = s0.ubar, D = c.D;
+  double val = s0.cgv;  // parked by res_source_begin
+  val = fmin(fmax(val, -1.0), 1.0);
+  const double asv = __any(fabs(val) > 0.3) ? asin(val) : asin_small(val);
+  const double g_off = c.sw_steer ? 0.5 * asv : 0.0;  // radians added to the commanded yaw
+  double dTI = 0.0;
+  {  // 5. yaw-added recovery [A.3-5] (the source's own transverse contribution is in V / W now)
+    double vsum = 0.0, wsum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { vsum += RES_ST(9 + q, i); wsum += RES_ST(18 + q, i); }
+    const double I = s0.TIs[0];
+    const double k_tke = (ubar * I) * (ubar * I) / (2.0 / 3.0);
+    const double vbar = vsum / 9.0, wbar = wsum / 9.0;
+    const double I_tot = sqrt((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) / ubar;
+    if (c.sw_yar) dTI = c.gch_gain * (I_tot - I);
+  }
+  // cosd(-g_eff) = cos(g + d), d = asin(val) / 2: half-angle formulas instead of a second cosine
+  const double c2d = sqrt(fmax(1.0 - val * val, 0.0)), cd = sqrt(0.5 * (1.0 + c2d)), sd = 0.5 * val / cd;
+  const double cgd = c.sw_steer ? cg * cd - sg * sd : cg;
+  const double gd_rad = -(RES_GR(i) + g_off);  // -(g + d) in radians
+  const double s_cc = sqrt(1.0 - ct * cgd), s_c = sqrt(1.0 - ct);
+  const double th0 = c.dm * (0.3 * gd_rad / cgd) * (1.0 - s_cc);
+  const double tan_th0 = __any(fabs(th0) > 0.5) ? tan(th0) : tan_small(th0);
+  const double C0 = 1.0 - s_c;
+  const double M0 = C0 * (2.0 - C0);
+  const double sz0d = D * 0.5 * sqrt((ct * cgd / (2.0 * (1.0 - s_cc))) / (1.0 + s_c));
+  const double sy0d = sz0d * cgd * c.cos_veer;
+  const double sM = sqrt(M0);
+  const double sz0v = D * 0.5 * sqrt((ct / (2.0 * (1.0 - s_c))) / (1.0 + s_c));
+  const int lane = threadIdx.x;
+  if (lane < 3) RES_ST(27 + lane, i) = s0.TIs[lane] + dTI;
+  if (lane == 0) {
+    SrcShared& s = R.s;
+    s.dTI = dTI; s.cgd = cgd; s.s_cc = s_cc; s.s_c = s_c; s.th0 = th0; s.tan_th0 = tan_th0; s.M0 = M0;
+    s.E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
+    s.sM = sM; s.sz0d = sz0d; s.sy0d = sy0d; s.is0d = 1.0 / (sy0d * sz0d); s.lnAB = (1.6 + sM) / (1.6 - sM);
+    s.sz0v = sz0v; s.sy0v = sz0v * cg * c.cos_veer; s.snw = c.near_c * sqrt(ct / 2.0); s.kdef = ct * cg * D * D / 8.0;
+    s.ch_pref = c.ch_constant * exp(c.ch_ai * log(s0.ai)) * c.ch_amb_pow;
+    s.cgv = cg;  // cosd(-g)
+    s.same = (s0.TIs[0] == s0.TIs[1]) && (s0.TIs[1] == s0.TIs[2]);
+  }
+}
+
+// ---- 3 + 6 + 7 + 8 on the turbines behind the source: deflection (TI before mixing, effective yaw), deficit (TI after
+// mixing, commanded yaw), SOSFS, Crespo-Hernandez with the overlap count taken as FLORIS takes it ----
+__device__ __noinline__ void res_deficit_pass(int i) {
+  const WfResolveConsts& c = R.c;
+  const SrcShared& s = R.s;
+  const int lane = threadIdx.x, N = R.N;
+  const bool veer_on = R.veer_on != 0, same = s.same != 0;
+  const double x_i = s.x_i, y_i = s.y_i, D = c.D;
+  const double q2 = c.off[2] * c.off[2];
+  for (int base = i + 1; base < N; base += 64) {
+    const int t = base + lane;
+    if (t >= N) continue;
+    const double x_t = RES_XS(t), y_t = RES_YS(t);
+    const double dx = x_t - x_i;
+    const double lin = c.ad + c.bd * dx;
+    int cnt = 0;
+    double delta = 0.0, amp = 0.0, isy2 = 0.0, isz2 = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+      if (j == 0 || !same) {  // (one column serves all three when the source's TIs agree)
+        // source-side constants of this column [A.3-3, A.3-6]
+        const double TIpre = s.TIs[j];
+        const double x0d = c.D * s.cgd * (1.0 + s.s_cc) / (c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - s.s_c))) + x_i;
+        const double ix0d_rel = 1.0 / (x0d - x_i);
+        const double kyd = c.defl_ka * TIpre + c.defl_kb;
+        const double d0 = s.tan_th0 * (x0d - x_i);
+        const double TIq = TIpre + s.dTI;
+        const double x0v = c.D * s.cgv * (1.0 + s.s_c) / (c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - s.s_c))) + x_i;
+        const double ix0v_rel = 1.0 / (x0v - x_i);
+        const double kyv = c.ka * TIq + c.kb;
+        // this turbine's column: deflection -> delta; deficit -> amplitude and the Gaussian's 1 / (2 sigma^2)
+        double d_near = (dx * ix0d_rel) * d0 + lin;
+        if (!(x_t <= x0d)) d_near = 0.0;  // [x >= x_i] holds here
+        double d_far = 0.0;
+        if (x_t > x0d) {
+          const double pfar = s.th0 * s.E0 / 5.2 * sqrt(s.sy0d * s.sz0d / (kyd * kyd * s.M0));
+          const double sy = kyd * (x_t - x0d) + s.sy0d, sz = kyd * (x_t - x0d) + s.sz0d;
+          const double sg_ = sqrt(sy * sz * s.is0d);
+          const double ln_arg = s.lnAB * (1.6 * sg_ - s.sM) * rcp64(1.6 * sg_ + s.sM);
+          d_far = d0 + pfar * log(ln_arg) + lin;
+        }
+        delta = d_near + d_far;
+        amp = 0.0; isy2 = 0.0; isz2 = 0.0;
+        double sy = 0.0, sz = 0.0;
+        bool on = false;
+        if (x_t > x_i + 0.1 && x_t < x0v) {  // the masks as FLORIS takes them on the coordinates
+          const double up = dx * ix0v_rel, dn = (x0v - x_t) * ix0v_rel;
+          sy = dn * s.snw + up * s.sy0v;
+          sz = dn * s.snw + up * s.sz0v;
+          on = true;
+        } else if (x_t >= x0v) {
+          sy = kyv * (x_t - x0v) + s.sy0v;
+          sz = kyv * (x_t - x0v) + s.sz0v;
+          on = true;
+        }
+        if (on) {
+          const double isy = rcp64(sy), isz = rcp64(sz);
+          double dd = 1.0 - s.kdef * isy * isz;
+          dd = fmin(fmax(dd, 0.0), 1.0);
+          amp = 1.0 - sqrt(dd);
+          isy2 = 0.5 * isy * isy;
+          isz2 = 0.5 * isz * isz;
+        }
+      }
+      const double yy = (y_t + c.off[j]) - y_i - delta;
+      double def[3];
+      if (!veer_on) {  // r = yy^2 / (2 sy^2) + zz^2 / (2 sz^2), zz = -q, 0, +q
+        const double e1 = amp * exp(-(yy * yy) * isy2);
+        const double e0 = e1 * exp(-q2 * isz2);
+        def[0] = e0; def[1] = e1; def[2] = e0;
+      } else {  // FLORIS rCalt [gauss.py]: the Gaussian rotated by the veer angle
+        const double ca = c.cos2_veer * isy2 + c.sin2_veer * isz2;
+        const double cb = 0.5 * c.sin_2veer * (isz2 - isy2);
+        const double cc = c.sin2_veer * isy2 + c.cos2_veer * isz2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double zz = c.off[k];
+          def[k] = amp * exp(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double dU = def[k] * R.Uinit[k];
+        if (dU > c.overlap_thr) ++cnt;  // the comparison as FLORIS takes it [A.3-8]
+        RES_ST(j * 3 + k, t) = fma(dU, dU, RES_ST(j * 3 + k, t));  // 7. SOSFS [A.3-7]: the sum of squares, root taken where needed
+      }
+    }
+    // 8. Crespo-Hernandez + overlap gating [A.3-8]
+    const bool reach = (x_t > x_i) && (x_t <= x_i + 15.0 * D);
+    bool gate[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gate[j] = reach && (fabs(y_i - (y_t + c.off[j])) < 2.0 * D);
+    if (gate[0] || gate[1] || gate[2]) {
+      const double dxp = (dx <= 0.1) ? dx + 1.0 : dx;  // dx > -0.1 holds for every downstream turbine
+      double ti = s.ch_pref * exp(c.ch_down * log(dxp / D));
+      if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
+      const double ti_added = ((double)cnt / 9.0) * ti;
+      const double cand = sqrt(ti_added * ti_added + c.amb * c.amb);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (gate[j] && cand > RES_ST(27 + j, t)) RES_ST(27 + j, t) = cand;
+    }
+  }
+}
+
+// ---- outputs [A.4] in the caller's turbine order; the farm's reward ----
+__device__ __noinline__ void res_outputs(const WfResolveArgs& a, int b, size_t gofs) {
+  const WfResolveConsts& c = R.c;
+  const int lane = threadIdx.x, N = R.N;
+  const double wd = R.wd;
+  double psum = 0.0, lsum = 0.0;
+  for (int t = lane; t < N; t += 64) {
+    const int o = a.gidx[gofs + t];
+    double m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0, dir = 0.0;
+    bool small = true;
+#pragma unroll 1
+    for (int q = 0; q < 9; ++q) {  // (runtime loops over the grid points: the state is read from LDS where it is needed)
+      const double u = R.Uinit[q % 3] - sqrt(RES_ST(q, t)), v = RES_ST(9 + q, t);
+      m3 += u * u * u;
+      mu += u; mv += v; mw += RES_ST(18 + q, t);
+      small = small && (u > 0.0) && (fabs(v) <= 0.1 * u);
+    }
+    if (__all(small)) {
+#pragma unroll 1
+      for (int q = 0; q < 9; ++q) {
+        const double u = R.Uinit[q % 3] - sqrt(RES_ST(q, t));
+        dir += wd - atan_small(RES_ST(9 + q, t) * rcp64(u)) / kDeg;
+      }
+    } else {
+#pragma unroll 1
+      for (int q = 0; q < 9; ++q) dir += wd - atan2(RES_ST(9 + q, t), R.Uinit[q % 3] - sqrt(RES_ST(q, t))) / kDeg;
+    }
+    mu /= 9.0; mv /= 9.0; mw /= 9.0;
+    double su = 0.0, sv = 0.0, sw = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < 9; ++q) {
+      const double u = R.Uinit[q % 3] - sqrt(RES_ST(q, t)), v = RES_ST(9 + q, t), w = RES_ST(18 + q, t);
+      su += (u - mu) * (u - mu);
+      sv += (v - mv) * (v - mv);
+      sw += (w - mw) * (w - mw);
+    }
+    const double wsp = cbrt(m3 / 9.0);
+    const double veff = c.dens_cbrt * (wsp * exp(c.pP3 * log(RES_CG(t))));
+    const double pw = c.rho_ref * interp_fill(veff, c.n_table, R.tws, R.tpw, 0.0, 0.0);
+    const double l0 = (RES_ST(27, t) + RES_ST(28, t) + RES_ST(29, t)) / 3.0, l1 = sqrt(su / 9.0), l2 = sqrt(sv / 9.0), l3 = sqrt(sw / 9.0);
+    psum += pw;
+    lsum += fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3);
+    const size_t oo = (size_t)b * N + o;
+    if (a.o_power) a.o_power[oo] = (float)pw;
+    if (a.o_ws) a.o_ws[oo] = (float)wsp;
+    if (a.o_wd) a.o_wd[oo] = (float)(dir / 9.0);
+    if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = make_float4((float)l0, (float)l1, (float)l2, (float)l3);
+  }
+  if (a.reward) {  // reference simple_env.py:78-84 on the float64 values
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+      psum += __shfl_xor(psum, w);
+      lsum += __shfl_xor(lsum, w);
+    }
+    if (lane == 0) {
+      const double wr = a.ws_prev ? a.ws_prev[b] : R.ws;
+      a.reward[b] = (float)(psum / N / 1.0e6 * 1.0e3 / (wr * wr * wr) - (double)a.load_coef * lsum / (4.0 * N));
+    }
+  }
+}
+
+#ifdef WF_RES_STAMP  // debug build (tools/res_stamps.py): wave cycles per phase, summed over the launch
+__device__ unsigned long long wf_res_stamp[8];
+#define RES_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define RES_ACC(k, a, b) st_acc[k] += (b) - (a)
+#else
+#define RES_T(v)
+#define RES_ACC(k, a, b)
+#endif
+__global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a, int n_pad) {
+  const int lane = threadIdx.x;
   const int N = c_arg.N;
-  for (int k = t; k < c_arg.n_table; k += THREADS) {
-    tws[k] = a.tab64[k];
-    tct[k] = a.tab64[WF_TABLE_PAD + k];
-    tpw[k] = a.tab64[2 * WF_TABLE_PAD + k];
+  if (lane == 0) {
+    R.c = c_arg;
+    R.N = N; R.n_pad = n_pad; R.veer_on = c_arg.sin2_veer != 0.0; R.mcore = c_arg.mirror_core;
+  }
+  for (int k = lane; k < c_arg.n_table; k += 64) {
+    R.tws[k] = a.tab64[k];
+    R.tct[k] = a.tab64[WF_TABLE_PAD + k];
+    R.tpw[k] = a.tab64[2 * WF_TABLE_PAD + k];
   }
   const int n_list = *a.count;
-  const bool live = t < N;
-  const bool veer_on = c_arg.sin2_veer != 0.0;
-  const bool mcore = c_arg.mirror_core != 0;
-
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
     const int b = a.list[li];
     size_t gofs = 0;
     if (a.farm_group) gofs = (size_t)((a.farm_group[b] + a.shift) % a.mod) * N;
     else gofs = (size_t)b * a.geom_stride;
-    const double ws = a.ws[(size_t)b * a.wind_stride];
-    double wd = fmod(a.wd[(size_t)b * a.wind_stride], 360.0);  // reference interface.py:664 (Python's %)
-    if (wd < 0.0) wd += 360.0;
     const float* yaw_b = (a.yaw_state ? a.yaw_state : a.yaw_in) + (size_t)b * N;
-    int o = 0;
-    double x_t = 0.0, y_t = 0.0, yaw_t = 0.0;
-    __syncthreads();  // the previous farm's last readers of xsL / bc are done; c is in place
-    if (live) {
-      o = a.gidx[gofs + t];
-      x_t = a.gx[gofs + t];
-      y_t = a.gy[gofs + t];
-      yaw_t = (double)yaw_b[o];
-      xsL[t] = x_t; ysL[t] = y_t; yawL[t] = yaw_t;
+    RES_T(t_farm);
+    __syncthreads();  // (one wave: orders the constants / the previous farm's last reads before the new contents)
+    if (lane == 0) {
+      const double ws = a.ws[(size_t)b * a.wind_stride];
+      double wd = fmod(a.wd[(size_t)b * a.wind_stride], 360.0);  // reference interface.py:664 (Python's %)
+      if (wd < 0.0) wd += 360.0;
+      R.ws = ws; R.wd = wd; R.Uinf = ws * c_arg.uinf1;  // inflow [A.2]
+      for (int k = 0; k < 3; ++k) R.Uinit[k] = ws * c_arg.shearf[k];
     }
-    const double D = c.D, eps2 = c.eps2, ieps2 = 1.0 / c.eps2;
-    // inflow [A.2]
-    double Uinit[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) Uinit[k] = ws * c.shearf[k];
-    const double Uinf = ws * c.uinf1;
-    // SOSFS [A.3-7]: FLORIS chains hypot(wake, deficit * Uinit); the sum of squares is kept and the root taken where the
-    // velocity is needed (the source's own rotor mean, the outputs)
-    double wake2[9], V[9], W[9], TI[3];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) { wake2[q] = 0.0; V[q] = 0.0; W[q] = 0.0; }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) TI[j] = c.amb;
-
+    for (int t = lane; t < N; t += 64) {
+      const double g = (double)yaw_b[a.gidx[gofs + t]];
+      double sg, cg;
+      sincos(g * kDeg, &sg, &cg);
+      RES_XS(t) = a.gx[gofs + t]; RES_YS(t) = a.gy[gofs + t]; RES_CG(t) = cg; RES_SG(t) = sg; RES_GR(t) = g * kDeg;
+#pragma unroll 1
+      for (int q = 0; q < 27; ++q) res_dyn[(5 + q) * n_pad + t] = 0.0;
+      for (int j = 0; j < 3; ++j) res_dyn[(32 + j) * n_pad + t] = c_arg.amb;
+    }
+    __syncthreads();
+    for (int t = lane; t < N; t += 64) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
+      int f = t;
+      while (f > 0 && RES_XS(f - 1) == RES_XS(t)) --f;
+      RES_TIE(t) = f;
+    }
+    __syncthreads();
+#ifdef WF_RES_STAMP
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    RES_T(t_a);
+    RES_ACC(4, t_farm, t_a);
     for (int i = 0; i < N; ++i) {
-      asm volatile("" ::: "memory");  // the constants in LDS are re-read per source, not hoisted into registers for all of them
-      if (t == i) {  // the source's state [A.3-1, A.3-2]
-        double m3 = 0.0, vs = 0.0;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          const double u = Uinit[q % 3] - sqrt(wake2[q]);
-          m3 += u * u * u;
-          vs += V[q];
-        }
-        bc[0] = m3 / 9.0; bc[1] = vs / 9.0; bc[2] = TI[0]; bc[3] = TI[1]; bc[4] = TI[2];
-      }
-      __syncthreads();
-      const double x_i = xsL[i], y_i = ysL[i], g = yawL[i];
-      const double dx = x_t - x_i;
-      const bool down = live && dx >= 0.0;  // ties (dx = 0) count as downstream for the transverse velocities [A.3-4]
-      const bool wave_on = __any(down);     // (the source's own wave always is)
-      double ct = 0.0, ai = 0.0, G_wr = 0.0, gam_top = 0.0, gam_bot = 0.0, cg = 1.0, sg = 0.0, ubar = 1.0;
-      if (wave_on) {
-        ubar = cbrt(bc[0]);
-        sincos(g * kDeg, &sg, &cg);
-        double ct_tab = interp_fill(ubar, c.n_table, tws, tct, 0.0001, 0.9999);
-        ct_tab = fmin(fmax(ct_tab, 0.0001), 0.9999);
-        ct = ct_tab * cg;
-        ai = 0.5 / cg * (1.0 - sqrt(1.0 - ct * cg));
-        G_wr = 0.25 * kTwoPi * D * (ai - ai * ai) * ubar / c.TSR;
-        gam_top = (kTwoPi / 16.0) * D * c.vel_top * Uinf * ct;
-        gam_bot = (kTwoPi / 16.0) * D * c.vel_bot * Uinf * ct;
-      }
-
-      // 4. transverse velocities (commanded yaw) on this thread's turbine: per grid column the 7 + 7 distinct vertical
-      // offsets of the three vortices and their ground mirrors on the 3 x 3 grid (wf_device.h: zc / zm classes)
-      if (c.sw_tv && wave_on && down) {
-        const double sc = sg * cg;
-        const double qd = c_arg.off[2], neps = c_arg.num_eps, twoHH = 2.0 * c_arg.HH;
-        const double Gt = sc * gam_top / kTwoPi, Gb = -sc * gam_bot / kTwoPi, Gw = G_wr / kTwoPi;
-        double dec[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dec[k] = eps2 * rcp64(4.0 * (c.nu1[k] * ws) * dx / Uinf + eps2);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const double yL = (y_t + c.off[j] - y_i) + c.num_eps;
-          const double yL2 = yL * yL;
-          const double Ey = exp(-yL2 * ieps2);
-          double Av[3] = {0.0, 0.0, 0.0}, Bw[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-          for (int m = 0; m < 7; ++m) {
-            // (offsets from the class index and three scalars; only the 7 core factors of the real vortices are tabulated:
-            // 42 tabulated constants cost 84 registers across this loop)
-            const double zc = (double)(m - 3) * qd + neps, zm = zc + twoHH;
-            const double tr = (1.0 - Ey * c_arg.ezc[m]) * rcp64(yL2 + zc * zc);   // core / r of a real vortex at offset zc
-            double tm = rcp64(yL2 + zm * zm);                                       // ... of a mirror vortex at zm
-            if (mcore) tm *= 1.0 - Ey * c.ezm7[m];  // (1 - Ey ezm == 1.0 exactly unless the hub is very low)
-            const double pr = zc * tr, pm = zm * tm;
-            if (m <= 2) {  // real top (k = m), mirror bottom (k = m)
-              Av[m] += Gt * pr - Gb * pm;
-              Bw[m] += Gt * tr - Gb * tm;
-            }
-            if (m >= 4) {  // real bottom (k = m - 4), mirror top (k = m - 4)
-              Av[m - 4] += Gb * pr - Gt * pm;
-              Bw[m - 4] += Gb * tr - Gt * tm;
-            }
-            if (m >= 2 && m <= 4) {  // wake rotation, real - mirror (k = m - 2)
-              Av[m - 2] += Gw * (pr - pm);
-              Bw[m - 2] += Gw * (tr - tm);
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            V[j * 3 + k] += Av[k] * dec[k];
-            const double w = -yL * Bw[k] * dec[k];
-            W[j * 3 + k] += (w < 0.0) ? 0.0 : w;  // quirk (5) [A.6]
-          }
-        }
-      }
-      if (t == i) {
-        double vs = 0.0, wsum = 0.0;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { vs += V[q]; wsum += W[q]; }
-        bc2[0] = vs / 9.0; bc2[1] = wsum / 9.0;
-      }
-      __syncthreads();
-      if (!wave_on) continue;
-      const double TIs[3] = {bc[2], bc[3], bc[4]};
-      // 2. secondary steering [A.3-2]: the three means on the source's own grid are geometry constants
-      const double v_top = gam_top * c.k_top, v_bot = -gam_bot * c.k_bot, v_core = G_wr * c.k_core;
-      double val = 2.0 * (bc[1] - v_core) / (v_top + v_bot);
-      val = fmin(fmax(val, -1.0), 1.0);
-      const double g_eff = c.sw_steer ? g + (0.5 * asin(val)) / kDeg : g;
-      // 5. yaw-added recovery [A.3-5]
-      double dTI = 0.0;
-      {
-        const double I = TIs[0];
-        const double k_tke = (ubar * I) * (ubar * I) / (2.0 / 3.0);
-        const double vbar = bc2[0], wbar = bc2[1];
-        const double I_tot = sqrt((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) / ubar;
-        if (c.sw_yar) dTI = c.gch_gain * (I_tot - I);
-      }
-      if (t == i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) TI[j] += dTI;
-      }
-      // 3 + 6. deflection (TI before mixing, effective yaw) and deficit (TI after mixing, commanded yaw) [A.3-3, A.3-6]:
-      // everything that depends on the source (and the column's TI) only
-      // cosd(-g_eff) = cos(g + d), d = asin(val) / 2: half-angle formulas instead of a second cosine
-      const double c2d = sqrt(fmax(1.0 - val * val, 0.0)), cd = sqrt(0.5 * (1.0 + c2d)), sd = 0.5 * val / cd;
-      const double cgd = c.sw_steer ? cg * cd - sg * sd : cg;
-      const double gd = -g_eff;
-      const double s_cc = sqrt(1.0 - ct * cgd), s_c = sqrt(1.0 - ct);
-      const double th0 = c.dm * (0.3 * (gd * kDeg) / cgd) * (1.0 - s_cc);
-      const double tan_th0 = tan(th0);
-      const double cgv = cg;  // cosd(-g)
-      const double C0 = 1.0 - s_c;
-      const double M0 = C0 * (2.0 - C0);
-      const double E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
-      const double sM = sqrt(M0);
-      const double sz0d = D * 0.5 * sqrt((ct * cgd / (2.0 * (1.0 - s_cc))) / (1.0 + s_c));
-      const double sy0d = sz0d * cgd * c.cos_veer;
-      const double is0d = 1.0 / (sy0d * sz0d);
-      const double lnAB = (1.6 + sM) / (1.6 - sM);
-      const double sz0v = D * 0.5 * sqrt((ct / (2.0 * (1.0 - s_c))) / (1.0 + s_c));
-      const double sy0v = sz0v * cgv * c.cos_veer;
-      const double snw = c.near_c * sqrt(ct / 2.0);
-      const double kdef = ct * cgv * D * D / 8.0;
-      const double ch_pref = c.ch_constant * exp(c.ch_ai * log(ai)) * c.ch_amb_pow;
-      auto column = [&](double TIpre) {
-        ColD k;
-        const double x0r = D * cgd * (1.0 + s_cc) / (c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - s_c)));
-        k.x0d = x0r + x_i;
-        k.ix0d_rel = 1.0 / (k.x0d - x_i);
-        k.kyd = c.defl_ka * TIpre + c.defl_kb;
-        k.d0 = tan_th0 * (k.x0d - x_i);
-        k.pfar = th0 * E0 / 5.2 * sqrt(sy0d * sz0d / (k.kyd * k.kyd * M0));
-        const double TIq = TIpre + dTI;
-        const double x0v = D * cgv * (1.0 + s_c) / (c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - s_c)));
-        k.x0v = x0v + x_i;
-        k.ix0v_rel = 1.0 / (k.x0v - x_i);
-        k.kyv = c.ka * TIq + c.kb;
-        return k;
-      };
-      const bool same = (TIs[0] == TIs[1]) && (TIs[1] == TIs[2]);  // (uniform: a property of the source)
-      if (!down) continue;
-      const double lin = c.ad + c.bd * dx;
-      // one target column: deflection -> delta; deficit -> amplitude and the Gaussian's 1 / (2 sigma^2)
-      struct ColT { double delta, amp, isy2, isz2; };
-      auto target_col = [&](const ColD& k) {
-        ColT r;
-        double d_near = (dx * k.ix0d_rel) * k.d0 + lin;
-        if (!(x_t <= k.x0d)) d_near = 0.0;  // [x >= x_i] holds here
-        double d_far = 0.0;
-        if (x_t > k.x0d) {
-          const double sy = k.kyd * (x_t - k.x0d) + sy0d, sz = k.kyd * (x_t - k.x0d) + sz0d;
-          const double s = sqrt(sy * sz * is0d);
-          const double ln_arg = lnAB * (1.6 * s - sM) * rcp64(1.6 * s + sM);
-          d_far = k.d0 + k.pfar * log(ln_arg) + lin;
-        }
-        r.delta = d_near + d_far;
-        r.amp = 0.0; r.isy2 = 0.0; r.isz2 = 0.0;
-        double sy = 0.0, sz = 0.0;
-        bool on = false;
-        if (x_t > x_i + 0.1 && x_t < k.x0v) {  // the masks as FLORIS takes them on the coordinates
-          const double up = dx * k.ix0v_rel, dn = (k.x0v - x_t) * k.ix0v_rel;
-          sy = dn * snw + up * sy0v;
-          sz = dn * snw + up * sz0v;
-          on = true;
-        } else if (x_t >= k.x0v) {
-          sy = k.kyv * (x_t - k.x0v) + sy0v;
-          sz = k.kyv * (x_t - k.x0v) + sz0v;
-          on = true;
-        }
-        if (on) {
-          const double isy = rcp64(sy), isz = rcp64(sz);
-          double dd = 1.0 - kdef * isy * isz;
-          dd = fmin(fmax(dd, 0.0), 1.0);
-          r.amp = 1.0 - sqrt(dd);
-          r.isy2 = 0.5 * isy * isy;
-          r.isz2 = 0.5 * isz * isz;
-        }
-        return r;
-      };
-      int cnt = 0;
-      const double q2 = c.off[2] * c.off[2];
-      ColT Tc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (j == 0 || !same) Tc = target_col(column(TIs[j]));  // (one column serves all three when the source's TIs agree)
-        const double yy = (y_t + c.off[j]) - y_i - Tc.delta;
-        double def[3];
-        if (!veer_on) {  // r = yy^2 / (2 sy^2) + zz^2 / (2 sz^2), zz = -q, 0, +q
-          const double e1 = Tc.amp * exp(-(yy * yy) * Tc.isy2);
-          const double e0 = e1 * exp(-q2 * Tc.isz2);
-          def[0] = e0; def[1] = e1; def[2] = e0;
-        } else {  // FLORIS rCalt [gauss.py]: the Gaussian rotated by the veer angle
-          const double ca = c.cos2_veer * Tc.isy2 + c.sin2_veer * Tc.isz2;
-          const double cb = 0.5 * c.sin_2veer * (Tc.isz2 - Tc.isy2);
-          const double cc = c.sin2_veer * Tc.isy2 + c.cos2_veer * Tc.isz2;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const double zz = c.off[k];
-            def[k] = Tc.amp * exp(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double dU = def[k] * Uinit[k];
-          if (dU > c.overlap_thr) ++cnt;  // the comparison as FLORIS takes it [A.3-8]
-          wake2[j * 3 + k] = fma(dU, dU, wake2[j * 3 + k]);
-        }
-      }
-      // 8. Crespo-Hernandez + overlap gating [A.3-8]
-      const bool reach = (x_t > x_i) && (x_t <= x_i + 15.0 * D);
-      bool gate[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) gate[j] = reach && (fabs(y_i - (y_t + c.off[j])) < 2.0 * D);
-      if (gate[0] || gate[1] || gate[2]) {
-        const double dxp = (dx <= 0.1) ? dx + 1.0 : dx;  // dx > -0.1 holds for every downstream turbine
-        double ti = ch_pref * exp(c.ch_down * log(dxp / D));
-        if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
-        const double ti_added = ((double)cnt / 9.0) * ti;
-        const double cand = sqrt(ti_added * ti_added + c.amb * c.amb);
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          if (gate[j] && cand > TI[j]) TI[j] = cand;
-      }
-    }  // sources
-
-    // ---- outputs [A.4] in the caller's turbine order; reward partial sums ----
-    double pw = 0.0, lsum = 0.0;
-    if (live) {
-      double m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0, dir = 0.0, U[9];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        U[q] = Uinit[q % 3] - sqrt(wake2[q]);
-        m3 += U[q] * U[q] * U[q];
-        mu += U[q]; mv += V[q]; mw += W[q];
-        dir += wd - atan2(V[q], U[q]) / kDeg;
-      }
-      mu /= 9.0; mv /= 9.0; mw /= 9.0;
-      double su = 0.0, sv = 0.0, sw = 0.0;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        su += (U[q] - mu) * (U[q] - mu);
-        sv += (V[q] - mv) * (V[q] - mv);
-        sw += (W[q] - mw) * (W[q] - mw);
-      }
-      const double wsp = cbrt(m3 / 9.0);
-      const double veff = c.dens_cbrt * (wsp * pow(cosd(yaw_t), c.pP3));
-      pw = c.rho_ref * interp_fill(veff, c.n_table, tws, tpw, 0.0, 0.0);
-      const double l0 = (TI[0] + TI[1] + TI[2]) / 3.0, l1 = sqrt(su / 9.0), l2 = sqrt(sv / 9.0), l3 = sqrt(sw / 9.0);
-      lsum = fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3);
-      const size_t oo = (size_t)b * N + o;
-      if (a.o_power) a.o_power[oo] = (float)pw;
-      if (a.o_ws) a.o_ws[oo] = (float)wsp;
-      if (a.o_wd) a.o_wd[oo] = (float)(dir / 9.0);
-      if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = make_float4((float)l0, (float)l1, (float)l2, (float)l3);
+      RES_T(t0);
+      res_source_begin(i);
+      RES_T(t1);
+      if (c_arg.sw_tv) res_transverse_pass();
+      RES_T(t2);
+      res_source_finish(i);
+      RES_T(t3);
+      if (i + 1 < N) res_deficit_pass(i);
+      RES_T(t4);
+      RES_ACC(0, t0, t1); RES_ACC(1, t1, t2); RES_ACC(2, t2, t3); RES_ACC(3, t3, t4);
     }
-    if (a.reward) {  // reference simple_env.py:78-84 on the float64 values
-#pragma unroll
-      for (int w = 32; w >= 1; w >>= 1) {
-        pw += __shfl_xor(pw, w);
-        lsum += __shfl_xor(lsum, w);
-      }
-      if ((t & 63) == 0) { red[0][t >> 6] = pw; red[1][t >> 6] = lsum; }
-      __syncthreads();
-      if (t == 0) {
-        double ps = 0.0, ls = 0.0;
-        for (int w = 0; w < THREADS / 64; ++w) { ps += red[0][w]; ls += red[1][w]; }
-        const double wr = a.ws_prev ? a.ws_prev[b] : ws;
-        a.reward[b] = (float)(ps / N / 1.0e6 * 1.0e3 / (wr * wr * wr) - (double)a.load_coef * ls / (4.0 * N));
-      }
+    RES_T(t_b);
+    res_outputs(a, b, gofs);
+    RES_T(t_c);
+    RES_ACC(5, t_b, t_c);
+    if (lane == 0) a.flags[b] = 0;
+#ifdef WF_RES_STAMP
+    if (lane == 0) {
+      for (int k = 0; k < 6; ++k) atomicAdd(&wf_res_stamp[k], st_acc[k]);
+      atomicAdd(&wf_res_stamp[6], 1ull);
     }
-    if (t == 0) a.flags[b] = 0;
+#endif
   }
 }
+
+#ifdef WF_RES_STAMP
+extern "C" int wfk_res_stamps(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res_stamp), sizeof(wf_res_stamp));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(wf_res_stamp), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
 
 extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags,
                                          hipStream_t s) {
@@ -409,12 +576,10 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(wf_compact_flagged_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a->flags, B, all, a->list, a->count, raw_flags);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  // persistent blocks over the compacted list: enough to fill the chip several times over, never more than farms
-  int grid = B < 2048 ? B : 2048;
-  const int N = c->N;
-  if (N <= 64) hipLaunchKernelGGL(wf_resolve_kernel<64>, dim3(grid), dim3(64), 0, s, *c, *a);
-  else if (N <= 128) hipLaunchKernelGGL(wf_resolve_kernel<128>, dim3(grid), dim3(128), 0, s, *c, *a);
-  else if (N <= 192) hipLaunchKernelGGL(wf_resolve_kernel<192>, dim3(grid), dim3(192), 0, s, *c, *a);
-  else hipLaunchKernelGGL(wf_resolve_kernel<256>, dim3(grid), dim3(256), 0, s, *c, *a);
+  // persistent one-wave blocks over the compacted list: enough to fill the chip several times over, never more than farms
+  const int grid = B < 8192 ? B : 8192;
+  const int n_pad = (c->N + 1) & ~1;  // (keeps the int array behind the doubles aligned)
+  const size_t dyn = sizeof(double) * 35 * (size_t)n_pad + sizeof(int) * (size_t)n_pad;
+  hipLaunchKernelGGL(wf_resolve_kernel, dim3(grid), dim3(64), dyn, s, *c, *a, n_pad);
   return hipGetLastError();
 }
