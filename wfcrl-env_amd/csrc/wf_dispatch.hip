@@ -55,12 +55,17 @@ const LlFamily kLlFamilies[] = {{0, 16, 2}, {(8 << 4) | 1, 32, 3}, {(4 << 4) | 2
 constexpr int kNumFamilies = 5, kNumRoundsN = 5;
 const int kRoundsN[kNumRoundsN] = {32, 48, 64, 80, 91};
 // [family][N index][blocks per CU - 1]
+// (N = 32, 48, 64: the first N turbines of HornsRev2 at 263 deg; N = 80, 91: HornsRev1 / HornsRev2 at 270 deg, the
+// BASELINE configs — profiles/r03_rounds_table.txt, r03_batch_sweep_fine.txt; layouts move these by up to 10 %)
 const double kRoundsMs[kNumFamilies][kNumRoundsN][3] = {
-    {{0.093, 0.116, 0.0}, {0.123, 0.149, 0.187}, {0.166, 0.213, 0.0}, {0.225, 0.285, 0.0}, {0.303, 0.366, 0.0}},            // slot (8x4, 16x3, 16x4, 16x5, 16x6)
-    {{0.086, 0.112, 0.144}, {0.152, 0.197, 0.254}, {0.230, 0.300, 0.386}, {0.327, 0.417, 0.543}, {0.432, 0.552, 0.720}},  // 8x1
-    {{0.118, 0.159, 0.0}, {0.220, 0.291, 0.0}, {0.349, 0.458, 0.0}, {0.506, 0.670, 0.0}, {0.661, 0.876, 0.0}},            // 4x2
-    {{0.127, 0.170, 0.226}, {0.241, 0.309, 0.418}, {0.377, 0.489, 0.657}, {0.546, 0.700, 0.946}, {0.690, 0.904, 1.215}},  // 4x1
-    {{0.190, 0.274, 0.0}, {0.377, 0.532, 0.0}, {0.607, 0.842, 0.0}, {0.934, 1.279, 0.0}, {1.168, 1.615, 0.0}}};           // 2x2
+    {{0.093, 0.116, 0.0}, {0.123, 0.149, 0.187}, {0.166, 0.213, 0.0}, {0.237, 0.294, 0.0}, {0.307, 0.372, 0.0}},            // slot (8x4, 16x3, 16x4, 16x5, 16x6)
+    {{0.086, 0.112, 0.144}, {0.152, 0.197, 0.254}, {0.230, 0.300, 0.386}, {0.332, 0.424, 0.551}, {0.430, 0.553, 0.730}},  // 8x1
+    {{0.118, 0.159, 0.0}, {0.220, 0.291, 0.0}, {0.349, 0.458, 0.0}, {0.486, 0.639, 0.0}, {0.638, 0.869, 0.0}},            // 4x2
+    {{0.127, 0.170, 0.226}, {0.241, 0.309, 0.418}, {0.377, 0.489, 0.657}, {0.550, 0.691, 0.910}, {0.690, 0.900, 1.231}},  // 4x1
+    {{0.190, 0.274, 0.0}, {0.377, 0.532, 0.0}, {0.607, 0.842, 0.0}, {0.853, 1.166, 0.0}, {1.100, 1.620, 0.0}}};           // 2x2
+// A partial round behind full ones overlaps with their tail: its cost relative to the same round on an idle chip, by
+// (blocks per CU it reaches, resident blocks per CU of the family) — fitted on profiles/r03_batch_sweep_fine.txt
+const double kTailFactor[2][3] = {{0.80, 0.95, 0.0}, {0.62, 0.79, 0.86}};  // [per_cu - 2][tail blocks per CU - 1]
 
 // farms per block and resident blocks per CU of family fi for N turbines (the register-slot kernel's follow from its
 // variant for N: three waves per SIMD where S <= 3, two otherwise — wf_kernels.hip)
@@ -97,14 +102,17 @@ double round_ms(int fi, int N, int per_cu) {
 }
 
 // ms for `farms` farm slots on family fi: whole rounds at full occupancy, then the partial round at the occupancy it
-// reaches; a partial round behind full ones overlaps with their tail (factor 0.8, measured)
+// reaches; a partial round behind full ones overlaps with their tail (kTailFactor)
 double ll_estimate(const wf_handle* h, int fi, int N, long farms) {
   int fpb, per_cu;
   family_shape(h, fi, N, &fpb, &per_cu);
   const long blocks = (farms + fpb - 1) / fpb, per_round = (long)h->n_cu * per_cu;
   const long full = blocks / per_round, rem = blocks % per_round;
   double t = full * round_ms(fi, N, per_cu);
-  if (rem) t += (full ? 0.8 : 1.0) * round_ms(fi, N, (int)((rem + h->n_cu - 1) / h->n_cu));
+  if (rem) {
+    const int p = (int)((rem + h->n_cu - 1) / h->n_cu);
+    t += (full ? kTailFactor[per_cu - 2][p - 1] : 1.0) * round_ms(fi, N, p);
+  }
   return t;
 }
 
