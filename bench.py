@@ -109,7 +109,13 @@ def counter_profile(config: str, B: int, info: dict):
         if any(info.get(k) != v for k, v in e.get("kernel", {}).items()):
             return None
         pmc = json.load(open(os.path.join(ROOT, e["file"])))
-        return {"hbm_bytes": (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, "insts_valu": pmc["SQ_INSTS_VALU"],
+        if "TCC_EA0_RDREQ_128B_sum" in pmc:  # the L2's requests to the fabric by size: exact bytes, no FETCH_SIZE correction
+            rd = 128.0 * pmc["TCC_EA0_RDREQ_128B_sum"] + 64.0 * pmc["TCC_EA0_RDREQ_64B_sum"] + 32.0 * pmc["TCC_EA0_RDREQ_32B_sum"]
+            wr = 64.0 * pmc["TCC_EA0_WRREQ_64B_sum"] + 32.0 * (pmc["TCC_EA0_WRREQ_sum"] - pmc["TCC_EA0_WRREQ_64B_sum"])
+            nbytes, how = rd + wr, "TCC_EA0_RDREQ_{128B,64B,32B} / WRREQ_{64B,32B} request counts x their sizes"
+        else:
+            nbytes, how = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, "(2 x FETCH_SIZE + WRITE_SIZE) KiB, the guide's gfx950 correction"
+        return {"hbm_bytes": nbytes, "traffic_how": how, "insts_valu": pmc["SQ_INSTS_VALU"],
                 "kernel_us": e.get("kernel_us"), "source": f'{e["file"]} (rocprofv3 --pmc, separate passes; kernel of commit '
                 f'{e["commit"]}; not measured in this run)'}
     except Exception:
@@ -387,6 +393,9 @@ def main():
                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                         "traffic": cp["hbm_bytes"] if cp else None,
                         "traffic_source": cp["source"] if cp else None,
+                        # what the number is: bytes the L2 requested from / sent to the fabric — an upper bound on HBM
+                        # bytes (Infinity Cache hits are in it: rocprofv3 exposes no MALL counter on this box)
+                        "traffic_kind": ("fabric bytes (L2 <-> EA): " + cp["traffic_how"]) if cp else None,
                         # what the kernel actually moves (the source log of the one-block kernel on top of the
                         # algorithmic bytes), as a fraction of the HBM peak at this run's kernel time
                         "traffic_frac_of_peak": (cp["hbm_bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if cp else None,
