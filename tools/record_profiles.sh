@@ -16,6 +16,10 @@ python3 tools/gs_sweep.py 2>&1 | grep ms/step > $O/variant_sweep.txt
 python3 tools/time_wind_modes.py 2>&1 | grep ms/step > $O/wind_modes.txt
 python3 tools/time_series_mode.py 64 2.0 2>&1 | grep ms/step > $O/series_modes.txt
 python3 tools/latency_b1.py 2>&1 | grep update_command > $O/latency_b1.txt
+python3 tests/tools/flag_stats.py 4096 > $O/flag_stats.txt 2>&1
+(python3 tools/resolve_cost.py HornsRev1_ 65536; python3 tools/resolve_cost.py HornsRev2_ 131072) 2>&1 | grep -v amdgpu.ids > $O/resolve_cost.txt
+python3 tools/batch_sweep_fine.py 2>&1 | grep -v amdgpu.ids > $O/batch_sweep_fine.txt
+bash tools/pmc_resolve.sh 2>&1 | grep -A12 counter_collection > $O/pmc_resolve.txt
 bash tools/run_pmc.sh $tag > /dev/null 2>&1
 python3 tools/parse_pmc.py $tag wf_step_ll_kernel > $O/pmc_cfg4.json
 rm -rf $R/gpurun_out/pmc_$tag
