@@ -132,47 +132,42 @@ __device__ __forceinline__ double cbrt_pos(double x) {
 }
 
 
-// One farm per 256-thread block.  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column TIs,
-// float64 — lives in LDS, structure-of-arrays over the sorted turbine index; a lane is not tied to a turbine: for source i
-// the lanes take the turbines the source can reach, t = first + lane (first = the start of the source's x' tie group for
-// the transverse velocities [A.3-4], i + 1 for deficit and wake-added turbulence), 64 at a time, so the triangle of the
-// recurrence costs 96 instead of 160 passes at N = 80.
-// The kernel is LATENCY-bound (a few thousand flagged farms are one to two waves per SIMD: every float64 operation of the
-// 80-stage dependent chain costs its full latency), so a source step is spread over the block's four waves:
-//   waves 0-2  one rotor-grid column each (lateral offset -D/4, 0, +D/4): the transverse pass and the deflection /
-//              deficit / SOSFS pass of that column on every reachable turbine;
-//   wave 3     the source-only chain of steering, deflection and deficit constants (asin, tan, six roots, the
-//              Crespo-Hernandez prefactor) BESIDE the transverse pass, which does not need it;
-//   all waves  the source's state and circulations (redundantly: each wave keeps its own copy, no barrier) and the
-//              yaw-added recovery once the transverse velocities of all three columns are in.
-// Three block barriers per source: after the transverse pass / the constant chain; after the deficit pass (the overlap
-// count of a turbine is the sum of its three columns' counts, exchanged through LDS); after the turbulence update.
-// The phases are separate NON-INLINED functions that talk through LDS (the per-source constants too): inlined into one
-// body the register allocator kept ~370 values live and spilled inside the source loop.
-// (History: a thread per turbine, state in registers, two __syncthreads per source, every wave re-deriving the source
-// constants: 1.95 ms for 1394 HornsRev1 farms; one wave per farm with the state in LDS: 1.37 ms; profiles/r03_*.)
+// One farm per WAVE (64-thread blocks).  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column
+// TIs, float64 — lives in LDS, structure-of-arrays over the sorted turbine index; a lane is not tied to a turbine:
+// for source i the lanes take the turbines the source can reach, t = first + lane (first = the start of the source's x'
+// tie group for the transverse velocities [A.3-4], i + 1 for deficit and wake-added turbulence), 64 at a time, so the
+// triangle of the recurrence costs 96 instead of 160 wave passes at N = 80 and nothing is done twice: the per-source
+// constants are derived once per farm (by every lane of the one wave).  No block-level barrier inside the solve: the
+// LDS operations of a wave execute in order.
+// The phases of a source step talk through LDS only (the per-source constants too), with a compiler barrier at every
+// phase boundary: written as one body with the constants in registers the allocator kept ~370 values live (the
+// per-source constants across both passes, the device library's temporaries) and spilled inside the source loop at any
+// occupancy above one wave per SIMD; as real (non-inlined) functions the calling convention's register saves cost 180
+// scratch accesses per source.
+// (First version, in the history: a thread per turbine, state in registers, two __syncthreads per source, every wave
+// re-deriving the source constants: 1.95 ms for 1394 HornsRev1 farms; the inlined one-wave version 1.42 ms; this one 1.37 ms.
+// Tried after it (commit 13d6d4d): four waves per farm — a wave per rotor-grid column for the two passes, the steering /
+// deflection-constant chain on a fourth wave beside the transverse pass, three block barriers per source: a farm's
+// latency drops from 1.04 to 0.73 ms, but a farm then takes four wave slots, 1394 farms no longer fit one residency
+// (two rounds at four waves per SIMD: 2.1 ms); better below ~500 flagged farms, worse at the benchmark's count.)
 #ifndef WF_RES_OCC
 #define WF_RES_OCC 2  // waves per SIMD the register allocator is asked to make room for (tools/res_occ_sweep.sh)
 #endif
-struct SrcShared {  // what res_source_begin leaves (one copy per wave)
-  double x_i, y_i, ct, ai, ubar, Vmean, val, TIs[3];
+struct SrcShared {  // what a source leaves for the two passes over its targets
+  double x_i, y_i, ct, ai, ubar, Vmean, TIs[3], dTI;
   double Gt, Gb, Gw;  // circulations / (2 pi): top, bottom, wake rotation (commanded yaw)
-  int first_tv;
-};
-struct FinShared {  // the source-only constants of deflection, deficit and wake-added turbulence (written by wave 3)
   double cgd, s_cc, s_c, th0, tan_th0, M0, E0, sM, sz0d, sy0d, is0d, lnAB, sz0v, sy0v, snw, kdef, ch_pref, cgv;
+  int same, first_tv;
 };
 struct ResShared {
   WfResolveConsts c;
   double tws[WF_TABLE_PAD], tct[WF_TABLE_PAD], tpw[WF_TABLE_PAD];
   double ws, wd, Uinf, Uinit[3];
-  double red[4][2];
   int N, n_pad, veer_on, mcore;
-  SrcShared s[4];
-  FinShared f;
+  SrcShared s;
 };
 __shared__ ResShared R;
-extern __shared__ double res_dyn[];  // per sorted turbine: x', y', cos / sin / radians of the commanded yaw, the 30 state values; tie start, 3 counts
+extern __shared__ double res_dyn[];  // per sorted turbine: x', y', cos / sin / radians of the commanded yaw, the 30 state values, tie start
 
 #define RES_XS(t) res_dyn[(t)]
 #define RES_YS(t) res_dyn[R.n_pad + (t)]
@@ -181,12 +176,10 @@ extern __shared__ double res_dyn[];  // per sorted turbine: x', y', cos / sin / 
 #define RES_GR(t) res_dyn[4 * R.n_pad + (t)]
 #define RES_ST(q, t) res_dyn[(5 + (q)) * R.n_pad + (t)]  // wake2 q = 0..8, V 9..17, W 18..26, TI 27..29
 #define RES_TIE(t) (reinterpret_cast<int*>(res_dyn + 35 * R.n_pad)[(t)])
-#define RES_CNT(j, t) (reinterpret_cast<int*>(res_dyn + 35 * R.n_pad)[(1 + (j)) * R.n_pad + (t)])  // overlap count of column j
 
-// ---- the source's state and circulations [A.3-1, A.3-2, A.3-4]: every wave, into its own copy ----
+// ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
 __device__ __noinline__ void res_source_begin(int i) {
   const WfResolveConsts& c = R.c;
-  const int wave = threadIdx.x >> 6;
   const double cg = RES_CG(i), sg = RES_SG(i);
   double m3 = 0.0, vs = 0.0;
 #pragma unroll
@@ -205,83 +198,95 @@ __device__ __noinline__ void res_source_begin(int i) {
   const double gam_top = (kTwoPi / 16.0) * c.D * c.vel_top * R.Uinf * ct;
   const double gam_bot = (kTwoPi / 16.0) * c.D * c.vel_bot * R.Uinf * ct;
   const double sc = sg * cg;
-  if ((threadIdx.x & 63) == 0) {
-    SrcShared& s = R.s[wave];
+  if (threadIdx.x == 0) {
+    SrcShared& s = R.s;
     s.x_i = RES_XS(i); s.y_i = RES_YS(i); s.ct = ct; s.ai = ai; s.ubar = ubar; s.Vmean = vs / 9.0;
     s.TIs[0] = RES_ST(27, i); s.TIs[1] = RES_ST(28, i); s.TIs[2] = RES_ST(29, i);
     s.Gt = sc * gam_top / kTwoPi; s.Gb = -sc * gam_bot / kTwoPi; s.Gw = G_wr / kTwoPi;
     s.first_tv = RES_TIE(i);
     // secondary steering [A.3-2]: the three means on the source's own grid are geometry constants
     const double v_top = gam_top * c.k_top, v_bot = -gam_bot * c.k_bot, v_core = G_wr * c.k_core;
-    s.val = 2.0 * (s.Vmean - v_core) / (v_top + v_bot);
+    s.cgv = 2.0 * (s.Vmean - v_core) / (v_top + v_bot);  // (val: parked here until res_source_finish overwrites it)
   }
 }
 
-// ---- 4. transverse velocities (commanded yaw) of grid column j on every turbine at or downstream of the source, ties
-// included; the 7 + 7 distinct vertical offsets of the three vortices and their ground mirrors ----
-__device__ __noinline__ void res_transverse_pass(int j) {
+// ---- 4. transverse velocities (commanded yaw) on every turbine at or downstream of the source, ties included; per grid
+// column the 7 + 7 distinct vertical offsets of the three vortices and their ground mirrors ----
+__device__ __noinline__ void res_transverse_pass() {
   const WfResolveConsts& c = R.c;
-  const SrcShared& s = R.s[threadIdx.x >> 6];
-  const int lane = threadIdx.x & 63, N = R.N;
-  const double x_i = s.x_i, y_i = s.y_i, Gt = s.Gt, Gb = s.Gb, Gw = s.Gw;
+  const int lane = threadIdx.x, N = R.N;
+  const double x_i = R.s.x_i, y_i = R.s.y_i, Gt = R.s.Gt, Gb = R.s.Gb, Gw = R.s.Gw;
   const double qd = c.off[2], neps = c.num_eps, twoHH = 2.0 * c.HH, eps2 = c.eps2, ieps2 = 1.0 / c.eps2;
   const bool mcore = R.mcore != 0;
-  for (int base = s.first_tv; base < N; base += 64) {
+  for (int base = R.s.first_tv; base < N; base += 64) {
     const int t = base + lane;
     if (t >= N) continue;
     const double dx = RES_XS(t) - x_i, y_t = RES_YS(t);
-    double dec[3], Vj[3], Wj[3];
+    double dec[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      dec[k] = eps2 * rcp64(4.0 * (c.nu1[k] * R.ws) * dx / R.Uinf + eps2);
-      Vj[k] = RES_ST(9 + j * 3 + k, t);
-      Wj[k] = RES_ST(18 + j * 3 + k, t);
-    }
-    const double yL = (y_t + c.off[j] - y_i) + neps;
-    const double yL2 = yL * yL;
-    const double Ey = exp(-yL2 * ieps2);
-    double Av[3] = {0.0, 0.0, 0.0}, Bw[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < 3; ++k) dec[k] = eps2 * rcp64(4.0 * (c.nu1[k] * R.ws) * dx / R.Uinf + eps2);
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {  // (a real loop: the state is addressed in LDS, nothing needs a static index)
+      double Vj[3], Wj[3];
 #pragma unroll
-    for (int m = 0; m < 7; ++m) {
-      const double zc = (double)(m - 3) * qd + neps, zm = zc + twoHH;
-      const double tr = (1.0 - Ey * c.ezc[m]) * rcp64(yL2 + zc * zc);   // core / r of a real vortex at offset zc
-      double tm = rcp64(yL2 + zm * zm);                                   // ... of a mirror vortex at zm
-      if (mcore) tm *= 1.0 - Ey * c.ezm7[m];  // (1 - Ey ezm == 1.0 exactly unless the hub is very low)
-      const double pr = zc * tr, pm = zm * tm;
-      if (m <= 2) {  // real top (k = m), mirror bottom (k = m)
-        Av[m] += Gt * pr - Gb * pm;
-        Bw[m] += Gt * tr - Gb * tm;
-      }
-      if (m >= 4) {  // real bottom (k = m - 4), mirror top (k = m - 4)
-        Av[m - 4] += Gb * pr - Gt * pm;
-        Bw[m - 4] += Gb * tr - Gt * tm;
-      }
-      if (m >= 2 && m <= 4) {  // wake rotation, real - mirror (k = m - 2)
-        Av[m - 2] += Gw * (pr - pm);
-        Bw[m - 2] += Gw * (tr - tm);
-      }
-      // (above two waves per SIMD the 14 interleaved reciprocal chains of a column would not fit the registers)
-      if (WF_RES_OCC > 2 && (m & 1)) __builtin_amdgcn_sched_barrier(0);
-    }
+      for (int k = 0; k < 3; ++k) { Vj[k] = RES_ST(9 + j * 3 + k, t); Wj[k] = RES_ST(18 + j * 3 + k, t); }
+      const double yL = (y_t + c.off[j] - y_i) + neps;
+      const double yL2 = yL * yL;
+      const double Ey = exp(-yL2 * ieps2);
+      double Av[3] = {0.0, 0.0, 0.0}, Bw[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double w = -yL * Bw[k] * dec[k];
-      RES_ST(9 + j * 3 + k, t) = Vj[k] + Av[k] * dec[k];
-      RES_ST(18 + j * 3 + k, t) = Wj[k] + ((w < 0.0) ? 0.0 : w);  // quirk (5) [A.6]
+      for (int m = 0; m < 7; ++m) {
+        const double zc = (double)(m - 3) * qd + neps, zm = zc + twoHH;
+        const double tr = (1.0 - Ey * c.ezc[m]) * rcp64(yL2 + zc * zc);   // core / r of a real vortex at offset zc
+        double tm = rcp64(yL2 + zm * zm);                                   // ... of a mirror vortex at zm
+        if (mcore) tm *= 1.0 - Ey * c.ezm7[m];  // (1 - Ey ezm == 1.0 exactly unless the hub is very low)
+        const double pr = zc * tr, pm = zm * tm;
+        if (m <= 2) {  // real top (k = m), mirror bottom (k = m)
+          Av[m] += Gt * pr - Gb * pm;
+          Bw[m] += Gt * tr - Gb * tm;
+        }
+        if (m >= 4) {  // real bottom (k = m - 4), mirror top (k = m - 4)
+          Av[m - 4] += Gb * pr - Gt * pm;
+          Bw[m - 4] += Gb * tr - Gt * tm;
+        }
+        if (m >= 2 && m <= 4) {  // wake rotation, real - mirror (k = m - 2)
+          Av[m - 2] += Gw * (pr - pm);
+          Bw[m - 2] += Gw * (tr - tm);
+        }
+        // (the scheduler interleaves all 14 reciprocal chains of a column otherwise: 250 registers; the other waves of
+        // the SIMD hide the latency of one chain at a time)
+        if (WF_RES_OCC > 2 && (m & 1)) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double w = -yL * Bw[k] * dec[k];
+        RES_ST(9 + j * 3 + k, t) = Vj[k] + Av[k] * dec[k];
+        RES_ST(18 + j * 3 + k, t) = Wj[k] + ((w < 0.0) ? 0.0 : w);  // quirk (5) [A.6]
+      }
     }
   }
 }
 
-// ---- 2 and the source-only part of 3 + 6 + 8: steering, deflection / deficit / turbulence constants (wave 3, beside the
-// transverse pass) ----
-__device__ __noinline__ void res_source_chain(int i) {
+// ---- 2, 5 and the source-only part of 3 + 6: steering, yaw-added recovery, deflection / deficit constants ----
+__device__ __noinline__ void res_source_finish(int i) {
   const WfResolveConsts& c = R.c;
-  const SrcShared& s0 = R.s[threadIdx.x >> 6];
-  const double cg = RES_CG(i), sg = RES_SG(i), ct = s0.ct, D = c.D;
-  double val = s0.val;
+  const SrcShared& s0 = R.s;
+  const double cg = RES_CG(i), sg = RES_SG(i), ct = s0.ct, ubar = s0.ubar, D = c.D;
+  double val = s0.cgv;  // parked by res_source_begin
   val = fmin(fmax(val, -1.0), 1.0);
   const double asv = __any(fabs(val) > 0.3) ? asin(val) : asin_small(val);
   const double g_off = c.sw_steer ? 0.5 * asv : 0.0;  // radians added to the commanded yaw
+  double dTI = 0.0;
+  {  // 5. yaw-added recovery [A.3-5] (the source's own transverse contribution is in V / W now)
+    double vsum = 0.0, wsum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { vsum += RES_ST(9 + q, i); wsum += RES_ST(18 + q, i); }
+    const double I = s0.TIs[0];
+    const double k_tke = (ubar * I) * (ubar * I) / (2.0 / 3.0);
+    const double vbar = vsum / 9.0, wbar = wsum / 9.0;
+    const double I_tot = sqrt((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) / ubar;
+    if (c.sw_yar) dTI = c.gch_gain * (I_tot - I);
+  }
   // cosd(-g_eff) = cos(g + d), d = asin(val) / 2: half-angle formulas instead of a second cosine
   const double c2d = sqrt(fmax(1.0 - val * val, 0.0)), cd = sqrt(0.5 * (1.0 + c2d)), sd = 0.5 * val / cd;
   const double cgd = c.sw_steer ? cg * cd - sg * sd : cg;
@@ -295,150 +300,132 @@ __device__ __noinline__ void res_source_chain(int i) {
   const double sy0d = sz0d * cgd * c.cos_veer;
   const double sM = sqrt(M0);
   const double sz0v = D * 0.5 * sqrt((ct / (2.0 * (1.0 - s_c))) / (1.0 + s_c));
-  if ((threadIdx.x & 63) == 0) {
-    FinShared& f = R.f;
-    f.cgd = cgd; f.s_cc = s_cc; f.s_c = s_c; f.th0 = th0; f.tan_th0 = tan_th0; f.M0 = M0;
-    f.E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
-    f.sM = sM; f.sz0d = sz0d; f.sy0d = sy0d; f.is0d = 1.0 / (sy0d * sz0d); f.lnAB = (1.6 + sM) / (1.6 - sM);
-    f.sz0v = sz0v; f.sy0v = sz0v * cg * c.cos_veer; f.snw = c.near_c * sqrt(ct / 2.0); f.kdef = ct * cg * D * D / 8.0;
-    f.ch_pref = c.ch_constant * exp(c.ch_ai * log(s0.ai)) * c.ch_amb_pow;
-    f.cgv = cg;  // cosd(-g)
+  const int lane = threadIdx.x;
+  if (lane < 3) RES_ST(27 + lane, i) = s0.TIs[lane] + dTI;
+  if (lane == 0) {
+    SrcShared& s = R.s;
+    s.dTI = dTI; s.cgd = cgd; s.s_cc = s_cc; s.s_c = s_c; s.th0 = th0; s.tan_th0 = tan_th0; s.M0 = M0;
+    s.E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
+    s.sM = sM; s.sz0d = sz0d; s.sy0d = sy0d; s.is0d = 1.0 / (sy0d * sz0d); s.lnAB = (1.6 + sM) / (1.6 - sM);
+    s.sz0v = sz0v; s.sy0v = sz0v * cg * c.cos_veer; s.snw = c.near_c * sqrt(ct / 2.0); s.kdef = ct * cg * D * D / 8.0;
+    s.ch_pref = c.ch_constant * exp(c.ch_ai * log(s0.ai)) * c.ch_amb_pow;
+    s.cgv = cg;  // cosd(-g)
+    s.same = (s0.TIs[0] == s0.TIs[1]) && (s0.TIs[1] == s0.TIs[2]);
   }
 }
 
-// ---- 5. yaw-added recovery [A.3-5]: the source's own transverse contribution is in V / W now (every wave; returns the
-// increment of the source's TI, which waves 0-2 apply to their column) ----
-__device__ __noinline__ double res_recovery(int i) {
+// ---- 3 + 6 + 7 + 8 on the turbines behind the source: deflection (TI before mixing, effective yaw), deficit (TI after
+// mixing, commanded yaw), SOSFS, Crespo-Hernandez with the overlap count taken as FLORIS takes it ----
+__device__ __noinline__ void res_deficit_pass(int i) {
   const WfResolveConsts& c = R.c;
-  const int wave = threadIdx.x >> 6;
-  const SrcShared& s0 = R.s[wave];
-  double vsum = 0.0, wsum = 0.0;
-#pragma unroll
-  for (int q = 0; q < 9; ++q) { vsum += RES_ST(9 + q, i); wsum += RES_ST(18 + q, i); }
-  const double I = s0.TIs[0], ubar = s0.ubar;
-  const double k_tke = (ubar * I) * (ubar * I) / (2.0 / 3.0);
-  const double vbar = vsum / 9.0, wbar = wsum / 9.0;
-  const double I_tot = sqrt((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) / ubar;
-  const double dTI = c.sw_yar ? c.gch_gain * (I_tot - I) : 0.0;
-  if (wave < 3 && (threadIdx.x & 63) == 0) RES_ST(27 + wave, i) = s0.TIs[wave] + dTI;
-  return dTI;
-}
-
-// ---- 3 + 6 + 7 of grid column j on the turbines behind the source: deflection (TI before mixing, effective yaw), deficit
-// (TI after mixing, commanded yaw), SOSFS; the column's part of the overlap count, taken as FLORIS takes it ----
-__device__ __noinline__ void res_deficit_pass(int i, int j, double dTI) {
-  const WfResolveConsts& c = R.c;
-  const SrcShared& s = R.s[threadIdx.x >> 6];
-  const FinShared& f = R.f;
-  const int lane = threadIdx.x & 63, N = R.N;
-  const bool veer_on = R.veer_on != 0;
-  const double x_i = s.x_i, y_i = s.y_i;
+  const SrcShared& s = R.s;
+  const int lane = threadIdx.x, N = R.N;
+  const bool veer_on = R.veer_on != 0, same = s.same != 0;
+  const double x_i = s.x_i, y_i = s.y_i, D = c.D;
   const double q2 = c.off[2] * c.off[2];
-  // source-side constants of this column [A.3-3, A.3-6]
-  const double TIpre = s.TIs[j];
-  const double x0d = c.D * f.cgd * (1.0 + f.s_cc) / (c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - f.s_c))) + x_i;
-  const double ix0d_rel = 1.0 / (x0d - x_i);
-  const double kyd = c.defl_ka * TIpre + c.defl_kb;
-  const double d0 = f.tan_th0 * (x0d - x_i);
-  const double pfar = f.th0 * f.E0 / 5.2 * sqrt(f.sy0d * f.sz0d / (kyd * kyd * f.M0));
-  const double TIq = TIpre + dTI;
-  const double x0v = c.D * f.cgv * (1.0 + f.s_c) / (c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - f.s_c))) + x_i;
-  const double ix0v_rel = 1.0 / (x0v - x_i);
-  const double kyv = c.ka * TIq + c.kb;
   for (int base = i + 1; base < N; base += 64) {
     const int t = base + lane;
     if (t >= N) continue;
     const double x_t = RES_XS(t), y_t = RES_YS(t);
     const double dx = x_t - x_i;
     const double lin = c.ad + c.bd * dx;
-    // this turbine's column: deflection -> delta; deficit -> amplitude and the Gaussian's 1 / (2 sigma^2)
-    double d_near = (dx * ix0d_rel) * d0 + lin;
-    if (!(x_t <= x0d)) d_near = 0.0;  // [x >= x_i] holds here
-    double d_far = 0.0;
-    if (x_t > x0d) {
-      const double sy = kyd * (x_t - x0d) + f.sy0d, sz = kyd * (x_t - x0d) + f.sz0d;
-      const double sg_ = sqrt(sy * sz * f.is0d);
-      const double ln_arg = f.lnAB * (1.6 * sg_ - f.sM) * rcp64(1.6 * sg_ + f.sM);
-      d_far = d0 + pfar * log(ln_arg) + lin;
-    }
-    const double delta = d_near + d_far;
-    double amp = 0.0, isy2 = 0.0, isz2 = 0.0, sy = 0.0, sz = 0.0;
-    bool on = false;
-    if (x_t > x_i + 0.1 && x_t < x0v) {  // the masks as FLORIS takes them on the coordinates
-      const double up = dx * ix0v_rel, dn = (x0v - x_t) * ix0v_rel;
-      sy = dn * f.snw + up * f.sy0v;
-      sz = dn * f.snw + up * f.sz0v;
-      on = true;
-    } else if (x_t >= x0v) {
-      sy = kyv * (x_t - x0v) + f.sy0v;
-      sz = kyv * (x_t - x0v) + f.sz0v;
-      on = true;
-    }
-    if (on) {
-      const double isy = rcp64(sy), isz = rcp64(sz);
-      double dd = 1.0 - f.kdef * isy * isz;
-      dd = fmin(fmax(dd, 0.0), 1.0);
-      amp = 1.0 - sqrt(dd);
-      isy2 = 0.5 * isy * isy;
-      isz2 = 0.5 * isz * isz;
-    }
-    const double yy = (y_t + c.off[j]) - y_i - delta;
-    double def[3];
-    if (!veer_on) {  // r = yy^2 / (2 sy^2) + zz^2 / (2 sz^2), zz = -q, 0, +q
-      const double e1 = amp * exp(-(yy * yy) * isy2);
-      const double e0 = e1 * exp(-q2 * isz2);
-      def[0] = e0; def[1] = e1; def[2] = e0;
-    } else {  // FLORIS rCalt [gauss.py]: the Gaussian rotated by the veer angle
-      const double ca = c.cos2_veer * isy2 + c.sin2_veer * isz2;
-      const double cb = 0.5 * c.sin_2veer * (isz2 - isy2);
-      const double cc = c.sin2_veer * isy2 + c.cos2_veer * isz2;
+    int cnt = 0;
+    double delta = 0.0, amp = 0.0, isy2 = 0.0, isz2 = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+      if (j == 0 || !same) {  // (one column serves all three when the source's TIs agree)
+        // source-side constants of this column [A.3-3, A.3-6]
+        const double TIpre = s.TIs[j];
+        const double x0d = c.D * s.cgd * (1.0 + s.s_cc) / (c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - s.s_c))) + x_i;
+        const double ix0d_rel = 1.0 / (x0d - x_i);
+        const double kyd = c.defl_ka * TIpre + c.defl_kb;
+        const double d0 = s.tan_th0 * (x0d - x_i);
+        const double TIq = TIpre + s.dTI;
+        const double x0v = c.D * s.cgv * (1.0 + s.s_c) / (c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - s.s_c))) + x_i;
+        const double ix0v_rel = 1.0 / (x0v - x_i);
+        const double kyv = c.ka * TIq + c.kb;
+        // this turbine's column: deflection -> delta; deficit -> amplitude and the Gaussian's 1 / (2 sigma^2)
+        double d_near = (dx * ix0d_rel) * d0 + lin;
+        if (!(x_t <= x0d)) d_near = 0.0;  // [x >= x_i] holds here
+        double d_far = 0.0;
+        if (x_t > x0d) {
+          const double pfar = s.th0 * s.E0 / 5.2 * sqrt(s.sy0d * s.sz0d / (kyd * kyd * s.M0));
+          const double sy = kyd * (x_t - x0d) + s.sy0d, sz = kyd * (x_t - x0d) + s.sz0d;
+          const double sg_ = sqrt(sy * sz * s.is0d);
+          const double ln_arg = s.lnAB * (1.6 * sg_ - s.sM) * rcp64(1.6 * sg_ + s.sM);
+          d_far = d0 + pfar * log(ln_arg) + lin;
+        }
+        delta = d_near + d_far;
+        amp = 0.0; isy2 = 0.0; isz2 = 0.0;
+        double sy = 0.0, sz = 0.0;
+        bool on = false;
+        if (x_t > x_i + 0.1 && x_t < x0v) {  // the masks as FLORIS takes them on the coordinates
+          const double up = dx * ix0v_rel, dn = (x0v - x_t) * ix0v_rel;
+          sy = dn * s.snw + up * s.sy0v;
+          sz = dn * s.snw + up * s.sz0v;
+          on = true;
+        } else if (x_t >= x0v) {
+          sy = kyv * (x_t - x0v) + s.sy0v;
+          sz = kyv * (x_t - x0v) + s.sz0v;
+          on = true;
+        }
+        if (on) {
+          const double isy = rcp64(sy), isz = rcp64(sz);
+          double dd = 1.0 - s.kdef * isy * isz;
+          dd = fmin(fmax(dd, 0.0), 1.0);
+          amp = 1.0 - sqrt(dd);
+          isy2 = 0.5 * isy * isy;
+          isz2 = 0.5 * isz * isz;
+        }
+      }
+      const double yy = (y_t + c.off[j]) - y_i - delta;
+      double def[3];
+      if (!veer_on) {  // r = yy^2 / (2 sy^2) + zz^2 / (2 sz^2), zz = -q, 0, +q
+        const double e1 = amp * exp(-(yy * yy) * isy2);
+        const double e0 = e1 * exp(-q2 * isz2);
+        def[0] = e0; def[1] = e1; def[2] = e0;
+      } else {  // FLORIS rCalt [gauss.py]: the Gaussian rotated by the veer angle
+        const double ca = c.cos2_veer * isy2 + c.sin2_veer * isz2;
+        const double cb = 0.5 * c.sin_2veer * (isz2 - isy2);
+        const double cc = c.sin2_veer * isy2 + c.cos2_veer * isz2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double zz = c.off[k];
+          def[k] = amp * exp(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const double zz = c.off[k];
-        def[k] = amp * exp(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
+        const double dU = def[k] * R.Uinit[k];
+        if (dU > c.overlap_thr) ++cnt;  // the comparison as FLORIS takes it [A.3-8]
+        RES_ST(j * 3 + k, t) = fma(dU, dU, RES_ST(j * 3 + k, t));  // 7. SOSFS [A.3-7]: the sum of squares, root taken where needed
       }
     }
-    int cnt = 0;
+    // 8. Crespo-Hernandez + overlap gating [A.3-8]
+    const bool reach = (x_t > x_i) && (x_t <= x_i + 15.0 * D);
+    bool gate[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double dU = def[k] * R.Uinit[k];
-      if (dU > c.overlap_thr) ++cnt;  // the comparison as FLORIS takes it [A.3-8]
-      RES_ST(j * 3 + k, t) = fma(dU, dU, RES_ST(j * 3 + k, t));  // 7. SOSFS [A.3-7]: the sum of squares, root taken where needed
+    for (int j = 0; j < 3; ++j) gate[j] = reach && (fabs(y_i - (y_t + c.off[j])) < 2.0 * D);
+    if (gate[0] || gate[1] || gate[2]) {
+      const double dxp = (dx <= 0.1) ? dx + 1.0 : dx;  // dx > -0.1 holds for every downstream turbine
+      double ti = s.ch_pref * exp(c.ch_down * log(dxp / D));
+      if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
+      const double ti_added = ((double)cnt / 9.0) * ti;
+      const double cand = sqrt(ti_added * ti_added + c.amb * c.amb);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (gate[j] && cand > RES_ST(27 + j, t)) RES_ST(27 + j, t) = cand;
     }
-    RES_CNT(j, t) = cnt;
-  }
-}
-
-// ---- 8. Crespo-Hernandez + overlap gating [A.3-8] of grid column j (the overlap count is the sum over the three columns) ----
-__device__ __noinline__ void res_turbulence_pass(int i, int j) {
-  const WfResolveConsts& c = R.c;
-  const SrcShared& s = R.s[threadIdx.x >> 6];
-  const int lane = threadIdx.x & 63, N = R.N;
-  const double x_i = s.x_i, y_i = s.y_i, D = c.D, ch_pref = R.f.ch_pref;
-  for (int base = i + 1; base < N; base += 64) {
-    const int t = base + lane;
-    if (t >= N) continue;
-    const double x_t = RES_XS(t), y_t = RES_YS(t);
-    const bool gate = (x_t > x_i) && (x_t <= x_i + 15.0 * D) && (fabs(y_i - (y_t + c.off[j])) < 2.0 * D);
-    if (!gate) continue;
-    const double dx = x_t - x_i;
-    const int cnt = RES_CNT(0, t) + RES_CNT(1, t) + RES_CNT(2, t);
-    const double dxp = (dx <= 0.1) ? dx + 1.0 : dx;  // dx > -0.1 holds for every downstream turbine
-    double ti = ch_pref * exp(c.ch_down * log(dxp / D));
-    if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
-    const double ti_added = ((double)cnt / 9.0) * ti;
-    const double cand = sqrt(ti_added * ti_added + c.amb * c.amb);
-    if (cand > RES_ST(27 + j, t)) RES_ST(27 + j, t) = cand;
   }
 }
 
 // ---- outputs [A.4] in the caller's turbine order; the farm's reward ----
 __device__ __noinline__ void res_outputs(const WfResolveArgs& a, int b, size_t gofs) {
   const WfResolveConsts& c = R.c;
-  const int N = R.N;
+  const int lane = threadIdx.x, N = R.N;
   const double wd = R.wd;
   double psum = 0.0, lsum = 0.0;
-  for (int t = threadIdx.x; t < N; t += 256) {
+  for (int t = lane; t < N; t += 64) {
     const int o = a.gidx[gofs + t];
     double m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0, dir = 0.0;
     bool small = true;
@@ -486,18 +473,14 @@ __device__ __noinline__ void res_outputs(const WfResolveArgs& a, int b, size_t g
       psum += __shfl_xor(psum, w);
       lsum += __shfl_xor(lsum, w);
     }
-    if ((threadIdx.x & 63) == 0) { R.red[threadIdx.x >> 6][0] = psum; R.red[threadIdx.x >> 6][1] = lsum; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double ps = 0.0, ls = 0.0;
-      for (int w = 0; w < 4; ++w) { ps += R.red[w][0]; ls += R.red[w][1]; }
+    if (lane == 0) {
       const double wr = a.ws_prev ? a.ws_prev[b] : R.ws;
-      a.reward[b] = (float)(ps / N / 1.0e6 * 1.0e3 / (wr * wr * wr) - (double)a.load_coef * ls / (4.0 * N));
+      a.reward[b] = (float)(psum / N / 1.0e6 * 1.0e3 / (wr * wr * wr) - (double)a.load_coef * lsum / (4.0 * N));
     }
   }
 }
 
-#ifdef WF_RES_STAMP  // debug build (tools/res_stamps.py): wave cycles per phase (wave 0), summed over the launch
+#ifdef WF_RES_STAMP  // debug build (tools/res_stamps.py): wave cycles per phase, summed over the launch
 __device__ unsigned long long wf_res_stamp[8];
 #define RES_T(v) const unsigned long long v = __builtin_readcyclecounter()
 #define RES_ACC(k, a, b) st_acc[k] += (b) - (a)
@@ -505,14 +488,14 @@ __device__ unsigned long long wf_res_stamp[8];
 #define RES_T(v)
 #define RES_ACC(k, a, b)
 #endif
-__global__ __launch_bounds__(256, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a, int n_pad) {
-  const int tid = threadIdx.x, wave = tid >> 6;
+__global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a, int n_pad) {
+  const int lane = threadIdx.x;
   const int N = c_arg.N;
-  if (tid == 0) {
+  if (lane == 0) {
     R.c = c_arg;
     R.N = N; R.n_pad = n_pad; R.veer_on = c_arg.sin2_veer != 0.0; R.mcore = c_arg.mirror_core;
   }
-  for (int k = tid; k < c_arg.n_table; k += 256) {
+  for (int k = lane; k < c_arg.n_table; k += 64) {
     R.tws[k] = a.tab64[k];
     R.tct[k] = a.tab64[WF_TABLE_PAD + k];
     R.tpw[k] = a.tab64[2 * WF_TABLE_PAD + k];
@@ -525,15 +508,15 @@ __global__ __launch_bounds__(256, WF_RES_OCC) void wf_resolve_kernel(const WfRes
     else gofs = (size_t)b * a.geom_stride;
     const float* yaw_b = (a.yaw_state ? a.yaw_state : a.yaw_in) + (size_t)b * N;
     RES_T(t_farm);
-    __syncthreads();  // the constants are in place / the previous farm's last readers are done
-    if (tid == 0) {
+    __syncthreads();  // (one wave: orders the constants / the previous farm's last reads before the new contents)
+    if (lane == 0) {
       const double ws = a.ws[(size_t)b * a.wind_stride];
       double wd = fmod(a.wd[(size_t)b * a.wind_stride], 360.0);  // reference interface.py:664 (Python's %)
       if (wd < 0.0) wd += 360.0;
       R.ws = ws; R.wd = wd; R.Uinf = ws * c_arg.uinf1;  // inflow [A.2]
       for (int k = 0; k < 3; ++k) R.Uinit[k] = ws * c_arg.shearf[k];
     }
-    for (int t = tid; t < N; t += 256) {
+    for (int t = lane; t < N; t += 64) {
       const double g = (double)yaw_b[a.gidx[gofs + t]];
       double sg, cg;
       sincos(g * kDeg, &sg, &cg);
@@ -543,7 +526,7 @@ __global__ __launch_bounds__(256, WF_RES_OCC) void wf_resolve_kernel(const WfRes
       for (int j = 0; j < 3; ++j) res_dyn[(32 + j) * n_pad + t] = c_arg.amb;
     }
     __syncthreads();
-    for (int t = tid; t < N; t += 256) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
+    for (int t = lane; t < N; t += 64) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
       int f = t;
       while (f > 0 && RES_XS(f - 1) == RES_XS(t)) --f;
       RES_TIE(t) = f;
@@ -558,21 +541,11 @@ __global__ __launch_bounds__(256, WF_RES_OCC) void wf_resolve_kernel(const WfRes
       RES_T(t0);
       res_source_begin(i);
       RES_T(t1);
-      if (wave < 3) {
-        if (c_arg.sw_tv) res_transverse_pass(wave);
-      } else {
-        res_source_chain(i);
-      }
-      __syncthreads();
+      if (c_arg.sw_tv) res_transverse_pass();
       RES_T(t2);
-      const double dTI = res_recovery(i);
+      res_source_finish(i);
       RES_T(t3);
-      if (i + 1 < N) {
-        if (wave < 3) res_deficit_pass(i, wave, dTI);
-        __syncthreads();
-        if (wave < 3) res_turbulence_pass(i, wave);
-      }
-      __syncthreads();
+      if (i + 1 < N) res_deficit_pass(i);
       RES_T(t4);
       RES_ACC(0, t0, t1); RES_ACC(1, t1, t2); RES_ACC(2, t2, t3); RES_ACC(3, t3, t4);
     }
@@ -580,9 +553,9 @@ __global__ __launch_bounds__(256, WF_RES_OCC) void wf_resolve_kernel(const WfRes
     res_outputs(a, b, gofs);
     RES_T(t_c);
     RES_ACC(5, t_b, t_c);
-    if (tid == 0) a.flags[b] = 0;
+    if (lane == 0) a.flags[b] = 0;
 #ifdef WF_RES_STAMP
-    if (tid == 0) {
+    if (lane == 0) {
       for (int k = 0; k < 6; ++k) atomicAdd(&wf_res_stamp[k], st_acc[k]);
       atomicAdd(&wf_res_stamp[6], 1ull);
     }
@@ -607,10 +580,10 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(wf_compact_flagged_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a->flags, B, all, a->list, a->count, raw_flags);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  // persistent blocks (one farm each at a time) over the compacted list: enough to fill the chip several times over, never more than farms
-  const int grid = B < 4096 ? B : 4096;
-  const int n_pad = (c->N + 1) & ~1;  // (keeps the int arrays behind the doubles aligned)
-  const size_t dyn = sizeof(double) * 35 * (size_t)n_pad + sizeof(int) * 4 * (size_t)n_pad;
-  hipLaunchKernelGGL(wf_resolve_kernel, dim3(grid), dim3(256), dyn, s, *c, *a, n_pad);
+  // persistent one-wave blocks over the compacted list: enough to fill the chip several times over, never more than farms
+  const int grid = B < 8192 ? B : 8192;
+  const int n_pad = (c->N + 1) & ~1;  // (keeps the int array behind the doubles aligned)
+  const size_t dyn = sizeof(double) * 35 * (size_t)n_pad + sizeof(int) * (size_t)n_pad;
+  hipLaunchKernelGGL(wf_resolve_kernel, dim3(grid), dim3(64), dyn, s, *c, *a, n_pad);
   return hipGetLastError();
 }
