@@ -130,6 +130,12 @@ int pick_ll(const wf_handle* h, int N, int B) {  // returns (G << 4) | S, 0 = ke
   // the cheapest estimate wins: at N = 80 the register-slot kernel up to ~8192 farms, G = 8 up to ~24576, then the two
   // G = 4 kernels depending on how the batch divides into rounds of 32768 / 49152, G = 2 x 2 on whole rounds of 65536
   if (N <= 16) return 0;
+  {  // less than one block per CU of the register-slot kernel: the latency regime, where pick_variant widens that kernel's
+     // lane group (fewer slot passes per source) — the table's throughput variants do not describe it
+    int fpb, per_cu;
+    family_shape(h, 0, N, &fpb, &per_cu);
+    if ((long)B <= (long)h->n_cu * fpb) return 0;
+  }
   int best = 0;
   double t_best = 1e300;
   for (int fi = 0; fi < kNumFamilies; ++fi) {
