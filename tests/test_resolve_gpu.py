@@ -237,3 +237,24 @@ def test_kernel_choice_round_trip_and_errors(layouts):
     assert (info["one_block_kernel"], info["lanes_per_env"], info["slots_per_lane"]) == (1, 4, 2)
     assert np.isfinite(w.step(np.zeros((256, 80), np.float32))["power"]).all()
     w.close()
+
+
+def test_float64_kernel_at_the_abi_turbine_limit():
+    """256 turbines (WF_MAX_TURBINES): the float64 kernel's LDS-resident state is 72 KB per farm there — more than the
+    64 KB a gfx9 workgroup used to get, inside gfx950's 160 KB."""
+    import parity
+    from wfcrl_env_amd.backend import WfStep
+
+    rng = np.random.default_rng(256)
+    N, B = 256, 12
+    x = (np.arange(N) % 16) * 640.0 + rng.uniform(-40, 40, N)
+    y = (np.arange(N) // 16) * 560.0 + rng.uniform(-40, 40, N)
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    ws, wd = rng.uniform(5, 14, B), rng.uniform(0, 360, B)
+    w = WfStep(x, y, env_batch=B)
+    w.set_risk_resolve(2)
+    w.set_wind(ws, wd)
+    out = w.step(yaw)
+    assert w.resolve_stats()["n_resolved"] == B
+    parity.check_strict(out, _oracle(x, y, ws, wd, yaw), parity.TOL_F64)
+    w.close()
