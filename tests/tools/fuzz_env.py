@@ -33,10 +33,8 @@ def run(n_episodes, seed):
             fits = [(g, s) for g in (4, 8, 16, 32) for s in range(1, 7) if g * s >= N0 and (s <= 4 or g == 16)]
             g, s = fits[rng.integers(0, len(fits))]
             gs = f"{g}x{s}"
-            os.environ["WF_KERNEL_GS"] = gs
-        else:
-            os.environ.pop("WF_KERNEL_GS", None)
-        kw = dict(controls=dict(controls), max_num_steps=T, continuous_control=not discrete, load_coef=load_coef)
+        kw = dict(controls=dict(controls), max_num_steps=T, continuous_control=not discrete, load_coef=load_coef,
+                  kernel_choice=dict(slot=gs) if gs else None)
         venv = envs.make(name + "Floris", env_batch=B, **kw)
         N = venv.num_turbines
         ctx = dict(ep=ep, name=name, B=B, T=T, discrete=discrete, controls=controls, load_coef=load_coef, gs=gs)
@@ -80,7 +78,6 @@ def run(n_episodes, seed):
             if why:
                 break
         venv.close()
-    os.environ.pop("WF_KERNEL_GS", None)
     print(f"env fuzz: {n_episodes} episodes, violations: {nbad}")
     return nbad
 
