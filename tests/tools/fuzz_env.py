@@ -33,9 +33,8 @@ def run(n_episodes, seed):
             fits = [(g, s) for g in (4, 8, 16, 32) for s in range(1, 7) if g * s >= N0 and (s <= 4 or g == 16)]
             g, s = fits[rng.integers(0, len(fits))]
             gs = f"{g}x{s}"
-        kw = dict(controls=dict(controls), max_num_steps=T, continuous_control=not discrete, load_coef=load_coef,
-                  kernel_choice=dict(slot=gs) if gs else None)
-        venv = envs.make(name + "Floris", env_batch=B, **kw)
+        kw = dict(controls=dict(controls), max_num_steps=T, continuous_control=not discrete, load_coef=load_coef)
+        venv = envs.make(name + "Floris", env_batch=B, kernel_choice=dict(slot=gs) if gs else None, **kw)
         N = venv.num_turbines
         ctx = dict(ep=ep, name=name, B=B, T=T, discrete=discrete, controls=controls, load_coef=load_coef, gs=gs)
         if rng.random() < 0.5:
