@@ -150,7 +150,8 @@ int wf_sync(wf_handle* h);
  *                       power for 1e-5 deg of wind direction (tests/golden/README: case bad_512_56); float32 wind
  *                       speeds (3e-7 relative each) are amplified the same way.
  * Farms with flag 0 match the float64 path within the parity tolerances; flagged farms may differ by a bounded amount
- * (tests/test_hip_parity.py).  All geometric discontinuities (upstream/downstream order, dx > 0.1, 15 D reach, 2 D
+ * (tests/parity.py: per flag type) — unless wf_set_risk_resolve is on, which solves exactly those farms again in float64
+ * and clears their flags (below).  All geometric discontinuities (upstream/downstream order, dx > 0.1, 15 D reach, 2 D
  * lateral gate) are decided in float64 on the device and need no flag.
  * wf_get_risk_flags copies the flags of the last wf_step / wf_env_step (env_batch ints). */
 #define WF_RISK_OVERLAP 1
