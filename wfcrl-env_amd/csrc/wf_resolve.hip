@@ -150,6 +150,10 @@ __device__ __forceinline__ double cbrt_pos(double x) {
 // deflection-constant chain on a fourth wave beside the transverse pass, three block barriers per source: a farm's
 // latency drops from 1.04 to 0.73 ms, but a farm then takes four wave slots, 1394 farms no longer fit one residency
 // (two rounds at four waves per SIMD: 2.1 ms); better below ~500 flagged farms, worse at the benchmark's count.)
+#ifndef WF_RES_UNROLL_J
+#define WF_RES_UNROLL_J 0  // 1: the three grid columns of the transverse pass interleaved (three times the registers): no gain
+                           // (4.80 against 4.78 ms per step with 1394 farms re-solved, tools/res_ab.sh)
+#endif
 #ifndef WF_RES_OCC
 #define WF_RES_OCC 2  // waves per SIMD the register allocator is asked to make room for (tools/res_occ_sweep.sh)
 #endif
@@ -178,7 +182,16 @@ extern __shared__ double res_dyn[];  // per sorted turbine: x', y', cos / sin / 
 #define RES_TIE(t) (reinterpret_cast<int*>(res_dyn + 35 * R.n_pad)[(t)])
 
 // ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
-__device__ __noinline__ void res_source_begin(int i) {
+#ifndef WF_RES_INLINE_SRC
+#define WF_RES_INLINE_SRC 0  // 1: the two source-only phases inlined into the kernel's loop (two calls per source instead of
+                             // four): slower, 5.18 against 4.78 ms (the loop body then carries their live ranges across the calls)
+#endif
+#if WF_RES_INLINE_SRC
+#define RES_SRC_FN __device__ __forceinline__
+#else
+#define RES_SRC_FN __device__ __noinline__
+#endif
+RES_SRC_FN void res_source_begin(int i) {
   const WfResolveConsts& c = R.c;
   const double cg = RES_CG(i), sg = RES_SG(i);
   double m3 = 0.0, vs = 0.0;
@@ -225,8 +238,12 @@ __device__ __noinline__ void res_transverse_pass() {
     double dec[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) dec[k] = eps2 * rcp64(4.0 * (c.nu1[k] * R.ws) * dx / R.Uinf + eps2);
+#if WF_RES_UNROLL_J
+#pragma unroll
+#else
 #pragma unroll 1
-    for (int j = 0; j < 3; ++j) {  // (a real loop: the state is addressed in LDS, nothing needs a static index)
+#endif
+    for (int j = 0; j < 3; ++j) {  // (a real loop unless WF_RES_UNROLL_J: the state is addressed in LDS, nothing needs a static index)
       double Vj[3], Wj[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { Vj[k] = RES_ST(9 + j * 3 + k, t); Wj[k] = RES_ST(18 + j * 3 + k, t); }
@@ -268,7 +285,7 @@ __device__ __noinline__ void res_transverse_pass() {
 }
 
 // ---- 2, 5 and the source-only part of 3 + 6: steering, yaw-added recovery, deflection / deficit constants ----
-__device__ __noinline__ void res_source_finish(int i) {
+RES_SRC_FN void res_source_finish(int i) {
   const WfResolveConsts& c = R.c;
   const SrcShared& s0 = R.s;
   const double cg = RES_CG(i), sg = RES_SG(i), ct = s0.ct, ubar = s0.ubar, D = c.D;
