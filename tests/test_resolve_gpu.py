@@ -258,3 +258,30 @@ def test_float64_kernel_at_the_abi_turbine_limit():
     assert w.resolve_stats()["n_resolved"] == B
     parity.check_strict(out, _oracle(x, y, ws, wd, yaw), parity.TOL_F64)
     w.close()
+
+
+def test_both_float64_kernels_by_flagged_count(layouts):
+    """Which float64 kernel serves the flagged farms is decided on the device by their number: up to one residency of the
+    four-wave kernel (1024 farms at four per CU on 256 CUs) it runs, beyond that the one-wave kernel.  Mode 2 (every farm)
+    at 700 and at 1500 farms exercises one and the other; both against the CPU oracle, and against each other bit for bit
+    on the farms they share."""
+    import parity
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["Ormonde_"]
+    x, y, N = l["xcoords"], l["ycoords"], l["num_turbines"]
+    rng = np.random.default_rng(1024)
+    Bmax = 1500
+    yaw = rng.uniform(-35, 35, (Bmax, N)).astype(np.float32)
+    ws, wd = _wind(rng, Bmax, "per_env")
+    outs = {}
+    for B in (700, Bmax):
+        w = WfStep(x, y, env_batch=B)
+        w.set_risk_resolve(2)
+        w.set_wind(ws[:B], wd[:B])
+        outs[B] = {k: v.copy() for k, v in w.step(yaw[:B]).items()}
+        assert w.resolve_stats()["n_resolved"] == B
+        parity.check_strict(outs[B], _oracle(x, y, ws[:B], wd[:B], yaw[:B]), parity.TOL_F64)
+        w.close()
+    for k in outs[700]:
+        assert np.abs(outs[700][k].astype(np.float64) - outs[Bmax][k][:700]).max() <= 2e-6 * max(1.0, np.abs(outs[700][k]).max()), k

@@ -367,7 +367,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
     ra.yaw_state = ea->yaw_state; ra.reward = ea->reward; ra.ws_prev = ea->ws_prev; ra.load_coef = ea->load_coef;
   }
   h->rconsts.N = h->N;
-  WF_HIP(h, wfk_launch_resolve(&h->rconsts, &ra, h->B, mode == 2 ? 1 : 0, h->d_flags_raw, h->stream));
+  WF_HIP(h, wfk_launch_resolve(&h->rconsts, &ra, h->B, mode == 2 ? 1 : 0, h->d_flags_raw, h->n_cu, h->stream));
   return WF_OK;
 }
 

@@ -25,7 +25,7 @@
 #include "wf_resolve.h"
 
 extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags,
-                                         hipStream_t s);
+                                         int n_cu, hipStream_t s);
 extern "C" int wfk_num_variants();
 extern "C" void wfk_variant(int i, int* G, int* S, const void** fn);
 extern "C" int wfk_variant_has_table(int i);

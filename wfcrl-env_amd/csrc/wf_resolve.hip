@@ -505,7 +505,7 @@ __device__ unsigned long long wf_res_stamp[8];
 #define RES_T(v)
 #define RES_ACC(k, a, b)
 #endif
-__global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a, int n_pad) {
+__global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a, int n_pad, int min_count) {
   const int lane = threadIdx.x;
   const int N = c_arg.N;
   if (lane == 0) {
@@ -518,6 +518,7 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
     R.tpw[k] = a.tab64[2 * WF_TABLE_PAD + k];
   }
   const int n_list = *a.count;
+  if (n_list < min_count) return;  // (few enough farms for one residency of the four-wave kernel below: it serves them)
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
     const int b = a.list[li];
     size_t gofs = 0;
@@ -580,6 +581,460 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same solve with FOUR waves per farm, for flagged counts that fit one residency of the chip (<= kRes4MaxFarms): there
+// the re-solve is pure latency — one farm's 80-stage chain, whatever the count — and spreading a source step over four
+// waves shortens it (HornsRev1: 1.04 -> 0.73 ms per farm).  Both kernels are enqueued behind the compaction; each reads
+// the count on the device and the one it is not meant for returns at once.
+#ifndef WF_RES4_OCC
+#define WF_RES4_OCC 4  // waves per SIMD = resident farms per CU
+#endif
+// One farm per 256-thread block.  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column TIs,
+// float64 — lives in LDS, structure-of-arrays over the sorted turbine index; a lane is not tied to a turbine: for source i
+// the lanes take the turbines the source can reach, t = first + lane (first = the start of the source's x' tie group for
+// the transverse velocities [A.3-4], i + 1 for deficit and wake-added turbulence), 64 at a time, so the triangle of the
+// recurrence costs 96 instead of 160 passes at N = 80.
+// The kernel is LATENCY-bound (a few thousand flagged farms are one to two waves per SIMD: every float64 operation of the
+// 80-stage dependent chain costs its full latency), so a source step is spread over the block's four waves:
+//   waves 0-2  one rotor-grid column each (lateral offset -D/4, 0, +D/4): the transverse pass and the deflection /
+//              deficit / SOSFS pass of that column on every reachable turbine;
+//   wave 3     the source-only chain of steering, deflection and deficit constants (asin, tan, six roots, the
+//              Crespo-Hernandez prefactor) BESIDE the transverse pass, which does not need it;
+//   all waves  the source's state and circulations (redundantly: each wave keeps its own copy, no barrier) and the
+//              yaw-added recovery once the transverse velocities of all three columns are in.
+// Three block barriers per source: after the transverse pass / the constant chain; after the deficit pass (the overlap
+// count of a turbine is the sum of its three columns' counts, exchanged through LDS); after the turbulence update.
+// The phases are separate NON-INLINED functions that talk through LDS (the per-source constants too): inlined into one
+// body the register allocator kept ~370 values live and spilled inside the source loop.
+// (History: a thread per turbine, state in registers, two __syncthreads per source, every wave re-deriving the source
+// constants: 1.95 ms for 1394 HornsRev1 farms; one wave per farm with the state in LDS: 1.37 ms; profiles/r03_*.)
+struct Src4Shared {  // what res4_source_begin leaves (one copy per wave)
+  double x_i, y_i, ct, ai, ubar, Vmean, val, TIs[3];
+  double Gt, Gb, Gw;  // circulations / (2 pi): top, bottom, wake rotation (commanded yaw)
+  int first_tv;
+};
+struct Fin4Shared {  // the source-only constants of deflection, deficit and wake-added turbulence (written by wave 3)
+  double cgd, s_cc, s_c, th0, tan_th0, M0, E0, sM, sz0d, sy0d, is0d, lnAB, sz0v, sy0v, snw, kdef, ch_pref, cgv;
+};
+struct Res4Shared {
+  WfResolveConsts c;
+  double tws[WF_TABLE_PAD], tct[WF_TABLE_PAD], tpw[WF_TABLE_PAD];
+  double ws, wd, Uinf, Uinit[3];
+  double red[4][2];
+  int N, n_pad, veer_on, mcore;
+  Src4Shared s[4];
+  Fin4Shared f;
+  double own[18];  // V (0..8) and W (9..17) of the source's own turbine after its transverse pass (see res4_transverse_pass)
+};
+__shared__ Res4Shared R4;
+
+#define RES4_XS(t) res_dyn[(t)]
+#define RES4_YS(t) res_dyn[R4.n_pad + (t)]
+#define RES4_CG(t) res_dyn[2 * R4.n_pad + (t)]
+#define RES4_SG(t) res_dyn[3 * R4.n_pad + (t)]
+#define RES4_GR(t) res_dyn[4 * R4.n_pad + (t)]
+#define RES4_ST(q, t) res_dyn[(5 + (q)) * R4.n_pad + (t)]  // wake2 q = 0..8, V 9..17, W 18..26, TI 27..29
+#define RES4_TIE(t) (reinterpret_cast<int*>(res_dyn + 35 * R4.n_pad)[(t)])
+#define RES4_CNT(j, t) (reinterpret_cast<int*>(res_dyn + 35 * R4.n_pad)[(1 + (j)) * R4.n_pad + (t)])  // overlap count of column j
+
+// ---- the source's state and circulations [A.3-1, A.3-2, A.3-4]: every wave, into its own copy ----
+__device__ __noinline__ void res4_source_begin(int i) {
+  const WfResolveConsts& c = R4.c;
+  const int wave = threadIdx.x >> 6;
+  const double cg = RES4_CG(i), sg = RES4_SG(i);
+  double m3 = 0.0, vs = 0.0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const double u = R4.Uinit[q % 3] - sqrt(RES4_ST(q, i));
+    m3 += u * u * u;
+    vs += RES4_ST(9 + q, i);
+  }
+  const double m3m = m3 / 9.0;
+  const double ubar = __any(!(m3m > 1.0e-6)) ? cbrt(m3m) : cbrt_pos(m3m);
+  double ct_tab = interp_fill_uniform(ubar, c.n_table, R4.tws, R4.tct, 0.0001, 0.9999);
+  ct_tab = fmin(fmax(ct_tab, 0.0001), 0.9999);
+  const double ct = ct_tab * cg;
+  const double ai = 0.5 / cg * (1.0 - sqrt(1.0 - ct * cg));
+  const double G_wr = 0.25 * kTwoPi * c.D * (ai - ai * ai) * ubar / c.TSR;
+  const double gam_top = (kTwoPi / 16.0) * c.D * c.vel_top * R4.Uinf * ct;
+  const double gam_bot = (kTwoPi / 16.0) * c.D * c.vel_bot * R4.Uinf * ct;
+  const double sc = sg * cg;
+  if ((threadIdx.x & 63) == 0) {
+    Src4Shared& s = R4.s[wave];
+    s.x_i = RES4_XS(i); s.y_i = RES4_YS(i); s.ct = ct; s.ai = ai; s.ubar = ubar; s.Vmean = vs / 9.0;
+    s.TIs[0] = RES4_ST(27, i); s.TIs[1] = RES4_ST(28, i); s.TIs[2] = RES4_ST(29, i);
+    s.Gt = sc * gam_top / kTwoPi; s.Gb = -sc * gam_bot / kTwoPi; s.Gw = G_wr / kTwoPi;
+    s.first_tv = RES4_TIE(i);
+    // secondary steering [A.3-2]: the three means on the source's own grid are geometry constants
+    const double v_top = gam_top * c.k_top, v_bot = -gam_bot * c.k_bot, v_core = G_wr * c.k_core;
+    s.val = 2.0 * (s.Vmean - v_core) / (v_top + v_bot);
+  }
+}
+
+// ---- 4. transverse velocities (commanded yaw) of grid column j on every turbine at or downstream of the source, ties
+// included; the 7 + 7 distinct vertical offsets of the three vortices and their ground mirrors ----
+// The new V / W of the SOURCE's own turbine go to a side buffer, not into the state: the other waves may still be reading
+// that turbine's V in res4_source_begin (its rotor mean feeds the steering) — res4_recovery commits them after the barrier.
+__device__ __noinline__ void res4_transverse_pass(int i, int j) {
+  const WfResolveConsts& c = R4.c;
+  const Src4Shared& s = R4.s[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63, N = R4.N;
+  const double x_i = s.x_i, y_i = s.y_i, Gt = s.Gt, Gb = s.Gb, Gw = s.Gw;
+  const double qd = c.off[2], neps = c.num_eps, twoHH = 2.0 * c.HH, eps2 = c.eps2, ieps2 = 1.0 / c.eps2;
+  const bool mcore = R4.mcore != 0;
+  for (int base = s.first_tv; base < N; base += 64) {
+    const int t = base + lane;
+    if (t >= N) continue;
+    const double dx = RES4_XS(t) - x_i, y_t = RES4_YS(t);
+    double dec[3], Vj[3], Wj[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      dec[k] = eps2 * rcp64(4.0 * (c.nu1[k] * R4.ws) * dx / R4.Uinf + eps2);
+      Vj[k] = RES4_ST(9 + j * 3 + k, t);
+      Wj[k] = RES4_ST(18 + j * 3 + k, t);
+    }
+    const double yL = (y_t + c.off[j] - y_i) + neps;
+    const double yL2 = yL * yL;
+    const double Ey = exp(-yL2 * ieps2);
+    double Av[3] = {0.0, 0.0, 0.0}, Bw[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+      const double zc = (double)(m - 3) * qd + neps, zm = zc + twoHH;
+      const double tr = (1.0 - Ey * c.ezc[m]) * rcp64(yL2 + zc * zc);   // core / r of a real vortex at offset zc
+      double tm = rcp64(yL2 + zm * zm);                                   // ... of a mirror vortex at zm
+      if (mcore) tm *= 1.0 - Ey * c.ezm7[m];  // (1 - Ey ezm == 1.0 exactly unless the hub is very low)
+      const double pr = zc * tr, pm = zm * tm;
+      if (m <= 2) {  // real top (k = m), mirror bottom (k = m)
+        Av[m] += Gt * pr - Gb * pm;
+        Bw[m] += Gt * tr - Gb * tm;
+      }
+      if (m >= 4) {  // real bottom (k = m - 4), mirror top (k = m - 4)
+        Av[m - 4] += Gb * pr - Gt * pm;
+        Bw[m - 4] += Gb * tr - Gt * tm;
+      }
+      if (m >= 2 && m <= 4) {  // wake rotation, real - mirror (k = m - 2)
+        Av[m - 2] += Gw * (pr - pm);
+        Bw[m - 2] += Gw * (tr - tm);
+      }
+      // (above two waves per SIMD the 14 interleaved reciprocal chains of a column would not fit the registers)
+      if (WF_RES4_OCC > 2 && (m & 1)) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double w = -yL * Bw[k] * dec[k];
+      const double vn = Vj[k] + Av[k] * dec[k], wn = Wj[k] + ((w < 0.0) ? 0.0 : w);  // quirk (5) [A.6]
+      if (t == i) {
+        R4.own[j * 3 + k] = vn;
+        R4.own[9 + j * 3 + k] = wn;
+      } else {
+        RES4_ST(9 + j * 3 + k, t) = vn;
+        RES4_ST(18 + j * 3 + k, t) = wn;
+      }
+    }
+  }
+}
+
+// ---- 2 and the source-only part of 3 + 6 + 8: steering, deflection / deficit / turbulence constants (wave 3, beside the
+// transverse pass) ----
+__device__ __noinline__ void res4_source_chain(int i) {
+  const WfResolveConsts& c = R4.c;
+  const Src4Shared& s0 = R4.s[threadIdx.x >> 6];
+  const double cg = RES4_CG(i), sg = RES4_SG(i), ct = s0.ct, D = c.D;
+  double val = s0.val;
+  val = fmin(fmax(val, -1.0), 1.0);
+  const double asv = __any(fabs(val) > 0.3) ? asin(val) : asin_small(val);
+  const double g_off = c.sw_steer ? 0.5 * asv : 0.0;  // radians added to the commanded yaw
+  // cosd(-g_eff) = cos(g + d), d = asin(val) / 2: half-angle formulas instead of a second cosine
+  const double c2d = sqrt(fmax(1.0 - val * val, 0.0)), cd = sqrt(0.5 * (1.0 + c2d)), sd = 0.5 * val / cd;
+  const double cgd = c.sw_steer ? cg * cd - sg * sd : cg;
+  const double gd_rad = -(RES4_GR(i) + g_off);  // -(g + d) in radians
+  const double s_cc = sqrt(1.0 - ct * cgd), s_c = sqrt(1.0 - ct);
+  const double th0 = c.dm * (0.3 * gd_rad / cgd) * (1.0 - s_cc);
+  const double tan_th0 = __any(fabs(th0) > 0.5) ? tan(th0) : tan_small(th0);
+  const double C0 = 1.0 - s_c;
+  const double M0 = C0 * (2.0 - C0);
+  const double sz0d = D * 0.5 * sqrt((ct * cgd / (2.0 * (1.0 - s_cc))) / (1.0 + s_c));
+  const double sy0d = sz0d * cgd * c.cos_veer;
+  const double sM = sqrt(M0);
+  const double sz0v = D * 0.5 * sqrt((ct / (2.0 * (1.0 - s_c))) / (1.0 + s_c));
+  if ((threadIdx.x & 63) == 0) {
+    Fin4Shared& f = R4.f;
+    f.cgd = cgd; f.s_cc = s_cc; f.s_c = s_c; f.th0 = th0; f.tan_th0 = tan_th0; f.M0 = M0;
+    f.E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
+    f.sM = sM; f.sz0d = sz0d; f.sy0d = sy0d; f.is0d = 1.0 / (sy0d * sz0d); f.lnAB = (1.6 + sM) / (1.6 - sM);
+    f.sz0v = sz0v; f.sy0v = sz0v * cg * c.cos_veer; f.snw = c.near_c * sqrt(ct / 2.0); f.kdef = ct * cg * D * D / 8.0;
+    f.ch_pref = c.ch_constant * exp(c.ch_ai * log(s0.ai)) * c.ch_amb_pow;
+    f.cgv = cg;  // cosd(-g)
+  }
+}
+
+// ---- 5. yaw-added recovery [A.3-5]: the source's own transverse contribution is in V / W now (every wave; returns the
+// increment of the source's TI, which waves 0-2 apply to their column) ----
+__device__ __noinline__ double res4_recovery(int i) {
+  const WfResolveConsts& c = R4.c;
+  const int wave = threadIdx.x >> 6;
+  const Src4Shared& s0 = R4.s[wave];
+  double vsum = 0.0, wsum = 0.0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { vsum += R4.own[q]; wsum += R4.own[9 + q]; }
+  const double I = s0.TIs[0], ubar = s0.ubar;
+  const double k_tke = (ubar * I) * (ubar * I) / (2.0 / 3.0);
+  const double vbar = vsum / 9.0, wbar = wsum / 9.0;
+  const double I_tot = sqrt((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) / ubar;
+  const double dTI = c.sw_yar ? c.gch_gain * (I_tot - I) : 0.0;
+  if (wave < 3 && (threadIdx.x & 63) == 0) RES4_ST(27 + wave, i) = s0.TIs[wave] + dTI;
+  if (wave < 3 && (threadIdx.x & 63) < 3) {  // commit the source's own column (nothing reads it before the next barrier)
+    const int q = wave * 3 + (threadIdx.x & 63);
+    RES4_ST(9 + q, i) = R4.own[q];
+    RES4_ST(18 + q, i) = R4.own[9 + q];
+  }
+  return dTI;
+}
+
+// ---- 3 + 6 + 7 of grid column j on the turbines behind the source: deflection (TI before mixing, effective yaw), deficit
+// (TI after mixing, commanded yaw), SOSFS; the column's part of the overlap count, taken as FLORIS takes it ----
+__device__ __noinline__ void res4_deficit_pass(int i, int j, double dTI) {
+  const WfResolveConsts& c = R4.c;
+  const Src4Shared& s = R4.s[threadIdx.x >> 6];
+  const Fin4Shared& f = R4.f;
+  const int lane = threadIdx.x & 63, N = R4.N;
+  const bool veer_on = R4.veer_on != 0;
+  const double x_i = s.x_i, y_i = s.y_i;
+  const double q2 = c.off[2] * c.off[2];
+  // source-side constants of this column [A.3-3, A.3-6]
+  const double TIpre = s.TIs[j];
+  const double x0d = c.D * f.cgd * (1.0 + f.s_cc) / (c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - f.s_c))) + x_i;
+  const double ix0d_rel = 1.0 / (x0d - x_i);
+  const double kyd = c.defl_ka * TIpre + c.defl_kb;
+  const double d0 = f.tan_th0 * (x0d - x_i);
+  const double pfar = f.th0 * f.E0 / 5.2 * sqrt(f.sy0d * f.sz0d / (kyd * kyd * f.M0));
+  const double TIq = TIpre + dTI;
+  const double x0v = c.D * f.cgv * (1.0 + f.s_c) / (c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - f.s_c))) + x_i;
+  const double ix0v_rel = 1.0 / (x0v - x_i);
+  const double kyv = c.ka * TIq + c.kb;
+  for (int base = i + 1; base < N; base += 64) {
+    const int t = base + lane;
+    if (t >= N) continue;
+    const double x_t = RES4_XS(t), y_t = RES4_YS(t);
+    const double dx = x_t - x_i;
+    const double lin = c.ad + c.bd * dx;
+    // this turbine's column: deflection -> delta; deficit -> amplitude and the Gaussian's 1 / (2 sigma^2)
+    double d_near = (dx * ix0d_rel) * d0 + lin;
+    if (!(x_t <= x0d)) d_near = 0.0;  // [x >= x_i] holds here
+    double d_far = 0.0;
+    if (x_t > x0d) {
+      const double sy = kyd * (x_t - x0d) + f.sy0d, sz = kyd * (x_t - x0d) + f.sz0d;
+      const double sg_ = sqrt(sy * sz * f.is0d);
+      const double ln_arg = f.lnAB * (1.6 * sg_ - f.sM) * rcp64(1.6 * sg_ + f.sM);
+      d_far = d0 + pfar * log(ln_arg) + lin;
+    }
+    const double delta = d_near + d_far;
+    double amp = 0.0, isy2 = 0.0, isz2 = 0.0, sy = 0.0, sz = 0.0;
+    bool on = false;
+    if (x_t > x_i + 0.1 && x_t < x0v) {  // the masks as FLORIS takes them on the coordinates
+      const double up = dx * ix0v_rel, dn = (x0v - x_t) * ix0v_rel;
+      sy = dn * f.snw + up * f.sy0v;
+      sz = dn * f.snw + up * f.sz0v;
+      on = true;
+    } else if (x_t >= x0v) {
+      sy = kyv * (x_t - x0v) + f.sy0v;
+      sz = kyv * (x_t - x0v) + f.sz0v;
+      on = true;
+    }
+    if (on) {
+      const double isy = rcp64(sy), isz = rcp64(sz);
+      double dd = 1.0 - f.kdef * isy * isz;
+      dd = fmin(fmax(dd, 0.0), 1.0);
+      amp = 1.0 - sqrt(dd);
+      isy2 = 0.5 * isy * isy;
+      isz2 = 0.5 * isz * isz;
+    }
+    const double yy = (y_t + c.off[j]) - y_i - delta;
+    double def[3];
+    if (!veer_on) {  // r = yy^2 / (2 sy^2) + zz^2 / (2 sz^2), zz = -q, 0, +q
+      const double e1 = amp * exp(-(yy * yy) * isy2);
+      const double e0 = e1 * exp(-q2 * isz2);
+      def[0] = e0; def[1] = e1; def[2] = e0;
+    } else {  // FLORIS rCalt [gauss.py]: the Gaussian rotated by the veer angle
+      const double ca = c.cos2_veer * isy2 + c.sin2_veer * isz2;
+      const double cb = 0.5 * c.sin_2veer * (isz2 - isy2);
+      const double cc = c.sin2_veer * isy2 + c.cos2_veer * isz2;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double zz = c.off[k];
+        def[k] = amp * exp(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
+      }
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double dU = def[k] * R4.Uinit[k];
+      if (dU > c.overlap_thr) ++cnt;  // the comparison as FLORIS takes it [A.3-8]
+      RES4_ST(j * 3 + k, t) = fma(dU, dU, RES4_ST(j * 3 + k, t));  // 7. SOSFS [A.3-7]: the sum of squares, root taken where needed
+    }
+    RES4_CNT(j, t) = cnt;
+  }
+}
+
+// ---- 8. Crespo-Hernandez + overlap gating [A.3-8] of grid column j (the overlap count is the sum over the three columns) ----
+__device__ __noinline__ void res4_turbulence_pass(int i, int j) {
+  const WfResolveConsts& c = R4.c;
+  const Src4Shared& s = R4.s[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63, N = R4.N;
+  const double x_i = s.x_i, y_i = s.y_i, D = c.D, ch_pref = R4.f.ch_pref;
+  for (int base = i + 1; base < N; base += 64) {
+    const int t = base + lane;
+    if (t >= N) continue;
+    const double x_t = RES4_XS(t), y_t = RES4_YS(t);
+    const bool gate = (x_t > x_i) && (x_t <= x_i + 15.0 * D) && (fabs(y_i - (y_t + c.off[j])) < 2.0 * D);
+    if (!gate) continue;
+    const double dx = x_t - x_i;
+    const int cnt = RES4_CNT(0, t) + RES4_CNT(1, t) + RES4_CNT(2, t);
+    const double dxp = (dx <= 0.1) ? dx + 1.0 : dx;  // dx > -0.1 holds for every downstream turbine
+    double ti = ch_pref * exp(c.ch_down * log(dxp / D));
+    if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
+    const double ti_added = ((double)cnt / 9.0) * ti;
+    const double cand = sqrt(ti_added * ti_added + c.amb * c.amb);
+    if (cand > RES4_ST(27 + j, t)) RES4_ST(27 + j, t) = cand;
+  }
+}
+
+// ---- outputs [A.4] in the caller's turbine order; the farm's reward ----
+__device__ __noinline__ void res4_outputs(const WfResolveArgs& a, int b, size_t gofs) {
+  const WfResolveConsts& c = R4.c;
+  const int N = R4.N;
+  const double wd = R4.wd;
+  double psum = 0.0, lsum = 0.0;
+  for (int t = threadIdx.x; t < N; t += 256) {
+    const int o = a.gidx[gofs + t];
+    double m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0, dir = 0.0;
+    bool small = true;
+#pragma unroll 1
+    for (int q = 0; q < 9; ++q) {  // (runtime loops over the grid points: the state is read from LDS where it is needed)
+      const double u = R4.Uinit[q % 3] - sqrt(RES4_ST(q, t)), v = RES4_ST(9 + q, t);
+      m3 += u * u * u;
+      mu += u; mv += v; mw += RES4_ST(18 + q, t);
+      small = small && (u > 0.0) && (fabs(v) <= 0.1 * u);
+    }
+    if (__all(small)) {
+#pragma unroll 1
+      for (int q = 0; q < 9; ++q) {
+        const double u = R4.Uinit[q % 3] - sqrt(RES4_ST(q, t));
+        dir += wd - atan_small(RES4_ST(9 + q, t) * rcp64(u)) / kDeg;
+      }
+    } else {
+#pragma unroll 1
+      for (int q = 0; q < 9; ++q) dir += wd - atan2(RES4_ST(9 + q, t), R4.Uinit[q % 3] - sqrt(RES4_ST(q, t))) / kDeg;
+    }
+    mu /= 9.0; mv /= 9.0; mw /= 9.0;
+    double su = 0.0, sv = 0.0, sw = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < 9; ++q) {
+      const double u = R4.Uinit[q % 3] - sqrt(RES4_ST(q, t)), v = RES4_ST(9 + q, t), w = RES4_ST(18 + q, t);
+      su += (u - mu) * (u - mu);
+      sv += (v - mv) * (v - mv);
+      sw += (w - mw) * (w - mw);
+    }
+    const double wsp = cbrt(m3 / 9.0);
+    const double veff = c.dens_cbrt * (wsp * exp(c.pP3 * log(RES4_CG(t))));
+    const double pw = c.rho_ref * interp_fill(veff, c.n_table, R4.tws, R4.tpw, 0.0, 0.0);
+    const double l0 = (RES4_ST(27, t) + RES4_ST(28, t) + RES4_ST(29, t)) / 3.0, l1 = sqrt(su / 9.0), l2 = sqrt(sv / 9.0), l3 = sqrt(sw / 9.0);
+    psum += pw;
+    lsum += fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3);
+    const size_t oo = (size_t)b * N + o;
+    if (a.o_power) a.o_power[oo] = (float)pw;
+    if (a.o_ws) a.o_ws[oo] = (float)wsp;
+    if (a.o_wd) a.o_wd[oo] = (float)(dir / 9.0);
+    if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = make_float4((float)l0, (float)l1, (float)l2, (float)l3);
+  }
+  if (a.reward) {  // reference simple_env.py:78-84 on the float64 values
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+      psum += __shfl_xor(psum, w);
+      lsum += __shfl_xor(lsum, w);
+    }
+    if ((threadIdx.x & 63) == 0) { R4.red[threadIdx.x >> 6][0] = psum; R4.red[threadIdx.x >> 6][1] = lsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double ps = 0.0, ls = 0.0;
+      for (int w = 0; w < 4; ++w) { ps += R4.red[w][0]; ls += R4.red[w][1]; }
+      const double wr = a.ws_prev ? a.ws_prev[b] : R4.ws;
+      a.reward[b] = (float)(ps / N / 1.0e6 * 1.0e3 / (wr * wr * wr) - (double)a.load_coef * ls / (4.0 * N));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfResolveConsts c_arg, const WfResolveArgs a, int n_pad, int max_count) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int N = c_arg.N;
+  if (tid == 0) {
+    R4.c = c_arg;
+    R4.N = N; R4.n_pad = n_pad; R4.veer_on = c_arg.sin2_veer != 0.0; R4.mcore = c_arg.mirror_core;
+  }
+  for (int k = tid; k < c_arg.n_table; k += 256) {
+    R4.tws[k] = a.tab64[k];
+    R4.tct[k] = a.tab64[WF_TABLE_PAD + k];
+    R4.tpw[k] = a.tab64[2 * WF_TABLE_PAD + k];
+  }
+  const int n_list = *a.count;
+  if (n_list > max_count) return;  // the one-wave-per-farm kernel serves counts beyond one residency of this one
+  for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const int b = a.list[li];
+    size_t gofs = 0;
+    if (a.farm_group) gofs = (size_t)((a.farm_group[b] + a.shift) % a.mod) * N;
+    else gofs = (size_t)b * a.geom_stride;
+    const float* yaw_b = (a.yaw_state ? a.yaw_state : a.yaw_in) + (size_t)b * N;
+    __syncthreads();  // the constants are in place / the previous farm's last readers are done
+    if (tid == 0) {
+      const double ws = a.ws[(size_t)b * a.wind_stride];
+      double wd = fmod(a.wd[(size_t)b * a.wind_stride], 360.0);  // reference interface.py:664 (Python's %)
+      if (wd < 0.0) wd += 360.0;
+      R4.ws = ws; R4.wd = wd; R4.Uinf = ws * c_arg.uinf1;  // inflow [A.2]
+      for (int k = 0; k < 3; ++k) R4.Uinit[k] = ws * c_arg.shearf[k];
+    }
+    for (int t = tid; t < N; t += 256) {
+      const double g = (double)yaw_b[a.gidx[gofs + t]];
+      double sg, cg;
+      sincos(g * kDeg, &sg, &cg);
+      RES4_XS(t) = a.gx[gofs + t]; RES4_YS(t) = a.gy[gofs + t]; RES4_CG(t) = cg; RES4_SG(t) = sg; RES4_GR(t) = g * kDeg;
+#pragma unroll 1
+      for (int q = 0; q < 27; ++q) res_dyn[(5 + q) * n_pad + t] = 0.0;
+      for (int j = 0; j < 3; ++j) res_dyn[(32 + j) * n_pad + t] = c_arg.amb;
+    }
+    __syncthreads();
+    for (int t = tid; t < N; t += 256) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
+      int f = t;
+      while (f > 0 && RES4_XS(f - 1) == RES4_XS(t)) --f;
+      RES4_TIE(t) = f;
+    }
+    __syncthreads();
+    for (int i = 0; i < N; ++i) {
+      res4_source_begin(i);
+      if (wave < 3) {
+        if (c_arg.sw_tv) res4_transverse_pass(i, wave);
+        else if ((tid & 63) < 3) {  // (no transverse velocities: the side buffer holds the unchanged — zero — state)
+          const int q = wave * 3 + (tid & 63);
+          R4.own[q] = RES4_ST(9 + q, i);
+          R4.own[9 + q] = RES4_ST(18 + q, i);
+        }
+      } else {
+        res4_source_chain(i);
+      }
+      __syncthreads();
+      const double dTI = res4_recovery(i);
+      if (i + 1 < N) {
+        if (wave < 3) res4_deficit_pass(i, wave, dTI);
+        __syncthreads();
+        if (wave < 3) res4_turbulence_pass(i, wave);
+      }
+      __syncthreads();
+    }
+    res4_outputs(a, b, gofs);
+    if (tid == 0) a.flags[b] = 0;
+  }
+}
+
+
 #ifdef WF_RES_STAMP
 extern "C" int wfk_res_stamps(unsigned long long* out, int reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res_stamp), sizeof(wf_res_stamp));
@@ -592,15 +1047,32 @@ extern "C" int wfk_res_stamps(unsigned long long* out, int reset) {
 #endif
 
 extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags,
-                                         hipStream_t s) {
+                                         int n_cu, hipStream_t s) {
   hipError_t e = hipMemsetAsync(a->count, 0, sizeof(int), s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(wf_compact_flagged_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a->flags, B, all, a->list, a->count, raw_flags);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  // persistent one-wave blocks over the compacted list: enough to fill the chip several times over, never more than farms
-  const int grid = B < 8192 ? B : 8192;
-  const int n_pad = (c->N + 1) & ~1;  // (keeps the int array behind the doubles aligned)
-  const size_t dyn = sizeof(double) * 35 * (size_t)n_pad + sizeof(int) * (size_t)n_pad;
-  hipLaunchKernelGGL(wf_resolve_kernel, dim3(grid), dim3(64), dyn, s, *c, *a, n_pad);
+  // Which kernel serves the list depends on how many farms it holds, and that number exists on the device only (no host
+  // round trip): up to kRes4MaxFarms — one residency of the four-wave kernel at WF_RES4_OCC farms per CU, where the
+  // re-solve is a single farm's latency — the four-wave kernel, beyond it the one-wave kernel (four times the farms per
+  // residency, the same throughput per instruction without the redundant per-wave parts).  Both are enqueued; the one
+  // the count is not meant for returns at once.  With `all` the count is B and only the right one is launched.
+  const int n_pad = (c->N + 1) & ~1;  // (keeps the int arrays behind the doubles aligned)
+  const size_t dyn4 = sizeof(double) * 35 * (size_t)n_pad + sizeof(int) * 4 * (size_t)n_pad;
+  const size_t lds4 = dyn4 + sizeof(Res4Shared);
+  int per_cu = (int)((160 * 1024) / lds4);
+  if (per_cu > WF_RES4_OCC) per_cu = WF_RES4_OCC;
+  const int max4 = per_cu >= 1 ? n_cu * per_cu : 0;  // farms the four-wave kernel holds at once
+  if (max4 > 0 && (!all || B <= max4)) {
+    const int grid4 = B < max4 ? B : max4;
+    hipLaunchKernelGGL(wf_resolve4_kernel, dim3(grid4), dim3(256), dyn4, s, *c, *a, n_pad, max4);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  if (!all || B > max4) {
+    // persistent one-wave blocks over the compacted list: enough to fill the chip several times over, never more than farms
+    const int grid = B < 8192 ? B : 8192;
+    const size_t dyn = sizeof(double) * 35 * (size_t)n_pad + sizeof(int) * (size_t)n_pad;
+    hipLaunchKernelGGL(wf_resolve_kernel, dim3(grid), dim3(64), dyn, s, *c, *a, n_pad, max4 + 1);
+  }
   return hipGetLastError();
 }
