@@ -262,8 +262,8 @@ def test_float64_kernel_at_the_abi_turbine_limit():
 
 def test_both_float64_kernels_by_flagged_count(layouts):
     """Which float64 kernel serves the flagged farms is decided on the device by their number: up to one residency of the
-    four-wave kernel (1024 farms at four per CU on 256 CUs) it runs, beyond that the one-wave kernel.  Mode 2 (every farm)
-    at 700 and at 1500 farms exercises one and the other; both against the CPU oracle, and against each other bit for bit
+    four-wave kernel (512 farms: two per CU on 256 CUs) it runs, beyond that the one-wave kernel.  Mode 2 (every farm)
+    at 400 and at 1500 farms exercises one and the other; both against the CPU oracle, and against each other bit for bit
     on the farms they share."""
     import parity
     from wfcrl_env_amd.backend import WfStep
@@ -275,7 +275,7 @@ def test_both_float64_kernels_by_flagged_count(layouts):
     yaw = rng.uniform(-35, 35, (Bmax, N)).astype(np.float32)
     ws, wd = _wind(rng, Bmax, "per_env")
     outs = {}
-    for B in (700, Bmax):
+    for B in (400, Bmax):
         w = WfStep(x, y, env_batch=B)
         w.set_risk_resolve(2)
         w.set_wind(ws[:B], wd[:B])
@@ -283,5 +283,5 @@ def test_both_float64_kernels_by_flagged_count(layouts):
         assert w.resolve_stats()["n_resolved"] == B
         parity.check_strict(outs[B], _oracle(x, y, ws[:B], wd[:B], yaw[:B]), parity.TOL_F64)
         w.close()
-    for k in outs[700]:
-        assert np.abs(outs[700][k].astype(np.float64) - outs[Bmax][k][:700]).max() <= 2e-6 * max(1.0, np.abs(outs[700][k]).max()), k
+    for k in outs[400]:
+        assert np.abs(outs[400][k].astype(np.float64) - outs[Bmax][k][:400]).max() <= 2e-6 * max(1.0, np.abs(outs[400][k]).max()), k
