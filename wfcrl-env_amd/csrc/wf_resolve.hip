@@ -146,10 +146,8 @@ __device__ __forceinline__ double cbrt_pos(double x) {
 // scratch accesses per source.
 // (First version, in the history: a thread per turbine, state in registers, two __syncthreads per source, every wave
 // re-deriving the source constants: 1.95 ms for 1394 HornsRev1 farms; the inlined one-wave version 1.42 ms; this one 1.37 ms.
-// Tried after it (commit 13d6d4d): four waves per farm — a wave per rotor-grid column for the two passes, the steering /
-// deflection-constant chain on a fourth wave beside the transverse pass, three block barriers per source: a farm's
-// latency drops from 1.04 to 0.73 ms, but a farm then takes four wave slots, 1394 farms no longer fit one residency
-// (two rounds at four waves per SIMD: 2.1 ms); better below ~500 flagged farms, worse at the benchmark's count.)
+// The four-wave kernel further down has the lower latency per farm (0.73 against 1.04 ms) but takes four wave slots per
+// farm: this kernel serves the counts beyond half a residency of that one.)
 #ifndef WF_RES_UNROLL_J
 #define WF_RES_UNROLL_J 0  // 1: the three grid columns of the transverse pass interleaved (three times the registers): no gain
                            // (4.80 against 4.78 ms per step with 1394 farms re-solved, tools/res_ab.sh)
