@@ -462,8 +462,9 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
   // Cache-line discipline of the log (the vector L1 is not updated by this CU's own stores): a farm's records start on
   // a 128-byte line (n_pad is a multiple of G, G is even), so a line belongs to ONE block and is never read before that
   // block has written it.  The 16-byte side records do share lines across blocks; they are read past the L1.
+#if !WF_LL_LOGT
   float* const logf = src_log + (size_t)slot * n_pad * WF_LOG_FLOATS;
-#if WF_LL_LOGT
+#else
   // the wave's part of the log (its EPW farm slots x n_pad records x 64 bytes, as before), record i at i * EPW * 64 bytes
   float* const logw = src_log + (size_t)(slot - eiw) * n_pad * WF_LOG_FLOATS;
   constexpr int RECF = EPW * WF_LOG_FLOATS;
