@@ -426,11 +426,11 @@ def main():
 
         nthreads = min(c_oracle.max_threads(), effective_cpus())
         ycpu = ring[0][: min(B, 4096)].cpu().numpy().astype(np.float64)
-        # accuracy sample: this very batch (fixed wind 8 m/s / 270 deg) against the float64 oracle, under the per-farm
+        # accuracy sample: this very batch under the wind of the timed leg against the float64 oracle, under the per-farm
         # contract of tests/parity.py (strict on every farm the kernel did not flag itself)
         ns = min(256, ycpu.shape[0])
-        ref = c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], 8.0, 270.0, ycpu[:ns], margin=True)
-        w.set_wind(8.0, 270.0)
+        ws_s, wd_s = w.get_wind()  # the wind the timed leg ended on: 8 m/s / 270 deg, the last direction of cfg5's sweep, or
+        ref = c_oracle.farm_step_batch(lay["xcoords"], lay["ycoords"], ws_s[:ns], wd_s[:ns], ycpu[:ns], margin=True)  # a wind per farm
         got = w.step(ring[0], out)
         flags_all = w.risk_flags()
         w.sync()
@@ -442,7 +442,7 @@ def main():
                                 "max_unflagged": sm["worst_unflagged"]["power"],
                                 "flagged_farm_frac_sample": sm["n_flagged"] / sm["n"],
                                 "flagged_farm_frac_batch": float((flags_all != 0).mean()),
-                                "contract": parity.classify(sm),
+                                "contract": parity.classify(sm), "n_mismatch_flagged": sm["n_mismatch_flagged"],
                                 "wind_speed_rel_max": float((np.abs(g["wind_speed"] - ref["wind_speed"]) / ref["wind_speed"]).max()),
                                 "wind_direction_abs_max_deg": float(np.abs(g["wind_direction"] - ref["wind_direction"]).max()),
                                 "ti_abs_max": float(np.abs(g["load"][..., 0] - ref["load"][..., 0]).max()),
