@@ -179,26 +179,68 @@ def test_resolve_on_grouped_launches_and_the_fused_env_step(layouts):
     w.close()
 
 
-def test_veer_is_served_by_the_float64_kernel(layouts):
-    """wind_veer != 0 (reference case.yaml:36 is user-editable and goes straight to FLORIS): the float32 kernels do not
-    implement the rotated Gaussian, so every farm of such a model is solved by the float64 kernel, whatever the mode."""
+@pytest.mark.parametrize("name,B", [("Ormonde_", 96), ("HornsRev1_", 160), ("Turb16_Row5_", 200), ("Ablaincourt_", 300)])
+def test_wind_veer(layouts, name, B):
+    """wind_veer != 0 (reference case.yaml:36 is user-editable and goes straight to FLORIS: the Gaussian of the deficit is
+    rotated by the veer angle, gauss.py rCalt).  Float32: wf_step_kernel's VEER instantiation (9 instead of 6 SOSFS sums
+    per slot; on the fly, no pair table, no one-block kernel) under the per-farm contract; with the re-solve on every farm
+    strict; mode 2 (every farm in float64) down to output rounding.  Shared 270 deg (exact x' ties on the grids) and a
+    wind per farm."""
     import parity
     from oracle.floris_gch_numpy import ModelParams
     from wfcrl_env_amd.backend import WfStep
 
-    l = layouts["Ormonde_"]
-    x, y, N, B = l["xcoords"], l["ycoords"], l["num_turbines"], 96
-    rng = np.random.default_rng(5)
+    l = layouts[name]
+    x, y, N = l["xcoords"], l["ycoords"], l["num_turbines"]
+    rng = np.random.default_rng(zlib.crc32(f"veer/{name}".encode()))
     yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
-    ws, wd = _wind(rng, B, "per_env")
-    w = WfStep(x, y, env_batch=B, model=dict(veer=3.0))
-    w.set_wind(ws, wd)
-    out = w.step(yaw)
-    assert w.resolve_stats()["n_resolved"] == B
-    ref = _oracle(x, y, ws, wd, yaw, ModelParams(veer=3.0))
-    parity.check_strict(out, ref, parity.TOL_F64)
+    for veer in (3.0, -7.5):
+        mp = ModelParams(veer=veer)
+        w = WfStep(x, y, env_batch=B, model=dict(veer=veer))
+        for mode in ("shared", "per_env"):
+            ws, wd = _wind(rng, B, mode)
+            w.set_wind(ws, wd)
+            info = w.kernel_info()
+            assert info["pair_table"] == 0 and info["one_block_kernel"] == 0
+            ref = _oracle(x, y, ws, wd, yaw, mp)
+            w.set_risk_resolve(0)
+            out = w.step(yaw)
+            parity.check({k: v.copy() for k, v in out.items()}, ref, w.risk_flags(), max_flagged_frac=0.1)
+            w.set_risk_resolve(1)
+            parity.check_strict(w.step(yaw), ref)
+            w.set_risk_resolve(2)
+            parity.check_strict(w.step(yaw), ref, parity.TOL_F64)
+        w.close()
     ref0 = _oracle(x, y, ws, wd, yaw)
     assert np.abs(ref["power"] / np.maximum(ref0["power"], 1e3) - 1).max() > 1e-3  # (veer does change the answer)
+
+
+def test_veer_toggles_the_kernel_family(layouts):
+    """Setting a model with veer on a live handle moves it to the VEER kernel (and back): the wind has to be set again,
+    as after wf_set_kernel_choice."""
+    import parity
+    from oracle.floris_gch_numpy import ModelParams
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    x, y, N, B = l["xcoords"], l["ycoords"], 80, 32768
+    w = WfStep(x, y, env_batch=B)
+    w.set_wind(8.0, 263.0)
+    assert w.kernel_info()["one_block_kernel"] == 1
+    w.set_model(dict(veer=2.0))
+    with pytest.raises(ValueError, match="wf_set_wind"):
+        w.step(np.zeros((B, N), np.float32))
+    w.set_wind(8.0, 263.0)
+    assert w.kernel_info()["one_block_kernel"] == 0 and w.kernel_info()["pair_table"] == 0
+    rng = np.random.default_rng(2)
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    out = w.step(yaw)
+    idx = np.arange(0, B, 256)
+    ref = _oracle(x, y, 8.0, 263.0, yaw[idx], ModelParams(veer=2.0))
+    parity.check({k: v[idx] for k, v in out.items()}, ref, w.risk_flags()[idx], max_flagged_frac=0.1)
+    w.set_model(dict(veer=0.0))
+    w.set_wind(8.0, 263.0)
+    assert w.kernel_info()["one_block_kernel"] == 1
     w.close()
 
 

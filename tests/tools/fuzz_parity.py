@@ -93,9 +93,10 @@ def run(n_cases, seed, only=-1, resolve=False):
             D = float(rng.choice([126.0, 100.5, 150.0]))
             model = dict(rotor_diameter=D, hub_height=float(rng.choice([0.56, 0.714, 0.9]) * D),
                          ambient_ti=float(rng.choice([0.06, 0.1])), shear=float(rng.choice([0.12, 0.0, 0.2])),
-                         ad=float(rng.choice([0.0, 0.01])), bd=float(rng.choice([0.0, -0.002])))
+                         ad=float(rng.choice([0.0, 0.01])), bd=float(rng.choice([0.0, -0.002])),
+                         veer=float(rng.choice([0.0, 0.0, 4.0, -6.0])))
             mp = ModelParams(D=model["rotor_diameter"], HH=model["hub_height"], ambient_ti=model["ambient_ti"],
-                             shear=model["shear"], ad=model["ad"], bd=model["bd"])
+                             shear=model["shear"], ad=model["ad"], bd=model["bd"], veer=model["veer"])
             x, y = x * (D / 126.0), y * (D / 126.0)  # keeps the grids on the thresholds
         run = only < 0 or case == only
         if run:

@@ -222,7 +222,7 @@ int wf_get_resolve_stats(wf_handle* h, int* n_resolved, int* raw_flags, int on_d
   if (!h) return WF_E_INVALID;
   if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called first");
   WF_ON_DEVICE(h);
-  if (!h->d_res_list || (h->resolve_mode == 0 && h->model.veer == 0.0)) {  // nothing is being resolved on this batch
+  if (!h->d_res_list || h->resolve_mode == 0) {  // nothing is being resolved on this batch
     if (n_resolved) *n_resolved = 0;
     if (raw_flags) return wf_get_risk_flags(h, raw_flags, on_device);
     return WF_OK;

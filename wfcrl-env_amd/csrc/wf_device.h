@@ -60,6 +60,12 @@ struct WfConsts {
   float ct_kappa;  // v |dCt/dv| above which a turbine counts as sitting on a ramp of the thrust table
   float guard_inv, inv_overlap_thr, knee_kappa;  // 1 / guard band (2^50 when the band is 0), 1 / overlap_thr
   double yc_d;  // centre of rotation (y): the float32 lateral distances are taken on y' - yc
+  // wind_veer (case.yaml:36) [FLORIS gauss.py rCalt]: the Gaussian of the deficit rotated by the veer angle phi.  Only the
+  // VEER instantiation of wf_step_kernel reads these; veer_on selects it at launch.
+  int veer_on;
+  float cos_veer;             // sigma_y0 = sigma_z0 cos(yaw) cos(phi)
+  float veer_c2, veer_s2;     // cos^2 phi, sin^2 phi
+  float veer_bq;              // sin(2 phi) * D/4 : the cross term's factor at the outer grid rows (z - HH = -+ D/4)
 };
 
 // Power/thrust table in global memory, staged to LDS by each block.

@@ -121,6 +121,7 @@ double ll_estimate(const wf_handle* h, int fi, int N, long farms) {
 // registers) and the batch fills the chip.  wf_set_kernel_choice: one_block = 0 disables it, 1 forces (ll_G, ll_S).
 int pick_ll(const wf_handle* h, int N, int B) {  // returns (G << 4) | S, 0 = keep wf_step_kernel
   if (h->choice.one_block == 0) return 0;
+  if (h->model.veer != 0.0) return 0;  // wind veer: wf_step_kernel's VEER instantiation (the one-block kernel keeps 6 sums per slot)
   if (N > WF_PAIR_MAX_N) return 0;
   if (h->choice.one_block == 1) {
     const int g = h->choice.ll_G, sl = h->choice.ll_S > 0 ? h->choice.ll_S : 1;
@@ -184,7 +185,7 @@ void set_ll_shape(wf_handle* h, int G, int S) {
 // or WF_NO_PAIR_TABLE set for A/B runs).
 int pair_table(wf_handle* h, const float** out) {
   *out = nullptr;
-  if ((h->wind_count != 1 && !h->shared_dir && h->n_groups == 0) || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->choice.pair_table == 0)
+  if ((h->wind_count != 1 && !h->shared_dir && h->n_groups == 0) || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->choice.pair_table == 0 || h->model.veer != 0.0)
     return WF_OK;
   int vG, vS; const void* vfn;
   wfk_variant(h->variant, &vG, &vS, &vfn);
@@ -344,7 +345,7 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
 int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
   int rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
   if (rc != WF_OK) return rc;
-  const int mode = h->model.veer != 0.0 ? 2 : h->resolve_mode;
+  const int mode = h->resolve_mode;
   if (mode == 0) return WF_OK;
   if (!h->d_res_list) {
     WF_HIP(h, hipMalloc(&h->d_res_list, sizeof(int) * h->cap_env));
@@ -384,8 +385,8 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   wfk_variant(h->variant, &G, &S, &fn);
   // the instantiation the next step would launch: pair table (shared wind), general mirror cores, or default
   if (h->model_dirty && h->N > 0) { int rc = build_consts(h); if (rc != WF_OK) return rc; }
-  const bool tab = (h->wind_count == 1 || h->shared_dir || h->n_groups > 0) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && h->choice.pair_table != 0;
-  fn = wfk_variant_fn(h->variant, tab ? (h->wind_count == 1 ? 2 : 3) : (h->consts.mirror_core_n <= 1 ? 0 : 1));
+  const bool tab = (h->wind_count == 1 || h->shared_dir || h->n_groups > 0) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && h->choice.pair_table != 0 && h->model.veer == 0.0;
+  fn = wfk_variant_fn(h->variant, tab ? (h->wind_count == 1 ? 2 : 3) : (h->model.veer != 0.0 ? 4 : (h->consts.mirror_core_n <= 1 ? 0 : 1)));
   info->pair_table = tab ? 1 : 0;
   info->direction_groups = h->n_groups;
   hipFuncAttributes a;

@@ -82,12 +82,12 @@ __device__ __forceinline__ float table_pw(const WfConsts& c, const TableLds& T, 
 }
 
 // Register-resident per-turbine state of one lane: S target slots x (9 + 9 + 9 + 3) floats.
-template <int S>
+template <int S, int NE = 6>
 struct Slots {
   // SOSFS [A.3-7]: FLORIS sums (deficit * Uinit(z))^2; Uinit(z_k) is the same for every source, so the sum of
   // deficit^2 is kept instead, and the Gaussian deficit is even in z - HH: rows k = 0 and k = 2 always hold the
   // same value.  esq[j*2] = rows 0 and 2 of column j, esq[j*2 + 1] = row 1:  u(j,k) = Uinit_k * (1 - sqrt(esq)).
-  float esq[S][6];
+  float esq[S][NE];  // NE = 9 with wind veer: [3 j + k], the rotated Gaussian is not even in z - HH
   float V[S][9], W[S][9];
   float TI[S][3];   // per grid column j (independent of k)            [A.3-8]
 };
@@ -139,6 +139,36 @@ __device__ __forceinline__ void column_deficit(const WfConsts& c, const SrcConst
   e0 = e1 * fexp2(-0.5f * kLog2e * zz * zz);
 }
 
+
+// The same with wind veer [FLORIS gauss.py rCalt]: r = a yy^2 - 2 b yy zz + c zz^2 with
+//   a = cos^2/(2 sy^2) + sin^2/(2 sz^2),  b = sin(2 phi)/4 (1/sz^2 - 1/sy^2),  c = sin^2/(2 sy^2) + cos^2/(2 sz^2):
+// the rows zz = -+ D/4 differ by the factor exp(-+ 2 b yy D/4).  Returns the deficits of rows k = 0, 1, 2.
+__device__ __forceinline__ void column_deficit_veer(const WfConsts& c, const SrcConsts& sc, const ColConsts& cc, float dx,
+                                                    float ylat, float lin, float amp_on, float& ea, float& e1, float& eb) {
+  const float xs = fmaxf(dx - cc.x0d, 0.0f);
+  const float syd = fmaf(cc.kyd, xs, sc.sy0d), szd = fmaf(cc.kyd, xs, sc.sz0d);
+  const float s = fsqrt(syd * szd * sc.inv_s0d);
+  const float arg = sc.lnA * fmaf(1.6f, s, -sc.sM) * frcp(sc.lnB * fmaf(1.6f, s, sc.sM));
+  const float d_far = fmaf(cc.pj, flog2(arg), cc.d0);
+  const float delta = ((dx > cc.x0d) ? d_far : dx * sc.tan_th0) + lin;
+  const bool far = dx >= cc.x0v;
+  const float up = dx * cc.ix0v;
+  const float xf = dx - cc.x0v;
+  const float sy = far ? fmaf(cc.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
+  const float sz = far ? fmaf(cc.kyv, xf, c.sz0v) : fmaf(up, c.sz0v - sc.snw, sc.snw);
+  const float isy = frcp(sy), isz = frcp(sz);
+  const float xarg = sc.kdef * isy * isz;
+  const float C = (xarg >= 1.0f) ? 1.0f : xarg * frcp(1.0f + fsqrt(fmaxf(1.0f - xarg, 0.0f)));
+  const float iy2 = kGs * kGs * isy * isy, iz2 = kGs * kGs * isz * isz;  // log2(e) / (2 sigma^2)
+  const float yy = ylat - delta;
+  const float q = c.off[2];
+  const float A = fmaf(c.veer_c2, iy2, c.veer_s2 * iz2), Cz = fmaf(c.veer_s2, iy2, c.veer_c2 * iz2);
+  const float f = fexp2(-(c.veer_bq * (iz2 - iy2)) * yy);  // exp(-2 b yy q)
+  e1 = amp_on * C * fexp2(-(A * yy * yy));
+  const float ez = e1 * fexp2(-(Cz * q * q));
+  ea = ez * f;          // zz = -q:  r = a yy^2 + 2 b yy q + c q^2
+  eb = ez * frcp(f);    // zz = +q
+}
 
 // The pair-coefficient record of (source i, target t) — sorted indices of one wind direction — at `o` (WF_PAIR_STRIDE
 // floats, layout in wf_device.h).  Everything of the transverse-velocity pass [A.3-4] that does not depend on the farm's

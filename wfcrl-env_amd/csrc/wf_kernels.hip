@@ -289,7 +289,9 @@ constexpr int min_blocks_per_cu() {
   return ((S <= 3 && 3 * (4 / WPB) * lds <= 160 * 1024) ? 3 : 2) * (4 / WPB);  // WPB is 4, or 2 in staging experiments
 }
 
-template <int G, int S, bool MC1, bool TAB, int WPB>
+// VEER: wind_veer != 0 [FLORIS gauss.py rCalt] — on-the-fly path only (MC1 = false, TAB = false): the rotated Gaussian is
+// not even in z - HH, so the SOSFS state holds 9 instead of 6 sums per slot and a column costs one more exp + rcp.
+template <int G, int S, bool MC1, bool TAB, int WPB, bool VEER = false>
 __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) void wf_step_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const double* __restrict__ gy,
     const int* __restrict__ gidx, int geom_stride, const double* __restrict__ ws_in, const double* __restrict__ wd_in,
@@ -373,6 +375,29 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   const float Ui[3] = {uni(ws * c.shearf[0]), uni(ws * c.shearf[1]), uni(ws * c.shearf[2])};
   const float offk = c.off[2] * kGs;
   const float U02c = uni(Ui[0] * Ui[0] * Ui[0] + Ui[2] * Ui[2] * Ui[2]), U1c = uni(Ui[1] * Ui[1] * Ui[1]);
+  // sum over the rotor grid of u^3 from the SOSFS sums of a turbine (rows 0 and 2 share their sum without veer)
+  auto cube_sum = [&](const float* e) {
+    if constexpr (VEER) {
+      float m = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float u = Ui[k] * (1.0f - fsqrt(e[3 * j + k]));
+          m = fmaf(u * u, u, m);
+        }
+      return m;
+    } else {
+      float fe = 0.0f, fc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float ue = 1.0f - fsqrt(e[2 * j]), uc = 1.0f - fsqrt(e[2 * j + 1]);
+        fe = fmaf(ue * ue, ue, fe);
+        fc = fmaf(uc * uc, uc, fc);
+      }
+      return fmaf(U02c, fe, U1c * fc);
+    }
+  };
   // overlap test "deficit * Uinit_k > threshold" [A.3-8] as a threshold on the deficit itself, with the guard band of
   // the risk flag folded in (see the wake-added-TI block): scale ovs[k] = 1 / (2 g thr_k), offset ovc = 1/2 - 1/(2 g)
   const float ovh = 0.5f * c.guard_inv;  // 1 / (2 g); g = 0 -> 2^49 (no band: f is 0 or 1 except at e == thr exactly)
@@ -432,7 +457,8 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   if (env_mode && ea.action && sub == 0 && env_ok) ea.moves[env] = moves_new;
   __syncthreads();
 
-  Slots<S> st;
+  constexpr int NE = VEER ? 9 : 6;
+  Slots<S, NE> st;
   // ambient TI exactly as the wake-added-TI candidate evaluates to with no added turbulence (sqrt(0 + amb^2) in
   // device arithmetic): a no-op update then leaves the three grid columns bit-identical (uniform fast path)
   const float amb0 = fsqrt(c.amb2);
@@ -444,7 +470,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       st.W[p][q] = 0.0f;
     }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) st.esq[p][q] = 0.0f;
+    for (int q = 0; q < NE; ++q) st.esq[p][q] = 0.0f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) st.TI[p][j] = amb0;
   }
@@ -544,16 +570,10 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       if (TAB && i + 1 < N) stage_row(i + 1);  // lands in the other buffer while this source is processed
 #endif
       // ---- A. the source's state (slot 0 of lane `li` of the group) ------------------------
-      float fe = 0.0f, fc = 0.0f, vsum = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float ue = 1.0f - fsqrt(st.esq[0][2 * j]), uc = 1.0f - fsqrt(st.esq[0][2 * j + 1]);
-        fe = fmaf(ue * ue, ue, fe);
-        fc = fmaf(uc * uc, uc, fc);
-      }
+      float vsum = 0.0f;
 #pragma unroll
       for (int q = 0; q < 9; ++q) vsum += st.V[0][q];
-      const float m3 = __shfl(fmaf(U02c, fe, U1c * fc), src);  // sum over the grid of u^3
+      const float m3 = __shfl(cube_sum(st.esq[0]), src);  // sum over the grid of u^3
       const float Vmean = __shfl(vsum, src) * (1.0f / 9.0f);
       float TIs[3];
 #pragma unroll
@@ -636,6 +656,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const float E0 = fmaf(om_sc, om_sc, fmaf(-c.e0c1, om_sc, c.e0c2));
       sc.sz0d = 0.5f * c.D * fsqrt((1.0f + s_cc) * frcp(2.0f * (1.0f + s_c)));
       sc.sy0d = sc.sz0d * cgd;
+      if constexpr (VEER) sc.sy0d *= c.cos_veer;
       const float th0 = c.dm03 * gd * frcp(cgd) * om_scc;
       {
         // |th0| < 0.3 for every admissible yaw: odd polynomial (rel. err < 1e-8 there).  Beyond 0.35 rad (not
@@ -673,6 +694,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         for (int j = 0; j < 3; ++j) st.TI[0][j] += dTI;
       }
       sc.sy0v = c.sz0v * cg;
+      if constexpr (VEER) sc.sy0v *= c.cos_veer;
       sc.snw = c.near_c * fsqrt(0.5f * ct);
       sc.kdef = ct * cg * c.kdef;
       const float ch_pref = c.ch_c * fexp2(c.ch_ai * flog2(a));
@@ -732,7 +754,13 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           const float lin = fmaf(c.bd, dx, c.ad);
           const float amp_on = (bits & 8) ? 1.0f : 0.0f;
           float e1[3], e0[3];
-          if (uni) {
+          float e2[VEER ? 3 : 1];  // with veer: the deficit of row k = 2 (e0 is row 0)
+          if constexpr (VEER) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              column_deficit_veer(c, sc, (j == 0 || uni) ? k0 : col_consts(TIs[j], TIs[j] + dTI), dx, dy + c.off[j], lin, amp_on,
+                                  e0[j], e1[j], e2[j]);
+          } else if (uni) {
             // column-independent part once
             const float xs = fmaxf(dx - k0.x0d, 0.0f);
             const float syd = fmaf(k0.kyd, xs, sc.sy0d), szd = fmaf(k0.kyd, xs, sc.sz0d);
@@ -766,8 +794,14 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           }
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-            st.esq[p][2 * j] = fmaf(e0[j], e0[j], st.esq[p][2 * j]);
-            st.esq[p][2 * j + 1] = fmaf(e1[j], e1[j], st.esq[p][2 * j + 1]);
+            if constexpr (VEER) {
+              st.esq[p][3 * j] = fmaf(e0[j], e0[j], st.esq[p][3 * j]);
+              st.esq[p][3 * j + 1] = fmaf(e1[j], e1[j], st.esq[p][3 * j + 1]);
+              st.esq[p][3 * j + 2] = fmaf(e2[j], e2[j], st.esq[p][3 * j + 2]);
+            } else {
+              st.esq[p][2 * j] = fmaf(e0[j], e0[j], st.esq[p][2 * j]);
+              st.esq[p][2 * j + 1] = fmaf(e1[j], e1[j], st.esq[p][2 * j + 1]);
+            }
           }
           // Wake-added TI reaches a target only within 15 D downstream and 2 D laterally [A.3-8]; elsewhere the
           // candidate is the ambient value, which never exceeds the running maximum: skipped when no lane needs it.
@@ -796,7 +830,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           for (int j = 0; j < 3; ++j) {
             const float f0 = __builtin_amdgcn_fmed3f(fmaf(e0[j], ovs[0], ovc), 0.0f, 1.0f);
             const float f1 = __builtin_amdgcn_fmed3f(fmaf(e1[j], ovs[1], ovc), 0.0f, 1.0f);
-            const float f2 = __builtin_amdgcn_fmed3f(fmaf(e0[j], ovs[2], ovc), 0.0f, 1.0f);
+            const float f2 = __builtin_amdgcn_fmed3f(fmaf((VEER ? e2[VEER ? j : 0] : e0[j]), ovs[2], ovc), 0.0f, 1.0f);
             cnt += (f0 + f1) + f2;
             fbits |= __float_as_uint(f0) | __float_as_uint(f1) | __float_as_uint(f2);
           }
@@ -848,20 +882,14 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           tied = __any(dx0 >= 0.0f);
         }
         if (!tied) break;  // ties are contiguous in the sort
-        float fe = 0.0f, fc = 0.0f;
+        float ee[NE];  // the SOSFS sums of that source's slot
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          float e0 = st.esq[S > 1 ? 1 : 0][2 * j], e1 = st.esq[S > 1 ? 1 : 0][2 * j + 1];
+        for (int q = 0; q < NE; ++q) {
+          ee[q] = st.esq[S > 1 ? 1 : 0][q];
 #pragma unroll
-          for (int p = 2; p < S; ++p) {
-            e0 = (p2 == p) ? st.esq[p][2 * j] : e0;
-            e1 = (p2 == p) ? st.esq[p][2 * j + 1] : e1;
-          }
-          const float ue = 1.0f - fsqrt(e0), uc = 1.0f - fsqrt(e1);
-          fe = fmaf(ue * ue, ue, fe);
-          fc = fmaf(uc * uc, uc, fc);
+          for (int p = 2; p < S; ++p) ee[q] = (p2 == p) ? st.esq[p][q] : ee[q];
         }
-        const float m3 = __shfl(fmaf(U02c, fe, U1c * fc), gbase + l2);
+        const float m3 = __shfl(cube_sum(ee), gbase + l2);
         float ubar, ct, a, Gwr, Gwt, gt, gb, Gt, Gb, Gy;
         circulations(m3, i2, Gt, Gb, Gwr, Gwt, Gy, ubar, ct, a, gt, gb);
         if constexpr (TAB) {
@@ -882,8 +910,13 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const float ue = 1.0f - fsqrt(st.esq[0][2 * j]), uc = 1.0f - fsqrt(st.esq[0][2 * j + 1]);
-          U[3 * j] = Ui[0] * ue; U[3 * j + 1] = Ui[1] * uc; U[3 * j + 2] = Ui[2] * ue;
+          if constexpr (VEER) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) U[3 * j + k] = Ui[k] * (1.0f - fsqrt(st.esq[0][3 * j + k]));
+          } else {
+            const float ue = 1.0f - fsqrt(st.esq[0][2 * j]), uc = 1.0f - fsqrt(st.esq[0][2 * j + 1]);
+            U[3 * j] = Ui[0] * ue; U[3 * j + 1] = Ui[1] * uc; U[3 * j + 2] = Ui[2] * ue;
+          }
         }
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
@@ -946,7 +979,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
 #pragma unroll
       for (int q = 0; q < 9; ++q) { st.V[p][q] = st.V[p + 1][q]; st.W[p][q] = st.W[p + 1][q]; }
 #pragma unroll
-      for (int q = 0; q < 6; ++q) st.esq[p][q] = st.esq[p + 1][q];
+      for (int q = 0; q < NE; ++q) st.esq[p][q] = st.esq[p + 1][q];
 #pragma unroll
       for (int j = 0; j < 3; ++j) st.TI[p][j] = st.TI[p + 1][j];
     }
@@ -978,6 +1011,7 @@ struct WfVariant {
   const void* fn_all;  // MC1 = false (general mirror cores)
   const void* fn_tab;     // shared-wind pair table
   const void* fn_tab_ws;  // pair table of a shared wind direction, a wind speed per farm
+  const void* fn_veer;    // wind_veer != 0: on the fly, general mirror cores
 };
 
 // The table path is instantiated only where two blocks per CU still fit in the 160 KiB LDS and N <= WF_PAIR_MAX_N.
@@ -997,7 +1031,7 @@ const void* tab_kernel() {
 }
 #define WF_VARIANT(G_, S_)                                                                              \
   {G_, S_, (const void*)&wf_step_kernel<G_, S_, true, false, 4>, (const void*)&wf_step_kernel<G_, S_, false, false, 4>, \
-   tab_kernel<G_, S_, true>(), tab_kernel<G_, S_, false>()}
+   tab_kernel<G_, S_, true>(), tab_kernel<G_, S_, false>(), (const void*)&wf_step_kernel<G_, S_, false, false, 4, true>}
 static const WfVariant kVariants[] = {
 #if WF_KSET != 2
     WF_VARIANT(4, 4),  WF_VARIANT(8, 4),  WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(32, 4), WF_VARIANT(64, 4),
@@ -1016,8 +1050,9 @@ static void local_variant(int i, int* G, int* S, const void** fn) {
   *S = kVariants[i].S;
   *fn = kVariants[i].fn;
 }
-// kind 0: MC1 on-the-fly, 1: general mirror cores, 2: shared-wind pair table, 3: pair table with a speed per farm
+// kind 0: MC1 on-the-fly, 1: general mirror cores, 2: shared-wind pair table, 3: pair table with a speed per farm, 4: wind veer
 static const void* local_variant_fn(int i, int kind) {
+  if (kind == 4) return kVariants[i].fn_veer;
   return kind == 3 ? kVariants[i].fn_tab_ws : (kind == 2 ? kVariants[i].fn_tab : (kind == 1 ? kVariants[i].fn_all : kVariants[i].fn));
 }
 static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx, const double* gy,
@@ -1026,7 +1061,7 @@ static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTabl
                                     const WfEnvArgs* env, const float* pair_tab, const int* pair_first,
                                     const WfGroupArgs* grp, hipStream_t s, int* grid_out) {
   const WfVariant& v = kVariants[variant];
-  const bool use_tab = pair_tab && v.fn_tab;
+  const bool use_tab = pair_tab && v.fn_tab && !c->veer_on;
   const int wpb = use_tab ? kTabWaves : 4;
   const int envs_per_block = wpb * (64 / v.G);
   WfGroupArgs ga = *grp;
@@ -1037,7 +1072,7 @@ static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTabl
   WfEnvArgs ea;
   if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
   void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &pair_tab, &pair_first, &ga};
-  const void* fn = use_tab ? (wind_stride == 0 ? v.fn_tab : v.fn_tab_ws) : (cc.mirror_core_n <= 1 ? v.fn : v.fn_all);
+  const void* fn = use_tab ? (wind_stride == 0 ? v.fn_tab : v.fn_tab_ws) : (cc.veer_on ? v.fn_veer : (cc.mirror_core_n <= 1 ? v.fn : v.fn_all));
   if (!use_tab) pair_tab = nullptr;
   return hipLaunchKernel(fn, dim3(grid), dim3(64 * wpb), args, 0, s);
 }

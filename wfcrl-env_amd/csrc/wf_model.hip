@@ -124,6 +124,13 @@ int build_consts(wf_handle* h) {
   c.yc_d = h->yc;
   c.ct_kappa = 5.0f;     // nrel_5MW: 5.9 on the cut-in ramp (2.5-3 m/s), 143 on the cut-out drop, <= 4.0 everywhere else
   c.knee_kappa = 30.0f;  // 30 x (wind-speed error ~3e-6) ~ 1e-4 of max(P, 1 kW)
+  {  // wind veer: the rotated Gaussian of the deficit [FLORIS gauss.py rCalt]
+    const double vr = m.veer * M_PI / 180.0;
+    c.veer_on = m.veer != 0.0 ? 1 : 0;
+    c.cos_veer = (float)std::cos(vr);
+    c.veer_c2 = (float)(std::cos(vr) * std::cos(vr)); c.veer_s2 = (float)(std::sin(vr) * std::sin(vr));
+    c.veer_bq = (float)(std::sin(2.0 * vr) * D / 4.0);
+  }
   c.rho = (float)m.ref_density; c.pw = (float)(m.pP / 3.0);
   c.dens_f = (float)std::cbrt(m.air_density / m.ref_density);
 
@@ -280,6 +287,7 @@ int wf_set_model(wf_handle* h, const wf_model_params* p) {
         return fail(h, WF_E_INVALID, "table wind speeds must be strictly ascending");
     }
   }
+  const bool veer_toggled = (h->model.veer != 0.0) != (p->veer != 0.0);
   h->model = *p;
   h->tws.assign(p->table_ws, p->table_ws + p->n_table);
   h->tct.assign(p->table_ct, p->table_ct + p->n_table);
@@ -287,6 +295,12 @@ int wf_set_model(wf_handle* h, const wf_model_params* p) {
   h->model.table_ws = h->model.table_ct = h->model.table_cp = nullptr;
   h->model_dirty = true;
   h->pair_dirty = true;
+  if (veer_toggled && h->N > 0) {  // another kernel family serves the handle (wf_dispatch.hip: veer models run wf_step_kernel's
+    WF_ON_DEVICE(h);               // VEER instantiation, on the fly): tables, groups and the wind were laid out for the old one
+    WF_HIP(h, hipStreamSynchronize(h->stream));
+    apply_kernel_pick(h, h->N, h->B, nullptr);
+    h->wind_count = 0; h->shared_dir = false; h->n_groups = 0; h->grid_step = 0.0; h->series_T = 0;
+  }
   return WF_OK;
 }
 
