@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT/wfcrl-env_amd/csrc
+for v in "-DWF_RES_GRID_PER_CU=8" "-DWF_RES_GRID_PER_CU=32"; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -fno-fast-math -ffp-contract=off -fno-slp-vectorize $v -c -o wf_resolve.o wf_resolve.hip
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libwfstep.so wf_kernels_1.o wf_kernels_2.o wf_kernels_ll.o wf_resolve.o wf_abi.o wf_model.o wf_dispatch.o wf_groups.o wf_wind_abi.o wf_env_abi.o
+  echo "== $v"; (cd ../.. && python tools/veer_rate.py 2>&1 | grep -v amdgpu)
+done

@@ -12,7 +12,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 lay = json.load(open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")))[name]
 N = lay["num_turbines"]
 yaw = (torch.rand((B, N), device="cuda") * 60 - 30).float()
-for label, model, mode in (("veer 0, float32 kernels", None, 0), ("veer 3 deg, float64 kernel on every farm", dict(veer=3.0), 0),
+for label, model, mode in (("veer 0, float32 kernels", None, 0), ("veer 3 deg, float32 VEER kernel", dict(veer=3.0), 0), ("veer 3 deg, float32 + float64 re-solve of the flagged farms", dict(veer=3.0), 1),
                            ("veer 0, float64 kernel on every farm (wf_set_risk_resolve mode 2)", None, 2)):
     w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B, model=model)
     w.set_risk_resolve(mode)

@@ -142,7 +142,7 @@ __device__ __forceinline__ void column_deficit(const WfConsts& c, const SrcConst
 
 // The same with wind veer [FLORIS gauss.py rCalt]: r = a yy^2 - 2 b yy zz + c zz^2 with
 //   a = cos^2/(2 sy^2) + sin^2/(2 sz^2),  b = sin(2 phi)/4 (1/sz^2 - 1/sy^2),  c = sin^2/(2 sy^2) + cos^2/(2 sz^2):
-// the rows zz = -+ D/4 differ by the factor exp(-+ 2 b yy D/4).  Returns the deficits of rows k = 0, 1, 2.
+// the rows zz = -+ D/4 carry the cross term -+ 2 b yy D/4.  Returns the deficits of rows k = 0, 1, 2.
 __device__ __forceinline__ void column_deficit_veer(const WfConsts& c, const SrcConsts& sc, const ColConsts& cc, float dx,
                                                     float ylat, float lin, float amp_on, float& ea, float& e1, float& eb) {
   const float xs = fmaxf(dx - cc.x0d, 0.0f);
@@ -163,11 +163,14 @@ __device__ __forceinline__ void column_deficit_veer(const WfConsts& c, const Src
   const float yy = ylat - delta;
   const float q = c.off[2];
   const float A = fmaf(c.veer_c2, iy2, c.veer_s2 * iz2), Cz = fmaf(c.veer_s2, iy2, c.veer_c2 * iz2);
-  const float f = fexp2(-(c.veer_bq * (iz2 - iy2)) * yy);  // exp(-2 b yy q)
-  e1 = amp_on * C * fexp2(-(A * yy * yy));
-  const float ez = e1 * fexp2(-(Cz * q * q));
-  ea = ez * f;          // zz = -q:  r = a yy^2 + 2 b yy q + c q^2
-  eb = ez * frcp(f);    // zz = +q
+  const float Bq = c.veer_bq * (iz2 - iy2) * yy;  // 2 b yy q (in log2 units)
+  const float r1 = A * yy * yy, rq = fmaf(Cz, q * q, r1);
+  // one exponential per row on the whole (positive definite) quadratic form: the factors exp(-+ 2 b yy q) overflow on
+  // their own where the Gaussian itself is zero (0 x inf behind a turbine below cut-in, whose near-wake sigma is < 1 m)
+  const float amp = amp_on * C;
+  e1 = amp * fexp2(-r1);
+  ea = amp * fexp2(-fmaxf(rq + Bq, 0.0f));  // zz = -q:  r = a yy^2 + 2 b yy q + c q^2
+  eb = amp * fexp2(-fmaxf(rq - Bq, 0.0f));  // zz = +q
 }
 
 // The pair-coefficient record of (source i, target t) — sorted indices of one wind direction — at `o` (WF_PAIR_STRIDE

@@ -584,6 +584,9 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
 // the re-solve is pure latency — one farm's 80-stage chain, whatever the count — and spreading a source step over four
 // waves shortens it (HornsRev1: 1.04 -> 0.73 ms per farm).  Both kernels are enqueued behind the compaction; each reads
 // the count on the device and the one it is not meant for returns at once.
+#ifndef WF_RES_GRID_PER_CU
+#define WF_RES_GRID_PER_CU 8  // persistent one-wave blocks per CU
+#endif
 #ifndef WF_RES4_OCC
 #define WF_RES4_OCC 4  // waves per SIMD = resident farms per CU
 #endif
@@ -1072,7 +1075,10 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
     // persistent one-wave blocks over the compacted list: enough to fill the chip several times over, never more than farms
     // (two waves per SIMD hold 8 farms per CU; more blocks than that only cost launch time when the list is empty — 20 us
     // for 8192 blocks that return at once, 7 us for 2048)
-    const int grid = B < n_cu * 8 ? B : n_cu * 8;
+    // (every farm — B is known here — runs 27 % faster from a grid of 32 blocks per CU than from 8 persistent ones: 53.5 against
+    // 73.7 ms at 65536 HornsRev1 farms, tools/gridab.sh; the flagged list is short and an empty launch should be cheap)
+    const int per_cu_grid = all ? 4 * WF_RES_GRID_PER_CU : WF_RES_GRID_PER_CU;
+    const int grid = B < n_cu * per_cu_grid ? B : n_cu * per_cu_grid;
     const size_t dyn = sizeof(double) * 35 * (size_t)n_pad + sizeof(int) * (size_t)n_pad;
     hipLaunchKernelGGL(wf_resolve_kernel, dim3(grid), dim3(64), dyn, s, *c, *a, n_pad, max4 + 1);
   }
