@@ -1,5 +1,5 @@
 // wf_resolve.hip — float64 farm solve on the device for the farms the float32 kernels flag (include/wfstep.h:
-// wf_set_risk_resolve), and for every farm of a model the float32 kernels do not implement (wind_veer != 0).
+// wf_set_risk_resolve); mode 2 solves every farm (validation).
 //
 // The reference evaluates the whole path in float64 (reference wfcrl/interface.py:564 `fi.calculate_wake`, FLORIS 3.5
 // sequential solver; SURVEY.md Appendix A, tags [A.x] below).  The float32 step kernels cannot reproduce a float64
