@@ -183,7 +183,7 @@ def test_resolve_on_grouped_launches_and_the_fused_env_step(layouts):
 def test_wind_veer(layouts, name, B):
     """wind_veer != 0 (reference case.yaml:36 is user-editable and goes straight to FLORIS: the Gaussian of the deficit is
     rotated by the veer angle, gauss.py rCalt).  Float32: wf_step_kernel's VEER instantiation (9 instead of 6 SOSFS sums
-    per slot; on the fly, no pair table, no one-block kernel) under the per-farm contract; with the re-solve on every farm
+    per slot; no one-block kernel) under the per-farm contract; with the re-solve on every farm
     strict; mode 2 (every farm in float64) down to output rounding.  Shared 270 deg (exact x' ties on the grids) and a
     wind per farm."""
     import parity
@@ -201,7 +201,8 @@ def test_wind_veer(layouts, name, B):
             ws, wd = _wind(rng, B, mode)
             w.set_wind(ws, wd)
             info = w.kernel_info()
-            assert info["pair_table"] == 0 and info["one_block_kernel"] == 0
+            # the pair table holds the transverse pass only (veer does not touch it): a shared wind keeps it
+            assert info["one_block_kernel"] == 0 and info["pair_table"] == (1 if mode == "shared" else 0)
             ref = _oracle(x, y, ws, wd, yaw, mp)
             w.set_risk_resolve(0)
             out = w.step(yaw)
@@ -231,7 +232,7 @@ def test_veer_toggles_the_kernel_family(layouts):
     with pytest.raises(ValueError, match="wf_set_wind"):
         w.step(np.zeros((B, N), np.float32))
     w.set_wind(8.0, 263.0)
-    assert w.kernel_info()["one_block_kernel"] == 0 and w.kernel_info()["pair_table"] == 0
+    assert w.kernel_info()["one_block_kernel"] == 0 and w.kernel_info()["pair_table"] == 1
     rng = np.random.default_rng(2)
     yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
     out = w.step(yaw)

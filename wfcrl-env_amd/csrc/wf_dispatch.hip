@@ -185,7 +185,7 @@ void set_ll_shape(wf_handle* h, int G, int S) {
 // or WF_NO_PAIR_TABLE set for A/B runs).
 int pair_table(wf_handle* h, const float** out) {
   *out = nullptr;
-  if ((h->wind_count != 1 && !h->shared_dir && h->n_groups == 0) || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->choice.pair_table == 0 || h->model.veer != 0.0)
+  if ((h->wind_count != 1 && !h->shared_dir && h->n_groups == 0) || h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->choice.pair_table == 0)
     return WF_OK;
   int vG, vS; const void* vfn;
   wfk_variant(h->variant, &vG, &vS, &vfn);
@@ -385,8 +385,9 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   wfk_variant(h->variant, &G, &S, &fn);
   // the instantiation the next step would launch: pair table (shared wind), general mirror cores, or default
   if (h->model_dirty && h->N > 0) { int rc = build_consts(h); if (rc != WF_OK) return rc; }
-  const bool tab = (h->wind_count == 1 || h->shared_dir || h->n_groups > 0) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && h->choice.pair_table != 0 && h->model.veer == 0.0;
-  fn = wfk_variant_fn(h->variant, tab ? (h->wind_count == 1 ? 2 : 3) : (h->model.veer != 0.0 ? 4 : (h->consts.mirror_core_n <= 1 ? 0 : 1)));
+  const bool tab = (h->wind_count == 1 || h->shared_dir || h->n_groups > 0) && h->N <= WF_PAIR_MAX_N && wfk_variant_has_table(h->variant) && h->choice.pair_table != 0;
+  const bool veer = h->model.veer != 0.0;
+  fn = wfk_variant_fn(h->variant, tab ? (h->wind_count == 1 ? (veer ? 5 : 2) : (veer ? 6 : 3)) : (veer ? 4 : (h->consts.mirror_core_n <= 1 ? 0 : 1)));
   info->pair_table = tab ? 1 : 0;
   info->direction_groups = h->n_groups;
   hipFuncAttributes a;

@@ -36,7 +36,7 @@ int group_unit(const wf_handle* h) {
 // Would a grouped launch over K direction groups pay off?  Every group is padded to whole blocks (half a block wasted
 // per group on average) against the ~2x cost of the on-the-fly path.
 bool groups_pay_off(const wf_handle* h, int K) {
-  if (h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->choice.pair_table == 0 || h->model.veer != 0.0 || K < 1) return false;
+  if (h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->choice.pair_table == 0 || K < 1) return false;
   if ((size_t)K * h->N > h->cap_bn) return false;  // group geometry lives in the per-farm geometry buffers
   const double waste = 0.5 * group_pad(h) * K / (double)h->B;
   int vG, vS; const void* vfn;

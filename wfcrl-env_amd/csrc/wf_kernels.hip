@@ -289,8 +289,8 @@ constexpr int min_blocks_per_cu() {
   return ((S <= 3 && 3 * (4 / WPB) * lds <= 160 * 1024) ? 3 : 2) * (4 / WPB);  // WPB is 4, or 2 in staging experiments
 }
 
-// VEER: wind_veer != 0 [FLORIS gauss.py rCalt] — on-the-fly path only (MC1 = false, TAB = false): the rotated Gaussian is
-// not even in z - HH, so the SOSFS state holds 9 instead of 6 sums per slot and a column costs one more exp + rcp.
+// VEER: wind_veer != 0 [FLORIS gauss.py rCalt] — on the fly (MC1 = false) and on the pair-table path (the table holds the
+// transverse pass only, which veer does not touch): the rotated Gaussian is not even in z - HH, so the SOSFS state holds 9 instead of 6 sums per slot and a column costs one more exp + rcp.
 template <int G, int S, bool MC1, bool TAB, int WPB, bool VEER = false>
 __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) void wf_step_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const double* __restrict__ gx, const double* __restrict__ gy,
@@ -1012,6 +1012,7 @@ struct WfVariant {
   const void* fn_tab;     // shared-wind pair table
   const void* fn_tab_ws;  // pair table of a shared wind direction, a wind speed per farm
   const void* fn_veer;    // wind_veer != 0: on the fly, general mirror cores
+  const void* fn_veer_tab, *fn_veer_tab_ws;  // ... on the pair-table path (the table holds the transverse pass only: no veer in it)
 };
 
 // The table path is instantiated only where two blocks per CU still fit in the 160 KiB LDS and N <= WF_PAIR_MAX_N.
@@ -1024,14 +1025,15 @@ constexpr bool tab_fits() {
 }
 // On the table path the MC1 parameter (meaningless there: no vortex core is evaluated) selects whether the wind
 // speed is shared as well (true: its derived constants live in SGPRs) or given per farm (false).
-template <int G, int S, bool SHARED_SPEED>
+template <int G, int S, bool SHARED_SPEED, bool VEER = false>
 const void* tab_kernel() {
-  if constexpr (tab_fits<G, S>()) return (const void*)&wf_step_kernel<G, S, SHARED_SPEED, true, kTabWaves>;
+  if constexpr (tab_fits<G, S>()) return (const void*)&wf_step_kernel<G, S, SHARED_SPEED, true, kTabWaves, VEER>;
   else return nullptr;
 }
 #define WF_VARIANT(G_, S_)                                                                              \
   {G_, S_, (const void*)&wf_step_kernel<G_, S_, true, false, 4>, (const void*)&wf_step_kernel<G_, S_, false, false, 4>, \
-   tab_kernel<G_, S_, true>(), tab_kernel<G_, S_, false>(), (const void*)&wf_step_kernel<G_, S_, false, false, 4, true>}
+   tab_kernel<G_, S_, true>(), tab_kernel<G_, S_, false>(), (const void*)&wf_step_kernel<G_, S_, false, false, 4, true>,     \
+   tab_kernel<G_, S_, true, true>(), tab_kernel<G_, S_, false, true>()}
 static const WfVariant kVariants[] = {
 #if WF_KSET != 2
     WF_VARIANT(4, 4),  WF_VARIANT(8, 4),  WF_VARIANT(16, 4), WF_VARIANT(16, 5), WF_VARIANT(32, 4), WF_VARIANT(64, 4),
@@ -1050,9 +1052,12 @@ static void local_variant(int i, int* G, int* S, const void** fn) {
   *S = kVariants[i].S;
   *fn = kVariants[i].fn;
 }
-// kind 0: MC1 on-the-fly, 1: general mirror cores, 2: shared-wind pair table, 3: pair table with a speed per farm, 4: wind veer
+// kind 0: MC1 on-the-fly, 1: general mirror cores, 2: shared-wind pair table, 3: pair table with a speed per farm;
+// 4, 5, 6: wind veer on the fly / with kinds 2 / 3
 static const void* local_variant_fn(int i, int kind) {
   if (kind == 4) return kVariants[i].fn_veer;
+  if (kind == 5) return kVariants[i].fn_veer_tab;
+  if (kind == 6) return kVariants[i].fn_veer_tab_ws;
   return kind == 3 ? kVariants[i].fn_tab_ws : (kind == 2 ? kVariants[i].fn_tab : (kind == 1 ? kVariants[i].fn_all : kVariants[i].fn));
 }
 static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx, const double* gy,
@@ -1061,7 +1066,7 @@ static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTabl
                                     const WfEnvArgs* env, const float* pair_tab, const int* pair_first,
                                     const WfGroupArgs* grp, hipStream_t s, int* grid_out) {
   const WfVariant& v = kVariants[variant];
-  const bool use_tab = pair_tab && v.fn_tab && !c->veer_on;
+  const bool use_tab = pair_tab && v.fn_tab;
   const int wpb = use_tab ? kTabWaves : 4;
   const int envs_per_block = wpb * (64 / v.G);
   WfGroupArgs ga = *grp;
@@ -1072,7 +1077,8 @@ static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTabl
   WfEnvArgs ea;
   if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
   void* args[] = {&cc, &tab, &gx, &gy, &gidx, &geom_stride, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &pair_tab, &pair_first, &ga};
-  const void* fn = use_tab ? (wind_stride == 0 ? v.fn_tab : v.fn_tab_ws) : (cc.veer_on ? v.fn_veer : (cc.mirror_core_n <= 1 ? v.fn : v.fn_all));
+  const void* fn = use_tab ? (cc.veer_on ? (wind_stride == 0 ? v.fn_veer_tab : v.fn_veer_tab_ws) : (wind_stride == 0 ? v.fn_tab : v.fn_tab_ws))
+                           : (cc.veer_on ? v.fn_veer : (cc.mirror_core_n <= 1 ? v.fn : v.fn_all));
   if (!use_tab) pair_tab = nullptr;
   return hipLaunchKernel(fn, dim3(grid), dim3(64 * wpb), args, 0, s);
 }
