@@ -328,3 +328,31 @@ def test_both_float64_kernels_by_flagged_count(layouts):
         w.close()
     for k in outs[400]:
         assert np.abs(outs[400][k].astype(np.float64) - outs[Bmax][k][:400]).max() <= 2e-6 * max(1.0, np.abs(outs[400][k]).max()), k
+
+
+def test_env_surface_switches(layouts):
+    """The single-farm drop-in (`HipFlorisInterface`, what `make("<layout>_Floris")` builds) has the re-solve on by default —
+    the reference computes every step in float64 — and the vectorised env takes `risk_resolve=True`.  On the farm the float32
+    kernel is known to flag (tests/golden/regime_cases.npz) the interface lands on the committed float64 values."""
+    import parity
+    from wfcrl_env_amd import environments as envs
+    from wfcrl_env_amd.interface import HipFlorisInterface
+
+    i, ref = _regime("overlap_flip")
+    N = len(i["x"])
+    fi = HipFlorisInterface(N, i["x"], i["y"], wind_speed=float(i["ws"][0]), wind_direction=float(i["wd"][0]))
+    fi.update_command(i["yaw"][0])
+    got = {"power": fi.avg_powers()[None], "wind_speed": fi.get_measure("wind_speed")[None],
+           "wind_direction": fi.get_measure("wind_direction")[None], "load": fi.get_measure("load")[None] / 1e7}
+    assert fi.fi.resolve_stats()["n_resolved"] == 1
+    parity.check_strict(got, ref)
+    off = HipFlorisInterface(N, i["x"], i["y"], wind_speed=float(i["ws"][0]), wind_direction=float(i["wd"][0]), risk_resolve=False)
+    off.update_command(i["yaw"][0])
+    assert off.fi.resolve_stats()["n_resolved"] == 0 and off.fi.risk_flags()[0] != 0
+    venv = envs.make("HornsRev1_Floris", env_batch=512, risk_resolve=True, log=False)
+    venv.reset(seed=3)
+    import torch
+
+    venv.step({"yaw": torch.zeros((512, 80), device="cuda")})
+    assert not venv.fi.risk_flags().any()
+    venv.close()

@@ -75,7 +75,7 @@ class HipFlorisInterface(BaseInterface):
 
     _REF_ARGS = ("simul_file", "max_iter", "log_file", "wind_speed", "wind_direction", "wind_time_series")
     _OWN_ARGS = ("xcoords", "ycoords", "max_iter", "log_file", "wind_speed", "wind_direction", "wind_time_series",
-                 "device_id", "model", "seed")
+                 "device_id", "model", "seed", "risk_resolve")
 
     def __init__(self, num_turbines: int, *args, **kw):
         """Two call forms.
@@ -90,7 +90,12 @@ class HipFlorisInterface(BaseInterface):
 
         Coordinate form of this build:
             HipFlorisInterface(num_turbines, xcoords, ycoords, max_iter=1e4, log_file=None, wind_speed=None,
-                               wind_direction=None, wind_time_series=None, device_id=0, model=None, seed=None)
+                               wind_direction=None, wind_time_series=None, device_id=0, model=None, seed=None,
+                               risk_resolve=True)
+        risk_resolve (default on for this single-farm drop-in): a step the float32 kernel flags — a deficit within rounding
+        of the overlap threshold, a turbine on the cut-in ramp or the cut-out drop — is solved again in float64 on the
+        device (include/wfstep.h: wf_set_risk_resolve), as the reference computes every step (interface.py:564); costs three
+        empty launches per step otherwise.
         """
         ref_form = (len(args) > 0 and isinstance(args[0], (str, os.PathLike))) or "simul_file" in kw
         names = self._REF_ARGS if ref_form else self._OWN_ARGS
@@ -126,12 +131,14 @@ class HipFlorisInterface(BaseInterface):
     def _construct(self, num_turbines: int, xcoords, ycoords, max_iter: int = int(1e4), log_file: str = None,
                    wind_speed: float = None, wind_direction: float = None,
                    wind_time_series: Union[str, np.ndarray] = None, device_id: int = 0, model: dict = None,
-                   seed: int = None):
+                   seed: int = None, risk_resolve: bool = True):
         BaseInterface.__init__(self)
         if len(xcoords) != num_turbines or len(ycoords) != num_turbines:
             raise ValueError("xcoords and ycoords layout coordinates must have num_turbines entries")
         self.num_turbines = num_turbines
         self.fi = self._make_backend(xcoords, ycoords, device_id, model)
+        if risk_resolve and hasattr(self.fi, "set_risk_resolve"):
+            self.fi.set_risk_resolve(1)
         self.measure_map = self.DEFAULT_MEASURE_MAP
         self._num_measures = sum(len(v) if isinstance(v, list) else 1 for v in self.measure_map.values()) - 1
         self.dt = 60

@@ -31,7 +31,7 @@ class VecWindFarmEnv:
                  reward_shaper=None, start_iter: int = 0, max_num_steps: int = 500, load_coef: float = 0.1,
                  device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None,
                  wind_sampling: str = "host", reuse_buffers: bool = False, wind_direction_step: float = None,
-                 actuation_budget: float = 0.1, kernel_choice: dict = None):
+                 actuation_budget: float = 0.1, kernel_choice: dict = None, risk_resolve: bool = False):
         controls = {"yaw": (-40, 40, 5)} if controls is None else dict(controls)
         if list(controls) != ["yaw"]:
             raise ValueError(f"Cannot control {list(controls)}. Interface HipFlorisInterface only allows for the "
@@ -56,6 +56,10 @@ class VecWindFarmEnv:
         p = self.farm_case.simul_params
         self.fi = backend if backend is not None else WfStep(p["xcoords"], p["ycoords"], env_batch=self.num_envs,
                                                               device_id=device_id, model=model, kernel_choice=kernel_choice)
+        # risk_resolve: every farm the float32 kernel flags is solved again in float64 behind each step (wf_set_risk_resolve):
+        # the reference's float64 answer on every farm, for ~1 ms per step where a wind per farm flags ~2 % of the batch
+        if risk_resolve:
+            self.fi.set_risk_resolve(1)
         self.fi.env_config(yaw_lo=spec[0], yaw_hi=spec[1], yaw_step=spec[2],
                            actuator_rate=WindFarmMDP.ACTUATORS_RATE["yaw"], dt=self.dt, budget=actuation_budget,
                            load_coef=load_coef, discrete=not continuous_control)
