@@ -47,7 +47,7 @@ typedef struct wf_handle wf_handle;
 typedef struct wf_model_params {
   /* flow field — case.yaml:30-39 */
   double air_density, ambient_ti, shear, veer; /* veer != 0: FLORIS' rotated Gaussian; served by the VEER instantiations of
-                                                   wf_step_kernel (no one-block kernel: about half the veer-free rate) */
+                                                   both step kernels (about 3/4 of the veer-free rate) */
   /* turbine — FLORIS turbine_library/nrel_5MW */
   double rotor_diameter, hub_height, tsr, pP, pT, gen_eff, ref_density;
   /* gauss velocity model — case.yaml:76-80 (alpha, beta, ka, kb); gauss deflection model — case.yaml:52-59 (ad, bd,

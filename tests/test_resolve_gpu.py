@@ -183,7 +183,7 @@ def test_resolve_on_grouped_launches_and_the_fused_env_step(layouts):
 def test_wind_veer(layouts, name, B):
     """wind_veer != 0 (reference case.yaml:36 is user-editable and goes straight to FLORIS: the Gaussian of the deficit is
     rotated by the veer angle, gauss.py rCalt).  Float32: wf_step_kernel's VEER instantiation (9 instead of 6 SOSFS sums
-    per slot; no one-block kernel) under the per-farm contract; with the re-solve on every farm
+    per slot; these batches are below the one-block kernel's) under the per-farm contract; with the re-solve on every farm
     strict; mode 2 (every farm in float64) down to output rounding.  Shared 270 deg (exact x' ties on the grids) and a
     wind per farm."""
     import parity
@@ -216,9 +216,44 @@ def test_wind_veer(layouts, name, B):
     assert np.abs(ref["power"] / np.maximum(ref0["power"], 1e3) - 1).max() > 1e-3  # (veer does change the answer)
 
 
+@pytest.mark.parametrize("one_block", ["4x1", "4x2", "2x2"])
+def test_wind_veer_one_block_kernel(layouts, one_block):
+    """The one-block kernel's VEER instantiations (9 SOSFS sums per slot; the source log's sigma_y0 carries cos(veer)):
+    table path at 4x1 / 4x2 / 2x2, on the fly at 4x2, forced at a batch the pick would leave to the register-slot
+    kernel; G = 8 is not instantiated with veer and falls back."""
+    import parity
+    from oracle.floris_gch_numpy import ModelParams
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    x, y, N, B = l["xcoords"], l["ycoords"], 80, 512
+    rng = np.random.default_rng(zlib.crc32(f"veer-ll/{one_block}".encode()))
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    mp = ModelParams(veer=-5.0)
+    w = WfStep(x, y, env_batch=B, model=dict(veer=-5.0), kernel_choice=dict(one_block=one_block))
+    for mode in ("shared", "shared_axis", "per_env"):
+        ws, wd = (9.0, 270.0) if mode == "shared_axis" else _wind(rng, B, mode)
+        w.set_wind(ws, wd)
+        info = w.kernel_info()
+        assert info["one_block_kernel"] == 1  # (on the fly: always 4x2)
+        assert f'{info["lanes_per_env"]}x{info["slots_per_lane"]}' == ("4x2" if mode == "per_env" else one_block)
+        ref = _oracle(x, y, ws, wd, yaw, mp)
+        w.set_risk_resolve(0)
+        out = w.step(yaw)
+        parity.check({k: v.copy() for k, v in out.items()}, ref, w.risk_flags(), max_flagged_frac=0.1)
+        w.set_risk_resolve(1)
+        parity.check_strict(w.step(yaw), ref)
+    w.close()
+    w = WfStep(x, y, env_batch=B, model=dict(veer=-5.0), kernel_choice=dict(one_block="8x1"))
+    w.set_wind(9.0, 263.0)
+    assert w.kernel_info()["one_block_kernel"] == 0
+    parity.check(w.step(yaw), _oracle(x, y, 9.0, 263.0, yaw, mp), w.risk_flags(), max_flagged_frac=0.1)
+    w.close()
+
+
 def test_veer_toggles_the_kernel_family(layouts):
-    """Setting a model with veer on a live handle moves it to the VEER kernel (and back): the wind has to be set again,
-    as after wf_set_kernel_choice."""
+    """Setting a model with veer on a live handle moves it to the VEER kernels (and back) — another family of the
+    one-block kernel may serve it: the wind has to be set again, as after wf_set_kernel_choice."""
     import parity
     from oracle.floris_gch_numpy import ModelParams
     from wfcrl_env_amd.backend import WfStep
@@ -232,7 +267,8 @@ def test_veer_toggles_the_kernel_family(layouts):
     with pytest.raises(ValueError, match="wf_set_wind"):
         w.step(np.zeros((B, N), np.float32))
     w.set_wind(8.0, 263.0)
-    assert w.kernel_info()["one_block_kernel"] == 0 and w.kernel_info()["pair_table"] == 1
+    info = w.kernel_info()  # the one-block kernel's VEER instantiations exist for G <= 4 only
+    assert info["one_block_kernel"] == 1 and info["lanes_per_env"] <= 4 and info["pair_table"] == 1
     rng = np.random.default_rng(2)
     yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
     out = w.step(yaw)

@@ -89,12 +89,13 @@ def run(n_cases, seed, only=-1, resolve=False):
         # every fourth case: a non-default model (low hub = general mirror cores, other D: 15 D no longer an integer
         # number of grid steps, other ambient TI / shear / deflection offsets)
         model, mp = {}, None
-        if rng.random() < 0.25:
+        all_veer = bool(os.environ.get("WF_FUZZ_VEER"))  # every case a veer model (the VEER kernel instantiations)
+        if rng.random() < 0.25 or all_veer:
             D = float(rng.choice([126.0, 100.5, 150.0]))
             model = dict(rotor_diameter=D, hub_height=float(rng.choice([0.56, 0.714, 0.9]) * D),
                          ambient_ti=float(rng.choice([0.06, 0.1])), shear=float(rng.choice([0.12, 0.0, 0.2])),
                          ad=float(rng.choice([0.0, 0.01])), bd=float(rng.choice([0.0, -0.002])),
-                         veer=float(rng.choice([0.0, 0.0, 4.0, -6.0])))
+                         veer=float(rng.choice([4.0, -6.0, 12.0] if all_veer else [0.0, 0.0, 4.0, -6.0])))
             mp = ModelParams(D=model["rotor_diameter"], HH=model["hub_height"], ambient_ti=model["ambient_ti"],
                              shear=model["shear"], ad=model["ad"], bd=model["bd"], veer=model["veer"])
             x, y = x * (D / 126.0), y * (D / 126.0)  # keeps the grids on the thresholds

@@ -121,12 +121,12 @@ double ll_estimate(const wf_handle* h, int fi, int N, long farms) {
 // registers) and the batch fills the chip.  wf_set_kernel_choice: one_block = 0 disables it, 1 forces (ll_G, ll_S).
 int pick_ll(const wf_handle* h, int N, int B) {  // returns (G << 4) | S, 0 = keep wf_step_kernel
   if (h->choice.one_block == 0) return 0;
-  if (h->model.veer != 0.0) return 0;  // wind veer: wf_step_kernel's VEER instantiation (the one-block kernel keeps 6 sums per slot)
+  const bool veer = h->model.veer != 0.0;  // wind veer: 9 sums per slot; the G <= 4 shapes are instantiated (wfk_ll_has_veer)
   if (N > WF_PAIR_MAX_N) return 0;
   if (h->choice.one_block == 1) {
     const int g = h->choice.ll_G, sl = h->choice.ll_S > 0 ? h->choice.ll_S : 1;
     const bool ok = ((g == 4 || g == 8 || g == 16) && sl == 1) || ((g == 4 || g == 2) && sl == 2);
-    return (ok && N > g * sl) ? ((g << 4) | sl) : 0;
+    return (ok && N > g * sl && (!veer || wfk_ll_has_veer(g, sl, 1))) ? ((g << 4) | sl) : 0;
   }
   // the cheapest estimate wins: at N = 80 the register-slot kernel up to ~8192 farms, G = 8 up to ~24576, then the two
   // G = 4 kernels depending on how the batch divides into rounds of 32768 / 49152, G = 2 x 2 on whole rounds of 65536
@@ -143,6 +143,7 @@ int pick_ll(const wf_handle* h, int N, int B) {  // returns (G << 4) | S, 0 = ke
     const LlFamily& f = kLlFamilies[fi];
     if (f.code && N <= (f.code >> 4) * (f.code & 15)) continue;  // needs more than one block
     if (f.code == ((8 << 4) | 1) && N <= 32) continue;           // (not instantiated to pay below that)
+    if (veer && f.code && !wfk_ll_has_veer(f.code >> 4, f.code & 15, 1)) continue;
     const double t = ll_estimate(h, fi, N, B);
     if (t < t_best) { t_best = t; best = f.code; }
   }
@@ -404,7 +405,7 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
     // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
     // fields above would describe) is enqueued behind it for the directions that have one
     const int ll_s = tab ? h->ll_S : ll_fly_S(h), ll_g = tab ? h->ll_G : ll_fly_G(h);
-    WF_HIP(h, wfk_ll_func_attributes(ll_g, ll_s, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, &a));
+    WF_HIP(h, wfk_ll_func_attributes(ll_g, ll_s, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, veer ? 1 : 0, &a));
     info->lanes_per_env = ll_g; info->slots_per_lane = ll_s;
     info->envs_per_block = wfk_ll_farms_per_block(ll_g); info->threads_per_block = 256;
     info->grid_blocks = (int)(((h->n_groups > 0 ? (size_t)h->n_slots : (size_t)h->B) + info->envs_per_block - 1) / info->envs_per_block);

@@ -35,6 +35,7 @@ extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, co
                                           const double* wd, double* gx, double* gy, int* gidx, int tie_block, int* farm_tie,
                                           int* any_tie, hipStream_t s);
 extern "C" int wfk_ll_has_fly(int G, int S);
+extern "C" int wfk_ll_has_veer(int G, int S, int table);
 extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* gx,
                                              const double* gy, const double* ws, const double* wd, const float* yaw,
                                              float* power, float* o_ws, float* o_wd, float* load, int B, const WfEnvArgs* env,
@@ -59,7 +60,7 @@ extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const 
                                          float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
                                          const int* cross_tie, float* src_log, size_t log_side_offset,
                                          const WfGroupArgs* grp, hipStream_t s);
-extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, hipFuncAttributes* a);
+extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, int veer, hipFuncAttributes* a);
 extern "C" hipError_t wfk_launch_fill(int n, double* a, hipStream_t s);  // a[1..n) = a[0]
 extern "C" hipError_t wfk_launch_wind_sample_binned(int B, unsigned long long seed, const double* dist, double step, double* ws,
                                                     double* wd, int* bin, hipStream_t s);

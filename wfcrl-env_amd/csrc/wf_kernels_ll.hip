@@ -134,7 +134,9 @@ __device__ unsigned long long wf_ll_stamp[16];
 #define WF_T(v)
 #define WF_ACC(k, a, b)
 #endif
-template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB>
+// VEER: wind_veer != 0 [FLORIS gauss.py rCalt]: the rotated Gaussian is not even in z - HH — 9 instead of 6 SOSFS sums per slot,
+// one exponential per grid row (wf_kernel_common.h: column_deficit_veer); instantiated for the throughput families only.
+template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB, bool VEER = false>
 #ifndef WF_LL_PINGPONG
 #define WF_LL_PINGPONG 0  // 1: two record buffers used alternately (2x unrolled replay): 20-30 spilled registers, slower
 #endif
@@ -227,6 +229,29 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
   const float Ui[3] = {uni(ws * c.shearf[0]), uni(ws * c.shearf[1]), uni(ws * c.shearf[2])};
   const float offk = c.off[2] * kGs;
   const float U02c = uni(Ui[0] * Ui[0] * Ui[0] + Ui[2] * Ui[2] * Ui[2]), U1c = uni(Ui[1] * Ui[1] * Ui[1]);
+  // sum over the rotor grid of u^3 from the SOSFS sums of a turbine (rows 0 and 2 share their sum without veer)
+  auto cube_sum = [&](const float* e) {
+    if constexpr (VEER) {
+      float m = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float u = Ui[k] * (1.0f - fsqrt(e[3 * j + k]));
+          m = fmaf(u * u, u, m);
+        }
+      return m;
+    } else {
+      float fe = 0.0f, fc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float ue = 1.0f - fsqrt(e[2 * j]), uc = 1.0f - fsqrt(e[2 * j + 1]);
+        fe = fmaf(ue * ue, ue, fe);
+        fc = fmaf(uc * uc, uc, fc);
+      }
+      return fmaf(U02c, fe, U1c * fc);
+    }
+  };
   const float ovh = 0.5f * c.guard_inv;
   const float ovs[3] = {uni(ovh * Ui[0] * c.inv_overlap_thr), uni(ovh * Ui[1] * c.inv_overlap_thr), uni(ovh * Ui[2] * c.inv_overlap_thr)};
   const float ovc = 0.5f - ovh;
@@ -268,7 +293,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
   __syncthreads();
 
   // ---- per-turbine state of the ONE target block in registers (as Slots<1> of wf_step_kernel) ----
-  float esq[S][6], V[S][9], W[S][9], TI[S][3];
+  constexpr int NE = VEER ? 9 : 6;
+  float esq[S][NE], V[S][9], W[S][9], TI[S][3];
   const float amb0 = fsqrt(c.amb2);
 
   // transverse velocities of one source on this lane's target [A.3-4]: record = 9 float4 {aV, bV, aW, bW}
@@ -347,8 +373,46 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     sc.tan_th0 = R.tan_th0; sc.sy0v = R.sy0v; sc.snw = R.snw; sc.kdef = R.kdef;
     const float d0 = R.tan_th0 * R.x0d, ix0v = R.ix0v;
     float e1[3], e0[3];
+    float e2[VEER ? 3 : 1];  // with veer: the deficit of row k = 2 (e0 is row 0)
     const bool same = !__any(R.ch_pref < 0.0f);  // the sign of ch_pref flags a split-TI source
-    if (same) {
+    if constexpr (VEER) {
+      // (general form per column; the split-TI side record is handled as below)
+      const bool mine = R.ch_pref < 0.0f;
+      WfLogSide X = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (!same && mine) {
+        if (side_from_log) {
+          X.TI0 = __hip_atomic_load(side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          X.TI1 = __hip_atomic_load(side + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          X.TI2 = __hip_atomic_load(side + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          X.dTI = __hip_atomic_load(side + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          X.TI0 = side[0]; X.TI1 = side[1]; X.TI2 = side[2]; X.dTI = side[3];
+        }
+      }
+      const float s_c = fsqrt(fmaxf(1.0f - R.sM * R.sM, 0.0f));
+      const float om_sc = R.sM * R.sM * frcp(1.0f + s_c);
+      const float b2om = c.beta2 * om_sc, b2om_d = c.beta2_d * om_sc;
+      const float x0num_d = R.x0d * fmaf(c.alpha4_d, X.TI0, b2om_d);
+      const float x0num_v = R.x0v * fmaf(c.alpha4, X.TI0 + X.dTI, b2om);
+      const float pfac = R.pj * R.kyd;
+      const float tis[3] = {X.TI0, X.TI1, X.TI2};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        ColConsts k;
+        if (j == 0 || same || !mine) {
+          k.x0d = R.x0d; k.kyd = R.kyd; k.d0 = d0; k.pj = R.pj; k.x0v = R.x0v; k.ix0v = ix0v; k.kyv = R.kyv;
+        } else {
+          k.x0d = x0num_d * frcp(fmaf(c.alpha4_d, tis[j], b2om_d));
+          k.kyd = fmaf(c.ka_d, tis[j], c.kb_d);
+          k.d0 = sc.tan_th0 * k.x0d;
+          k.pj = pfac * frcp(k.kyd);
+          k.x0v = x0num_v * frcp(fmaf(c.alpha4, tis[j] + X.dTI, b2om));
+          k.ix0v = frcp(k.x0v);
+          k.kyv = fmaf(c.ka, tis[j] + X.dTI, c.kb);
+        }
+        column_deficit_veer(c, sc, k, dx, dy + c.off[j], lin, amp_on, e0[j], e1[j], e2[j]);
+      }
+    } else if (same) {
       const float xs = fmaxf(dx - R.x0d, 0.0f);
       const float syd = fmaf(R.kyd, xs, sc.sy0d), szd = fmaf(R.kyd, xs, sc.sz0d);
       const float s = fsqrt(syd * szd * sc.inv_s0d);
@@ -415,8 +479,14 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      esq[p][2 * j] = fmaf(e0[j], e0[j], esq[p][2 * j]);
-      esq[p][2 * j + 1] = fmaf(e1[j], e1[j], esq[p][2 * j + 1]);
+      if constexpr (VEER) {
+        esq[p][3 * j] = fmaf(e0[j], e0[j], esq[p][3 * j]);
+        esq[p][3 * j + 1] = fmaf(e1[j], e1[j], esq[p][3 * j + 1]);
+        esq[p][3 * j + 2] = fmaf(e2[j], e2[j], esq[p][3 * j + 2]);
+      } else {
+        esq[p][2 * j] = fmaf(e0[j], e0[j], esq[p][2 * j]);
+        esq[p][2 * j + 1] = fmaf(e1[j], e1[j], esq[p][2 * j + 1]);
+      }
     }
     // wake-added TI [A.3-8]: only within 15 D downstream and 2 D laterally (float64 decisions)
     float tipow = ex.z;
@@ -437,7 +507,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     for (int j = 0; j < 3; ++j) {
       const float f0 = __builtin_amdgcn_fmed3f(fmaf(e0[j], ovs[0], ovc), 0.0f, 1.0f);
       const float f1 = __builtin_amdgcn_fmed3f(fmaf(e1[j], ovs[1], ovc), 0.0f, 1.0f);
-      const float f2 = __builtin_amdgcn_fmed3f(fmaf(e0[j], ovs[2], ovc), 0.0f, 1.0f);
+      const float f2 = __builtin_amdgcn_fmed3f(fmaf((VEER ? e2[VEER ? j : 0] : e0[j]), ovs[2], ovc), 0.0f, 1.0f);
       cnt += (f0 + f1) + f2;
       fbits |= __float_as_uint(f0) | __float_as_uint(f1) | __float_as_uint(f2);
     }
@@ -491,7 +561,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
 #pragma unroll
       for (int k = 0; k < 9; ++k) { V[p][k] = 0.0f; W[p][k] = 0.0f; }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) esq[p][k] = 0.0f;
+      for (int k = 0; k < NE; ++k) esq[p][k] = 0.0f;
 #pragma unroll
       for (int j = 0; j < 3; ++j) TI[p][j] = amb0;
       yaw_t[p] = yawL[tvalid[p] ? tt[p] : 0];
@@ -545,16 +615,10 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       const int src = gbase + ((i - first_own) - ps * G);  // owner lane
       WF_T(so_0);
       // A. the source's state
-      float fe = 0.0f, fc = 0.0f, vsum = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float ue = 1.0f - fsqrt(esq[ps][2 * j]), uc = 1.0f - fsqrt(esq[ps][2 * j + 1]);
-        fe = fmaf(ue * ue, ue, fe);
-        fc = fmaf(uc * uc, uc, fc);
-      }
+      float vsum = 0.0f;
 #pragma unroll
       for (int k2 = 0; k2 < 9; ++k2) vsum += V[ps][k2];
-      const float m3 = __shfl(fmaf(U02c, fe, U1c * fc), src);
+      const float m3 = __shfl(cube_sum(esq[ps]), src);
       const float Vmean = __shfl(vsum, src) * (1.0f / 9.0f);
       float TIs[3];
 #pragma unroll
@@ -629,6 +693,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       const float E0 = fmaf(om_sc, om_sc, fmaf(-c.e0c1, om_sc, c.e0c2));
       Sc.sz0d = 0.5f * c.D * fsqrt((1.0f + s_cc) * frcp(2.0f * (1.0f + s_c)));
       Sc.sy0d = Sc.sz0d * cgd;
+      if constexpr (VEER) Sc.sy0d *= c.cos_veer;
       const float th0 = c.dm03 * gd * frcp(cgd) * om_scc;
       {
         const float t2 = th0 * th0;
@@ -657,6 +722,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         for (int j = 0; j < 3; ++j) TI[ps][j] += X.dTI;
       }
       Sc.sy0v = c.sz0v * cg;
+      if constexpr (VEER) Sc.sy0v *= c.cos_veer;
       Sc.snw = c.near_c * fsqrt(0.5f * ct);
       Sc.kdef = ct * cg * c.kdef;
       Sc.ch_pref = c.ch_c * fexp2(c.ch_ai * flog2(a));
@@ -847,8 +913,13 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const float ue = 1.0f - fsqrt(esq[p][2 * j]), uc = 1.0f - fsqrt(esq[p][2 * j + 1]);
-        U[3 * j] = Ui[0] * ue; U[3 * j + 1] = Ui[1] * uc; U[3 * j + 2] = Ui[2] * ue;
+        if constexpr (VEER) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) U[3 * j + k] = Ui[k] * (1.0f - fsqrt(esq[p][3 * j + k]));
+        } else {
+          const float ue = 1.0f - fsqrt(esq[p][2 * j]), uc = 1.0f - fsqrt(esq[p][2 * j + 1]);
+          U[3 * j] = Ui[0] * ue; U[3 * j + 1] = Ui[1] * uc; U[3 * j + 2] = Ui[2] * ue;
+        }
       }
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
@@ -932,7 +1003,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
 // ---------------------------------------------------------------------------------------------
 constexpr int kLLWaves = 4;
 
-template <int G, int S, bool TAB, bool MC1>
+template <int G, int S, bool TAB, bool MC1, bool VEER = false>
 static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws, const double* wd,
                             int wind_stride, const float* yaw, float* power, float* o_ws, float* o_wd, float* load, int B,
                             const WfEnvArgs* env, const float* ll_tab, const int* cross_tie, float* src_log, size_t log_side_offset,
@@ -948,9 +1019,9 @@ static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* g
   const size_t dyn_lds = sizeof(float) * (size_t)fpb * n_pad;
   void* args[] = {&cc, &tab, &gidx, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &ll_tab,
                   &group_floats, &cross_tie, &src_log, &log_side_offset, &n_pad, &ga, &gx, &gy};
-  const void* fn = (const void*)&wf_step_ll_kernel<G, S, false, TAB, MC1, kLLWaves>;
+  const void* fn = (const void*)&wf_step_ll_kernel<G, S, false, TAB, MC1, kLLWaves, VEER>;
   if constexpr (TAB) {
-    if (wind_stride == 0) fn = (const void*)&wf_step_ll_kernel<G, S, true, TAB, MC1, kLLWaves>;
+    if (wind_stride == 0) fn = (const void*)&wf_step_ll_kernel<G, S, true, TAB, MC1, kLLWaves, VEER>;
   }
   return hipLaunchKernel(fn, dim3(grid), dim3(64 * kLLWaves), args, dyn_lds, s);
 }
@@ -978,6 +1049,13 @@ extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const 
                                          const int* cross_tie, float* src_log, size_t log_side_offset,
                                          const WfGroupArgs* grp, hipStream_t s) {
 #define WF_LL_LAUNCH(G_, S_) launch_ll<G_, S_, true, true>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, nullptr, nullptr, s)
+#define WF_LL_LAUNCH_VEER(G_, S_) launch_ll<G_, S_, true, true, true>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, nullptr, nullptr, s)
+  if (c->veer_on) {  // wind veer: the throughput families only (wfk_ll_has_veer)
+    WF_LL_DISPATCH(4, 1, WF_LL_LAUNCH_VEER);
+    WF_LL_DISPATCH(4, 2, WF_LL_LAUNCH_VEER);
+    WF_LL_DISPATCH(2, 2, WF_LL_LAUNCH_VEER);
+    return hipErrorInvalidValue;
+  }
   WF_LL_DISPATCH(4, 1, WF_LL_LAUNCH);
   WF_LL_DISPATCH(8, 1, WF_LL_LAUNCH);
   WF_LL_DISPATCH(16, 1, WF_LL_LAUNCH);
@@ -985,6 +1063,9 @@ extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const 
   WF_LL_DISPATCH(2, 2, WF_LL_LAUNCH);
   return hipErrorInvalidValue;
 }
+
+// (G, S) shapes instantiated with wind veer: table path 4x1, 4x2, 2x2; on the fly 4x2
+extern "C" int wfk_ll_has_veer(int G, int S, int table) { return table ? ((G == 4 && S <= 2) || (G == 2 && S == 2)) : (G == 4 && S == 2); }
 
 extern "C" int wfk_ll_has_fly(int G, int S) { return (G == 4 && S <= 2) || (G == 8 && S == 1); }
 
@@ -1000,13 +1081,27 @@ extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, co
                                         log_side_offset, grp, gx, gy, s)                                                       \
        : launch_ll<G_, S_, false, false>(c, tab, gidx, ws, wd, 1, yaw, power, o_ws, o_wd, load, B, env, nullptr, farm_tie,      \
                                          src_log, log_side_offset, grp, gx, gy, s))
+  if (c->veer_on) {
+    if (G == 4 && S == 2)
+      return launch_ll<4, 2, false, false, true>(c, tab, gidx, ws, wd, 1, yaw, power, o_ws, o_wd, load, B, env, nullptr, farm_tie, src_log,
+                                                 log_side_offset, grp, gx, gy, s);
+    return hipErrorInvalidValue;
+  }
   WF_LL_DISPATCH(4, 2, WF_LL_LAUNCH_FLY);
   WF_LL_DISPATCH(4, 1, WF_LL_LAUNCH_FLY);
   WF_LL_DISPATCH(8, 1, WF_LL_LAUNCH_FLY);
   return hipErrorInvalidValue;
 }
 
-extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, hipFuncAttributes* a) {
+extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, int veer, hipFuncAttributes* a) {
+#define WF_LL_ATTR_VEER(G_, S_) hipFuncGetAttributes(a, shared_speed ? (const void*)&wf_step_ll_kernel<G_, S_, true, true, true, kLLWaves, true> : (const void*)&wf_step_ll_kernel<G_, S_, false, true, true, kLLWaves, true>)
+  if (veer) {
+    if (!table) return (G == 4 && S == 2) ? hipFuncGetAttributes(a, (const void*)&wf_step_ll_kernel<4, 2, false, false, true, kLLWaves, true>) : hipErrorInvalidValue;
+    WF_LL_DISPATCH(4, 1, WF_LL_ATTR_VEER);
+    WF_LL_DISPATCH(4, 2, WF_LL_ATTR_VEER);
+    WF_LL_DISPATCH(2, 2, WF_LL_ATTR_VEER);
+    return hipErrorInvalidValue;
+  }
 #define WF_LL_ATTR(G_, S_) hipFuncGetAttributes(a, shared_speed ? (const void*)&wf_step_ll_kernel<G_, S_, true, true, true, kLLWaves> : (const void*)&wf_step_ll_kernel<G_, S_, false, true, true, kLLWaves>)
 #define WF_LL_ATTR_FLY(G_, S_) hipFuncGetAttributes(a, (const void*)&wf_step_ll_kernel<G_, S_, false, false, true, kLLWaves>)
   if (!table) {
