@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 3
+#define WF_ABI_VERSION 4
 
 /* status codes (0 = ok, negative = error; text via wf_last_error) */
 #define WF_OK 0
@@ -103,6 +103,17 @@ int wf_set_layout(wf_handle* h, int n_turbines, const double* x, const double* y
 
 /* Number of independent farm instances evaluated per step (not in the reference: it holds one). */
 int wf_set_batch(wf_handle* h, int env_batch);
+
+/* Several layouts in one batch (not in the reference: one env holds one layout, envs.make builds one per case — here a
+ * batch may mix them, e.g. to train one policy across layouts).  n_layouts layouts of the n_turbines of wf_set_layout,
+ * x / y: [n_layouts][n_turbines]; layout_of: [env_batch] layout of each farm, or NULL with n_layouts == env_batch (farm
+ * b has layout b).  Call after wf_set_batch (which returns the handle to the first layout for every farm); the wind has
+ * to be set again.  Every farm is rotated and sorted on its own; under ONE wind direction the farms of a layout share
+ * geometry and pair table (a grouped launch, as for direction groups), with a direction per farm the on-the-fly kernels
+ * serve the batch; series playback and binned sampling fall back to a geometry per farm.  The float32 lateral offsets
+ * are taken relative to one centre per handle: the layouts' bounding-box centres must lie within 4096 m in y
+ * (WF_E_INVALID otherwise; the model is translation invariant, shift them).  n_layouts == 1 equals wf_set_layout. */
+int wf_set_layouts(wf_handle* h, int n_layouts, const double* x, const double* y, const int* layout_of);
 
 /* Replaces FlorisInterface.update_wind -> fi.reinitialize (interface.py:663-671).
  * count == 1: one (ws, wd) shared by the whole batch; count == env_batch: one per instance.

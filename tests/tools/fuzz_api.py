@@ -51,9 +51,23 @@ def run(n_sessions, n_ops, seed):
         w.env_reset()
         log = []
 
+        multi = None  # (X [K][N], Y, layout_of [B]) after wf_set_layouts; None: the one layout (x, y)
+
         def oracle(yaw64):
             ws, wd = w.get_wind()
-            return c_oracle.farm_step_batch(x, y, ws, wd, yaw64, mp, margin=True), ws
+            if multi is None:
+                return c_oracle.farm_step_batch(x, y, ws, wd, yaw64, mp, margin=True), ws
+            out = None
+            for l in range(multi[0].shape[0]):
+                idx = np.flatnonzero(multi[2] == l)
+                if idx.size == 0:
+                    continue
+                r = c_oracle.farm_step_batch(multi[0][l], multi[1][l], ws[idx], wd[idx], yaw64[idx], mp, margin=True)
+                if out is None:
+                    out = {k: np.zeros((yaw64.shape[0],) + np.asarray(v).shape[1:], np.asarray(v).dtype) for k, v in r.items()}
+                for k, v in r.items():
+                    out[k][idx] = v
+            return out, ws
 
         last_yaw = None
 
@@ -82,10 +96,12 @@ def run(n_sessions, n_ops, seed):
         for _ in range(n_ops):
             op = rng.choice(["step", "step", "step_torch", "wind_shared", "wind_per_farm", "wind_device", "wind_sample", "series",
                              "series_step", "batch", "model", "layout", "env_step", "env_step", "env_reset", "env_config",
-                             "resolve", "kernel_choice"])
+                             "resolve", "kernel_choice", "layouts"])
             log.append(str(op))
             N = x.size
-            if op in ("layout", "batch", "wind_shared", "wind_per_farm", "wind_device", "wind_sample"):
+            if op in ("layout", "batch", "layouts"):
+                multi = None  # (wf_set_batch returns the handle to the first layout)
+            if op in ("layout", "batch", "layouts", "wind_shared", "wind_per_farm", "wind_device", "wind_sample"):
                 w._series_left = 0  # any other way of setting the wind leaves series mode
                 w._ws_prev = None
             if op == "resolve":  # float64 re-solve of the flagged farms on / off (wf_set_risk_resolve)
@@ -105,6 +121,20 @@ def run(n_sessions, n_ops, seed):
                 w.env_batch = B
                 w.set_wind(float(rng.uniform(4, 15)), float(rng.choice([270.0, 90.0, rng.uniform(0, 360)])))
                 w.env_reset()
+            elif op == "layouts":  # several layouts in the batch (wf_set_layouts): shifted / jittered copies of the current one
+                K = B if rng.random() < 0.3 else int(rng.integers(1, min(B, 4) + 1))
+                X = np.repeat(x[None, :], K, axis=0) + rng.choice([0.0, 126.0, -378.0], (K, 1))
+                Y = np.repeat(y[None, :], K, axis=0) + rng.choice([0.0, 252.0, -126.0], (K, 1))
+                jit = rng.random(K) < 0.5
+                X[jit] += rng.uniform(-50, 50, (int(jit.sum()), N))
+                Y[jit] += rng.uniform(-50, 50, (int(jit.sum()), N))
+                lof = None if K == B and rng.random() < 0.5 else rng.integers(0, K, B).astype(np.int32)
+                if K == 1:
+                    lof = None
+                w.set_layouts(X, Y, lof)
+                x, y = X[0].copy(), Y[0].copy()
+                multi = None if K == 1 else (X, Y, np.arange(B) if lof is None else lof)
+                w.set_wind(float(rng.uniform(4, 15)), float(rng.choice([270.0, 90.0, rng.uniform(0, 360)])))
             elif op == "batch":
                 B = int(rng.choice([1, rng.integers(1, 40), rng.integers(200, 3000)]))
                 w.set_batch(B)

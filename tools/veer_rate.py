@@ -28,7 +28,10 @@ for label, model, mode, choice in (
             continue
         w.set_wind(ws, wd)
         info = w.kernel_info()
-        out = w.step(yaw); w.sync()
+        out = w.step(yaw)
+        for _ in range(10 if mode != 2 else 0):  # (clocks ramp up over the first launches)
+            w.step(yaw, out)
+        w.sync()
         w.timing_begin()
         for _ in range(3):
             w.step(yaw, out)

@@ -52,8 +52,15 @@ class WfStep:
         self.env_batch = 0
         if model is not None:
             self.set_model(model)
-        self.set_layout(xcoords, ycoords)
-        self.set_batch(env_batch)
+        xy = np.asarray(xcoords, dtype=np.float64), np.asarray(ycoords, dtype=np.float64)
+        if xy[0].ndim == 2:  # several layouts in the batch: [n_layouts][n_turbines], `layout_of` through set_layouts
+            self.set_layout(xy[0][0], xy[1][0])
+            self.set_batch(env_batch)
+            if xy[0].shape[0] == env_batch:
+                self.set_layouts(*xy)
+        else:
+            self.set_layout(*xy)
+            self.set_batch(env_batch)
         if kernel_choice:  # keyword arguments of set_kernel_choice: which kernels may serve this handle
             self.set_kernel_choice(**kernel_choice)
 
@@ -90,6 +97,21 @@ class WfStep:
             raise ValueError("xcoords and ycoords layout coordinates must have the same length")
         check(self._lib.wf_set_layout(self._h, x.size, x.ctypes.data, y.ctypes.data), self._h)
         self.num_turbines = int(x.size)
+
+    def set_layouts(self, xcoords, ycoords, layout_of=None):
+        """Several layouts in one batch (include/wfstep.h: wf_set_layouts): xcoords / ycoords [n_layouts][n_turbines],
+        layout_of [env_batch] the layout of each farm (None: n_layouts == env_batch, farm b has layout b).  After
+        set_batch; the wind has to be set again."""
+        x = np.ascontiguousarray(xcoords, dtype=np.float64)
+        y = np.ascontiguousarray(ycoords, dtype=np.float64)
+        if x.ndim != 2 or x.shape != y.shape or x.shape[1] != self.num_turbines:
+            raise ValueError("xcoords and ycoords must both be [n_layouts][num_turbines]")
+        lo = None
+        if layout_of is not None:
+            lo = np.ascontiguousarray(layout_of, dtype=np.int32)
+            if lo.shape != (self.env_batch,):
+                raise ValueError("layout_of must have one entry per env")
+        check(self._lib.wf_set_layouts(self._h, x.shape[0], x.ctypes.data, y.ctypes.data, lo.ctypes.data if lo is not None else None), self._h)
 
     def set_batch(self, env_batch: int):
         check(self._lib.wf_set_batch(self._h, int(env_batch)), self._h)

@@ -98,7 +98,7 @@ int wf_destroy(wf_handle* h) {
   DeviceGuard guard(h->device);
   hipStreamSynchronize(h->stream);
   free_batch(h);
-  hipFree(h->d_tab); hipFree(h->d_tab64); hipFree(h->d_lx); hipFree(h->d_ly);
+  hipFree(h->d_tab); hipFree(h->d_tab64); hipFree(h->d_lx); hipFree(h->d_ly); hipFree(h->d_centre); hipFree(h->d_layout_of);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
   hipStreamDestroy(h->own_stream);
   delete h;
@@ -117,6 +117,48 @@ int wf_set_stream(wf_handle* h, void* s, int external) {
 }
 void* wf_get_stream(wf_handle* h) { return h ? (void*)h->stream : nullptr; }
 
+// Layout data of the handle: K layouts of n turbines, their centres of rotation [A.1-1] and the farm -> layout map.
+static int upload_layouts(wf_handle* h, int n, int K, const double* x, const double* y, const int* layout_of) {
+  std::vector<double> centre(2 * (size_t)K);
+  double yc_lo = 0, yc_hi = 0;
+  for (int l = 0; l < K; ++l) {
+    const double *xl = x + (size_t)l * n, *yl = y + (size_t)l * n;
+    double xmin = xl[0], xmax = xl[0], ymin = yl[0], ymax = yl[0];
+    for (int i = 0; i < n; ++i) {
+      if (!std::isfinite(xl[i]) || !std::isfinite(yl[i])) return fail(h, WF_E_INVALID, "turbine coordinates must be finite");
+      xmin = std::fmin(xmin, xl[i]); xmax = std::fmax(xmax, xl[i]);
+      ymin = std::fmin(ymin, yl[i]); ymax = std::fmax(ymax, yl[i]);
+    }
+    centre[2 * l] = (xmin + xmax) / 2.0; centre[2 * l + 1] = (ymin + ymax) / 2.0;  // centre of rotation [A.1-1]
+    yc_lo = l ? std::fmin(yc_lo, centre[2 * l + 1]) : centre[1];
+    yc_hi = l ? std::fmax(yc_hi, centre[2 * l + 1]) : centre[1];
+  }
+  // the float32 lateral distances are taken on y' - yc with ONE yc per handle (WfConsts::yc_d): layouts far apart in
+  // y would lose the low bits of their lateral offsets.  The model is translation invariant: the caller can shift them.
+  if (yc_hi - yc_lo > 4096.0)
+    return fail(h, WF_E_INVALID, "layouts of one batch must share a frame: bounding-box centres within 4096 m in y (translate them)");
+  WF_HIP(h, hipStreamSynchronize(h->stream));
+  hipFree(h->d_lx); hipFree(h->d_ly); hipFree(h->d_centre); hipFree(h->d_layout_of);
+  h->d_lx = h->d_ly = h->d_centre = nullptr; h->d_layout_of = nullptr;
+  const size_t kn = (size_t)K * n;
+  WF_HIP(h, hipMalloc(&h->d_lx, sizeof(double) * kn));
+  WF_HIP(h, hipMalloc(&h->d_ly, sizeof(double) * kn));
+  WF_HIP(h, hipMalloc(&h->d_centre, sizeof(double) * 2 * K));
+  WF_HIP(h, hipMemcpy(h->d_lx, x, sizeof(double) * kn, hipMemcpyHostToDevice));
+  WF_HIP(h, hipMemcpy(h->d_ly, y, sizeof(double) * kn, hipMemcpyHostToDevice));
+  WF_HIP(h, hipMemcpy(h->d_centre, centre.data(), sizeof(double) * 2 * K, hipMemcpyHostToDevice));
+  h->layout_of.clear();
+  if (layout_of) {
+    h->layout_of.assign(layout_of, layout_of + h->B);
+    WF_HIP(h, hipMalloc(&h->d_layout_of, sizeof(int) * h->B));
+    WF_HIP(h, hipMemcpy(h->d_layout_of, layout_of, sizeof(int) * h->B, hipMemcpyHostToDevice));
+  }
+  h->lx.assign(x, x + kn); h->ly.assign(y, y + kn);
+  h->n_layouts = K;
+  h->xc = centre[0]; h->yc = (yc_lo + yc_hi) / 2.0;
+  return WF_OK;
+}
+
 int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
   if (!h || !x || !y) return WF_E_INVALID;
   if (n < 1 || n > WF_MAX_TURBINES) return fail(h, WF_E_INVALID, "n_turbines must be in 1..256");
@@ -128,18 +170,10 @@ int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
     if (n != h->N) set_ll_shape(h, 0, 1);  // table and source log are laid out for (N, G, S)
     set_ll_shape(h, llg >> 4, llg ? (llg & 15) : 1);
   }
-  h->lx.assign(x, x + n); h->ly.assign(y, y + n);
-  double xmin = x[0], xmax = x[0], ymin = y[0], ymax = y[0];
-  for (int i = 1; i < n; ++i) {
-    xmin = std::fmin(xmin, x[i]); xmax = std::fmax(xmax, x[i]);
-    ymin = std::fmin(ymin, y[i]); ymax = std::fmax(ymax, y[i]);
+  {
+    int rc = upload_layouts(h, n, 1, x, y, nullptr);
+    if (rc != WF_OK) return rc;
   }
-  h->xc = (xmin + xmax) / 2.0; h->yc = (ymin + ymax) / 2.0;  // centre of rotation [A.1-1]
-  hipFree(h->d_lx); hipFree(h->d_ly); h->d_lx = h->d_ly = nullptr;
-  WF_HIP(h, hipMalloc(&h->d_lx, sizeof(double) * n));
-  WF_HIP(h, hipMalloc(&h->d_ly, sizeof(double) * n));
-  WF_HIP(h, hipMemcpy(h->d_lx, x, sizeof(double) * n, hipMemcpyHostToDevice));
-  WF_HIP(h, hipMemcpy(h->d_ly, y, sizeof(double) * n, hipMemcpyHostToDevice));
   if (n != h->N) { free_batch(h); h->B = 0; }
   h->N = n; h->variant = v; h->wind_count = 0; h->shared_dir = false; h->model_dirty = true;
   h->n_groups = 0; h->grid_step = 0.0;
@@ -153,6 +187,12 @@ int wf_set_batch(wf_handle* h, int B) {
   WF_ON_DEVICE(h);
   WF_HIP(h, hipStreamSynchronize(h->stream));
   if (pick_variant(h, h->N, B) < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
+  if (h->n_layouts > 1) {  // the farm -> layout map was for the old batch: back to the first layout for every farm
+    std::vector<double> x0(h->lx.begin(), h->lx.begin() + h->N), y0(h->ly.begin(), h->ly.begin() + h->N);
+    int rc = upload_layouts(h, h->N, 1, x0.data(), y0.data(), nullptr);
+    if (rc != WF_OK) return rc;
+    h->model_dirty = true;
+  }
   apply_kernel_pick(h, h->N, B, nullptr);
   if ((size_t)B != h->cap_env) {
     free_batch(h);
@@ -173,6 +213,26 @@ int wf_set_batch(wf_handle* h, int B) {
   h->n_groups = 0; h->grid_step = 0.0;
   return WF_OK;
 }
+int wf_set_layouts(wf_handle* h, int n_layouts, const double* x, const double* y, const int* layout_of) {
+  if (!h || !x || !y) return WF_E_INVALID;
+  if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_layout and wf_set_batch must be called before wf_set_layouts");
+  if (n_layouts < 1 || n_layouts > h->B) return fail(h, WF_E_INVALID, "n_layouts must be in 1..env_batch");
+  if (!layout_of && n_layouts != 1 && n_layouts != h->B)
+    return fail(h, WF_E_INVALID, "without layout_of, n_layouts must be 1 or env_batch (farm b has layout b)");
+  if (layout_of)
+    for (int b = 0; b < h->B; ++b)
+      if (layout_of[b] < 0 || layout_of[b] >= n_layouts) return fail(h, WF_E_INVALID, "layout_of entry out of range");
+  WF_ON_DEVICE(h);
+  {
+    int rc = upload_layouts(h, h->N, n_layouts, x, y, n_layouts > 1 ? layout_of : nullptr);
+    if (rc != WF_OK) return rc;
+  }
+  h->wind_count = 0; h->shared_dir = false; h->model_dirty = true; h->pair_dirty = true;  // (yc of the kernels' constants)
+  h->series_T = 0; h->grid_step = 0.0;
+  ungroup(h);
+  return WF_OK;
+}
+
 int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, int on_device) {
   if (!h || !yaw) return WF_E_INVALID;
   if (h->wind_count == 0) return fail(h, WF_E_INVALID, "wf_set_wind must be called before wf_step");

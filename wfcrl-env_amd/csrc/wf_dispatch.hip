@@ -255,7 +255,9 @@ int ll_fly_S(const wf_handle* h);
 int ll_fly_G(const wf_handle* h);
 int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
   const bool per_farm = n_env == h->B && h->B > 1 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h));
-  WF_HIP(h, wfk_launch_geometry(n_env, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd, h->d_gx, h->d_gy, h->d_gidx,
+  // several layouts in the batch (wf_set_layouts): a geometry per farm whatever the wind (the callers pass n_env == B)
+  WF_HIP(h, wfk_launch_geometry(n_env, h->N, h->d_lx, h->d_ly, h->d_centre, h->n_layouts == 1 ? 0 : (h->d_layout_of ? 2 : 1),
+                                h->d_layout_of, d_wd, 1, h->d_gx, h->d_gy, h->d_gidx,
                                 per_farm ? ll_fly_G(h) * ll_fly_S(h) : 0, h->d_farm_tie, h->d_farm_tie ? h->d_farm_tie + h->B : nullptr,
                                 h->stream));
   h->farm_ties = 2;
@@ -359,7 +361,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   ra.geom_stride = (h->wind_count == 1 || h->shared_dir) ? 0 : (size_t)h->N;
   ra.mod = 1;
   if (h->n_groups > 0) {
-    ra.farm_group = h->series_T > 0 ? h->d_series_start : h->d_bins;
+    ra.farm_group = h->n_layouts > 1 ? h->d_layout_of : (h->series_T > 0 ? h->d_series_start : h->d_bins);  // what build_groups partitioned by
     ra.shift = h->group_shift; ra.mod = h->n_groups;
   }
   ra.ws = h->d_ws; ra.wd = h->d_wd; ra.wind_stride = h->wind_count == 1 ? 0 : 1;

@@ -1,5 +1,7 @@
 // wf_groups.hip — direction groups: farms partitioned by a small set of distinct wind directions (the rows of a shared
 // wind series, the grid directions of binned reset sampling), one sorted geometry + pair table per group.
+#include <algorithm>
+
 #include "wf_handle.h"
 
 namespace wfi {
@@ -24,21 +26,25 @@ int farms_per_block(const wf_handle* h) {
   return wfk_tab_waves() * (64 / vG);
 }
 int group_pad(const wf_handle* h) {
-  // (a grouped launch never runs the G = 2 kernel: build_groups)
-  const int a = farms_per_block(h), b = h->ll_G ? wfk_ll_farms_per_block(h->ll_G == 2 ? 4 : h->ll_G) : 0;
+  const int a = farms_per_block(h), b = h->ll_G ? wfk_ll_farms_per_block(h->ll_G) : 0;
   return a > b ? a : b;
 }
 int group_unit(const wf_handle* h) {
-  const int a = farms_per_block(h), b = h->ll_G ? wfk_ll_farms_per_block(h->ll_G == 2 ? 4 : h->ll_G) : a;
+  const int a = farms_per_block(h), b = h->ll_G ? wfk_ll_farms_per_block(h->ll_G) : a;
   return a < b ? a : b;
 }
 
 // Would a grouped launch over K direction groups pay off?  Every group is padded to whole blocks (half a block wasted
 // per group on average) against the ~2x cost of the on-the-fly path.
-bool groups_pay_off(const wf_handle* h, int K) {
+bool groups_pay_off(const wf_handle* h, int K) { return h->n_layouts == 1 && groups_fit(h, K); }
+// ... the same question for any partition of the farms into K groups with a geometry each (direction groups of one
+// layout; the layouts of a batch under one direction: wf_set_layouts)
+bool groups_fit(const wf_handle* h, int K) {
   if (h->N > WF_PAIR_MAX_N || !wfk_variant_has_table(h->variant) || h->choice.pair_table == 0 || K < 1) return false;
   if ((size_t)K * h->N > h->cap_bn) return false;  // group geometry lives in the per-farm geometry buffers
-  const double waste = 0.5 * group_pad(h) * K / (double)h->B;
+  // (priced at the 64-farm blocks of G = 4: build_groups leaves the G = 2 kernel unless its 128-farm blocks are cheaper)
+  const int pad = std::max(farms_per_block(h), h->ll_G ? wfk_ll_farms_per_block(h->ll_G == 2 ? 4 : h->ll_G) : 0);
+  const double waste = 0.5 * pad * K / (double)h->B;
   int vG, vS; const void* vfn;
   wfk_variant(h->variant, &vG, &vS, &vfn);
   const size_t bytes = (size_t)K * h->N * WF_PAIR_ROW_FLOATS(vG * vS) * sizeof(float);
@@ -49,18 +55,30 @@ bool groups_pay_off(const wf_handle* h, int K) {
 // whole blocks (d_perm, -1 = padding), group of each block (d_blk_group).  Then the sorted geometry of the K
 // directions `d_wd_groups` (device) is built into the geometry buffers; the pair tables follow lazily (pair_table()).
 int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_wd_groups, bool rebuild_geometry) {
-  // the 128-farm blocks of the G = 2 kernel would double the padding of every group: grouped launches use G = 4
-  // (the choice between its two kernels follows the padded count, below)
-  if (h->ll_G == 2) {  // (also when WF_LL_G forces it for the plain batch: the group lists are laid out in 64-farm blocks)
-    WF_HIP(h, hipStreamSynchronize(h->stream));
-    set_ll_shape(h, 4, 2);
-  }
-  const int epb = group_pad(h), unit = group_unit(h);
   std::vector<int> count(K, 0);
   for (int b = 0; b < h->B; ++b) {
     if (group_of_farm[b] < 0 || group_of_farm[b] >= K) return fail(h, WF_E_INVALID, "direction group out of range");
     ++count[group_of_farm[b]];
   }
+  // The 128-farm blocks of the G = 2 kernel double the padding of every group: it stays only where the padded launch
+  // is still its cheapest (few large groups that divide into its blocks: 65 536 farms over two layouts); otherwise
+  // G = 4 (the choice between its two kernels follows the padded count, below).  (Also when the choice forces G = 2
+  // for the plain batch: the lists are laid out for the block size decided here.)
+  if (h->ll_G == 2) {
+    auto padded = [&](int pad) {
+      long n = 0;
+      for (int g = 0; g < K; ++g) n += (long)((count[g] + pad - 1) / pad) * pad;
+      return n;
+    };
+    const int fs = farms_per_block(h), p2 = std::max(fs, wfk_ll_farms_per_block(2)), p4 = std::max(fs, wfk_ll_farms_per_block(4));
+    const double t2 = ll_estimate(h, 4, h->N, padded(p2));
+    const double t4 = std::min(ll_estimate(h, 2, h->N, padded(p4)), ll_estimate(h, 3, h->N, padded(p4)));
+    if (!(t2 < t4)) {
+      WF_HIP(h, hipStreamSynchronize(h->stream));
+      set_ll_shape(h, 4, 2);
+    }
+  }
+  const int epb = group_pad(h), unit = group_unit(h);
   std::vector<int> first_slot(K, 0), blk_group;
   int slots = 0;
   for (int g = 0; g < K; ++g) {
@@ -93,7 +111,9 @@ int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_
     if (s_new != h->ll_S) set_ll_shape(h, h->ll_G, s_new);
   }
   if (rebuild_geometry) {
-    WF_HIP(h, wfk_launch_geometry(K, h->N, h->d_lx, h->d_ly, h->xc, h->yc, d_wd_groups, h->d_gx, h->d_gy, h->d_gidx, 0, nullptr, nullptr, h->stream));
+    // group g: direction g of the one layout, or layout g under its direction (wf_set_layouts: groups are the layouts)
+    WF_HIP(h, wfk_launch_geometry(K, h->N, h->d_lx, h->d_ly, h->d_centre, h->n_layouts == 1 ? 0 : 1, nullptr, d_wd_groups, 1, h->d_gx, h->d_gy,
+                                  h->d_gidx, 0, nullptr, nullptr, h->stream));
     h->pair_dirty = true;
   }
   return WF_OK;

@@ -31,9 +31,9 @@ extern "C" void wfk_variant(int i, int* G, int* S, const void** fn);
 extern "C" int wfk_variant_has_table(int i);
 extern "C" int wfk_tab_waves();
 extern "C" const void* wfk_variant_fn(int i, int kind);
-extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
-                                          const double* wd, double* gx, double* gy, int* gidx, int tie_block, int* farm_tie,
-                                          int* any_tie, hipStream_t s);
+extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, const double* centre,
+                                          int layout_mode, const int* layout_of, const double* wd, int wd_stride, double* gx,
+                                          double* gy, int* gidx, int tie_block, int* farm_tie, int* any_tie, hipStream_t s);
 extern "C" int wfk_ll_has_fly(int G, int S);
 extern "C" int wfk_ll_has_veer(int G, int S, int table);
 extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* gx,
@@ -81,8 +81,13 @@ struct wf_handle {
   bool model_dirty = true;
 
   int N = 0;
-  std::vector<double> lx, ly;
-  double xc = 0, yc = 0;
+  std::vector<double> lx, ly;  // [n_layouts][N]
+  double xc = 0, yc = 0;       // centre of rotation of layout 0
+  // wf_set_layouts: n_layouts > 1 layouts in one batch, layout_of[b] the layout of farm b (empty: farm b has layout b)
+  int n_layouts = 1;
+  std::vector<int> layout_of;
+  int* d_layout_of = nullptr;
+  double* d_centre = nullptr;  // [n_layouts][2] centres of rotation
   int B = 0;
   int wind_count = 0;  // 0 = not set
   int variant = -1;
@@ -210,6 +215,8 @@ int farms_per_block(const wf_handle* h);
 int group_pad(const wf_handle* h);
 int group_unit(const wf_handle* h);
 bool groups_pay_off(const wf_handle* h, int K);
+bool groups_fit(const wf_handle* h, int K);
+double ll_estimate(const wf_handle* h, int fi, int N, long farms);  // wf_dispatch.hip: ms for `farms` farm slots on family fi
 int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_wd_groups, bool rebuild_geometry);
 
 }  // namespace wfi

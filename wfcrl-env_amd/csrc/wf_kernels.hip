@@ -61,15 +61,21 @@
 // ---------------------------------------------------------------------------------------------
 // tie_block > 0: also flag the farms whose sorted order has an exact x' tie across a boundary of blocks of tie_block
 // turbines (farm_tie[e] = 1, *any_tie = 1): the one-block-at-a-time kernel leaves those to wf_step_kernel.
-__global__ void wf_geometry_kernel(int N, const double* __restrict__ lx, const double* __restrict__ ly, double xc,
-                                   double yc, const double* __restrict__ wd, double* __restrict__ gx,
+// Layouts: lx, ly hold one layout of N turbines (layout_mode 0), one per wind condition (1: layout e), or a set indexed
+// by layout_of[e] (2) — wf_set_layouts; centre[2 l], centre[2 l + 1] is the centre of rotation of layout l.
+__global__ void wf_geometry_kernel(int N, const double* __restrict__ lx, const double* __restrict__ ly,
+                                   const double* __restrict__ centre, int layout_mode, const int* __restrict__ layout_of,
+                                   const double* __restrict__ wd, int wd_stride, double* __restrict__ gx,
                                    double* __restrict__ gy, int* __restrict__ gidx, int tie_block, int* __restrict__ farm_tie,
                                    int* __restrict__ any_tie) {
   __shared__ double sx[WF_TABLE_PAD * 4];
   __shared__ double sorted_x[WF_TABLE_PAD * 4];
   const int e = blockIdx.x;
   const int t = threadIdx.x;
-  double w = fmod(wd[e], 360.0);
+  const int l = layout_mode == 0 ? 0 : (layout_mode == 1 ? e : layout_of[e]);
+  lx += (size_t)l * N; ly += (size_t)l * N;
+  const double xc = centre[2 * l], yc = centre[2 * l + 1];
+  double w = fmod(wd[(size_t)e * wd_stride], 360.0);
   if (w < 0.0) w += 360.0;
   double dev = fmod(w - 270.0, 360.0);
   if (dev < 0.0) dev += 360.0;
@@ -1126,16 +1132,16 @@ extern "C" const void* wfk_variant_fn(int i, int kind) {
   return i < kNumLocal ? local_variant_fn(i, kind) : wfk2_variant_fn(i - kNumLocal, kind);
 }
 
-extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, double xc, double yc,
-                                          const double* wd, double* gx, double* gy, int* gidx, int tie_block, int* farm_tie,
-                                          int* any_tie, hipStream_t s) {
+extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, const double* centre,
+                                          int layout_mode, const int* layout_of, const double* wd, int wd_stride, double* gx,
+                                          double* gy, int* gidx, int tie_block, int* farm_tie, int* any_tie, hipStream_t s) {
   const int threads = ((N + 63) / 64) * 64;
   if (tie_block > 0) {
     hipError_t e = hipMemsetAsync(any_tie, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(wf_geometry_kernel, dim3(n_env), dim3(threads), 0, s, N, lx, ly, xc, yc, wd, gx, gy, gidx, tie_block,
-                     farm_tie, any_tie);
+  hipLaunchKernelGGL(wf_geometry_kernel, dim3(n_env), dim3(threads), 0, s, N, lx, ly, centre, layout_mode, layout_of, wd,
+                     wd_stride, gx, gy, gidx, tie_block, farm_tie, any_tie);
   return hipGetLastError();
 }
 

@@ -4,6 +4,38 @@
 
 using namespace wfi;
 
+// Several layouts in the batch (wf_set_layouts): every farm has its own geometry, so the wind is always held per farm.
+// Under ONE direction the farms of a layout share a geometry: the layouts become the groups of a grouped launch (pair
+// table path) when that pays off; otherwise, and with a direction per farm, the on-the-fly path.
+static int set_wind_layouts(wf_handle* h, int n_ws, bool one_dir, int on_device) {
+  if (n_ws == 1) {  // (d_wd was filled by the caller when a speed per farm came with one direction)
+    WF_HIP(h, wfk_launch_fill(h->B, h->d_ws, h->stream));
+    WF_HIP(h, wfk_launch_fill(h->B, h->d_wd, h->stream));
+  }
+  h->series_T = 0; h->grid_step = 0.0;
+  ungroup(h);
+  const int K = h->n_layouts;
+  if (one_dir && !h->layout_of.empty() && groups_fit(h, K)) {
+    hipFree(h->d_group_wd); h->d_group_wd = nullptr;
+    WF_HIP(h, hipMalloc(&h->d_group_wd, sizeof(double) * K));
+    WF_HIP(h, hipMemcpyAsync(h->d_group_wd, h->d_wd, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    WF_HIP(h, wfk_launch_fill(K, h->d_group_wd, h->stream));
+    int rc = build_groups(h, h->layout_of.data(), K, h->d_group_wd, true);
+    if (rc != WF_OK) return rc;
+    h->wind_sync = true;
+  } else {
+    int rc = run_geometry(h, h->B, h->d_wd, !on_device);
+    if (rc != WF_OK) return rc;
+    h->wind_sync = !on_device;
+  }
+  if (!on_device) WF_HIP(h, hipStreamSynchronize(h->stream));  // caller's host arrays may go away
+  h->shared_dir = false;
+  h->wind_count = h->B;
+  h->ws_prev_valid = false;
+  h->pair_dirty = true;
+  return WF_OK;
+}
+
 extern "C" {
 
 int wf_set_wind_counts(wf_handle* h, const double* ws, int n_ws, const double* wd, int n_wd, int on_device) {
@@ -23,12 +55,13 @@ int wf_set_wind_counts(wf_handle* h, const double* ws, int n_ws, const double* w
   // is the shared-wind path with a speed per farm.
   bool same_dir = n_ws > 1 && (n_wd == 1 || !on_device);
   for (int i = 1; same_dir && i < n_wd; ++i) same_dir = wd[i] == wd[0];
-  const int count = n_ws;
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   WF_HIP(h, hipMemcpyAsync(h->d_ws, ws, sizeof(double) * n_ws, kind, h->stream));
   WF_HIP(h, hipMemcpyAsync(h->d_wd, wd, sizeof(double) * n_wd, kind, h->stream));
   if (n_wd == 1 && n_ws > 1)  // the step kernel reads a direction per farm next to the speed per farm
     WF_HIP(h, wfk_launch_fill(h->B, h->d_wd, h->stream));
+  if (h->n_layouts > 1) return set_wind_layouts(h, n_ws, n_ws == 1 || same_dir, on_device);
+  const int count = n_ws;
   {
     int rc = run_geometry(h, same_dir ? 1 : count, h->d_wd, !on_device);
     if (rc != WF_OK) return rc;

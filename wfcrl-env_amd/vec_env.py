@@ -31,7 +31,8 @@ class VecWindFarmEnv:
                  reward_shaper=None, start_iter: int = 0, max_num_steps: int = 500, load_coef: float = 0.1,
                  device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None,
                  wind_sampling: str = "host", reuse_buffers: bool = False, wind_direction_step: float = None,
-                 actuation_budget: float = 0.1, kernel_choice: dict = None, risk_resolve: bool = False):
+                 actuation_budget: float = 0.1, kernel_choice: dict = None, risk_resolve: bool = False,
+                 layouts: dict = None):
         controls = {"yaw": (-40, 40, 5)} if controls is None else dict(controls)
         if list(controls) != ["yaw"]:
             raise ValueError(f"Cannot control {list(controls)}. Interface HipFlorisInterface only allows for the "
@@ -60,6 +61,11 @@ class VecWindFarmEnv:
         # the reference's float64 answer on every farm, for ~1 ms per step where a wind per farm flags ~2 % of the batch
         if risk_resolve:
             self.fi.set_risk_resolve(1)
+        # layouts: several layouts in the batch — dict(xcoords=[K][N], ycoords=[K][N], layout_of=[env_batch] or None for
+        # K == env_batch), each with the case's number of turbines (backend.WfStep.set_layouts); the case's own layout is
+        # then only the default the handle returns to
+        if layouts is not None:
+            self.fi.set_layouts(layouts["xcoords"], layouts["ycoords"], layouts.get("layout_of"))
         self.fi.env_config(yaw_lo=spec[0], yaw_hi=spec[1], yaw_step=spec[2],
                            actuator_rate=WindFarmMDP.ACTUATORS_RATE["yaw"], dt=self.dt, budget=actuation_budget,
                            load_coef=load_coef, discrete=not continuous_control)
