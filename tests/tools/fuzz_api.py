@@ -122,7 +122,7 @@ def run(n_sessions, n_ops, seed):
                 w.set_wind(float(rng.uniform(4, 15)), float(rng.choice([270.0, 90.0, rng.uniform(0, 360)])))
                 w.env_reset()
             elif op == "layouts":  # several layouts in the batch (wf_set_layouts): shifted / jittered copies of the current one
-                K = B if rng.random() < 0.3 else int(rng.integers(1, min(B, 4) + 1))
+                K = B if (rng.random() < 0.3 and B <= 64) else int(rng.integers(1, min(B, 4) + 1))  # (the oracle runs layout by layout)
                 X = np.repeat(x[None, :], K, axis=0) + rng.choice([0.0, 126.0, -378.0], (K, 1))
                 Y = np.repeat(y[None, :], K, axis=0) + rng.choice([0.0, 252.0, -126.0], (K, 1))
                 jit = rng.random(K) < 0.5
