@@ -271,3 +271,45 @@ def test_full_size_batch_over_layouts_keeps_the_widest_kernel(layouts):
         ref = _oracle_layouts(X, Y, layout_of[idx], 8.0, 263.0, yaw[idx])
         parity.check({k: v[idx] for k, v in out.items()}, ref, w.risk_flags()[idx], max_flagged_frac=0.1)
     w.close()
+
+
+@pytest.mark.parametrize("one_block", ["", "4x2", "2x2", "4"])
+def test_wind_veer_with_direction_groups_and_layouts(layouts, one_block):
+    """wind_veer != 0 on the grouped launches: a wind series (groups = rows), binned reset directions (groups = grid
+    directions) and several layouts under one direction (groups = layouts), register-slot kernel and each VEER shape of the
+    one-block kernel."""
+    import parity
+    from oracle import c_oracle
+    from oracle.floris_gch_numpy import ModelParams
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    x, y, N, B, T = np.array(l["xcoords"]), np.array(l["ycoords"]), 80, 600, 5
+    rng = np.random.default_rng(zlib.crc32(f"veer-groups/{one_block}".encode()))
+    mp = ModelParams(veer=6.0)
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    w = WfStep(x, y, env_batch=B, model=dict(veer=6.0), kernel_choice=dict(one_block=one_block) if one_block else None)
+    series = np.stack([rng.uniform(5, 14, T), rng.uniform(200, 340, T)], axis=1)
+    w.set_wind_series(series, seed=3)
+    for t in range(2):
+        if t:
+            w.wind_series_step()
+        info = w.kernel_info()
+        assert info["direction_groups"] == T and info["one_block_kernel"] == (1 if one_block else 0)
+        ws, wd = w.get_wind()
+        ref = c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64), mp, margin=True)
+        parity.check(w.step(yaw), ref, w.risk_flags(), max_flagged_frac=0.1)
+    w.sample_wind(11, direction_step=45.0)
+    assert w.kernel_info()["direction_groups"] == 8
+    ws, wd = w.get_wind()
+    ref = c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64), mp, margin=True)
+    parity.check(w.step(yaw), ref, w.risk_flags(), max_flagged_frac=0.1)
+    K = 3
+    X, Y = x + rng.uniform(-60, 60, (K, N)), y + rng.uniform(-60, 60, (K, N))
+    layout_of = rng.integers(0, K, B).astype(np.int32)
+    w.set_layouts(X, Y, layout_of)
+    w.set_wind(9.0, 255.0)
+    assert w.kernel_info()["direction_groups"] == K
+    w.set_risk_resolve(1)
+    parity.check_strict(w.step(yaw), _oracle_layouts(X, Y, layout_of, 9.0, 255.0, yaw, mp))
+    w.close()
