@@ -1,5 +1,5 @@
 """GPU box: HornsRev1 x 65536 — shared wind vs series playback (grouped tables) vs binned reset directions vs a continuous
-direction per farm.  usage: python tools/time_series_mode.py [T] [step_deg]"""
+direction per farm.  usage: python tools/time_series_mode.py [T] [step_deg] [B]"""
 import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
@@ -7,7 +7,8 @@ from wfcrl_env_amd.backend import WfStep
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 step = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
 L = json.load(open("wfcrl-env_amd/environments/layouts.json"))["HornsRev1_"]
-B, N = 65536, 80
+B, N = (int(sys.argv[3]) if len(sys.argv) > 3 else 65536), 80
+print(f"# HornsRev1 x {B}")
 w = WfStep(L["xcoords"], L["ycoords"], env_batch=B)
 g = torch.Generator(device="cuda").manual_seed(1)
 yaw = (torch.rand((B, N), device="cuda", generator=g) * 60 - 30).float()
