@@ -139,6 +139,38 @@ __device__ __forceinline__ void column_deficit(const WfConsts& c, const SrcConst
   e0 = e1 * fexp2(-0.5f * kLog2e * zz * zz);
 }
 
+// The part of column_deficit that depends on the column's constants only (not on its lateral offset): one evaluation
+// serves every grid column that shares the constants (split-TI sources: usually two of the three columns agree).
+struct ColWake { float delta, isy, amp, ez; };
+__device__ __forceinline__ ColWake column_wake(const WfConsts& c, const SrcConsts& sc, const ColConsts& cc, float dx, float lin,
+                                               float amp_on) {
+  const float xs = fmaxf(dx - cc.x0d, 0.0f);
+  const float syd = fmaf(cc.kyd, xs, sc.sy0d), szd = fmaf(cc.kyd, xs, sc.sz0d);
+  const float s = fsqrt(syd * szd * sc.inv_s0d);
+  const float arg = sc.lnA * fmaf(1.6f, s, -sc.sM) * frcp(sc.lnB * fmaf(1.6f, s, sc.sM));
+  const float d_far = fmaf(cc.pj, flog2(arg), cc.d0);
+  ColWake w;
+  w.delta = ((dx > cc.x0d) ? d_far : dx * sc.tan_th0) + lin;
+  const bool far = dx >= cc.x0v;
+  const float up = dx * cc.ix0v;
+  const float xf = dx - cc.x0v;
+  const float sy = far ? fmaf(cc.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
+  const float sz = far ? fmaf(cc.kyv, xf, c.sz0v) : fmaf(up, c.sz0v - sc.snw, sc.snw);
+  const float isz = frcp(sz);
+  w.isy = frcp(sy);
+  const float xarg = sc.kdef * w.isy * isz;
+  const float C = (xarg >= 1.0f) ? 1.0f : xarg * frcp(1.0f + fsqrt(fmaxf(1.0f - xarg, 0.0f)));
+  const float zz = c.off[2] * isz;
+  w.amp = amp_on * C;
+  w.ez = fexp2(-0.5f * kLog2e * zz * zz);
+  return w;
+}
+// ... and the column's own part: (e1, e0) = deficit at k = 1 and at k = 0, 2 (the arithmetic of column_deficit)
+__device__ __forceinline__ void column_rows(const ColWake& w, float ylat, float& e1, float& e0) {
+  const float yy = (ylat - w.delta) * w.isy;
+  e1 = w.amp * fexp2(-0.5f * kLog2e * yy * yy);
+  e0 = e1 * w.ez;
+}
 
 // The same with wind veer [FLORIS gauss.py rCalt]: r = a yy^2 - 2 b yy zz + c zz^2 with
 //   a = cos^2/(2 sy^2) + sin^2/(2 sz^2),  b = sin(2 phi)/4 (1/sz^2 - 1/sy^2),  c = sin^2/(2 sy^2) + cos^2/(2 sz^2):

@@ -460,8 +460,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       const float x0num_v = R.x0v * fmaf(c.alpha4, X.TI0 + X.dTI, b2om);
       const float pfac = R.pj * R.kyd;
       const float tis[3] = {X.TI0, X.TI1, X.TI2};
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      auto col_consts = [&](int j) {
         ColConsts k;
         if (j == 0 || !mine) {
           k.x0d = R.x0d; k.kyd = R.kyd; k.d0 = d0; k.pj = R.pj; k.x0v = R.x0v; k.ix0v = ix0v; k.kyv = R.kyv;
@@ -474,8 +473,23 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
           k.ix0v = frcp(k.x0v);
           k.kyv = fmaf(c.ka, tis[j] + X.dTI, c.kb);
         }
-        column_deficit(c, sc, k, dx, dy + c.off[j], lin, amp_on, e1[j], e0[j]);
+        return k;
+      };
+      // One evaluation of the column-independent part (deflection, sigmas, amplitude) per DISTINCT set of constants:
+      // a turbine partly inside an upstream lateral gate has one or two columns covered, so two of its three TIs agree
+      // — two evaluations instead of three (wave-uniform: the farms of a wave share the pattern on the table path)
+      const bool need1 = __any(mine && X.TI1 != X.TI0), need2 = __any(mine && X.TI2 != X.TI0);
+      const bool same12 = !__any(mine && X.TI2 != X.TI1);
+      const ColWake w0 = column_wake(c, sc, col_consts(0), dx, lin, amp_on);
+      ColWake w1 = w0, w2 = w0;
+      if (need1) w1 = column_wake(c, sc, col_consts(1), dx, lin, amp_on);
+      if (need2) {
+        if (need1 && same12) w2 = w1;
+        else w2 = column_wake(c, sc, col_consts(2), dx, lin, amp_on);
       }
+      column_rows(w0, dy + c.off[0], e1[0], e0[0]);
+      column_rows(w1, dy + c.off[1], e1[1], e0[1]);
+      column_rows(w2, dy + c.off[2], e1[2], e0[2]);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
