@@ -64,8 +64,7 @@ def test_layouts_with_a_farm_to_layout_map(N, K, B):
     X, Y = _cloud(rng, K, N, extent=10.0 + N / 4)
     layout_of = rng.integers(0, K, B).astype(np.int32)
     yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
-    w = WfStep(X[0], Y[0], env_batch=B)
-    w.set_layouts(X, Y, layout_of)
+    w = WfStep(X, Y, env_batch=B, layout_of=layout_of)  # (= WfStep(X[0], Y[0], ...) + set_layouts(X, Y, layout_of))
     with pytest.raises(ValueError, match="wf_set_wind"):
         w.step(yaw)
     for mode in ("shared", "shared_dir", "per_farm"):
@@ -180,6 +179,10 @@ def test_layouts_error_behaviour():
 
     rng = np.random.default_rng(3)
     X, Y = _cloud(rng, 3, 8)
+    with pytest.raises(ValueError, match="without layout_of"):
+        WfStep(X, Y, env_batch=6)  # three layouts, six farms, no map
+    with pytest.raises(ValueError, match="2-D coordinates"):
+        WfStep(X[0], Y[0], env_batch=6, layout_of=np.zeros(6, np.int32))
     w = WfStep(X[0], Y[0], env_batch=2)
     with pytest.raises(ValueError, match="n_layouts must be in 1..env_batch"):
         w.set_layouts(X, Y, None)

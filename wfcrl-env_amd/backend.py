@@ -43,7 +43,7 @@ def turbine_table(name: str = "nrel_5MW_floris3") -> dict:
 
 class WfStep:
     def __init__(self, xcoords, ycoords, env_batch: int = 1, device_id: int = 0, model: dict | None = None,
-                 kernel_choice: dict | None = None):
+                 kernel_choice: dict | None = None, layout_of=None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         check(self._lib.wf_create(int(device_id), C.byref(self._h)))
@@ -53,12 +53,13 @@ class WfStep:
         if model is not None:
             self.set_model(model)
         xy = np.asarray(xcoords, dtype=np.float64), np.asarray(ycoords, dtype=np.float64)
-        if xy[0].ndim == 2:  # several layouts in the batch: [n_layouts][n_turbines], `layout_of` through set_layouts
+        if xy[0].ndim == 2:  # several layouts in the batch: [n_layouts][n_turbines], layout_of[env_batch] (set_layouts)
             self.set_layout(xy[0][0], xy[1][0])
             self.set_batch(env_batch)
-            if xy[0].shape[0] == env_batch:
-                self.set_layouts(*xy)
+            self.set_layouts(xy[0], xy[1], layout_of)
         else:
+            if layout_of is not None:
+                raise ValueError("layout_of needs 2-D coordinates [n_layouts][num_turbines]")
             self.set_layout(*xy)
             self.set_batch(env_batch)
         if kernel_choice:  # keyword arguments of set_kernel_choice: which kernels may serve this handle
