@@ -687,9 +687,6 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       // once per target instead of once per column, from column 0's constants.  Wave-uniform choice,
       // identical results.
       const bool uni = __all((TIs[0] == TIs[1]) && (TIs[1] == TIs[2]));
-      // split-TI source: which columns need their own evaluation of the column-independent part (column_wake) — a
-      // turbine partly inside an upstream lateral gate has one or two columns covered, so two of the three agree
-      const bool need1 = !__all(TIs[1] == TIs[0]), need2 = !__all(TIs[2] == TIs[0]), same12 = __all(TIs[2] == TIs[1]);
       // ---- D. yaw-added recovery [A.3-5] and deficit constants [A.3-6] -----------------------
       const float I0 = TIs[0];
       const float uI = ubar * I0;
@@ -797,16 +794,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
               e0[j] = e1[j] * ez;
             }
           } else {
-            const ColWake w0 = column_wake(c, sc, k0, dx, lin, amp_on);
-            ColWake w1 = w0, w2 = w0;
-            if (need1) w1 = column_wake(c, sc, col_consts(TIs[1], TIs[1] + dTI), dx, lin, amp_on);
-            if (need2) {
-              if (need1 && same12) w2 = w1;
-              else w2 = column_wake(c, sc, col_consts(TIs[2], TIs[2] + dTI), dx, lin, amp_on);
-            }
-            column_rows(w0, dy + c.off[0], e1[0], e0[0]);
-            column_rows(w1, dy + c.off[1], e1[1], e0[1]);
-            column_rows(w2, dy + c.off[2], e1[2], e0[2]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              column_deficit(c, sc, j == 0 ? k0 : col_consts(TIs[j], TIs[j] + dTI), dx, dy + c.off[j], lin, amp_on, e1[j], e0[j]);
           }
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
