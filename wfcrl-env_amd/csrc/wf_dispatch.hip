@@ -51,8 +51,9 @@ int pick_variant(const wf_handle* h, int N, int B) {
 // (a partitioned or smaller part has shorter rounds, the same time per round).
 //   code = (G << 4) | S of wf_step_ll_kernel, 0 = the register-slot kernel wf_step_kernel (its variant for N: pick_variant)
 struct LlFamily { int code, farms_per_block, per_cu; };
-const LlFamily kLlFamilies[] = {{0, 16, 2}, {(8 << 4) | 1, 32, 3}, {(4 << 4) | 2, 64, 2}, {(4 << 4) | 1, 64, 3}, {(2 << 4) | 2, 128, 2}};
-constexpr int kNumFamilies = 5, kNumRoundsN = 5;
+const LlFamily kLlFamilies[] = {{0, 16, 2}, {(8 << 4) | 1, 32, 3}, {(4 << 4) | 2, 64, 2}, {(4 << 4) | 1, 64, 3}, {(2 << 4) | 2, 128, 2},
+                                {(16 << 4) | 1, 16, 3}};
+constexpr int kNumFamilies = 6, kNumRoundsN = 5;
 const int kRoundsN[kNumRoundsN] = {32, 48, 64, 80, 91};
 // [family][N index][blocks per CU - 1]
 // (N = 32, 48, 64: the first N turbines of HornsRev2 at 263 deg; N = 80, 91: HornsRev1 / HornsRev2 at 270 deg, the
@@ -62,7 +63,8 @@ const double kRoundsMs[kNumFamilies][kNumRoundsN][3] = {
     {{0.086, 0.112, 0.144}, {0.152, 0.197, 0.254}, {0.230, 0.300, 0.386}, {0.332, 0.424, 0.551}, {0.430, 0.553, 0.730}},  // 8x1
     {{0.118, 0.159, 0.0}, {0.220, 0.291, 0.0}, {0.349, 0.458, 0.0}, {0.486, 0.639, 0.0}, {0.638, 0.869, 0.0}},            // 4x2
     {{0.127, 0.170, 0.226}, {0.241, 0.309, 0.418}, {0.377, 0.489, 0.657}, {0.550, 0.691, 0.910}, {0.690, 0.900, 1.231}},  // 4x1
-    {{0.190, 0.274, 0.0}, {0.377, 0.532, 0.0}, {0.607, 0.842, 0.0}, {0.853, 1.166, 0.0}, {1.100, 1.620, 0.0}}};           // 2x2
+    {{0.190, 0.274, 0.0}, {0.377, 0.532, 0.0}, {0.607, 0.842, 0.0}, {0.853, 1.166, 0.0}, {1.100, 1.620, 0.0}},            // 2x2
+    {{0.068, 0.088, 0.116}, {0.114, 0.148, 0.192}, {0.167, 0.211, 0.270}, {0.225, 0.290, 0.367}, {0.292, 0.365, 0.467}}};  // 16x1 (profiles/r03_rounds_table_16x1.txt)
 // A partial round behind full ones overlaps with their tail: its cost relative to the same round on an idle chip, by
 // (blocks per CU it reaches, resident blocks per CU of the family) — fitted on profiles/r03_batch_sweep_fine.txt
 const double kTailFactor[2][3] = {{0.80, 0.95, 0.0}, {0.62, 0.79, 0.86}};  // [per_cu - 2][tail blocks per CU - 1]
@@ -144,7 +146,10 @@ int pick_ll(const wf_handle* h, int N, int B) {  // returns (G << 4) | S, 0 = ke
     if (f.code && N <= (f.code >> 4) * (f.code & 15)) continue;  // needs more than one block
     if (f.code == ((8 << 4) | 1) && N <= 32) continue;           // (not instantiated to pay below that)
     if (veer && f.code && !wfk_ll_has_veer(f.code >> 4, f.code & 15, 1)) continue;
-    const double t = ll_estimate(h, fi, N, B);
+    double t = ll_estimate(h, fi, N, B);
+    // G = 16 runs neck and neck with the register-slot kernel up to two blocks per CU (0.290 against 0.294 ms at
+    // HornsRev1 x 8192, either way round from layout to layout): it has to win by 4 % — its case is the third block
+    if (f.code == ((16 << 4) | 1)) t *= 1.04;
     if (t < t_best) { t_best = t; best = f.code; }
   }
   return best;
@@ -273,8 +278,9 @@ int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
 // Target slots per lane of the one-block kernel ON THE FLY (a wind per farm): two at G = 4 whatever the table path
 // uses — there the second slot halves the per-source geometry work as well (HornsRev1 x 65536: 3.48 ms against 4.14).
 int ll_fly_S(const wf_handle* h) { return h->ll_G <= 4 ? 2 : h->ll_S; }
-// ... and its lane-group width: the table path's, except that G = 2 has no on-the-fly instantiation (G = 4 x 2 serves)
-int ll_fly_G(const wf_handle* h) { return h->ll_G == 2 ? 4 : h->ll_G; }
+// ... and its lane-group width: the table path's, except that G = 2 and G = 16 have no on-the-fly instantiation
+// (G = 4 x 2 / G = 8 serve)
+int ll_fly_G(const wf_handle* h) { return h->ll_G == 2 ? 4 : (h->ll_G == 16 ? 8 : h->ll_G); }
 
 // turbines per farm in the source log of the one-block kernel: whole lane-group blocks (of the larger of the two
 // block sizes: the table path and the on-the-fly path share the buffer)
