@@ -65,3 +65,14 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "libwforacle" not in src, f
+
+
+def test_graft_entry_build_passes():
+    """The driver's "does it build" check: make (a no-op when the libraries are current) + the import and ABI checks of
+    __graft_entry__.build() — an ABI bump that forgets one of its asserts fails here, not at the round's end."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("graft_entry_for_test", os.path.join(ROOT, "__graft_entry__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()
