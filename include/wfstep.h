@@ -110,9 +110,8 @@ int wf_set_batch(wf_handle* h, int env_batch);
  * b has layout b).  Call after wf_set_batch (which returns the handle to the first layout for every farm); the wind has
  * to be set again.  Every farm is rotated and sorted on its own; under ONE wind direction the farms of a layout share
  * geometry and pair table (a grouped launch, as for direction groups), with a direction per farm the on-the-fly kernels
- * serve the batch; series playback and binned sampling fall back to a geometry per farm.  The float32 lateral offsets
- * are taken relative to one centre per handle: the layouts' bounding-box centres must lie within 4096 m in y
- * (WF_E_INVALID otherwise; the model is translation invariant, shift them).  n_layouts == 1 equals wf_set_layout. */
+ * serve the batch; series playback and binned sampling fall back to a geometry per farm.  The layouts may lie anywhere
+ * (every lateral offset is taken from the float64 coordinates).  n_layouts == 1 equals wf_set_layout. */
 int wf_set_layouts(wf_handle* h, int n_layouts, const double* x, const double* y, const int* layout_of);
 
 /* Replaces FlorisInterface.update_wind -> fi.reinitialize (interface.py:663-671).

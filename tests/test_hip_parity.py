@@ -1026,3 +1026,45 @@ def test_two_threads_force_different_kernel_families_on_two_handles(layouts):
     for r in results:
         _check(r, ref)
     assert np.abs(results[0]["power"] / results[1]["power"] - 1).max() < 2e-5
+
+
+@pytest.mark.parametrize("hh,shear,veer", [(0.9, 0.0, 0.0), (0.56, 0.0, -6.0), (0.714, 0.12, 0.0)])
+def test_on_the_fly_kernels_on_an_aligned_grid(hh, shear, veer):
+    """An 8 x 14 grid at exactly 360 deg: every turbine has up to thirteen sources exactly upstream (lateral offset 1e-14
+    m), where the rotation vortex' core factor 1 - exp(-r^2 / eps^2) has r^2 = 2e-6 m^2 and cancels in float32.  The
+    on-the-fly kernels returned 0 for it and stood at wd 3e-4 .. 1e-3 deg / power 3e-4 here (fuzz seed 611 case 516, seed
+    622 case 506, found with the re-solve on: not a flagged event; tests/tools/wd_error_probe.py, wd_error_small.py); with
+    the series of the core factor they are where the table path (float64 coefficients) is.  Lateral offsets are taken
+    from the float64 coordinates, so the layout may as well sit in UTM-like coordinates."""
+    import torch
+
+    import parity
+    from oracle import c_oracle
+    from oracle.floris_gch_numpy import ModelParams
+    from wfcrl_env_amd.backend import WfStep
+
+    D = 100.5
+    gx, gy = np.meshgrid(np.arange(8) * 5 * D, np.arange(14) * 4 * D, indexing="ij")
+    N, B = gx.size, 48
+    rng = np.random.default_rng(7)
+    yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
+    ws, wd = rng.uniform(5, 20, B), np.full(B, 360.0)
+    model = dict(rotor_diameter=D, hub_height=hh * D, shear=shear, veer=veer)
+    mp = ModelParams(D=D, HH=hh * D, shear=shear, veer=veer)
+    for x0, y0 in ((0.0, 0.0), (512000.0, 6175000.0)):
+        x, y = gx.ravel() + x0, gy.ravel() + y0
+        ref = c_oracle.farm_step_batch(x, y, ws, wd, yaw.astype(np.float64), mp, margin=True)
+        for choice, per_farm in ((dict(one_block=False, pair_table=False), False), (dict(one_block="4x2"), True), (dict(one_block=False), False)):
+            w = WfStep(x, y, env_batch=B, model=model, kernel_choice=choice)
+            if per_farm:  # device arrays: a direction per farm, the one-block kernel on the fly
+                w.set_wind(torch.from_numpy(ws).cuda(), torch.from_numpy(wd).cuda())
+            else:
+                w.set_wind(ws, wd)
+            assert w.kernel_info()["pair_table"] == (0 if (per_farm or "pair_table" in choice) else 1)
+            got = w.step(yaw)
+            got = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in got.items()}
+            fl = w.risk_flags()
+            parity.check({k: v.copy() for k, v in got.items()}, ref, fl, max_flagged_frac=0.2)
+            e = parity.errors(got, ref)
+            assert e["wd"][fl == 0].max() < 1e-4 and e["power"][fl == 0].max() < 3e-5, {k: float(v[fl == 0].max()) for k, v in e.items()}
+            w.close()

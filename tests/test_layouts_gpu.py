@@ -62,6 +62,8 @@ def test_layouts_with_a_farm_to_layout_map(N, K, B):
 
     rng = np.random.default_rng(zlib.crc32(f"layouts/{N}/{K}".encode()))
     X, Y = _cloud(rng, K, N, extent=10.0 + N / 4)
+    Y[K - 1] += 250000.0  # the layouts may lie anywhere: every lateral offset comes from the float64 coordinates
+    X[K - 1] -= 80000.0
     layout_of = rng.integers(0, K, B).astype(np.int32)
     yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
     w = WfStep(X, Y, env_batch=B, layout_of=layout_of)  # (= WfStep(X[0], Y[0], ...) + set_layouts(X, Y, layout_of))
@@ -193,10 +195,6 @@ def test_layouts_error_behaviour():
         w.set_layouts(X, Y, np.array([0, 1, 2, 3, 0, 1]))
     with pytest.raises(ValueError, match="num_turbines"):
         w.set_layouts(X[:, :7], Y[:, :7], np.zeros(6, np.int32))
-    far = Y.copy()
-    far[2] += 10000.0
-    with pytest.raises(ValueError, match="share a frame"):
-        w.set_layouts(X, far, np.array([0, 1, 2, 0, 1, 2]))
     bad = X.copy()
     bad[1, 3] = np.nan
     with pytest.raises(ValueError, match="finite"):

@@ -61,6 +61,8 @@ int wf_create(int device_id, wf_handle** out) {
     const char* gs = getenv("WF_KERNEL_GS");  // e.g. "16x5"
     int og = 0, os = 0;
     if (gs && sscanf(gs, "%dx%d", &og, &os) == 2 && og > 0 && os > 0) { c.slot_G = og; c.slot_S = os; }
+    const char* zc = getenv("WF_ZERO_COPY");
+    if (zc && zc[0] == '0') h->zero_copy_max = 0;
     const char* off = getenv("WF_LL");
     if (off && off[0] == '0') c.one_block = 0;
     const char* force = getenv("WF_LL_G");  // "8" or "4x2"
@@ -120,7 +122,6 @@ void* wf_get_stream(wf_handle* h) { return h ? (void*)h->stream : nullptr; }
 // Layout data of the handle: K layouts of n turbines, their centres of rotation [A.1-1] and the farm -> layout map.
 static int upload_layouts(wf_handle* h, int n, int K, const double* x, const double* y, const int* layout_of) {
   std::vector<double> centre(2 * (size_t)K);
-  double yc_lo = 0, yc_hi = 0;
   for (int l = 0; l < K; ++l) {
     const double *xl = x + (size_t)l * n, *yl = y + (size_t)l * n;
     double xmin = xl[0], xmax = xl[0], ymin = yl[0], ymax = yl[0];
@@ -130,13 +131,7 @@ static int upload_layouts(wf_handle* h, int n, int K, const double* x, const dou
       ymin = std::fmin(ymin, yl[i]); ymax = std::fmax(ymax, yl[i]);
     }
     centre[2 * l] = (xmin + xmax) / 2.0; centre[2 * l + 1] = (ymin + ymax) / 2.0;  // centre of rotation [A.1-1]
-    yc_lo = l ? std::fmin(yc_lo, centre[2 * l + 1]) : centre[1];
-    yc_hi = l ? std::fmax(yc_hi, centre[2 * l + 1]) : centre[1];
   }
-  // the float32 lateral distances are taken on y' - yc with ONE yc per handle (WfConsts::yc_d): layouts far apart in
-  // y would lose the low bits of their lateral offsets.  The model is translation invariant: the caller can shift them.
-  if (yc_hi - yc_lo > 4096.0)
-    return fail(h, WF_E_INVALID, "layouts of one batch must share a frame: bounding-box centres within 4096 m in y (translate them)");
   WF_HIP(h, hipStreamSynchronize(h->stream));
   hipFree(h->d_lx); hipFree(h->d_ly); hipFree(h->d_centre); hipFree(h->d_layout_of);
   h->d_lx = h->d_ly = h->d_centre = nullptr; h->d_layout_of = nullptr;
@@ -155,7 +150,7 @@ static int upload_layouts(wf_handle* h, int n, int K, const double* x, const dou
   }
   h->lx.assign(x, x + kn); h->ly.assign(y, y + kn);
   h->n_layouts = K;
-  h->xc = centre[0]; h->yc = (yc_lo + yc_hi) / 2.0;
+  h->xc = centre[0]; h->yc = centre[1];
   return WF_OK;
 }
 
@@ -227,7 +222,7 @@ int wf_set_layouts(wf_handle* h, int n_layouts, const double* x, const double* y
     int rc = upload_layouts(h, h->N, n_layouts, x, y, n_layouts > 1 ? layout_of : nullptr);
     if (rc != WF_OK) return rc;
   }
-  h->wind_count = 0; h->shared_dir = false; h->model_dirty = true; h->pair_dirty = true;  // (yc of the kernels' constants)
+  h->wind_count = 0; h->shared_dir = false; h->pair_dirty = true;
   h->series_T = 0; h->grid_step = 0.0;
   ungroup(h);
   return WF_OK;
@@ -243,10 +238,26 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
   }
   const size_t bn = (size_t)h->B * h->N;
   if (on_device) return launch_step(h, yaw, power, wspd, wdir, load, nullptr);
-  if (!h->d_yaw) {
-    WF_HIP(h, hipMalloc(&h->d_yaw, sizeof(float) * bn));
-    WF_HIP(h, hipHostMalloc(&h->h_yaw, sizeof(float) * bn, hipHostMallocDefault));
+  // Small batches (the reference's single-farm env: B = 1): the kernels read the commands from and write the outputs
+  // to the handle's pinned host buffers directly (device-visible, coherent) — no staging copies around a launch that
+  // lasts tens of microseconds (N = 3: 50 -> 3x us per update_command; tools/latency_b1.py).  WF_ZERO_COPY=0 at wf_create: off.
+  if (bn <= h->zero_copy_max) {
+    if (!h->h_yaw) WF_HIP(h, hipHostMalloc(&h->h_yaw, sizeof(float) * bn, hipHostMallocDefault));
+    if (!h->h_out) WF_HIP(h, hipHostMalloc(&h->h_out, sizeof(float) * bn * 7, hipHostMallocDefault));
+    std::memcpy(h->h_yaw, yaw, sizeof(float) * bn);
+    {
+      int rc = launch_step(h, h->h_yaw, h->h_out, h->h_out + bn, h->h_out + 2 * bn, h->h_out + 3 * bn, nullptr);
+      if (rc != WF_OK) return rc;
+    }
+    WF_HIP(h, hipStreamSynchronize(h->stream));
+    if (power) std::memcpy(power, h->h_out, sizeof(float) * bn);
+    if (wspd) std::memcpy(wspd, h->h_out + bn, sizeof(float) * bn);
+    if (wdir) std::memcpy(wdir, h->h_out + 2 * bn, sizeof(float) * bn);
+    if (load) std::memcpy(load, h->h_out + 3 * bn, sizeof(float) * bn * 4);
+    return WF_OK;
   }
+  if (!h->d_yaw) WF_HIP(h, hipMalloc(&h->d_yaw, sizeof(float) * bn));
+  if (!h->h_yaw) WF_HIP(h, hipHostMalloc(&h->h_yaw, sizeof(float) * bn, hipHostMallocDefault));
   if (!h->d_out) WF_HIP(h, hipMalloc(&h->d_out, sizeof(float) * bn * 7));
   if (!h->h_out) WF_HIP(h, hipHostMalloc(&h->h_out, sizeof(float) * bn * 7, hipHostMallocDefault));
   std::memcpy(h->h_yaw, yaw, sizeof(float) * bn);

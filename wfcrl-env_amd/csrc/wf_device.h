@@ -23,6 +23,7 @@ struct WfConsts {
   // offsets z_k + h + eps the 7 values 2HH + m*q + eps: class index = m + 3.
   //   real:   top m = k'-2, bottom m = k'+2, rotation m = k'      mirror: top k'+2, bottom k'-2, rotation k'
   float zc[7], zc2[7], ez[7];    // zc = m q + eps       ; ez  = exp(-zc^2/eps^2)
+  float inv_eps2, m_half_inv_eps4, yl2_small;  // 1 / eps^2, -1 / (2 eps^4); yL^2 below which class 0 takes the series of its core factor (wf_model.hip)
   float zm[7], zm2[7], ezm[7];   // zm = 2HH + m q + eps ; ezm = exp(-zm^2/eps^2)
   int mirror_core_n;             // mirror classes [0, n) need the core factor; for the others 1 - Ey*ezm == 1.0f exactly
   float gam_top, gam_bot;  // (1/2pi)(pi/8) D vel_{top,bot} uinf_f : Gamma/(2pi) = gam*ws*ct
@@ -59,7 +60,6 @@ struct WfConsts {
   // which a turbine counts as sitting on a knee of the curve
   float ct_kappa;  // v |dCt/dv| above which a turbine counts as sitting on a ramp of the thrust table
   float guard_inv, inv_overlap_thr, knee_kappa;  // 1 / guard band (2^50 when the band is 0), 1 / overlap_thr
-  double yc_d;  // centre of rotation (y): the float32 lateral distances are taken on y' - yc
   // wind_veer (case.yaml:36) [FLORIS gauss.py rCalt]: the Gaussian of the deficit rotated by the veer angle phi.  Only the
   // VEER instantiation of wf_step_kernel reads these; veer_on selects it at launch.
   int veer_on;

@@ -97,8 +97,7 @@ struct Slots {
 template <int EPW, int NP, bool WITH_XY>
 struct GeoLds {
   double x[WITH_XY ? EPW : 1][WITH_XY ? NP : 1];  // sorted x' (float64: the sign of dx decides every mask)
-  double yd[WITH_XY ? EPW : 1][WITH_XY ? NP : 1]; // sorted y' (float64: the 2 D lateral gate is decided on it; table mode takes dx, dy, gates from the pair table)
-  float y[WITH_XY ? EPW : 1][WITH_XY ? NP : 1];   // sorted y' - yc (float32 copy for the lateral distances)
+  double yd[WITH_XY ? EPW : 1][WITH_XY ? NP : 1]; // sorted y' (float64: the 2 D lateral gate is decided on it and the lateral offsets are taken from it; table mode takes dx, dy, gates from the pair table)
   float yaw[EPW][NP]; // commanded yaw in sorted order, degrees
   float cg[EPW][NP], sg[EPW][NP];  // cos / sin of the commanded yaw (evaluated once per turbine)
 };

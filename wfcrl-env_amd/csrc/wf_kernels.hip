@@ -428,7 +428,6 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       L.x[eiw][t] = ok ? gx[gofs + tt] : -1.0e300;  // padding is never downstream of anything
       const double ygd = gy[gofs + tt];
       L.yd[eiw][t] = ygd;
-      L.y[eiw][t] = (float)(ygd - c.yc_d);
     }
     const size_t oi = yofs + gidx[gofs + tt];
     float yw;
@@ -514,7 +513,16 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       float A[3] = {0.0f, 0.0f, 0.0f}, Bw[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int mi = 0; mi < 7; ++mi) {
-        const float tr = fmaf(-Ey, c.ez[mi], 1.0f) * frcp(yL2 + c.zc2[mi]);
+        float tr = fmaf(-Ey, c.ez[mi], 1.0f) * frcp(yL2 + c.zc2[mi]);
+        if (mi == 3) {
+          // class 0 (zc = num_eps): a target column within ~2 m of the vortex line has r^2 / eps^2 so small that
+          // 1 - Ey ez cancels in float32 — exactly behind the source it returns 0 for 5e-9, and on an aligned grid every
+          // upstream source leaves 3e-5 of V standing (wd 3e-4 deg, power 3e-4 on 112 turbines: tests/tools/
+          // wd_error_probe.py).  There: (1 - exp(-s)) / r^2 = (1 - s / 2) / eps^2 (s < 0.005: the next term is 4e-6 of a
+          // coefficient that is itself 1e-4 of its neighbours).  Branch-free: a wave-uniform branch here cost 8 %.
+          const float ts = fmaf(yL2 + c.zc2[3], c.m_half_inv_eps4, c.inv_eps2);
+          tr = (yL2 < c.yl2_small) ? ts : tr;
+        }
         const float pr = c.zc[mi] * tr;
         float tm = frcp(yL2 + c.zm2[mi]);
         if (mi == 0 || !MC1) tm *= fmaf(-Ey, c.ezm[mi], 1.0f);  // compile-time: see mirror_core_n
@@ -585,12 +593,13 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
 #pragma unroll
       for (int j = 0; j < 3; ++j) TIs[j] = __shfl(st.TI[0][j], src);
       double x_i = 0.0;
-      float y_i = 0.0f;
+      double yd_i = 0.0;  // lateral offsets from the float64 coordinates, as the pair table has them (the difference of two
+                          // float32 y' - yc leaves 6e-7 of the offset standing where symmetric neighbours cancel)
       int first_i = 0;
       if constexpr (TAB) first_i = __builtin_amdgcn_readfirstlane(pfirst[i]);
       if constexpr (!TAB) {
         x_i = L.x[eiw][i];
-        y_i = L.y[eiw][i];
+        yd_i = L.yd[eiw][i];
       }
       const float yaw_i = L.yaw[eiw][i];
 
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
          if constexpr (TAB) {
           apply_tab(p, reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]), Gy, Gwt);
          } else {
-          apply_fly(p, dx, L.y[eiw][t] - y_i, Gt, Gb, Gwt);
+          apply_fly(p, dx, (float)(L.yd[eiw][t] - yd_i), Gt, Gb, Gwt);
          }
         }
         if (p == 0) {
@@ -756,7 +765,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
 #endif
           float dy;
           if constexpr (TAB) dy = ex.y;
-          else dy = L.y[eiw][t] - y_i;
+          else dy = (float)(L.yd[eiw][t] - yd_i);
           const float lin = fmaf(c.bd, dx, c.ad);
           const float amp_on = (bits & 8) ? 1.0f : 0.0f;
           float e1[3], e0[3];
@@ -903,7 +912,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           const float* rec = pair_tab + (size_t)i2 * WF_PAIR_ROW_FLOATS(NP) + (size_t)t0 * WF_PAIR_STRIDE;
           if (rec[WF_PAIR_DX] >= 0.0f) apply_tab(0, reinterpret_cast<const float4*>(rec), Gy, Gwt);
         } else {
-          if (dx0 >= 0.0f) apply_fly(0, dx0, L.y[eiw][t0] - L.y[eiw][i2], Gt, Gb, Gwt);
+          if (dx0 >= 0.0f) apply_fly(0, dx0, (float)(L.yd[eiw][t0] - L.yd[eiw][i2]), Gt, Gb, Gwt);
         }
       }
     }

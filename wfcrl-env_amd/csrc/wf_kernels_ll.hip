@@ -329,7 +329,16 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       float A[3] = {0.0f, 0.0f, 0.0f}, Bw[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int mi = 0; mi < 7; ++mi) {
-        const float tr = fmaf(-Ey, c.ez[mi], 1.0f) * frcp(yL2 + c.zc2[mi]);
+        float tr = fmaf(-Ey, c.ez[mi], 1.0f) * frcp(yL2 + c.zc2[mi]);
+        if (mi == 3) {
+          // class 0 (zc = num_eps): a target column within ~2 m of the vortex line has r^2 / eps^2 so small that
+          // 1 - Ey ez cancels in float32 — exactly behind the source it returns 0 for 5e-9, and on an aligned grid every
+          // upstream source leaves 3e-5 of V standing (wd 3e-4 deg, power 3e-4 on 112 turbines: tests/tools/
+          // wd_error_probe.py).  There: (1 - exp(-s)) / r^2 = (1 - s / 2) / eps^2 (s < 0.005: the next term is 4e-6 of a
+          // coefficient that is itself 1e-4 of its neighbours).  Branch-free: a wave-uniform branch here cost 8 %.
+          const float ts = fmaf(yL2 + c.zc2[3], c.m_half_inv_eps4, c.inv_eps2);
+          tr = (yL2 < c.yl2_small) ? ts : tr;
+        }
         const float pr = c.zc[mi] * tr;
         float tm = frcp(yL2 + c.zm2[mi]);
         if (mi == 0 || !MC1) tm *= fmaf(-Ey, c.ezm[mi], 1.0f);  // compile-time: see mirror_core_n
@@ -562,7 +571,6 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     bool tvalid[S];
     float yaw_t[S], sg_t[S], cg_t[S];
     double xt_d[TAB ? 1 : S] = {}, yt_d[TAB ? 1 : S] = {};  // on the fly: this lane's targets' sorted coordinates (float64:
-    float yt_f[TAB ? 1 : S] = {};  // every geometric decision is taken on them), y' - yc in float32 for the distances
 #pragma unroll
     for (int p = 0; p < S; ++p) {
       tt[p] = J * GS + p * G + sub;
@@ -570,7 +578,6 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       if constexpr (!TAB) {
         xt_d[p] = tvalid[p] ? gx[gofs + tt[p]] : -1.0e300;  // padding is never downstream of anything
         yt_d[p] = gy[gofs + (tvalid[p] ? tt[p] : 0)];
-        yt_f[p] = (float)(yt_d[p] - c.yc_d);
       }
 #pragma unroll
       for (int k = 0; k < 9; ++k) { V[p][k] = 0.0f; W[p][k] = 0.0f; }
@@ -611,12 +618,16 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     }
 
     // on the fly: the {dx, dy, 15 D reach, bit 3} of (source at (xi, yi), this lane's target in slot p), decided in float64
-    auto fly_record = [&](auto PP, double xi, float yi_f) {
+    auto fly_record = [&](auto PP, double xi, double yi) {
       constexpr int p = decltype(PP)::value;
       constexpr int q = TAB ? 0 : p;
       float4 r;
       r.x = (float)(xt_d[q] - xi);
-      r.y = yt_f[q] - yi_f;
+      // the lateral offset from the float64 coordinates, as the pair table has it: the difference of two float32
+      // y' - yc (2.4e-4 m apart at 2.6 km) is 6e-7 of a 400 m offset — harmless on its own, but on an aligned grid the
+      // transverse velocities of symmetric neighbours cancel and leave that error standing (wd 3e-4 deg, power 3e-4 on
+      // a 112-turbine grid at exactly 360 deg: tests/tools/wd_error_probe.py)
+      r.y = (float)(yt_d[q] - yi);
       r.z = (xt_d[q] <= xi + c.fifteenD_d) ? 1.0f : 0.0f;
       r.w = __int_as_float((xt_d[q] > xi + 0.1) ? 8 : 0);
       return r;
@@ -660,11 +671,9 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       // block, and the lanes of EARLIER slots that tie with it in x' (dx = 0 counts as downstream here [A.3-4])
       float4 ex[S];
       double xi_d = 0.0, yi_d = 0.0;
-      float yi_f = 0.0f;
       if constexpr (!TAB) {  // the source's own coordinates (every lane of the group reads the same two words)
         xi_d = gx[gofs + i];
         yi_d = gy[gofs + i];
-        yi_f = (float)(yi_d - c.yc_d);
       }
       auto pass1_slot = [&](auto PP) {
         constexpr int p = decltype(PP)::value;
@@ -676,7 +685,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
             if (act1) apply_tab(PP, reinterpret_cast<const float4*>(rec), Sc.Gy, Sc.Gwt);
           }
         } else {
-          ex[p] = fly_record(PP, xi_d, yi_f);
+          ex[p] = fly_record(PP, xi_d, yi_d);
           const bool act1 = (p > ps) ? tvalid[p] : (ex[p].x >= 0.0f);
           if (p >= ps || __any(act1)) {
             if (act1) apply_fly(PP, ex[p].x, ex[p].y, Sc.Gy, Sc.Gwt);
@@ -833,11 +842,9 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         // no lane mask on the transverse pass: every real turbine of this block is at or downstream of an earlier
         // block's source (dx >= 0), and the lanes beyond N (last block only) carry all-zero records
         double xs_d = 0.0, ys_d = 0.0;
-        float ys_f = 0.0f;
         if constexpr (!TAB) {
           xs_d = xs_cur;
           ys_d = ys_cur;
-          ys_f = (float)(ys_d - c.yc_d);
         }
         if constexpr (TAB) {
           // deflection / deficit / TI of every slot first, on the {dx, dy, tipow, decision bits} float4 of the pair records
@@ -867,7 +874,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
           constexpr int p = decltype(PP)::value;
           if constexpr (TAB) {
           } else {
-            const float4 exr = fly_record(PP, xs_d, ys_f);
+            const float4 exr = fly_record(PP, xs_d, ys_d);
             if (tvalid[p]) apply_fly(PP, exr.x, exr.y, Sl.Gy, Sl.Gwt);
             pass2(PP, Sl, side, true, exr, tvalid[p], yt_d[TAB ? 0 : p], ys_d);
           }

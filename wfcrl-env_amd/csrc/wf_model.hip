@@ -82,6 +82,12 @@ int build_consts(wf_handle* h) {
     c.zc[m + 3] = (float)zc; c.zc2[m + 3] = (float)(zc * zc); c.ez[m + 3] = (float)std::exp(-zc * zc / eps2);
     c.zm[m + 3] = (float)zm; c.zm2[m + 3] = (float)(zm * zm); c.ezm[m + 3] = (float)std::exp(-zm * zm / eps2);
   }
+  // class 0 (the rotation vortex seen from the hub row: zc = num_eps): with the target column within a couple of metres
+  // of the vortex line, r^2 / eps^2 is so small that 1 - exp(-r^2 / eps^2) cancels in float32 (r^2 = 2e-6 m^2 exactly
+  // behind the source: the plain form returns 0) — below yl2_small the kernels take the series of (1 - exp(-s)) / r^2
+  c.inv_eps2 = (float)(1.0 / eps2);
+  c.m_half_inv_eps4 = (float)(-0.5 / (eps2 * eps2));
+  c.yl2_small = (float)(0.005 * eps2);
   // 1 - Ey*ezm with Ey <= 1 rounds to exactly 1.0f once ezm < 2^-25: those classes skip the core factor
   c.mirror_core_n = 0;
   for (int m = 0; m < 7; ++m)
@@ -121,7 +127,6 @@ int build_consts(wf_handle* h) {
   c.q_d = D / 4.0;
   c.guard_inv = h->guard_rel > 0.0 ? (float)(1.0 / h->guard_rel) : 1125899906842624.0f;
   c.inv_overlap_thr = (float)(1.0 / m.overlap_thresh);
-  c.yc_d = h->yc;
   c.ct_kappa = 5.0f;     // nrel_5MW: 5.9 on the cut-in ramp (2.5-3 m/s), 143 on the cut-out drop, <= 4.0 everywhere else
   c.knee_kappa = 30.0f;  // 30 x (wind-speed error ~3e-6) ~ 1e-4 of max(P, 1 kW)
   {  // wind veer: the rotated Gaussian of the deficit [FLORIS gauss.py rCalt]
