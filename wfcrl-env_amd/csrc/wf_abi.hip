@@ -61,8 +61,6 @@ int wf_create(int device_id, wf_handle** out) {
     const char* gs = getenv("WF_KERNEL_GS");  // e.g. "16x5"
     int og = 0, os = 0;
     if (gs && sscanf(gs, "%dx%d", &og, &os) == 2 && og > 0 && os > 0) { c.slot_G = og; c.slot_S = os; }
-    const char* zc = getenv("WF_ZERO_COPY");
-    if (zc && zc[0] == '0') h->zero_copy_max = 0;
     const char* off = getenv("WF_LL");
     if (off && off[0] == '0') c.one_block = 0;
     const char* force = getenv("WF_LL_G");  // "8" or "4x2"
@@ -238,24 +236,6 @@ int wf_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wd
   }
   const size_t bn = (size_t)h->B * h->N;
   if (on_device) return launch_step(h, yaw, power, wspd, wdir, load, nullptr);
-  // Small batches (the reference's single-farm env: B = 1): the kernels read the commands from and write the outputs
-  // to the handle's pinned host buffers directly (device-visible, coherent) — no staging copies around a launch that
-  // lasts tens of microseconds (N = 3: 50 -> 3x us per update_command; tools/latency_b1.py).  WF_ZERO_COPY=0 at wf_create: off.
-  if (bn <= h->zero_copy_max) {
-    if (!h->h_yaw) WF_HIP(h, hipHostMalloc(&h->h_yaw, sizeof(float) * bn, hipHostMallocDefault));
-    if (!h->h_out) WF_HIP(h, hipHostMalloc(&h->h_out, sizeof(float) * bn * 7, hipHostMallocDefault));
-    std::memcpy(h->h_yaw, yaw, sizeof(float) * bn);
-    {
-      int rc = launch_step(h, h->h_yaw, h->h_out, h->h_out + bn, h->h_out + 2 * bn, h->h_out + 3 * bn, nullptr);
-      if (rc != WF_OK) return rc;
-    }
-    WF_HIP(h, hipStreamSynchronize(h->stream));
-    if (power) std::memcpy(power, h->h_out, sizeof(float) * bn);
-    if (wspd) std::memcpy(wspd, h->h_out + bn, sizeof(float) * bn);
-    if (wdir) std::memcpy(wdir, h->h_out + 2 * bn, sizeof(float) * bn);
-    if (load) std::memcpy(load, h->h_out + 3 * bn, sizeof(float) * bn * 4);
-    return WF_OK;
-  }
   if (!h->d_yaw) WF_HIP(h, hipMalloc(&h->d_yaw, sizeof(float) * bn));
   if (!h->h_yaw) WF_HIP(h, hipHostMalloc(&h->h_yaw, sizeof(float) * bn, hipHostMallocDefault));
   if (!h->d_out) WF_HIP(h, hipMalloc(&h->d_out, sizeof(float) * bn * 7));

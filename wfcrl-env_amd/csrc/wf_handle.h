@@ -106,7 +106,6 @@ struct wf_handle {
                                             // threshold sits in the Gaussian tail: its float32 error reaches 1-3e-5)
   float *d_yaw = nullptr, *d_out = nullptr;  // staging for host callers: yaw [B*N], out [B*N*7]
   float *h_yaw = nullptr, *h_out = nullptr;  // pinned
-  size_t zero_copy_max = 4096;               // B * N up to which wf_step's host path lets the kernels use the pinned buffers directly
   size_t cap_env = 0, cap_bn = 0;
   // fused env state
   wf_env_params env{-40.f, 40.f, 5.f, 0.3f, 60.f, 0.1f, 0.1f, 0};
