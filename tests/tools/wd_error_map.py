@@ -1,3 +1,6 @@
+"""GPU box: map of the wind-direction and power error over an 8 x 14 grid at exactly 360 deg, on-the-fly kernel against
+the table path (float64 oracle as the reference) — how the core-factor cancellation of DESIGN.md §5 showed up: a bias
+growing by one step per upstream row.  usage: python tests/tools/wd_error_map.py [zero]   (zero: all yaw angles 0)"""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np

@@ -1,3 +1,6 @@
+"""GPU box: wind-direction error of ONE turbine (its own rotation vortex on its own rotor grid) on the fly against the
+table path, over num_eps, rotor diameter, hub height, shear and wind speed — the error scaled with 1 / num_eps and
+changed sign with D: the float32 cancellation of 1 - exp(-r^2 / eps^2) at r^2 = 2 num_eps^2."""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
