@@ -33,19 +33,21 @@ def time_it(lay, B, choice):
     return best, ("slot" if not k["one_block_kernel"] else f"{k['lanes_per_env']}x{k['slots_per_lane']}")
 
 
-for name in (sys.argv[1:] or ["HornsRev1_", "HornsRev2_"]):
-    lay = L[name]
-    print(f"# {name} N={lay['num_turbines']}  (ms per step; farm-steps/s of the pick; pick / best family at this batch; pick / envelope)")
-    env_best = 0.0
-    worst_fam, worst_env = 1.0, 1.0
-    for B in range(4096, 131072 + 1, 4096):
-        t_pick, fam_pick = time_it(lay, B, None)
-        ts = {f: time_it(lay, B, c)[0] for f, c in FAMS}
-        t_best = min(ts.values())
-        thr = B / t_pick * 1e3
-        env_best = max(env_best, B / min(t_best, t_pick) * 1e3)
-        r_fam, r_env = min(t_best / t_pick, 1.0), thr / env_best
-        worst_fam, worst_env = min(worst_fam, r_fam), min(worst_env, r_env)
-        print(f"B={B:7d} pick {fam_pick:4s} {t_pick:.3f} ms {thr:.3e}  " + " ".join(f"{f}={t:.3f}" for f, t in ts.items())
-              + f"  pick/best {r_fam:.3f}  pick/envelope {r_env:.3f}", flush=True)
-    print(f"# {name}: worst pick / best family {worst_fam:.3f}, worst pick / envelope {worst_env:.3f}")
+if __name__ == "__main__":
+    for name in (sys.argv[1:] or ["HornsRev1_", "HornsRev2_"]):
+        lay = L[name]
+        print(f"# {name} N={lay['num_turbines']}  (ms per step; farm-steps/s of the pick; pick / best family at this batch; pick / envelope)")
+        env_best = 0.0
+        worst_fam, worst_env = 1.0, 1.0
+        for B in range(4096, 131072 + 1, 4096):
+            time_it(lay, B, None)  # (the first handle after a change of batch runs ~5 % slow whatever it is: tools/pick_vs_forced.py)
+            ts = {f: time_it(lay, B, c)[0] for f, c in FAMS}
+            t_pick, fam_pick = time_it(lay, B, None)
+            t_best = min(ts.values())
+            thr = B / t_pick * 1e3
+            env_best = max(env_best, B / min(t_best, t_pick) * 1e3)
+            r_fam, r_env = min(t_best / t_pick, 1.0), thr / env_best
+            worst_fam, worst_env = min(worst_fam, r_fam), min(worst_env, r_env)
+            print(f"B={B:7d} pick {fam_pick:4s} {t_pick:.3f} ms {thr:.3e}  " + " ".join(f"{f}={t:.3f}" for f, t in ts.items())
+                  + f"  pick/best {r_fam:.3f}  pick/envelope {r_env:.3f}", flush=True)
+        print(f"# {name}: worst pick / best family {worst_fam:.3f}, worst pick / envelope {worst_env:.3f}")
