@@ -96,8 +96,11 @@ def run(n_cases, seed, only=-1, resolve=False):
                          ambient_ti=float(rng.choice([0.06, 0.1])), shear=float(rng.choice([0.12, 0.0, 0.2])),
                          ad=float(rng.choice([0.0, 0.01])), bd=float(rng.choice([0.0, -0.002])),
                          veer=float(rng.choice([4.0, -6.0, 12.0] if all_veer else [0.0, 0.0, 4.0, -6.0])))
+            if os.environ.get("WF_FUZZ_GCH"):  # also the GCH internals FLORIS exposes: vortex core size, recovery gain
+                model.update(eps_gain=float(rng.choice([0.2, 0.1, 0.35])), gch_gain=float(rng.choice([2.0, 1.0])))
             mp = ModelParams(D=model["rotor_diameter"], HH=model["hub_height"], ambient_ti=model["ambient_ti"],
-                             shear=model["shear"], ad=model["ad"], bd=model["bd"], veer=model["veer"])
+                             shear=model["shear"], ad=model["ad"], bd=model["bd"], veer=model["veer"],
+                             eps_gain=model.get("eps_gain", 0.2), gch_gain=model.get("gch_gain", 2.0))
             x, y = x * (D / 126.0), y * (D / 126.0)  # keeps the grids on the thresholds
         run = only < 0 or case == only
         if run:
