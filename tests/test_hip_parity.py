@@ -1068,3 +1068,30 @@ def test_on_the_fly_kernels_on_an_aligned_grid(hh, shear, veer):
             e = parity.errors(got, ref)
             assert e["wd"][fl == 0].max() < 1e-4 and e["power"][fl == 0].max() < 3e-5, {k: float(v[fl == 0].max()) for k, v in e.items()}
             w.close()
+
+
+def test_rounds_model_picks_the_16x1_family_at_three_blocks_per_cu(layouts):
+    """12 288 farms of 80 turbines are one round of the G = 16 one-block kernel (three blocks per CU) and 1.5 of the
+    register-slot kernel: the rounds model picks it (wf_dispatch.hip); a wind per farm on that handle runs the G = 8
+    on-the-fly kernel.  Sampled farms against the oracle on both."""
+    import parity
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    x, y, N, B = l["xcoords"], l["ycoords"], 80, 12288
+    rng = np.random.default_rng(3)
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    w = WfStep(x, y, env_batch=B)
+    idx = np.arange(0, B, 97)
+    w.set_wind(8.0, 263.0)
+    info = w.kernel_info()
+    assert (info["one_block_kernel"], info["lanes_per_env"], info["slots_per_lane"]) == (1, 16, 1)
+    out = w.step(yaw)
+    parity.check({k: v[idx] for k, v in out.items()}, _oracle(x, y, 8.0, 263.0, yaw[idx]), w.risk_flags()[idx], max_flagged_frac=0.1)
+    ws, wd = np.clip(8 * rng.weibull(8, B), 3, 28), rng.normal(270, 20, B) % 360
+    w.set_wind(ws, wd)
+    info = w.kernel_info()
+    assert (info["one_block_kernel"], info["lanes_per_env"], info["slots_per_lane"], info["pair_table"]) == (1, 8, 1, 0)
+    out = w.step(yaw)
+    parity.check({k: v[idx] for k, v in out.items()}, _oracle(x, y, ws[idx], wd[idx], yaw[idx]), w.risk_flags()[idx], max_flagged_frac=0.1)
+    w.close()
