@@ -57,14 +57,15 @@ constexpr int kNumFamilies = 6, kNumRoundsN = 5;
 const int kRoundsN[kNumRoundsN] = {32, 48, 64, 80, 91};
 // [family][N index][blocks per CU - 1]
 // (N = 32, 48, 64: the first N turbines of HornsRev2 at 263 deg; N = 80, 91: HornsRev1 / HornsRev2 at 270 deg, the
-// BASELINE configs — profiles/r03_rounds_table.txt, r03_batch_sweep_fine.txt; layouts move these by up to 10 %)
+// BASELINE configs — profiles/r03_v34_rounds_table.txt, r03_v34_batch_sweep_fine.txt, measured with the far-pair skip of pass 2
+// (wf_kernels_ll.hip: WF_LL_FAR_SKIP), whose yield depends on layout and direction; layouts move these by up to 10 %)
 const double kRoundsMs[kNumFamilies][kNumRoundsN][3] = {
-    {{0.093, 0.116, 0.0}, {0.123, 0.149, 0.187}, {0.166, 0.213, 0.0}, {0.237, 0.294, 0.0}, {0.307, 0.372, 0.0}},            // slot (8x4, 16x3, 16x4, 16x5, 16x6)
-    {{0.086, 0.112, 0.144}, {0.152, 0.197, 0.254}, {0.230, 0.300, 0.386}, {0.332, 0.424, 0.551}, {0.430, 0.553, 0.730}},  // 8x1
-    {{0.118, 0.159, 0.0}, {0.220, 0.291, 0.0}, {0.349, 0.458, 0.0}, {0.486, 0.639, 0.0}, {0.638, 0.869, 0.0}},            // 4x2
-    {{0.127, 0.170, 0.226}, {0.241, 0.309, 0.418}, {0.377, 0.489, 0.657}, {0.550, 0.691, 0.910}, {0.690, 0.900, 1.231}},  // 4x1
-    {{0.190, 0.274, 0.0}, {0.377, 0.532, 0.0}, {0.607, 0.842, 0.0}, {0.853, 1.166, 0.0}, {1.100, 1.620, 0.0}},            // 2x2
-    {{0.068, 0.088, 0.116}, {0.114, 0.148, 0.192}, {0.167, 0.211, 0.270}, {0.225, 0.290, 0.367}, {0.292, 0.365, 0.467}}};  // 16x1 (profiles/r03_rounds_table_16x1.txt)
+    {{0.094, 0.118, 0.0}, {0.124, 0.148, 0.187}, {0.166, 0.210, 0.0}, {0.230, 0.288, 0.0}, {0.304, 0.366, 0.0}},            // slot (8x4, 16x3, 16x4, 16x5, 16x6)
+    {{0.088, 0.110, 0.143}, {0.152, 0.192, 0.247}, {0.228, 0.284, 0.363}, {0.337, 0.413, 0.530}, {0.418, 0.506, 0.641}},  // 8x1
+    {{0.117, 0.156, 0.0}, {0.210, 0.271, 0.0}, {0.326, 0.414, 0.0}, {0.473, 0.600, 0.0}, {0.600, 0.777, 0.0}},            // 4x2
+    {{0.126, 0.166, 0.215}, {0.227, 0.296, 0.379}, {0.353, 0.438, 0.591}, {0.515, 0.623, 0.812}, {0.637, 0.800, 1.081}},  // 4x1
+    {{0.183, 0.255, 0.0}, {0.346, 0.472, 0.0}, {0.551, 0.768, 0.0}, {0.796, 1.030, 0.0}, {1.025, 1.409, 0.0}},            // 2x2
+    {{0.066, 0.085, 0.109}, {0.110, 0.141, 0.183}, {0.164, 0.207, 0.263}, {0.230, 0.288, 0.365}, {0.290, 0.352, 0.448}}};  // 16x1
 // A partial round behind full ones overlaps with their tail: its cost relative to the same round on an idle chip, by
 // (blocks per CU it reaches, resident blocks per CU of the family) — fitted on profiles/r03_batch_sweep_fine.txt
 const double kTailFactor[2][3] = {{0.80, 0.95, 0.0}, {0.62, 0.79, 0.86}};  // [per_cu - 2][tail blocks per CU - 1]

@@ -140,6 +140,9 @@ template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB, bool VEER = false
 #ifndef WF_LL_PINGPONG
 #define WF_LL_PINGPONG 0  // 1: two record buffers used alternately (2x unrolled replay): 20-30 spilled registers, slower
 #endif
+#ifndef WF_LL_FAR_SKIP
+#define WF_LL_FAR_SKIP 1  // pass 2 returns early for pairs whose lateral offset is beyond 6.12 sigma_y of the wake (below)
+#endif
 #ifndef WF_LL_LOGT
 #define WF_LL_LOGT 1  // 1: wave-major source log [source][float4 q][farm of the wave] — a record of the wave is one contiguous
                       // piece (2 KiB at G = 2), fetched by one or two fully coalesced loads per lane and handed to the farms'
@@ -432,6 +435,16 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       const float up = dx * ix0v;
       const float xf = dx - R.x0v;
       const float sy = far ? fmaf(R.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
+#if WF_LL_FAR_SKIP
+      // More than 6.12 sigma_y + D/4 off the wake's centre line, the nearest grid column gets exp2(-27) = 7.5e-9 of the
+      // amplitude: below the resolution of 1 - sqrt(esq) in float32 and far below the overlap threshold, so the deficit,
+      // the SOSFS update and the wake-added TI of this pair are all no-ops.  Wave-uniform: on the table path the farms of
+      // a wave share the geometry, and most pairs of a wide farm are this far apart.
+      // (on the fly every farm of the wave has its own geometry: the test would rarely be uniform, and costs 3 %)
+      if constexpr (TAB) {
+        if (!__any(fabsf(dy - delta) < fmaf(6.12f, sy, c.off[2]))) return;
+      }
+#endif
       const float sz = far ? fmaf(R.kyv, xf, c.sz0v) : fmaf(up, c.sz0v - sc.snw, sc.snw);
       const float isy = frcp(sy), isz = frcp(sz);
       const float xarg = sc.kdef * isy * isz;
