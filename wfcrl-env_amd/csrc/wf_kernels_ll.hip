@@ -425,16 +425,27 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
         column_deficit_veer(c, sc, k, dx, dy + c.off[j], lin, amp_on, e0[j], e1[j], e2[j]);
       }
     } else if (same) {
+      const bool far = dx >= R.x0v;
+      const float up = dx * ix0v;
+      const float xf = dx - R.x0v;
+      const float sy = far ? fmaf(R.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
+#if WF_LL_FAR_SKIP
+      // (first against a bound of the deflection, before its sqrt / rcp / log2: |delta| <= |d0| + |pj| log2(lnA / lnB) +
+      // |lin| — the log term rises from 0 towards log2((1.6 + sM) / (1.6 - sM)) <= 2.12 for sM <= 1 — then, below,
+      // against the deflection itself)
+      // (G = 2 only: with two targets per pass the bound test returns often enough to pay — 1.02 -> 0.99 ms at HornsRev1 x
+      // 65536; with four it cost cfg5's G = 4 kernel 3 %)
+      if constexpr (TAB && G == 2) {
+        const float dmax = fabsf(d0) + fmaf(2.2f, fabsf(R.pj), fabsf(lin));
+        if (!__any(fabsf(dy) < fmaf(6.12f, sy, c.off[2] + dmax))) return;
+      }
+#endif
       const float xs = fmaxf(dx - R.x0d, 0.0f);
       const float syd = fmaf(R.kyd, xs, sc.sy0d), szd = fmaf(R.kyd, xs, sc.sz0d);
       const float s = fsqrt(syd * szd * sc.inv_s0d);
       const float arg = sc.lnA * fmaf(1.6f, s, -sc.sM) * frcp(sc.lnB * fmaf(1.6f, s, sc.sM));
       const float d_far = fmaf(R.pj, flog2(arg), d0);
       const float delta = ((dx > R.x0d) ? d_far : dx * sc.tan_th0) + lin;
-      const bool far = dx >= R.x0v;
-      const float up = dx * ix0v;
-      const float xf = dx - R.x0v;
-      const float sy = far ? fmaf(R.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
 #if WF_LL_FAR_SKIP
       // More than 6.12 sigma_y + D/4 off the wake's centre line, the nearest grid column gets exp2(-27) = 7.5e-9 of the
       // amplitude: below the resolution of 1 - sqrt(esq) in float32 and far below the overlap threshold, so the deficit,
