@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 4
+#define WF_ABI_VERSION 5
 
 /* status codes (0 = ok, negative = error; text via wf_last_error) */
 #define WF_OK 0
@@ -159,10 +159,20 @@ int wf_sync(wf_handle* h);
  *                       (Ct 0 -> 0.99 between 2.5 and 3 m/s, 20x steeper than anywhere in the operating range) and its
  *                       cut-out drop.  With a row of turbines on the ramp the float64 result itself moves by 7e-5 in
  *                       power for 1e-5 deg of wind direction (tests/golden/README: case bad_512_56); float32 wind
- *                       speeds (3e-7 relative each) are amplified the same way.
- * Farms with flag 0 match the float64 path within the parity tolerances; flagged farms may differ by a bounded amount
- * (tests/parity.py: per flag type) — unless wf_set_risk_resolve is on, which solves exactly those farms again in float64
- * and clears their flags (below).  All geometric discontinuities (upstream/downstream order, dx > 0.1, 15 D reach, 2 D
+ *                       speeds (3e-7 relative each) are amplified the same way.  Also raised for a turbine whose thrust
+ *                       coefficient exceeds 0.995 (user tables only: nrel_5MW peaks at 0.99): 1 - Ct cancels in float32
+ *                       and the velocity behind such a turbine is a small difference of O(1) numbers.
+ * Farms with flag 0 match the float64 path within the parity tolerances (power 1e-4 of max(P, 1 kW), wind speed 5e-5,
+ * direction 3e-4 deg, TI 5e-6).  A FLAGGED farm left in float32 (wf_set_risk_resolve mode 0 — the C default; the Python
+ * envs of this package switch mode 1 on) may differ by the bounded signature of its event, per flag combination
+ * (tests/parity.py, measured maxima in brackets):
+ *   POWER_KNEE alone        power 5e-2 [1.3e-2 on the cut-out drop]; wind field as an unflagged farm's
+ *   THRUST_RAMP, no OVERLAP power 1e-2, wind speed 1e-3, direction 1e-2 deg, TI 2e-4
+ *   OVERLAP                 power 1e-1 [5.7e-2], wind speed 2e-2, direction 0.1 deg, TI 2e-2   (one overlap count flipped)
+ *   OVERLAP | THRUST_RAMP   power 4e-1 [2.7e-1], wind speed 4e-2, direction 0.2 deg [0.13]     (a flip below ~4 m/s, where
+ *                           the thrust ramp and the power curve both amplify it: 1.5 x the one measured case)
+ * With wf_set_risk_resolve on, exactly those farms are solved again in float64 and their flags cleared (below): no
+ * exemption is left.  All geometric discontinuities (upstream/downstream order, dx > 0.1, 15 D reach, 2 D
  * lateral gate) are decided in float64 on the device and need no flag.
  * wf_get_risk_flags copies the flags of the last wf_step / wf_env_step (env_batch ints). */
 #define WF_RISK_OVERLAP 1
@@ -180,7 +190,8 @@ int wf_get_risk_flags(wf_handle* h, int* flags, int on_device);
  * when no farm is flagged (three tiny launches); otherwise the latency of one farm's float64 chain — 0.7 to 1.4 ms for up
  * to ~1400 flagged 80-turbine farms.
  * mode 2 solves every farm in float64 (validation: 1.2e6 farm-steps/s on HornsRev1).
- * mode 0 (default): float32 results with flags, as before.
+ * mode 0 (the C default; `VecWindFarmEnv` and `HipFlorisInterface` set mode 1 unless told risk_resolve=False): float32
+ * results with flags, flagged farms within the per-flag bounds listed above.
  * wf_get_resolve_stats: number of farms the last step solved in float64, and (raw_flags != NULL, env_batch ints) the
  * flags as the float32 kernels raised them before they were cleared. */
 int wf_set_risk_resolve(wf_handle* h, int mode);
@@ -288,6 +299,10 @@ typedef struct wf_kernel_choice {
   int ll_G, ll_S;       /* one of 4x1, 8x1, 16x1, 4x2, 2x2 (used when one_block == 1) */
   int pair_table;       /* -1 whenever the batch shares a wind direction, 0 never (everything on the fly) */
   int fly_one_block;    /* -1: a wind per farm runs wf_step_ll_kernel on the fly where it pays; 0: stays on wf_step_kernel */
+  int far_skip;         /* -1 / 1: wf_step_ll_kernel leaves out the deficit / turbulence work of (source, target block) pairs
+                           more than 6.12 sigma_y + D/4 off the wake's centre line (the nearest rotor-grid column would get
+                           exp2(-27) of the amplitude: no effect on any float32 result); 0: every pair is evaluated (A/B
+                           and the bit-identity test, tests/test_hip_parity.py) */
 } wf_kernel_choice;
 int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c);
 int wf_get_kernel_choice(wf_handle* h, wf_kernel_choice* c);

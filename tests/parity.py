@@ -47,7 +47,11 @@ RAMP_BOUND = dict(power=1e-2, ws=1e-3, wd=1e-2, ti=2e-4, std=1e-2)
 # Both at once — an overlap-count flip at a turbine on the thrust ramp (below ~4 m/s, where Ct is steep and the power
 # curve amplifies a wind-speed change 6x): the two amplifiers compound.  Measured: power 0.27, ws 2.7e-2, wd 0.13 deg on
 # one farm of 1962 (42 turbines, float64 margin 1.3e-5) — fuzz_api seed 501, session 64.
-OVERLAP_RAMP_BOUND = dict(power=5e-1, ws=5e-2, wd=0.3, ti=2e-2, std=5e-2)
+# The bound is 1.5x that measurement, not a round number above it, and it only matters on the OPT-OUT path:
+# the batched env and the single-farm interface run with the float64 re-solve on by default (round 4), where every farm
+# — flagged or not — is held to TOL (check_strict).  include/wfstep.h states these per-flag bounds for float32-only use.
+OVERLAP_RAMP_BOUND = dict(power=4e-1, ws=4e-2, wd=0.2, ti=2e-2, std=5e-2)
+_SCALED_FOR_LARGE_FARMS = ("power", "ws", "std")  # what LARGE_FARM_FACTOR widens, in every bound (within() and below)
 
 
 def flagged_within(e, flags, n_turbines):
@@ -61,8 +65,8 @@ def flagged_within(e, flags, n_turbines):
     ramp_no_overlap = ((flags & RISK_OVERLAP) == 0) & ((flags & RISK_THRUST_RAMP) != 0)
     for mask, bound in ((ramp_no_overlap, RAMP_BOUND), (flags == RISK_POWER_KNEE, KNEE_ONLY_BOUND)):
         inside = np.ones_like(ok)
-        for k, t in bound.items():
-            inside &= e[k] <= t * f
+        for k, t in bound.items():  # direction and TI keep their bound on large farms, as within(TOL) keeps them
+            inside &= e[k] <= t * (f if k in _SCALED_FOR_LARGE_FARMS else 1.0)
         ok &= inside | ~mask
     return ok
 
@@ -88,7 +92,7 @@ def within(e, tol, n_turbines=0):
     ok = np.ones_like(e["power"], dtype=bool)
     f = LARGE_FARM_FACTOR if n_turbines > 128 else 1.0
     for k, t in tol.items():
-        ok &= e[k] <= t * (f if (k in ("power", "ws", "std") or tol is FLAGGED_BOUND or tol is OVERLAP_RAMP_BOUND) else 1.0)
+        ok &= e[k] <= t * (f if (k in _SCALED_FOR_LARGE_FARMS or tol is FLAGGED_BOUND or tol is OVERLAP_RAMP_BOUND) else 1.0)
     return ok
 
 
@@ -97,7 +101,7 @@ def table_flag_conditions(ref, slack=0.05, near=2e-4):
     margin=True): (knee, ramp) bool (B,) — True where SOME turbine of the farm sits, in float64, on (or within `near`
     relative of a knot next to) a segment whose condition number is within `slack` of the kernel's thresholds:
       WF_RISK_POWER_KNEE   rho v |dP/dv| > 30 max(P, 1 kW) at v = (rho/rho_ref)^(1/3) wind_speed cos(yaw)^(pP/3)
-      WF_RISK_THRUST_RAMP  v |dCt/dv| > 5 at the turbine's rotor wind speed, Ct strictly inside (0.0001, 0.9999)
+      WF_RISK_THRUST_RAMP  v |dCt/dv| > 5 at the turbine's rotor wind speed, Ct strictly inside (0.0001, 0.9999); or Ct > 0.995
     (csrc/wf_kernel_common.h: table_pw / table_ct; wf_abi.hip: knee_kappa, ct_kappa).  A raised flag without it is spurious."""
     p = ref.model
     tws = np.asarray(p.table_ws, float)
@@ -117,6 +121,7 @@ def table_flag_conditions(ref, slack=0.05, near=2e-4):
                 out |= inside & (p.ref_density * np.abs(slope) * vv > 30.0 * (1 - slack) * np.maximum(p.ref_density * val, 1e3))
             else:
                 out |= inside & (val > 0.0001 * (1 - slack)) & (val < 0.9999 * (1 + slack)) & (np.abs(slope) * vv > 5.0 * (1 - slack))
+                out |= inside & (val > 0.995 - 1e-4)  # thrust coefficient within 0.005 of 1 (user tables): 1 - Ct cancels in float32
         return out.reshape(out.shape[0], -1).any(axis=1)
 
     return cond(veff, tpw, "knee"), cond(wsd, tct, "ramp")

@@ -36,7 +36,13 @@ def test_a_flag_only_excuses_what_its_event_can_move():
     assert not parity.flagged_within(_e(wd=0.15), np.array([ovl | knee]), 80).any()
     # overlap flip at a turbine on the thrust ramp: the two amplifiers compound (fuzz_api seed 501, session 64)
     assert parity.flagged_within(_e(power=0.27, ws=2.7e-2, wd=0.13), np.array([ovl | ramp]), 42).all()
-    assert not parity.flagged_within(_e(power=0.6), np.array([ovl | ramp]), 42).any()
+    assert not parity.flagged_within(_e(power=0.45), np.array([ovl | ramp]), 42).any()  # 1.5x the measurement, no more
+    assert not parity.flagged_within(_e(wd=0.25), np.array([ovl | ramp]), 42).any()
+    # farms of more than 128 turbines: the knee / ramp bounds widen on power / speed / std only, like TOL
+    assert parity.flagged_within(_e(power=0.12), np.array([knee]), 200).all()
+    assert not parity.flagged_within(_e(wd=4e-4), np.array([knee]), 200).any()
+    assert not parity.flagged_within(_e(wd=2e-2), np.array([ramp]), 200).any()
+    assert not parity.flagged_within(_e(ti=3e-4), np.array([ramp]), 200).any()
     assert not parity.flagged_within(_e(ti=3e-2), np.array([ovl | ramp | knee]), 42).any()
 
 

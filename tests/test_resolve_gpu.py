@@ -301,7 +301,7 @@ def test_kernel_choice_round_trip_and_errors(layouts):
 
     l = layouts["HornsRev1_"]
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=256)
-    assert w.kernel_choice() == dict(slot_G=0, slot_S=0, one_block=-1, ll_G=0, ll_S=0, pair_table=-1, fly_one_block=-1)
+    assert w.kernel_choice() == dict(slot_G=0, slot_S=0, one_block=-1, ll_G=0, ll_S=0, pair_table=-1, fly_one_block=-1, far_skip=-1)
     w.set_wind(8.0, 263.0)
     w.set_kernel_choice(one_block="4x2", slot="16x5")
     c = w.kernel_choice()
@@ -367,8 +367,8 @@ def test_both_float64_kernels_by_flagged_count(layouts):
 
 
 def test_env_surface_switches(layouts):
-    """The single-farm drop-in (`HipFlorisInterface`, what `make("<layout>_Floris")` builds) has the re-solve on by default —
-    the reference computes every step in float64 — and the vectorised env takes `risk_resolve=True`.  On the farm the float32
+    """The single-farm drop-in (`HipFlorisInterface`, what `make("<layout>_Floris")` builds) AND the vectorised env have the
+    re-solve on by default — the reference computes every step in float64 —; `risk_resolve=False` opts out.  On the farm the float32
     kernel is known to flag (tests/golden/regime_cases.npz) the interface lands on the committed float64 values."""
     import parity
     from wfcrl_env_amd import environments as envs
@@ -384,11 +384,18 @@ def test_env_surface_switches(layouts):
     parity.check_strict(got, ref)
     off = HipFlorisInterface(N, i["x"], i["y"], wind_speed=float(i["ws"][0]), wind_direction=float(i["wd"][0]), risk_resolve=False)
     off.update_command(i["yaw"][0])
-    assert off.fi.resolve_stats()["n_resolved"] == 0 and off.fi.risk_flags()[0] != 0
-    venv = envs.make("HornsRev1_Floris", env_batch=512, risk_resolve=True, log=False)
-    venv.reset(seed=3)
+    assert off.fi.risk_flags()[0] != 0
+    with pytest.raises(RuntimeError):  # nothing is recorded with the re-solve off: stale flags are not handed out
+        off.fi.resolve_stats()
     import torch
 
+    venv = envs.make("HornsRev1_Floris", env_batch=512, log=False)  # default: strict
+    venv.reset(seed=3)
     venv.step({"yaw": torch.zeros((512, 80), device="cuda")})
     assert not venv.fi.risk_flags().any()
     venv.close()
+    fast = envs.make("HornsRev1_Floris", env_batch=512, log=False, risk_resolve=False)  # opt-out: flags stay up
+    fast.reset(seed=3)
+    fast.step({"yaw": torch.zeros((512, 80), device="cuda")})
+    assert fast.fi.risk_flags().any()
+    fast.close()

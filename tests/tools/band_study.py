@@ -1,0 +1,81 @@
+"""GPU box: how wide does the guard band of WF_RISK_OVERLAP have to be?  
+
+The float32 kernels flag a farm when a deficit comes within a RELATIVE band of the overlap threshold "deficit * Uinit >
+0.05" (include/wfstep.h); every flagged farm is solved again in float64 when the re-solve is on.  The band has to cover
+the float32 error of the deficit at the threshold, and no more: every farm it flags costs a float64 chain.
+
+Measured directly and at scale: the float64 DEVICE kernel (wf_set_risk_resolve mode 2, itself held to the CPU oracle at
+5e-7 by tests/test_resolve_gpu.py) solves every farm of large batches, the float32 kernel runs on the same inputs with
+the band at several widths, and for every width we count
+  flagged      farms carrying WF_RISK_OVERLAP,
+  missed       farms with NO flag of any kind that are outside the parity tolerances (tests/parity.py TOL) — the farms
+               a band of that width lets through wrongly; must be 0 at the shipped width,
+and, independent of the band, the smallest band that would have caught every farm outside TOL ("needed": the largest
+width at which a wrong farm is still unflagged, from the sweep).
+usage: python tests/tools/band_study.py [layout] [n_batches] [B] [mode: reset|shared|wide]"""
+import json, os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import torch
+
+ROOT = os.getcwd()
+BANDS = [5e-5, 4e-5, 3e-5, 2.5e-5, 2e-5, 1.5e-5, 1e-5, 5e-6]
+TOL = dict(power=1e-4, ws=5e-5, wd=3e-4, ti=5e-6)
+
+
+def errs(f32, f64):
+    p = ((f32["power"] - f64["power"]).abs() / f64["power"].clamp_min(1e3)).amax(1)
+    s = ((f32["wind_speed"] - f64["wind_speed"]).abs() / f64["wind_speed"].clamp_min(0.1)).amax(1)
+    d = (f32["wind_direction"] - f64["wind_direction"]).abs().amax(1)
+    t = (f32["load"][..., 0] - f64["load"][..., 0]).abs().amax(1)
+    return p, s, d, t
+
+
+def main():
+    from wfcrl_env_amd.backend import WfStep
+
+    name = sys.argv[1] if len(sys.argv) > 1 else "HornsRev1_"
+    nb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+    mode = sys.argv[4] if len(sys.argv) > 4 else "reset"
+    lay = json.load(open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")))[name]
+    N = len(lay["xcoords"])
+    w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B)
+    tot = {b: dict(flagged=0, missed=0) for b in BANDS}
+    n_farms = 0
+    worst_missed = {}
+    for it in range(nb):
+        rng = np.random.default_rng(4000 + it)
+        if mode == "shared":
+            w.set_wind(float(rng.uniform(6, 11)), float(270 + rng.uniform(-30, 30)))
+        elif mode == "wide":
+            w.set_wind(rng.uniform(2.6, 26, B), rng.uniform(0, 360, B))
+        else:
+            w.set_wind(np.clip(8 * rng.weibull(8, B), 3, 28), rng.normal(270, 20, B) % 360)
+        yaw = torch.from_numpy(rng.uniform(-40, 40, (B, N)).astype(np.float32)).cuda()
+        w.set_risk_resolve(2)
+        f64 = {k: v.clone() for k, v in w.step(yaw).items()}  # outputs are float32-rounded float64 results
+        w.set_risk_resolve(0)
+        n_farms += B
+        for b in BANDS:
+            w.set_risk_guard(b)
+            f32 = w.step(yaw)
+            fl = w.risk_flags(as_torch=True)
+            p, s, d, t = errs(f32, f64)
+            bad = (p > TOL["power"]) | (s > TOL["ws"]) | (d > TOL["wd"]) | (t > TOL["ti"])
+            missed = bad & (fl == 0)
+            tot[b]["flagged"] += int(((fl & 1) != 0).sum())
+            tot[b]["missed"] += int(missed.sum())
+            if missed.any():
+                i = int(torch.nonzero(missed)[0])
+                worst_missed.setdefault(b, []).append(dict(batch=it, farm=i, power=float(p[i]), ws=float(s[i]), wd=float(d[i]), ti=float(t[i])))
+        w.set_risk_guard(5e-5)
+    print(f"{name} N={N} mode={mode}: {n_farms} farms (float64 device kernel as the checker)")
+    for b in BANDS:
+        print(f"  band {b:.1e}: overlap-flagged {tot[b]['flagged']} ({100.0 * tot[b]['flagged'] / n_farms:.3f} %), unflagged farms outside TOL {tot[b]['missed']}"
+              + (f"  e.g. {worst_missed[b][:2]}" if b in worst_missed else ""))
+    w.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,15 @@ VARIANTS = [(g, s) for g, smax in ((4, 4), (8, 4), (16, 6), (32, 4), (64, 4)) fo
 
 def make_layout(rng):
     kind = rng.integers(0, 4)
+    if os.environ.get("WF_FUZZ_SKIP"):  # dense farms (2-3 D spacing): 6.12 sigma_y reaches the neighbours of a wake
+        nc, nr = rng.integers(2, 14), rng.integers(2, 10)
+        sx, sy = rng.choice([252.0, 315.0, 378.0, 504.0]), rng.choice([252.0, 290.0, 378.0])
+        x = np.repeat(np.arange(nc) * sx, nr) + np.tile(np.arange(nr) * rng.choice([0.0, 31.0, 90.0]), nc)
+        y = np.tile(np.arange(nr) * sy, nc)
+        if rng.random() < 0.5:
+            x = x + rng.uniform(-40, 40, x.size)
+            y = y + rng.uniform(-40, 40, y.size)
+        return x, y
     if rng.random() < float(os.environ.get("FUZZ_BIG", "0.03")):  # up to the 256-turbine limit of the ABI
         nc, nr = rng.integers(8, 17), rng.integers(8, 17)
         x = np.repeat(np.arange(nc) * 630.0, nr) + (rng.uniform(-50, 50, nc * nr) if rng.random() < 0.5 else 0.0)
@@ -80,11 +89,16 @@ def run(n_cases, seed, only=-1, resolve=False):
         # every other case also forces the one-block-at-a-time kernel (csrc/wf_kernels_ll.hip) at a random lane-group
         # width: it serves the table-path modes of farms with more than one block, wf_step_kernel the rest
         llg = str(rng.choice(["0", "0", "4", "8", "16", "4x2", "4x2", "2x2"]))
+        skip_leg = bool(os.environ.get("WF_FUZZ_SKIP"))  # the far-pair skip of the table-path one-block kernels
+        if skip_leg:
+            llg = str(rng.choice(["2x2", "2x2", "4x2", "4"]))
         if llg != "0" and N > eval(llg.replace("x", "*")):
             choice["one_block"] = llg
         B = int(rng.integers(1, 9))
-        yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
+        yaw = rng.uniform(-40, 40, (B, N)).astype(np.float32) if skip_leg else rng.uniform(-35, 35, (B, N)).astype(np.float32)
         wd0 = float(rng.choice([0.0, 90.0, 180.0, 270.0, 360.0, rng.uniform(0, 360), rng.uniform(250, 290)]))
+        if skip_leg:  # mostly oblique: the axis-aligned directions tie across blocks and leave the one-block kernel
+            wd0 = float(rng.choice([270.0, rng.uniform(0, 360), rng.uniform(250, 290), rng.uniform(0, 360)]))
         ws0 = float(rng.uniform(*WS_RANGE))
         # every fourth case: a non-default model (low hub = general mirror cores, other D: 15 D no longer an integer
         # number of grid steps, other ambient TI / shear / deflection offsets)
@@ -102,6 +116,27 @@ def run(n_cases, seed, only=-1, resolve=False):
                              shear=model["shear"], ad=model["ad"], bd=model["bd"], veer=model["veer"],
                              eps_gain=model.get("eps_gain", 0.2), gch_gain=model.get("gch_gain", 2.0))
             x, y = x * (D / 126.0), y * (D / 126.0)  # keeps the grids on the thresholds
+        if skip_leg:
+            # models that move what the skip's bound rests on: wake growth ka / kb x {0.25, 1, 4}, a deflection set of its
+            # own (sigma ratios < 1: the log argument of the far-wake deflection below 1), deflection offsets ad / bd,
+            # rotor sizes 60-220 m, a user thrust table reaching Ct 0.9999
+            D = float(rng.choice([60.0, 90.0, 126.0, 170.0, 220.0]))
+            kf, df = float(rng.choice([0.25, 1.0, 4.0])), float(rng.choice([0.25, 1.0, 4.0]))
+            model = dict(rotor_diameter=D, hub_height=float(rng.choice([0.6, 0.714, 0.9]) * D),
+                         ambient_ti=float(rng.choice([0.04, 0.06, 0.12])), ka=0.38 * kf, kb=0.004 * kf,
+                         defl_ka=0.38 * df, defl_kb=0.004 * df, defl_alpha=float(rng.choice([0.58, 0.3, 1.2])),
+                         defl_beta=float(rng.choice([0.077, 0.03, 0.2])), alpha=float(rng.choice([0.58, 0.4, 0.9])),
+                         beta=float(rng.choice([0.077, 0.05, 0.15])), ad=float(rng.choice([0.0, 0.02, -0.05])) * D / 126.0,
+                         bd=float(rng.choice([0.0, -0.01, 0.006])), dm=float(rng.choice([1.0, 1.3])))
+            mp = ModelParams(D=D, HH=model["hub_height"], ambient_ti=model["ambient_ti"], ka=model["ka"], kb=model["kb"],
+                             defl_ka=model["defl_ka"], defl_kb=model["defl_kb"], defl_alpha=model["defl_alpha"],
+                             defl_beta=model["defl_beta"], alpha=model["alpha"], beta=model["beta"], ad=model["ad"],
+                             bd=model["bd"], dm=model["dm"])
+            if rng.random() < 0.3:  # thrust table up to the clip
+                tct = np.clip(np.asarray(mp.table_ct) * 1.35, 0.0, 0.9999)
+                model["table_ws"], model["table_ct"], model["table_cp"] = list(mp.table_ws), list(tct), list(mp.table_cp)
+                mp.table_ct = list(tct)
+            x, y = x * (D / 126.0), y * (D / 126.0)
         run = only < 0 or case == only
         if run:
             w = WfStep(x, y, env_batch=B, model=dict(model) if model else None, kernel_choice=choice)
@@ -109,7 +144,7 @@ def run(n_cases, seed, only=-1, resolve=False):
                 w.set_risk_resolve(1)
             info = w.kernel_info()
             assert (info["lanes_per_env"], info["slots_per_lane"]) == (G, S)
-        for mode in ("shared", "per_farm", "shared_dir"):
+        for mode in (("shared", "shared_dir", "shared_dir") if skip_leg else ("shared", "per_farm", "shared_dir")):
             if mode == "shared":
                 ws, wd = np.array([ws0]), np.array([wd0])
             elif mode == "shared_dir":  # a speed per farm under one direction: table path with per-farm speeds
@@ -132,7 +167,8 @@ def run(n_cases, seed, only=-1, resolve=False):
             nflip += k == "flip"
             if k != "ok":
                 nbad += k == "BAD"
-                print(k, dict(case=case, N=N, G=G, S=S, LL=w.kernel_info()["one_block_kernel"] and llg, B=B, mode=mode, wd0=wd0, ws0=ws0, model=model,
+                print(k, dict(case=case, N=N, G=G, S=S, LL=w.kernel_info()["one_block_kernel"] and llg, B=B, mode=mode, wd0=wd0, ws0=ws0,
+                              model={a: (b if not isinstance(b, list) else f"<{len(b)} values, max {max(b):.4f}>") for a, b in model.items()},
                               table=w.kernel_info()["pair_table"]), r, flush=True)
             if only >= 0:
                 np.set_printoptions(linewidth=220, precision=5, suppress=True)

@@ -1,5 +1,5 @@
 """GPU box: where a wave of wf_step_ll_kernel spends its cycles.  Needs a stamp build:
-    LLFLAGS="-mllvm -amdgpu-sched-strategy=iterative-ilp -DWF_LL_STAMP" tools/build_alt.sh stamp
+    tools/build_alt.sh stamp -DWF_LL_STAMP
     python tools/ll_stamps.py build/alt/lib_stamp.so
 Phases (s_memtime cycles summed over the waves of one launch, divided by the wave count): replay of logged sources,
 this block's own sources, the chunk barrier, outputs; the rest is the prologue (yaw staging, tables)."""
@@ -43,6 +43,7 @@ tot = buf[4] / nw
 print(f"{name} B={B} {w.kernel_info()}  {ms:.3f} ms with stamps; {nw} waves, {tot:.0f} cycles per wave")
 for k in range(4):
     print(f"  {names[k]:14s} {buf[k] / nw:10.0f} cycles  {buf[k] / buf[4]:.3f}")
+print(f"  {'  of replay: transverse pass':28s} {buf[11] / nw:10.0f} cycles  {buf[11] / buf[4]:.3f}   deficit pass + chunk test {(buf[0] - buf[11]) / nw:10.0f}  {(buf[0] - buf[11]) / buf[4]:.3f}")
 print(f"  {'prologue/rest':14s} {(buf[4] - sum(buf[:4])) / nw:10.0f} cycles  {(buf[4] - sum(buf[:4])) / buf[4]:.3f}")
 print("  own-source step, cycles per source (the stamps themselves add ~10 %):")
 for k, nm in zip(range(6, 11), ["A state + broadcasts", "B cbrt, Ct lookup, induction", "C transverse pass in the block", "D steering, deflection/deficit constants, log store", "E deficit / TI pass in the block"]):

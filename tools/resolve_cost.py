@@ -30,7 +30,7 @@ for label, ws, wd in (("shared 8 m/s 270 deg", 8.0, 270.0),
         for _ in range(10):
             w.step(yaw, out)
         ms = w.timing_end() / 10
-        st = w.resolve_stats()
+        st = w.resolve_stats() if mode else {"raw_flags": w.risk_flags(), "n_resolved": 0}
         print(f"{name} B={B} {label}: resolve {'on ' if mode else 'off'} {ms:.3f} ms/step, "
               f"flagged {int((st['raw_flags'] != 0).sum())}, re-solved {st['n_resolved']}", flush=True)
 w.close()

@@ -64,7 +64,7 @@ class KernelInfo(C.Structure):
 class KernelChoice(C.Structure):
     """Mirror of `struct wf_kernel_choice`."""
 
-    _fields_ = [(n, C.c_int) for n in ("slot_G", "slot_S", "one_block", "ll_G", "ll_S", "pair_table", "fly_one_block")]
+    _fields_ = [(n, C.c_int) for n in ("slot_G", "slot_S", "one_block", "ll_G", "ll_S", "pair_table", "fly_one_block", "far_skip")]
 
 
 # every symbol include/wfstep.h declares: name -> (restype, argtypes)

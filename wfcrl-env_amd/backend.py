@@ -308,9 +308,15 @@ class WfStep:
         """Float64 re-solve of the farms the float32 kernels flag (include/wfstep.h: wf_set_risk_resolve): 0 / False off,
         1 / True the flagged farms, 2 every farm.  Afterwards every farm meets the parity tolerances and its flag is 0."""
         check(self._lib.wf_set_risk_resolve(self._h, int(mode)), self._h)
+        self._resolve_mode = int(mode)
 
     def resolve_stats(self) -> dict:
-        """{"n_resolved": farms the last step solved in float64, "raw_flags": int32 (B,) flags before they were cleared}."""
+        """{"n_resolved": farms the last step solved in float64, "raw_flags": int32 (B,) flags before they were cleared}.
+        Only meaningful after a step with the re-solve on: with it off (set_risk_resolve(0)) nothing is recorded and
+        this raises instead of returning stale flags — read risk_flags() there."""
+        if not getattr(self, "_resolve_mode", 0):
+            raise RuntimeError("resolve_stats() needs the float64 re-solve on (set_risk_resolve(1)); with it off the flags "
+                               "of the last step are risk_flags()")
         n = C.c_int(0)
         raw = np.empty(self.env_batch, np.int32)
         check(self._lib.wf_get_resolve_stats(self._h, C.byref(n), raw.ctypes.data, 0), self._h)
@@ -339,14 +345,18 @@ class WfStep:
         check(self._lib.wf_timing_end(self._h, C.byref(ms)), self._h)
         return float(ms.value)
 
-    def set_kernel_choice(self, slot=None, one_block=None, pair_table=None, fly_one_block=None):
+    def set_kernel_choice(self, slot=None, one_block=None, pair_table=None, fly_one_block=None, far_skip=None):
         """Which kernels may serve THIS handle (include/wfstep.h: wf_set_kernel_choice); None = automatic.
           slot=(G, S) or "16x5"      wf_step_kernel<G,S>
           one_block=False            never wf_step_ll_kernel;  one_block=(G, S) / "4x2" / "8": always, with that shape
           pair_table=False           everything on the fly
           fly_one_block=False        a wind per farm stays on wf_step_kernel
+          far_skip=False             wf_step_ll_kernel evaluates every (source, target) pair (no far-source / far-pair skip)
         Drops the current wind: set it again before the next step."""
         def gs(v, default_s=1):
+            if isinstance(v, bool):
+                raise ValueError("a kernel shape is (G, S), 'GxS' or G — not a bool (one_block=False disables the one-block "
+                                 "kernel, None leaves the choice to the rounds model)")
             if isinstance(v, str):
                 parts = v.lower().split("x")
                 return int(parts[0]), (int(parts[1]) if len(parts) > 1 else default_s)
@@ -354,11 +364,11 @@ class WfStep:
                 return v, default_s
             return int(v[0]), int(v[1])
 
-        c = KernelChoice(0, 0, -1, 0, 0, -1, -1)
+        c = KernelChoice(0, 0, -1, 0, 0, -1, -1, -1)
         if slot:
             c.slot_G, c.slot_S = gs(slot)
         if one_block is not None:
-            if one_block is False or one_block == 0:
+            if one_block is False or (not isinstance(one_block, bool) and one_block == 0):
                 c.one_block = 0
             else:
                 c.one_block = 1
@@ -367,6 +377,8 @@ class WfStep:
             c.pair_table = int(bool(pair_table)) if pair_table is False else -1
         if fly_one_block is not None:
             c.fly_one_block = 0 if fly_one_block is False else -1
+        if far_skip is not None:
+            c.far_skip = 0 if far_skip is False or far_skip == 0 else -1
         check(self._lib.wf_set_kernel_choice(self._h, C.byref(c)), self._h)
 
     def kernel_choice(self) -> dict:

@@ -10,6 +10,9 @@ thread_local std::string g_create_error;
 void free_batch(wf_handle* h) {
   hipFree(h->d_ws); hipFree(h->d_wd); hipFree(h->d_gx); hipFree(h->d_gy); hipFree(h->d_gidx); hipFree(h->d_flags);
   hipFree(h->d_farm_tie);
+  hipFree(h->d_dir_perm); hipFree(h->d_sort_keys); hipFree(h->d_sort_vals); hipFree(h->d_sort_tmp);
+  h->d_dir_perm = h->d_sort_vals = nullptr; h->d_sort_keys = nullptr; h->d_sort_tmp = nullptr;
+  h->sort_tmp_bytes = h->dir_perm_cap = 0; h->dir_slots = 0;
   hipFree(h->d_res_list); hipFree(h->d_res_count); hipFree(h->d_flags_raw);
   h->d_res_list = h->d_res_count = h->d_flags_raw = nullptr;
   h->d_flags = h->d_farm_tie = nullptr;
@@ -63,6 +66,8 @@ int wf_create(int device_id, wf_handle** out) {
     if (gs && sscanf(gs, "%dx%d", &og, &os) == 2 && og > 0 && os > 0) { c.slot_G = og; c.slot_S = os; }
     const char* off = getenv("WF_LL");
     if (off && off[0] == '0') c.one_block = 0;
+    const char* fs = getenv("WF_LL_FAR_SKIP");
+    if (fs && fs[0] == '0') c.far_skip = 0;
     const char* force = getenv("WF_LL_G");  // "8" or "4x2"
     if (force && c.one_block != 0) {
       int g = 0, sl = 1;

@@ -41,6 +41,11 @@ struct WfConsts {
   float sz0v;              // D/2 * sqrt(uR/(Uinf+u0)) of the deficit model == D/(2 sqrt 2)
   float near_c;            // 0.501 * D
   float kdef;              // D^2/8
+  float kdef_sy0v;         // kdef / (sz0v [cos veer]): ct cos(yaw) kdef = sM^2 sy0v kdef_sy0v (wf_step_ll_kernel's replay)
+  // far-source / far-pair skip of wf_step_ll_kernel (wf_kernels_ll.hip): far_k = 6.12 sigma_y widths (1e30 and
+  // far_on = 0 with the skip disabled — wf_kernel_choice::far_skip = 0, or a model with a negative wake growth rate)
+  float far_k;
+  int far_on;
   // crespo-hernandez + overlap gating                                               [A.3-8]
   float ch_c, ch_ai, ch_down;  // ch_c = constant * ambient^initial
   float amb, amb2, gch_gain, overlap_thr, twoD;
@@ -152,9 +157,13 @@ inline size_t wf_ll_block_offset(int J, int N, int G) {
   }
   return off;
 }
-// Source log of wf_step_ll_kernel: WF_LOG_FLOATS floats (64 bytes) per (farm, source) + a 16-byte side record that only
-// split-TI sources write and read (wf_kernels_ll.hip: SrcLog, WfLogSide); the side array follows the main one.
-#define WF_LOG_FLOATS 16
+// Source log of wf_step_ll_kernel per (farm slot, source): a HOT part of 2 floats (the circulations: read by every later
+// block), a COLD part of 12 floats (deflection / deficit / turbulence constants: read by the blocks the wake can reach)
+// and a 16-byte side record that only split-TI sources write and read (wf_kernels_ll.hip: SrcLog, ColdRec, WfLogSide).
+// One allocation of R = (farm slots) x (padded turbines) records: [R x 2 floats][R x 12 floats][R x 4 floats].
+#define WF_LOG_HOT_FLOATS 2
+#define WF_LOG_COLD_FLOATS 12
+#define WF_LOG_FLOATS (WF_LOG_HOT_FLOATS + WF_LOG_COLD_FLOATS)
 #define WF_LOG_SIDE_FLOATS 4
 
 struct WfPairConsts {

@@ -267,6 +267,26 @@ int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
                                 per_farm ? ll_fly_G(h) * ll_fly_S(h) : 0, h->d_farm_tie, h->d_farm_tie ? h->d_farm_tie + h->B : nullptr,
                                 h->stream));
   h->farm_ties = 2;
+  h->dir_slots = 0;
+  if (per_farm && h->n_layouts == 1 && h->choice.fly_one_block != 0 && h->choice.far_skip != 0) {
+    // launch order of the on-the-fly one-block kernel: ascending wind direction (wf_sort.hip), padded to its whole blocks
+    const int fpb = wfk_ll_farms_per_block(ll_fly_G(h));
+    const size_t slots = (size_t)((h->B + fpb - 1) / fpb) * fpb;
+    if (slots > h->dir_perm_cap) {
+      WF_HIP(h, hipStreamSynchronize(h->stream));
+      hipFree(h->d_dir_perm); hipFree(h->d_sort_keys); hipFree(h->d_sort_vals); hipFree(h->d_sort_tmp);
+      h->d_dir_perm = h->d_sort_vals = nullptr; h->d_sort_keys = nullptr; h->d_sort_tmp = nullptr; h->dir_perm_cap = 0;
+      WF_HIP(h, wfk_sort_tmp_bytes(h->B, &h->sort_tmp_bytes));
+      WF_HIP(h, hipMalloc(&h->d_dir_perm, sizeof(int) * slots));
+      WF_HIP(h, hipMalloc(&h->d_sort_keys, sizeof(float) * 2 * (size_t)h->B));
+      WF_HIP(h, hipMalloc(&h->d_sort_vals, sizeof(int) * (size_t)h->B));
+      WF_HIP(h, hipMalloc(&h->d_sort_tmp, h->sort_tmp_bytes > 0 ? h->sort_tmp_bytes : 16));
+      h->dir_perm_cap = slots;
+    }
+    WF_HIP(h, wfk_sort_by_direction(h->B, (int)slots, d_wd, h->d_sort_keys, h->d_sort_vals, h->d_sort_tmp, h->sort_tmp_bytes,
+                                    h->d_dir_perm, h->stream));
+    h->dir_slots = (int)slots;
+  }
   if (per_farm && sync_ok) {
     int any = 0;
     WF_HIP(h, hipMemcpyAsync(&any, h->d_farm_tie + h->B, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -324,7 +344,7 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
     if (h->ll_ties != 1)
       WF_HIP(h, wfk_launch_step_ll(h->ll_G, h->ll_S, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
                                    load, h->B, ea, h->d_ll_tab, h->d_ll_flag, h->d_src_log,
-                                   h->log_slots_cap * ll_npad(h) * WF_LOG_FLOATS, &ga, h->stream));
+                                   h->log_slots_cap * ll_npad(h), &ga, h->stream));
     if (h->ll_ties == 0) return WF_OK;
     ga.pred = h->d_ll_flag;
   }
@@ -339,9 +359,11 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
       WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * ll_npad(h) * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
       h->log_slots_cap = slots;
     }
+    WfGroupArgs gf = ga;
+    if (h->dir_slots > 0 && h->n_groups == 0) gf.perm = h->d_dir_perm;  // farms of like direction share a wave (run_geometry)
     WF_HIP(h, wfk_launch_step_ll_fly(ll_fly_G(h), ll_fly_S(h), &h->consts, h->d_tab, h->d_gidx, h->d_gx, h->d_gy, h->d_ws, h->d_wd, yaw,
                                      power, wspd, wdir, load, h->B, ea, h->d_farm_tie, h->d_src_log,
-                                     h->log_slots_cap * ll_npad(h) * WF_LOG_FLOATS, &ga, h->stream));
+                                     h->log_slots_cap * ll_npad(h), &gf, h->stream));
     if (h->farm_ties == 0) return WF_OK;
     ga.farm_pred = h->d_farm_tie;
   }
@@ -350,8 +372,9 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
   return WF_OK;
 }
 
-// The step as the ABI sees it: the float32 kernels, then — when asked for (wf_set_risk_resolve) or when the model needs
-// it (wind_veer != 0) — the float64 solve of the flagged (or all) farms on the same stream, overwriting their outputs.
+// The step as the ABI sees it: the float32 kernels, then — when asked for (wf_set_risk_resolve) — the float64 solve of
+// the flagged (or all) farms on the same stream, overwriting their outputs.  (wind_veer != 0 no longer forces it: the
+// VEER instantiations of the float32 kernels serve such models, with the same flags.)
 int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
   int rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
   if (rc != WF_OK) return rc;
@@ -429,7 +452,8 @@ int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c) {
   if (!h || !c) return WF_E_INVALID;
   if ((c->slot_G > 0) != (c->slot_S > 0) || (c->slot_G > 0 && find_variant(c->slot_G, c->slot_S) < 0))
     return fail(h, WF_E_INVALID, "no wf_step_kernel variant with these lanes per farm x slots per lane");
-  if (c->one_block < -1 || c->one_block > 1 || c->pair_table < -1 || c->pair_table > 1 || c->fly_one_block < -1 || c->fly_one_block > 1)
+  if (c->one_block < -1 || c->one_block > 1 || c->pair_table < -1 || c->pair_table > 1 || c->fly_one_block < -1 || c->fly_one_block > 1 ||
+      c->far_skip < -1 || c->far_skip > 1)
     return fail(h, WF_E_INVALID, "kernel choice switches must be -1 (automatic), 0 or 1");
   if (c->one_block == 1) {
     const int g = c->ll_G, sl = c->ll_S > 0 ? c->ll_S : 1;
@@ -438,6 +462,7 @@ int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c) {
   }
   WF_ON_DEVICE(h);
   WF_HIP(h, hipStreamSynchronize(h->stream));
+  if (c->far_skip != h->choice.far_skip) h->model_dirty = true;  // WfConsts::far_on / far_k follow the choice (build_consts)
   h->choice = *c;
   if (h->N > 0) {
     const int v = pick_variant(h, h->N, h->B);

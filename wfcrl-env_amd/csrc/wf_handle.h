@@ -39,7 +39,7 @@ extern "C" int wfk_ll_has_veer(int G, int S, int table);
 extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* gx,
                                              const double* gy, const double* ws, const double* wd, const float* yaw,
                                              float* power, float* o_ws, float* o_wd, float* load, int B, const WfEnvArgs* env,
-                                             const int* farm_tie, float* src_log, size_t log_side_offset,
+                                             const int* farm_tie, float* src_log, size_t log_records,
                                              const WfGroupArgs* grp, hipStream_t s);
 extern "C" hipError_t wfk_launch_step(int variant, const WfConsts* c, const WfTables* tab, const double* gx,
                                       const double* gy, const int* gidx, int geom_stride, const double* ws,
@@ -58,10 +58,13 @@ extern "C" hipError_t wfk_launch_pair_table_ll(const WfPairConsts* pc, int G, in
 extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
                                          const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
                                          float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
-                                         const int* cross_tie, float* src_log, size_t log_side_offset,
+                                         const int* cross_tie, float* src_log, size_t log_records,
                                          const WfGroupArgs* grp, hipStream_t s);
 extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, int veer, hipFuncAttributes* a);
 extern "C" hipError_t wfk_launch_fill(int n, double* a, hipStream_t s);  // a[1..n) = a[0]
+extern "C" hipError_t wfk_sort_tmp_bytes(int B, size_t* bytes);
+extern "C" hipError_t wfk_sort_by_direction(int B, int n_slots, const double* wd, float* keys, int* vals, void* tmp, size_t tmp_bytes,
+                                            int* perm, hipStream_t s);
 extern "C" hipError_t wfk_launch_wind_sample_binned(int B, unsigned long long seed, const double* dist, double step, double* ws,
                                                     double* wd, int* bin, hipStream_t s);
 extern "C" hipError_t wfk_launch_bin_centres(int K, double step, double* wd, hipStream_t s);
@@ -141,17 +144,26 @@ struct wf_handle {
   int ll_G = 0, ll_S = 1;      // lanes per farm and target slots per lane of that kernel; ll_G = 0: not used
   float* d_ll_tab = nullptr;   // [groups][wfk_ll_table_floats]
   int* d_ll_flag = nullptr;    // [groups] 1 = cross-block tie
-  float* d_src_log = nullptr;  // [launch slots][N][WF_LOG_FLOATS], then [launch slots][N][WF_LOG_SIDE_FLOATS]
+  float* d_src_log = nullptr;  // R = launch slots x padded N records: [R][2] hot, [R][12] cold, [R][4] side (wf_device.h)
   size_t ll_groups_cap = 0, log_slots_cap = 0;
   int* d_farm_tie = nullptr;   // [B] + 1: per-farm cross-block-tie flag of the per-farm geometry, then the "any" flag
+  // a wind per farm: launch slots of the on-the-fly one-block kernel in ascending wind direction (wf_sort.hip), so that the
+  // farms of a wave nearly share their geometry and the kernel's wave-uniform skips take
+  int* d_dir_perm = nullptr;   // [dir_slots] farm per launch slot, -1 = padding
+  float* d_sort_keys = nullptr;  // [2 B]
+  int* d_sort_vals = nullptr;    // [B]
+  void* d_sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0, dir_perm_cap = 0;
+  int dir_slots = 0;           // 0 = no direction order (identity)
   int farm_ties = 2;           // a wind per farm: 0 no farm has such a tie, 1 some have, 2 not read back
   bool wind_sync = true;       // the wind was set by a call that synchronises anyway (host arrays, series, binned sampling)
   int ll_ties = 2;             // cross-block ties of the current directions: 0 none, 1 all of them, 2 some / not read back
   // which kernels may serve this handle (wf_set_kernel_choice; the WF_* environment variables only seed it at wf_create)
-  wf_kernel_choice choice{0, 0, -1, 0, 0, -1, -1};
+  wf_kernel_choice choice{0, 0, -1, 0, 0, -1, -1, -1};
   int n_cu = 256;              // compute units of the handle's device (hipDeviceProp_t::multiProcessorCount)
   // float64 re-solve of the farms the float32 kernels flag (wf_resolve.hip)
-  int resolve_mode = 0;        // 0 off, 1 flagged farms, 2 every farm (forced when the model has wind_veer != 0)
+  int resolve_mode = 0;        // 0 off, 1 flagged farms, 2 every farm (wf_set_risk_resolve; wind_veer models are served by
+                               // the VEER float32 instantiations and take the same modes — nothing forces mode 2)
   WfResolveConsts rconsts{};
   double* d_tab64 = nullptr;   // [3][WF_TABLE_PAD] wind speed, Ct, power in float64
   int *d_res_list = nullptr, *d_res_count = nullptr, *d_flags_raw = nullptr;  // [B], [1], [B]

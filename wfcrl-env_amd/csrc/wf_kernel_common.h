@@ -68,7 +68,11 @@ __device__ __forceinline__ float table_ct(const WfConsts& c, const TableLds& T, 
   int j = table_segment(c, T, v);
   float r = fmaf(T.cts[j], v - T.knot[j], T.ct[j]);
   const bool inside = v >= T.knot[0] && v <= T.knot[c.n_table - 1] && r > 0.0001f && r < 0.9999f;
-  steep = inside && fabsf(T.cts[j]) * v > c.ct_kappa;
+  // ... or the thrust coefficient is within 0.005 of 1 (a user table; nrel_5MW peaks at 0.99): the wake amplitude
+  // Ct / (1 + sqrt(1 - Ct)) then loses 1e-5 to the cancellation in 1 - Ct, and behind such a turbine the velocity
+  // u = Uinit (1 - deficit) is a tenth or less of the deficit — the error reaches 1e-4 of u (layout fuzzer, round 4:
+  // a table clipped at 0.9999 over 3-11 m/s)
+  steep = (inside && fabsf(T.cts[j]) * v > c.ct_kappa) || (v >= T.knot[0] && v <= T.knot[c.n_table - 1] && r > 0.995f);
   r = (v < T.knot[0]) ? 0.0001f : r;
   r = (v > T.knot[c.n_table - 1]) ? 0.9999f : r;
   return fminf(fmaxf(r, 0.0001f), 0.9999f);

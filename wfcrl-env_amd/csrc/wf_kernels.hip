@@ -31,17 +31,15 @@
 //          global_load_lds_dwordx4 (LDS-DMA) one source ahead, one __syncthreads() per source;
 //     WPB  waves per block.
 //   * optional fused env step (WfEnvArgs): actuation-budget gate, clipped yaw transition and reward in the launch.
-// Diagnostic-only preprocessor hooks (never defined in the product build): WF_ABLATE (skip a pass body, keeping its
-// inputs alive — the ablation timings of profiles/), WF_DIAG_NOBARRIER / WF_DIAG_NODMA (staging experiments).
+// (The ablation / staging-experiment hooks of rounds 1-3 — WF_ABLATE, WF_DIAG_* — are gone from the source; their
+// measurements are in DESIGN_HISTORY.md, the builds in the commits named there.)
 #include <hip/hip_runtime.h>
 
 #include <cstring>
 
 #include "wf_device.h"
 
-#ifndef WF_TAB_WAVES
-#define WF_TAB_WAVES 4
-#endif
+#define WF_TAB_WAVES 4  // waves per block on the pair-table path (two-wave blocks: +8 %, twice the row staging per farm; eight: slower)
 // The library is built from this file twice (csrc/Makefile): WF_KSET=1 carries the step-kernel variants with one, two,
 // four or five target slots per lane — they have registers to spare at their occupancy — compiled with LLVM's
 // iterative-ilp scheduling strategy (-3 % on HornsRev1/65536, -2 % on the B = 1 latency), plus the small kernels
@@ -580,9 +578,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
     for (int li = 0; li < nsrc; ++li) {
       const int src = gbase + li;
       const int i = blk * G + li;
-#if !defined(WF_DIAG_NODMA)
       if (TAB && i + 1 < N) stage_row(i + 1);  // lands in the other buffer while this source is processed
-#endif
       // ---- A. the source's state (slot 0 of lane `li` of the group) ------------------------
       float vsum = 0.0f;
 #pragma unroll
@@ -628,12 +624,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           if constexpr (!TAB) dx = (float)(L.x[eiw][t] - x_i);
           act = t < N;
         }
-#if defined(WF_ABLATE) && (WF_ABLATE & 1)
-        if (act) { st.V[p][0] += Gt * dx; st.W[p][0] += Gb + Gwr; }
-        if (false) {
-#else
         if (act) {
-#endif
          if constexpr (TAB) {
           apply_tab(p, reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]), Gy, Gwt);
          } else {
@@ -757,12 +748,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         // slots p >= 1: all real turbines have dx >= 0 (see pass 1), and at 0 <= dx <= 0.1 (ties) everything below is
         // an exact no-op: amp_on = 0 zeroes the deficits and the TI candidate is the ambient value
         const bool act = (p == 0) ? (dx > 0.0f) : (t < N);
-#if defined(WF_ABLATE) && (WF_ABLATE & 2)
-        if (act) { st.esq[p][0] += sc.sy0v * k0.x0v * k0.kyv * k0.pj * ch_pref * dx * 1e-9f; st.TI[p][0] += (uni ? 1e-9f : 2e-9f) * k0.d0 * sc.snw * sc.kdef; }
-        if (false) {
-#else
         if (act) {
-#endif
           float dy;
           if constexpr (TAB) dy = ex.y;
           else dy = (float)(L.yd[eiw][t] - yd_i);
@@ -870,9 +856,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           }
         }
       }
-#if !defined(WF_DIAG_NOBARRIER)
       if constexpr (TAB) __syncthreads();  // next row has landed; everyone is done with the current one
-#endif
     }  // li
 
     // ---- x' ties across the block boundary ------------------------------------------------------

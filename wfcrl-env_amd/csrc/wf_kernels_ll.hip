@@ -63,20 +63,51 @@ __device__ __forceinline__ void sincos_yaw(float x, float& s, float& c) {
   }
 }
 
-// What a source leaves behind for the target blocks after its own: WF_LOG_FLOATS floats (four float4, one 64-byte
-// record: two per 128-byte line, and a block's G records are whole lines, so no line is shared between a block that is
-// still being written and one that is being read).  Whatever follows from these by one or two instructions (1.6 +- sM,
-// 1 / (sy0d sz0d), tan_th0 x0d) is re-derived by the reader; all sixteen floats are read by it — a dead component of
-// a record load that is still in flight gets reused as a scratch register, which makes the compiler wait for the load
-// (the prefetch of the next record) on the spot.  The sign of ch_pref (> 0 by construction)
-// carries the split-TI flag; the three column TIs and dTI such a source needs live in a side array (WfLogSide).
+// max over the wave of a value that the G lanes of a farm hold alike (G a power of two), wave-uniform: v_max_f32 with DPP
+// operands — quad swaps, half-row and row mirrors, then the row broadcasts that leave the total in lane 63 — six
+// instructions and no LDS traffic (a __shfl_xor butterfly is five ds_bpermute with their address arithmetic)
+template <int G>
+__device__ __forceinline__ float wave_max(float v) {
+  auto dpp = [](float x, auto ctrl, auto rows) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xf, false));
+  };
+  using I = std::integral_constant<int, 0>;
+  (void)sizeof(I);
+  if constexpr (G < 2) v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{}));   // quad_perm [1,0,3,2]
+  if constexpr (G < 4) v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{}));   // quad_perm [2,3,0,1]
+  if constexpr (G < 8) v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{}));  // row_half_mirror
+  if constexpr (G < 16) v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{})); // row_mirror
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}));                       // row_bcast:15 into rows 1, 3
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}));                       // row_bcast:31 into rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// What a source leaves behind for the target blocks after its own, in registers (SrcLog) and in the per-wave source log:
+//   HOT  (8 bytes per farm):   {Gy / Gwt, Gwt} — the two circulations, all the transverse pass needs; read by EVERY later block;
+//   COLD (48 bytes per farm):  three float4 {sy0d, sz0d, sM, tan_th0} {sy0v, x0d, kyd, pj} {x0v, kyv, +-ch_pref, 1 / x0v} —
+//        what the deflection / deficit / turbulence pass needs; read only by the later blocks the source's wake can reach
+//        (the far-source test below).  Whatever follows from these by one or two instructions (1.6 +- sM, 1 / (sy0d sz0d),
+//        tan_th0 x0d, the near-wake sigma 0.501 D sqrt(ct / 2), the amplitude factor ct cos(yaw) D^2 / 8) is re-derived by
+//        the reader; every stored float is read by it — a dead component of a load that is still in flight gets reused as
+//        a scratch register, which makes the compiler wait for the load (the prefetch of the next record) on the spot.
+//        The sign of ch_pref (> 0 by construction) carries the split-TI flag; the three column TIs and dTI such a source
+//        needs live in a side array (WfLogSide).
+// Both parts are wave-major — [wave][source i][farm of the wave] float2, [wave][source i][q = 0..2][farm] float4 — so that
+// a lane's load of its farm's piece is part of one contiguous 64 / G x 8 or x 16 byte run per wave-instruction (the lanes
+// of a farm ask for the same address).  A block's G S records are whole 128-byte lines in either part (S x 512 and
+// S x 3072 bytes), so no line is shared between a block that is still being written and one that is being read.
+//   BOUND (wave-private LDS, 16 bytes per source): {k6, b6, n6} with, over the farms of the wave,
+//        6.12 sigma_y(dx) + D/4 + |deflection| - |ad + bd dx|  <=  max(k6 dx + b6, n6)   for every dx >= 0
+//        — see far_bound() —: a later block whose targets ALL sit further than that from the source's centre line skips the
+//        source's cold record and its whole deflection / deficit / turbulence pass.
 struct SrcLog {
   float Gy, Gwt, sy0d, sz0d;        // circulations of the transverse pass (table path), deflection sigma_0
   float sM, tan_th0, sy0v, snw;     // sqrt(ct), deflection angle; deficit sigma_y0, near-wake sigma
   float kdef, x0d, kyd, pj;         // deficit amplitude factor; column 0: deflection near-wake length, expansion rate, log prefactor
   float x0v, kyv, ch_pref, ix0v;    // column 0: deficit near-wake length, expansion rate; +-Crespo-Hernandez prefactor; 1 / x0v
 };
-static_assert(sizeof(SrcLog) == WF_LOG_FLOATS * 4, "source log record");
+struct ColdRec { float4 a, b, c; };  // the cold part as stored: {sy0d, sz0d, sM, tan_th0} {sy0v, x0d, kyd, pj} {x0v, kyv, ch_pref, ix0v}
+static_assert(WF_LOG_HOT_FLOATS == 2 && WF_LOG_COLD_FLOATS == 12, "source log record");
 struct WfLogSide { float TI0, TI1, TI2, dTI; };  // the source's column TIs before mixing, the yaw-added-recovery increment
 
 }  // namespace
@@ -136,33 +167,17 @@ __device__ unsigned long long wf_ll_stamp[16];
 #endif
 // VEER: wind_veer != 0 [FLORIS gauss.py rCalt]: the rotated Gaussian is not even in z - HH — 9 instead of 6 SOSFS sums per slot,
 // one exponential per grid row (wf_kernel_common.h: column_deficit_veer); instantiated for the throughput families only.
+// Waves per SIMD the register allocator is asked to make room for: three with one slot (first version of the kernel,
+// G = 8: 2 -> 1.87 ms, 3 -> 1.60 ms, 4 -> 2.9 ms with 168 B of spills; G = 4: 3 -> 1.24 ms, 4 -> 1.35 ms with 96 B of
+// scratch; HornsRev1 x 65536), two with two slots (54 state registers).
 template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB, bool VEER = false>
-#ifndef WF_LL_PINGPONG
-#define WF_LL_PINGPONG 0  // 1: two record buffers used alternately (2x unrolled replay): 20-30 spilled registers, slower
-#endif
-#ifndef WF_LL_FAR_SKIP
-#define WF_LL_FAR_SKIP 1  // pass 2 returns early for pairs whose lateral offset is beyond 6.12 sigma_y of the wake (below)
-#endif
-#ifndef WF_LL_LOGT
-#define WF_LL_LOGT 1  // 1: wave-major source log [source][float4 q][farm of the wave] — a record of the wave is one contiguous
-                      // piece (2 KiB at G = 2), fetched by one or two fully coalesced loads per lane and handed to the farms'
-                      // lanes through a wave-private LDS slab; 0: farm-major log [farm][source][16 floats] (round 2: four
-                      // 16-byte gathers per record over 64 / G lines 5 KB apart)
-#endif
-#ifndef WF_LL_OCC2
-#define WF_LL_OCC2 2  // ... for the two-slot variants
-#endif
-#ifndef WF_LL_OCC
-#define WF_LL_OCC 3  // waves per SIMD the register allocator is asked to make room for (first version of the kernel, G = 8:
-                     // 2 -> 1.87 ms, 3 -> 1.60 ms, 4 -> 2.9 ms with 168 B of spills; final version, G = 4: 3 -> 1.24 ms,
-                     // 4 -> 1.35 ms with 96 B of scratch; HornsRev1 x 65536)
-#endif
-__global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / WPB) void wf_step_ll_kernel(
+__global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_ll_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const int* __restrict__ gidx, const double* __restrict__ ws_in,
     const double* __restrict__ wd_in, int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power,
     float* __restrict__ o_ws, float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea,
     const float* __restrict__ ll_tab, size_t group_floats, const int* __restrict__ cross_tie, float* __restrict__ src_log,
-    size_t log_side_offset, int n_pad, const WfGroupArgs ga, const double* __restrict__ gx, const double* __restrict__ gy) {
+    size_t log_cold_offset, size_t log_side_offset, int n_pad, const WfGroupArgs ga, const double* __restrict__ gx,
+    const double* __restrict__ gy) {
   constexpr int EPW = 64 / G;   // farms per wave
   constexpr int GS = G * S;     // turbines per block
   constexpr int CH = 64 / GS;   // sources per staged chunk (64 records)
@@ -170,12 +185,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
   __shared__ TableLds T;
   __shared__ __attribute__((aligned(16))) float prow[2][CHUNK_FLOATS];
   __shared__ unsigned risk_lds[WPB][EPW];
-  extern __shared__ float yaw_lds[];  // [WPB][EPW][n_pad] commanded yaw in sorted order, degrees
-#if WF_LL_LOGT
-  constexpr int PIECES = 4 * EPW;              // 16-byte pieces of a wave's record: piece q * EPW + f = float4 q of farm f
-  constexpr int PPL = (PIECES + 63) / 64;      // pieces a lane fetches: 2 at G = 2, else 1
-  __shared__ float4 recslab[WPB][PIECES];      // the current record of each wave, transposed through LDS
-#endif
+  extern __shared__ __attribute__((aligned(16))) float yaw_lds[];  // [WPB][EPW][n_pad] commanded yaw in sorted order, degrees; then [WPB][n_pad] float4 far bounds
 
   int grp = 0;
   if (ga.blk_group) {
@@ -316,6 +326,22 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     }
   };
 
+  // The same for a LOGGED source, whose hot record holds {rho = Gy / Gwt, Gwt}:  max(Gy aW + Gwt bW, 0) = Gwt max(rho aW + bW, 0)
+  // for Gwt > 0 — the wake-rotation circulation gam_wr (a - a^2) ubar is positive — and Gwt min(rho aW + bW, 0) for Gwt < 0
+  // (a rotor wind speed driven negative by an unphysically tight layout: the reference keeps computing, so does this):
+  // both are  Gwt med3(rho aW + bW, 0, copysign(inf, Gwt)).  Five instead of six instructions per grid point — two FMAs for
+  // V, FMA + med3 + FMA for W.  (Transverse velocities switched off: Gwt = 0 and rho = 0 in the record: nothing is added.)
+  auto apply_tab_ratio = [&](auto PP, const float4* pr, float rho, float Gwt) {
+    constexpr int p = decltype(PP)::value;
+    const float lim = copysignf(__builtin_inff(), Gwt);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const float4 cf = pr[q];
+      V[p][q] = fmaf(Gwt, fmaf(rho, cf.x, cf.y), V[p][q]);
+      W[p][q] = fmaf(Gwt, __builtin_amdgcn_fmed3f(fmaf(rho, cf.z, cf.w), 0.0f, lim), W[p][q]);  // W[W<0] = 0, quirk (5)
+    }
+  };
+
   // the same on the fly (a wind per farm): wf_step_kernel's apply_fly — 7 + 7 distinct vortex offsets per grid column,
   // circulations Gt = gam_top Gy, Gb = -gam_bot Gy (the tip vortices share their farm-dependent factor)
   auto apply_fly = [&](auto PP, float dx, float dy, float Gy, float Gwt) {
@@ -429,33 +455,20 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       const float up = dx * ix0v;
       const float xf = dx - R.x0v;
       const float sy = far ? fmaf(R.kyv, xf, sc.sy0v) : fmaf(up, sc.sy0v - sc.snw, sc.snw);
-#if WF_LL_FAR_SKIP
-      // (first against a bound of the deflection, before its sqrt / rcp / log2: |delta| <= |d0| + |pj| log2(lnA / lnB) +
-      // |lin| — the log term rises from 0 towards log2((1.6 + sM) / (1.6 - sM)) <= 2.12 for sM <= 1 — then, below,
-      // against the deflection itself)
-      // (G = 2 only: with two targets per pass the bound test returns often enough to pay — 1.02 -> 0.99 ms at HornsRev1 x
-      // 65536; with four it cost cfg5's G = 4 kernel 3 %)
-      if constexpr (TAB && G == 2) {
-        const float dmax = fabsf(d0) + fmaf(2.2f, fabsf(R.pj), fabsf(lin));
-        if (!__any(fabsf(dy) < fmaf(6.12f, sy, c.off[2] + dmax))) return;
-      }
-#endif
       const float xs = fmaxf(dx - R.x0d, 0.0f);
       const float syd = fmaf(R.kyd, xs, sc.sy0d), szd = fmaf(R.kyd, xs, sc.sz0d);
       const float s = fsqrt(syd * szd * sc.inv_s0d);
       const float arg = sc.lnA * fmaf(1.6f, s, -sc.sM) * frcp(sc.lnB * fmaf(1.6f, s, sc.sM));
       const float d_far = fmaf(R.pj, flog2(arg), d0);
       const float delta = ((dx > R.x0d) ? d_far : dx * sc.tan_th0) + lin;
-#if WF_LL_FAR_SKIP
-      // More than 6.12 sigma_y + D/4 off the wake's centre line, the nearest grid column gets exp2(-27) = 7.5e-9 of the
-      // amplitude: below the resolution of 1 - sqrt(esq) in float32 and far below the overlap threshold, so the deficit,
-      // the SOSFS update and the wake-added TI of this pair are all no-ops.  Wave-uniform: on the table path the farms of
-      // a wave share the geometry, and most pairs of a wide farm are this far apart.
-      // (on the fly every farm of the wave has its own geometry: the test would rarely be uniform, and costs 3 %)
-      if constexpr (TAB) {
-        if (!__any(fabsf(dy - delta) < fmaf(6.12f, sy, c.off[2]))) return;
-      }
-#endif
+      // Far-pair skip.  More than 6.12 sigma_y + D/4 off the wake's centre line, the nearest grid column gets exp2(-27) =
+      // 7.5e-9 of the amplitude: below the resolution of 1 - sqrt(esq) in float32 and far below the overlap threshold, so
+      // the deficit, the SOSFS update and the wake-added TI of this pair are all no-ops (the TI candidate is the ambient
+      // value the running maximum starts from; the clamped overlap terms are exactly 0: no flag).  Wave-uniform: on the
+      // table path the farms of a wave share the geometry; on the fly they do once wf_set_wind has put farms of like
+      // direction into one wave.  c.far_k = 6.12 (1e30 with the skip disabled: wf_kernel_choice::far_skip = 0 — never taken).
+      // Sources whose wake cannot reach ANY target of the block never get here: far_bound() / the replay loop.
+      if (!__any(fabsf(dy - delta) < fmaf(c.far_k, sy, c.off[2]))) return;
       const float sz = far ? fmaf(R.kyv, xf, c.sz0v) : fmaf(up, c.sz0v - sc.snw, sc.snw);
       const float isy = frcp(sy), isz = frcp(sz);
       const float xarg = sc.kdef * isy * isz;
@@ -572,23 +585,42 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
 
   float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
 #ifdef WF_LL_STAMP
-  unsigned long long st_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   WF_T(st_begin);
 #endif
   int q = 0;                        // running chunk index (LDS buffer q & 1)
   // Cache-line discipline of the log (the vector L1 is not updated by this CU's own stores): a farm's records start on
   // a 128-byte line (n_pad is a multiple of G, G is even), so a line belongs to ONE block and is never read before that
   // block has written it.  The 16-byte side records do share lines across blocks; they are read past the L1.
-#if !WF_LL_LOGT
-  float* const logf = src_log + (size_t)slot * n_pad * WF_LOG_FLOATS;
-#else
-  // the wave's part of the log (its EPW farm slots x n_pad records x 64 bytes, as before), record i at i * EPW * 64 bytes
-  float* const logw = src_log + (size_t)(slot - eiw) * n_pad * WF_LOG_FLOATS;
-  constexpr int RECF = EPW * WF_LOG_FLOATS;
-  int piece[PPL];
-#pragma unroll
-  for (int kk = 0; kk < PPL; ++kk) piece[kk] = (lane + 64 * kk) % PIECES;  // (fewer pieces than lanes at G >= 8: fetched twice)
-#endif
+  // the wave's parts of the log: record i of the hot part at i * EPW float2, of the cold part at i * 3 EPW float4
+  const size_t wave_rec0 = (size_t)(slot - eiw) * n_pad;  // (records before this wave's, per farm slot)
+  // hot part: the records of sources 2m and 2m + 1 are the two halves of ONE float4 per farm — [wave][m][farm] float4 —, so
+  // that the transverse pass of the table path fetches two sources with one load (a block's sources are whole pairs: G S
+  // is even, and so is every chunk's count of logged sources)
+  float2* const log_hot = reinterpret_cast<float2*>(src_log + wave_rec0 * WF_LOG_HOT_FLOATS);
+  float4* const log_cold = reinterpret_cast<float4*>(src_log + log_cold_offset + wave_rec0 * WF_LOG_COLD_FLOATS) + eiw;
+  float4* const bndL = reinterpret_cast<float4*>(yaw_lds + (size_t)WPB * EPW * n_pad) + (size_t)wave * n_pad;  // far bounds
+  auto hot_index = [&](int i) { return 2 * ((size_t)(i >> 1) * EPW + eiw) + (i & 1); };
+  auto load_hot = [&](int i) { return log_hot[hot_index(i)]; };
+  auto load_hot2 = [&](int i) { return reinterpret_cast<const float4*>(log_hot)[(size_t)(i >> 1) * EPW + eiw]; };  // i even: sources i, i + 1
+  auto load_cold = [&](int i) {
+    const float4* lp = log_cold + (size_t)i * (3 * EPW);
+    ColdRec r;
+    r.a = lp[0]; r.b = lp[EPW]; r.c = lp[2 * EPW];
+    return r;
+  };
+  // the in-register record of a replayed source from its two parts (pass2 does not read Gy / Gwt)
+  const float snw_f = c.near_c * 0.70710678118f;
+  auto unpack = [&](const float2 h, const ColdRec& r) {
+    SrcLog R;
+    R.Gy = h.x * h.y; R.Gwt = h.y;  // (hot record: {Gy / Gwt, Gwt})
+    R.sy0d = r.a.x; R.sz0d = r.a.y; R.sM = r.a.z; R.tan_th0 = r.a.w;
+    R.sy0v = r.b.x; R.x0d = r.b.y; R.kyd = r.b.z; R.pj = r.b.w;
+    R.x0v = r.c.x; R.kyv = r.c.y; R.ch_pref = r.c.z; R.ix0v = r.c.w;
+    R.snw = snw_f * R.sM;                               // 0.501 D sqrt(ct / 2)
+    R.kdef = (R.sM * R.sM) * (R.sy0v * c.kdef_sy0v);   // ct cos(yaw) D^2 / 8, cos(yaw) = sy0v / (sz0v [cos veer])
+    return R;
+  };
   float* const logx = src_log + log_side_offset + (size_t)slot * n_pad * WF_LOG_SIDE_FLOATS;
   for (int J = 0; J < nblk; ++J) {
     int tt[S];
@@ -617,25 +649,15 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     const int n_src = min(N, first_own + GS);
     const int n_chunks = (n_src + CH - 1) / CH;
     // the first logged source's record is fetched ahead; every later one while its predecessor is being applied
-#if WF_LL_LOGT
-    struct RecPieces { float4 v[PPL]; };
-    RecPieces nxt;
-#else
-    SrcLog nxt;
-#endif
+    float2 hot_nx = make_float2(0.0f, 0.0f);   // on the fly: the hot record of the next source
+    float4 hot2_nx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // table path: the hot records of the next PAIR of sources
+    ColdRec cold_nx = {};             // (on the fly; the table path fetches cold records per chunk, for the near sources only)
     double xs_nx = 0.0, ys_nx = 0.0;  // on the fly: the sorted coordinates of that source come with its record
     if (first_own > 0) {
-#if WF_LL_LOGT
-      const float4* lp = reinterpret_cast<const float4*>(logw);
-#pragma unroll
-      for (int k = 0; k < PPL; ++k) nxt.v[k] = lp[piece[k]];
-#else
-      const float4* lp = reinterpret_cast<const float4*>(logf);
-      float4* d = reinterpret_cast<float4*>(&nxt);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) d[k] = lp[k];
-#endif
+      if constexpr (TAB) hot2_nx = load_hot2(0);
       if constexpr (!TAB) {
+        hot_nx = load_hot(0);
+        cold_nx = load_cold(0);
         xs_nx = gx[gofs];
         ys_nx = gy[gofs];
       }
@@ -785,18 +807,41 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       Sc.ch_pref = split ? -Sc.ch_pref : Sc.ch_pref;  // the flag travels in the sign
       Sc.ix0v = frcp(Sc.x0v);
       // the later blocks replay this source from the log
-      if (J + 1 < nblk && sub == 0) {
-        const float4* sp = reinterpret_cast<const float4*>(&Sc);
-#if WF_LL_LOGT
-        float4* lp = reinterpret_cast<float4*>(logw + (size_t)i * RECF);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) lp[kk * EPW + eiw] = sp[kk];  // EPW * 16 contiguous bytes per store instruction
-#else
-        float4* lp = reinterpret_cast<float4*>(logf + (size_t)i * WF_LOG_FLOATS);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) lp[kk] = sp[kk];
-#endif
-        if (split) *reinterpret_cast<float4*>(logx + (size_t)i * WF_LOG_SIDE_FLOATS) = make_float4(X.TI0, X.TI1, X.TI2, X.dTI);
+      if (J + 1 < nblk) {
+        if (sub == 0) {
+          // (Gwt == 0: transverse velocities switched off, Gy is 0 as well)
+          log_hot[hot_index(i)] = make_float2(Sc.Gwt != 0.0f ? Sc.Gy * frcp(Sc.Gwt) : 0.0f, Sc.Gwt);
+          float4* lp = log_cold + (size_t)i * (3 * EPW);           // EPW * 16 each
+          lp[0] = make_float4(Sc.sy0d, Sc.sz0d, Sc.sM, Sc.tan_th0);
+          lp[EPW] = make_float4(Sc.sy0v, Sc.x0d, Sc.kyd, Sc.pj);
+          lp[2 * EPW] = make_float4(Sc.x0v, Sc.kyv, Sc.ch_pref, Sc.ix0v);
+          if (split) *reinterpret_cast<float4*>(logx + (size_t)i * WF_LOG_SIDE_FLOATS) = make_float4(X.TI0, X.TI1, X.TI2, X.dTI);
+        }
+        // Far bound of this source over the farms of the wave (far_bound): for every dx >= 0 and every farm
+        //   sigma_y(dx) <= max(kyv dx + (sy0v - kyv x0v), max(snw, sy0v))   [far wake: equality; near wake: sigma_y lies
+        //                                                                    between snw and sy0v]
+        //   |deflection - (ad + bd dx)| <= |tan_th0 x0d| + 2.2 |pj|         [near wake: |dx tan_th0| <= |tan_th0| x0d; far
+        //        wake: d0 + pj log2(arg) with arg rising from 1 at sigma = sigma_0 to (1.6 + sM) / (1.6 - sM), whose log2
+        //        is <= 2.115 for sM = sqrt(ct) <= 1 — ct is clipped to 0.9999 — and the wake only widens: kyd >= 0]
+        // hold; with per-column constants (split TI) the growth rate is taken at the largest column TI, the near-wake
+        // length and the log prefactor at the smallest (both fall with TI), and the near-wake credit is dropped.
+        float kyv_m = Sc.kyv, bb = fmaf(-Sc.kyv, Sc.x0v, Sc.sy0v);
+        float db = fabsf(Sc.tan_th0 * Sc.x0d) + 2.2f * fabsf(Sc.pj);
+        if (__any(split)) {
+          const float TImax = fmaxf(TIs[0], fmaxf(TIs[1], TIs[2])), TImin = fminf(TIs[0], fminf(TIs[1], TIs[2]));
+          const float x0d_m = x0num_d * frcp(fmaf(c.alpha4_d, TImin, b2om_d));
+          const float pj_m = pfac * frcp(fmaf(c.ka_d, TImin, c.kb_d));
+          kyv_m = fmaf(c.ka, TImax + X.dTI, c.kb);
+          bb = split ? Sc.sy0v : bb;
+          db = fabsf(Sc.tan_th0 * x0d_m) + 2.2f * fabsf(pj_m);
+        }
+        const float dbo = db + c.off[2];
+        float k6 = c.far_k * kyv_m, b6 = fmaf(c.far_k, bb, dbo), n6 = fmaf(c.far_k, fmaxf(Sc.snw, Sc.sy0v), dbo);
+        k6 = wave_max<G>(k6);
+        b6 = wave_max<G>(b6);
+        n6 = wave_max<G>(n6);
+        if (!c.far_on || VEER) { k6 = 0.0f; b6 = 0.0f; n6 = 3.0e38f; }  // never far (the rotated Gaussian of a veer model is not bounded this way)
+        if (lane == 0) bndL[i] = make_float4(k6, b6, n6, 0.0f);
       }
       WF_T(so_4);
       WF_ACC(9, so_3, so_4);
@@ -821,114 +866,117 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
       const int k_log = min(max(first_own - i0, 0), CH);  // records [0, k_log) of the chunk belong to earlier blocks
       const int k_end = min(n_src - i0, CH);
       // ---- sources of earlier blocks: replayed from the log on this block's targets ----------------------
-      // (a loop of its own: the two kinds of source step share no loop-carried copies)
+      // Every logged source applies its transverse velocities (hot record: two circulations); its deflection / deficit /
+      // turbulence pass and the cold record that needs are skipped when NO target of the block, in any farm of the wave, is
+      // within the source's far bound (bndL, written with the record: own_source).  The two passes touch disjoint state
+      // (V, W / deficit sums, TI) and each keeps its own order of sources, so they run as two loops per chunk: the results
+      // are bit for bit those of one loop.
       WF_T(st_a);
-#if WF_LL_LOGT
-      auto replay_one = [&](int k, const RecPieces& cur, RecPieces& nxt) {
-#else
-      auto replay_one = [&](int k, const SrcLog& Sl, SrcLog& nxt) {
-#endif
-        const int i = i0 + k;
-        auto prefetch_next = [&]() {
-          // unconditional (the last logged source re-reads its own record): a conditional load leaves "nxt keeps its
-          // value" on the other path, which costs sixteen register copies per iteration
-#if WF_LL_LOGT
-          const float4* lp = reinterpret_cast<const float4*>(logw + (size_t)min(i + 1, first_own - 1) * RECF);
-#pragma unroll
-          for (int kk = 0; kk < PPL; ++kk) nxt.v[kk] = lp[piece[kk]];
-#else
-          const float4* lp = reinterpret_cast<const float4*>(logf + (size_t)min(i + 1, first_own - 1) * WF_LOG_FLOATS);
-          float4* d = reinterpret_cast<float4*>(&nxt);
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) d[kk] = lp[kk];
-#endif
-          if constexpr (!TAB) {
-            xs_nx = gx[gofs + min(i + 1, first_own - 1)];
-            ys_nx = gy[gofs + min(i + 1, first_own - 1)];
-          }
-        };
-        const double xs_cur = xs_nx, ys_cur = ys_nx;
-#if WF_LL_LOGT
-        // the record fetched during the previous iteration: through the wave's LDS slab to the lanes of its farms
-        // (LDS operations of a wave execute in order: the slab is free again once these reads have returned)
-        SrcLog Sl;
-        auto slab_exchange = [&]() {
-#pragma unroll
-          for (int kk = 0; kk < PPL; ++kk) recslab[wave][piece[kk]] = cur.v[kk];
-          float4* d = reinterpret_cast<float4*>(&Sl);
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) d[kk] = recslab[wave][kk * EPW + eiw];
-        };
-        if constexpr (!TAB) slab_exchange();
-#endif
-        if constexpr (!TAB) prefetch_next();
-        const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
-        // no lane mask on the transverse pass: every real turbine of this block is at or downstream of an earlier
-        // block's source (dx >= 0), and the lanes beyond N (last block only) carry all-zero records
-        double xs_d = 0.0, ys_d = 0.0;
-        if constexpr (!TAB) {
-          xs_d = xs_cur;
-          ys_d = ys_cur;
-        }
-        if constexpr (TAB) {
-          // deflection / deficit / TI of every slot first, on the {dx, dy, tipow, decision bits} float4 of the pair records
-          // alone; the 9 coefficient float4 per slot are read behind a compiler barrier, right before the transverse
-          // pass uses them — read at the top of the iteration (where the compiler hoists them by itself) they stay
-          // live across both pass2 bodies, 36 registers per slot, and all of them are waited for before the first one
-          float4 exs[S];
-#pragma unroll
-          for (int p = 0; p < S; ++p)
-            exs[p] = *reinterpret_cast<const float4*>(buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE + WF_PAIR_DX);
-          // the next record's loads are issued BEHIND the first LDS reads of the iteration: the compiler guards the first
-          // read of the staged chunk with s_waitcnt vmcnt(0) (the chunk arrives by LDS-DMA, counted in vmcnt), and a
-          // prefetch issued before that read would be waited for on the spot
-          asm volatile("" ::: "memory");
-#if WF_LL_LOGT
-          slab_exchange();
-#endif
-          prefetch_next();
-          static_for<S>([&](auto PP) { pass2(PP, Sl, side, true, exs[decltype(PP)::value], tvalid[decltype(PP)::value]); });
-          asm volatile("" ::: "memory");
-          static_for<S>([&](auto PP) {
-            apply_tab(PP, reinterpret_cast<const float4*>(buf + (k * GS + decltype(PP)::value * G + sub) * WF_PAIR_STRIDE), Sl.Gy, Sl.Gwt);
-          });
-          return;
-        }
-        auto replay_slot = [&](auto PP) {
-          constexpr int p = decltype(PP)::value;
-          if constexpr (TAB) {
-          } else {
-            const float4 exr = fly_record(PP, xs_d, ys_d);
-            if (tvalid[p]) apply_fly(PP, exr.x, exr.y, Sl.Gy, Sl.Gwt);
-            pass2(PP, Sl, side, true, exr, tvalid[p], yt_d[TAB ? 0 : p], ys_d);
-          }
-        };
-        static_for<S>(replay_slot);
+      auto within_bound = [&](const float4 bnd, float dx, float dy) {  // lin = ad + bd dx: the model's linear deflection offset
+        return fabsf(dy) < fmaxf(fmaf(bnd.x, dx, bnd.y), bnd.z) + fabsf(fmaf(c.bd, dx, c.ad));
       };
-#if WF_LL_PINGPONG && !WF_LL_LOGT
-      // two record buffers used alternately: no copy of the prefetched record into the current one per iteration
-      {
-        SrcLog nxt2;
-        int k = 0;
+      if constexpr (TAB) {
+        if (k_log > 0) {
+          // Which logged sources of this chunk are within reach of the block?  On the table path the farms of a wave share
+          // the pair geometry and the bound is the wave's own, so the answer does not depend on the farm: ONE lane per
+          // (source, target of the block) pair of the chunk — 64 / GS sources x GS targets = 64 lanes — tests its pair;
+          // the ballot, folded to one bit per source (at bit k GS), is the whole chunk's answer.
+          unsigned long long near_bits;
+          {
+            const int kk = lane / GS, rr = lane % GS;
+            const float2 e = *reinterpret_cast<const float2*>(buf + (kk * GS + rr) * WF_PAIR_STRIDE + WF_PAIR_DX);
+            const float4 bnd = bndL[min(i0 + kk, n_pad - 1)];
+            near_bits = __ballot(kk < k_log && (J * GS + rr) < N && within_bound(bnd, e.x, e.y));
+#pragma unroll
+            for (int sh = 1; sh < GS; sh <<= 1) near_bits |= near_bits >> sh;
+            unsigned long long rep = 0ull;
+#pragma unroll
+            for (int kq = 0; kq < CH; ++kq) rep |= 1ull << (kq * GS);
+            near_bits &= rep;
+          }
+          // the first near source's cold record is fetched now and lands while the transverse pass runs
+          ColdRec cold_nx = {};
+          if (near_bits) cold_nx = load_cold(i0 + (__builtin_ctzll(near_bits) / GS));
+          // -- transverse pass: every logged source of the chunk, two per iteration (their hot records are one float4,
+          // fetched one iteration ahead, across chunk boundaries: started at the top of the block).  The compiler guards
+          // the first read of the staged chunk in an iteration with s_waitcnt vmcnt(0) (the chunk arrives by LDS-DMA,
+          // counted in vmcnt), so no load can stay in flight for longer than one iteration: two sources make that ~230
+          // instructions.  No lane mask: every real turbine of this block is at or downstream of an earlier block's
+          // source (dx >= 0), and the lanes beyond N (last block only) carry all-zero records. --
+          static_assert(GS % 2 == 0 && CH % 2 == 0, "logged sources come in pairs");
 #pragma unroll 1
-        for (; k + 1 < k_log; k += 2) {
-          replay_one(k, nxt, nxt2);
-          replay_one(k + 1, nxt2, nxt);
+          for (int k = 0; k < k_log; k += 2) {
+            const float4 hot2 = hot2_nx;
+            float4 cf[S][9];
+#pragma unroll
+            for (int p = 0; p < S; ++p)
+#pragma unroll
+              for (int qq = 0; qq < 9; ++qq)
+                cf[p][qq] = *reinterpret_cast<const float4*>(buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE + 4 * qq);
+            asm volatile("" ::: "memory");
+            hot2_nx = load_hot2(min(i0 + k + 2, first_own - 2));
+            static_for<S>([&](auto PP) { apply_tab_ratio(PP, cf[decltype(PP)::value], hot2.x, hot2.y); });
+#pragma unroll
+            for (int p = 0; p < S; ++p)
+#pragma unroll
+              for (int qq = 0; qq < 9; ++qq)
+                cf[p][qq] = *reinterpret_cast<const float4*>(buf + ((k + 1) * GS + p * G + sub) * WF_PAIR_STRIDE + 4 * qq);
+            static_for<S>([&](auto PP) { apply_tab_ratio(PP, cf[decltype(PP)::value], hot2.z, hot2.w); });
+          }
+          WF_T(st_ab);
+          WF_ACC(11, st_a, st_ab);  // (the transverse pass's share of the replay)
+          // -- deflection / deficit / turbulence pass: the near sources only; the next one's cold record one step ahead --
+#pragma unroll 1
+          while (near_bits) {
+            const int k = __builtin_ctzll(near_bits) / GS;
+            near_bits &= near_bits - 1ull;
+            const int i = i0 + k;
+            const ColdRec cold = cold_nx;
+            float4 exs[S];
+#pragma unroll
+            for (int p = 0; p < S; ++p)
+              exs[p] = *reinterpret_cast<const float4*>(buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE + WF_PAIR_DX);
+            asm volatile("" ::: "memory");
+            // unconditional (the last near source re-reads its own record, which is in the cache): a conditional load leaves
+            // "keeps its value" on the other path, a register copy per float and iteration
+            cold_nx = load_cold(near_bits ? i0 + (__builtin_ctzll(near_bits) / GS) : i);
+            const SrcLog Sl = unpack(make_float2(0.0f, 0.0f), cold);
+            const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
+            static_for<S>([&](auto PP) { pass2(PP, Sl, side, true, exs[decltype(PP)::value], tvalid[decltype(PP)::value]); });
+          }
         }
-        if (k < k_log) replay_one(k, nxt, nxt2);
-      }
-#else
+      } else {
+        // a wind per farm: the pair geometry comes from the farm's own float64 coordinates (the source's travel with its
+        // record), so the far test is on THIS source, after the fact: it saves the pass, not the cold record
 #pragma unroll 1
-      for (int k = 0; k < k_log; ++k) {
-#if WF_LL_LOGT
-        const RecPieces cur = nxt;
-        replay_one(k, cur, nxt);
-#else
-        const SrcLog Sl = nxt;
-        replay_one(k, Sl, nxt);
-#endif
+        for (int k = 0; k < k_log; ++k) {
+          const int i = i0 + k;
+          const float2 hot = hot_nx;       // fetched during the previous iteration
+          const ColdRec cold = cold_nx;
+          const int inx = min(i + 1, first_own - 1);
+          const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
+          const double xs_d = xs_nx, ys_d = ys_nx;
+          hot_nx = load_hot(inx);
+          cold_nx = load_cold(inx);
+          xs_nx = gx[gofs + inx];
+          ys_nx = gy[gofs + inx];
+          const float4 bnd = bndL[i];
+          float4 exr[S];
+          int nr = 0;
+          static_for<S>([&](auto PP) {
+            constexpr int p = decltype(PP)::value;
+            exr[p] = fly_record(PP, xs_d, ys_d);
+            nr |= (int)tvalid[p] & (int)within_bound(bnd, exr[p].x, exr[p].y);
+          });
+          const bool near = __any(nr != 0);
+          const SrcLog Sl = unpack(hot, cold);
+          static_for<S>([&](auto PP) {
+            constexpr int p = decltype(PP)::value;
+            if (tvalid[p]) apply_fly(PP, exr[p].x, exr[p].y, hot.x * hot.y, hot.y);  // Gy = rho Gwt
+            if (near) pass2(PP, Sl, side, true, exr[p], tvalid[p], yt_d[TAB ? 0 : p], ys_d);
+          });
+        }
       }
-#endif
       // ---- sources of this block ------------------------------------------------------------------------
       WF_T(st_b);
       WF_ACC(0, st_a, st_b);
@@ -1023,7 +1071,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? WF_LL_OCC : WF_LL_OCC2) * 4 / W
     st_acc[4] = __builtin_readcyclecounter() - st_begin;
     for (int k = 0; k < 5; ++k) atomicAdd(&wf_ll_stamp[k], st_acc[k]);
     atomicAdd(&wf_ll_stamp[5], 1ull);
-    for (int k = 6; k < 11; ++k) atomicAdd(&wf_ll_stamp[k], st_acc[k]);  // parts of an own-source step (tools/ll_stamps.py)
+    for (int k = 6; k < 12; ++k) atomicAdd(&wf_ll_stamp[k], st_acc[k]);  // parts of an own-source step; 11: transverse pass of the replay (tools/ll_stamps.py)
   }
 #endif
 
@@ -1051,7 +1099,7 @@ constexpr int kLLWaves = 4;
 template <int G, int S, bool TAB, bool MC1, bool VEER = false>
 static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws, const double* wd,
                             int wind_stride, const float* yaw, float* power, float* o_ws, float* o_wd, float* load, int B,
-                            const WfEnvArgs* env, const float* ll_tab, const int* cross_tie, float* src_log, size_t log_side_offset,
+                            const WfEnvArgs* env, const float* ll_tab, const int* cross_tie, float* src_log, size_t log_records,
                             const WfGroupArgs* grp, const double* gx, const double* gy, hipStream_t s) {
   constexpr int fpb = kLLWaves * (64 / G);
   WfGroupArgs ga = *grp;
@@ -1061,9 +1109,12 @@ static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* g
   if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
   size_t group_floats = wfk_ll_table_floats(cc.N, G * S);
   int n_pad = ((cc.N + G * S - 1) / (G * S)) * (G * S);
-  const size_t dyn_lds = sizeof(float) * (size_t)fpb * n_pad;
+  // dynamic LDS: the commanded yaw of every farm of the block, then the far bounds of every wave (16 bytes per source)
+  const size_t dyn_lds = sizeof(float) * (size_t)fpb * n_pad + sizeof(float4) * (size_t)kLLWaves * n_pad;
+  // the log allocation holds log_records (farm slot, source) records: hot part, cold part, side records (wf_device.h)
+  size_t log_cold_offset = log_records * WF_LOG_HOT_FLOATS, log_side_offset = log_records * WF_LOG_FLOATS;
   void* args[] = {&cc, &tab, &gidx, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &ll_tab,
-                  &group_floats, &cross_tie, &src_log, &log_side_offset, &n_pad, &ga, &gx, &gy};
+                  &group_floats, &cross_tie, &src_log, &log_cold_offset, &log_side_offset, &n_pad, &ga, &gx, &gy};
   const void* fn = (const void*)&wf_step_ll_kernel<G, S, false, TAB, MC1, kLLWaves, VEER>;
   if constexpr (TAB) {
     if (wind_stride == 0) fn = (const void*)&wf_step_ll_kernel<G, S, true, TAB, MC1, kLLWaves, VEER>;
@@ -1091,10 +1142,10 @@ extern "C" int wfk_ll_stamps(unsigned long long* out, int reset) {
 extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* ws,
                                          const double* wd, int wind_stride, const float* yaw, float* power, float* o_ws,
                                          float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
-                                         const int* cross_tie, float* src_log, size_t log_side_offset,
+                                         const int* cross_tie, float* src_log, size_t log_records,
                                          const WfGroupArgs* grp, hipStream_t s) {
-#define WF_LL_LAUNCH(G_, S_) launch_ll<G_, S_, true, true>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, nullptr, nullptr, s)
-#define WF_LL_LAUNCH_VEER(G_, S_) launch_ll<G_, S_, true, true, true>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_side_offset, grp, nullptr, nullptr, s)
+#define WF_LL_LAUNCH(G_, S_) launch_ll<G_, S_, true, true>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_records, grp, nullptr, nullptr, s)
+#define WF_LL_LAUNCH_VEER(G_, S_) launch_ll<G_, S_, true, true, true>(c, tab, gidx, ws, wd, wind_stride, yaw, power, o_ws, o_wd, load, B, env, ll_tab, cross_tie, src_log, log_records, grp, nullptr, nullptr, s)
   if (c->veer_on) {  // wind veer: the throughput families only (wfk_ll_has_veer)
     WF_LL_DISPATCH(4, 1, WF_LL_LAUNCH_VEER);
     WF_LL_DISPATCH(4, 2, WF_LL_LAUNCH_VEER);
@@ -1118,18 +1169,18 @@ extern "C" int wfk_ll_has_fly(int G, int S) { return (G == 4 && S <= 2) || (G ==
 extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* gx,
                                              const double* gy, const double* ws, const double* wd, const float* yaw,
                                              float* power, float* o_ws, float* o_wd, float* load, int B, const WfEnvArgs* env,
-                                             const int* farm_tie, float* src_log, size_t log_side_offset,
+                                             const int* farm_tie, float* src_log, size_t log_records,
                                              const WfGroupArgs* grp, hipStream_t s) {
 #define WF_LL_LAUNCH_FLY(G_, S_)                                                                                              \
   (c->mirror_core_n <= 1                                                                                                      \
        ? launch_ll<G_, S_, false, true>(c, tab, gidx, ws, wd, 1, yaw, power, o_ws, o_wd, load, B, env, nullptr, farm_tie, src_log, \
-                                        log_side_offset, grp, gx, gy, s)                                                       \
+                                        log_records, grp, gx, gy, s)                                                       \
        : launch_ll<G_, S_, false, false>(c, tab, gidx, ws, wd, 1, yaw, power, o_ws, o_wd, load, B, env, nullptr, farm_tie,      \
-                                         src_log, log_side_offset, grp, gx, gy, s))
+                                         src_log, log_records, grp, gx, gy, s))
   if (c->veer_on) {
     if (G == 4 && S == 2)
       return launch_ll<4, 2, false, false, true>(c, tab, gidx, ws, wd, 1, yaw, power, o_ws, o_wd, load, B, env, nullptr, farm_tie, src_log,
-                                                 log_side_offset, grp, gx, gy, s);
+                                                 log_records, grp, gx, gy, s);
     return hipErrorInvalidValue;
   }
   WF_LL_DISPATCH(4, 2, WF_LL_LAUNCH_FLY);

@@ -127,6 +127,11 @@ int build_consts(wf_handle* h) {
   c.q_d = D / 4.0;
   c.guard_inv = h->guard_rel > 0.0 ? (float)(1.0 / h->guard_rel) : 1125899906842624.0f;
   c.inv_overlap_thr = (float)(1.0 / m.overlap_thresh);
+  // far-source / far-pair skip of the one-block kernel: its bounds assume wakes that only widen downstream and near-wake
+  // lengths that fall with TI — every physical parameter set; anything else runs without the skip
+  c.far_on = (h->choice.far_skip != 0 && m.ka >= 0.0 && m.kb >= 0.0 && m.defl_ka >= 0.0 && m.defl_kb >= 0.0 && m.alpha >= 0.0 &&
+              m.beta >= 0.0 && m.defl_alpha >= 0.0 && m.defl_beta >= 0.0) ? 1 : 0;
+  c.far_k = c.far_on ? 6.12f : 1.0e30f;
   c.ct_kappa = 5.0f;     // nrel_5MW: 5.9 on the cut-in ramp (2.5-3 m/s), 143 on the cut-out drop, <= 4.0 everywhere else
   c.knee_kappa = 30.0f;  // 30 x (wind-speed error ~3e-6) ~ 1e-4 of max(P, 1 kW)
   {  // wind veer: the rotated Gaussian of the deficit [FLORIS gauss.py rCalt]
@@ -135,6 +140,7 @@ int build_consts(wf_handle* h) {
     c.cos_veer = (float)std::cos(vr);
     c.veer_c2 = (float)(std::cos(vr) * std::cos(vr)); c.veer_s2 = (float)(std::sin(vr) * std::sin(vr));
     c.veer_bq = (float)(std::sin(2.0 * vr) * D / 4.0);
+    c.kdef_sy0v = (float)((D * D / 8.0) / ((D / (2.0 * std::sqrt(2.0))) * std::cos(vr)));
   }
   c.rho = (float)m.ref_density; c.pw = (float)(m.pP / 3.0);
   c.dens_f = (float)std::cbrt(m.air_density / m.ref_density);
@@ -222,7 +228,12 @@ int build_consts(wf_handle* h) {
       hipError_t e64 = hipMalloc(&h->d_tab64, sizeof(double) * 3 * WF_TABLE_PAD);
       if (e64 != hipSuccess) return fail(h, WF_E_HIP, std::string("table64 alloc: ") + hipGetErrorString(e64));
     }
-    hipError_t e64 = hipMemcpy(h->d_tab64, t64.data(), sizeof(double) * t64.size(), hipMemcpyHostToDevice);
+    // on the handle's stream, like d_tab below: a blocking copy on the null stream is NOT ordered behind a float64 solve
+    // still running on h->stream (non-blocking or adopted from torch), which stages this very table into LDS; the
+    // source is pageable host memory, so the call returns once the bytes are staged and the sync below covers the rest
+    hipError_t e64 = hipStreamSynchronize(h->stream);
+    if (e64 == hipSuccess) e64 = hipMemcpyAsync(h->d_tab64, t64.data(), sizeof(double) * t64.size(), hipMemcpyHostToDevice, h->stream);
+    if (e64 == hipSuccess) e64 = hipStreamSynchronize(h->stream);
     if (e64 != hipSuccess) return fail(h, WF_E_HIP, std::string("table64 upload: ") + hipGetErrorString(e64));
   }
   hipError_t e = hipMemcpyAsync(h->d_tab, &t, sizeof(WfTables), hipMemcpyHostToDevice, h->stream);

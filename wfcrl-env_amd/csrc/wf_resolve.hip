@@ -148,13 +148,7 @@ __device__ __forceinline__ double cbrt_pos(double x) {
 // re-deriving the source constants: 1.95 ms for 1394 HornsRev1 farms; the inlined one-wave version 1.42 ms; this one 1.37 ms.
 // The four-wave kernel further down has the lower latency per farm (0.73 against 1.04 ms) but takes four wave slots per
 // farm: this kernel serves the counts beyond half a residency of that one.)
-#ifndef WF_RES_UNROLL_J
-#define WF_RES_UNROLL_J 0  // 1: the three grid columns of the transverse pass interleaved (three times the registers): no gain
-                           // (4.80 against 4.78 ms per step with 1394 farms re-solved, tools/res_ab.sh)
-#endif
-#ifndef WF_RES_OCC
-#define WF_RES_OCC 2  // waves per SIMD the register allocator is asked to make room for (tools/res_occ_sweep.sh)
-#endif
+#define WF_RES_OCC 2  // waves per SIMD the register allocator is asked to make room for (three / four spill: 1.48 / 1.76 ms)
 struct SrcShared {  // what a source leaves for the two passes over its targets
   double x_i, y_i, ct, ai, ubar, Vmean, TIs[3], dTI;
   double Gt, Gb, Gw;  // circulations / (2 pi): top, bottom, wake rotation (commanded yaw)
@@ -180,15 +174,9 @@ extern __shared__ double res_dyn[];  // per sorted turbine: x', y', cos / sin / 
 #define RES_TIE(t) (reinterpret_cast<int*>(res_dyn + 35 * R.n_pad)[(t)])
 
 // ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
-#ifndef WF_RES_INLINE_SRC
-#define WF_RES_INLINE_SRC 0  // 1: the two source-only phases inlined into the kernel's loop (two calls per source instead of
-                             // four): slower, 5.18 against 4.78 ms (the loop body then carries their live ranges across the calls)
-#endif
-#if WF_RES_INLINE_SRC
-#define RES_SRC_FN __device__ __forceinline__
-#else
+// (the source-only phases stay out of line: inlined, the loop body carries their live ranges across the calls — 5.18
+// against 4.78 ms per step with 1394 farms re-solved)
 #define RES_SRC_FN __device__ __noinline__
-#endif
 RES_SRC_FN void res_source_begin(int i) {
   const WfResolveConsts& c = R.c;
   const double cg = RES_CG(i), sg = RES_SG(i);
@@ -236,12 +224,8 @@ __device__ __noinline__ void res_transverse_pass() {
     double dec[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) dec[k] = eps2 * rcp64(4.0 * (c.nu1[k] * R.ws) * dx / R.Uinf + eps2);
-#if WF_RES_UNROLL_J
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
-    for (int j = 0; j < 3; ++j) {  // (a real loop unless WF_RES_UNROLL_J: the state is addressed in LDS, nothing needs a static index)
+    for (int j = 0; j < 3; ++j) {  // (a real loop: the state is addressed in LDS, nothing needs a static index; the three columns interleaved gained nothing)
       double Vj[3], Wj[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { Vj[k] = RES_ST(9 + j * 3 + k, t); Wj[k] = RES_ST(18 + j * 3 + k, t); }
@@ -584,12 +568,8 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
 // the re-solve is pure latency — one farm's 80-stage chain, whatever the count — and spreading a source step over four
 // waves shortens it (HornsRev1: 1.04 -> 0.73 ms per farm).  Both kernels are enqueued behind the compaction; each reads
 // the count on the device and the one it is not meant for returns at once.
-#ifndef WF_RES_GRID_PER_CU
 #define WF_RES_GRID_PER_CU 8  // persistent one-wave blocks per CU
-#endif
-#ifndef WF_RES4_OCC
-#define WF_RES4_OCC 4  // waves per SIMD = resident farms per CU
-#endif
+#define WF_RES4_OCC 4          // waves per SIMD = resident farms per CU
 // One farm per 256-thread block.  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column TIs,
 // float64 — lives in LDS, structure-of-arrays over the sorted turbine index; a lane is not tied to a turbine: for source i
 // the lanes take the turbines the source can reach, t = first + lane (first = the start of the source's x' tie group for
