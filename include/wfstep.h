@@ -178,7 +178,8 @@ int wf_sync(wf_handle* h);
 #define WF_RISK_OVERLAP 1
 #define WF_RISK_POWER_KNEE 2
 #define WF_RISK_THRUST_RAMP 4
-int wf_set_risk_guard(wf_handle* h, double rel_band); /* default 5e-5; 0 disables WF_RISK_OVERLAP */
+int wf_set_risk_guard(wf_handle* h, double rel_band); /* default 2e-5 (20 x the float32 deficit error measured at the
+                                                         threshold); 0 disables WF_RISK_OVERLAP */
 int wf_get_risk_flags(wf_handle* h, int* flags, int on_device);
 
 /* ---- Float64 re-solve: the 1e-4 contract without exemptions ------------------------------------------------
@@ -303,8 +304,16 @@ typedef struct wf_kernel_choice {
                            more than 6.12 sigma_y + D/4 off the wake's centre line (the nearest rotor-grid column would get
                            exp2(-27) of the amplitude: no effect on any float32 result); 0: every pair is evaluated (A/B
                            and the bit-identity test, tests/test_hip_parity.py) */
+  int calibrate;        /* -1 / 1: with one_block == -1, the third plain step after a (re)configuration times one launch of
+                           every kernel family the rounds model prices within 35 % of its best guess, on the handle's own
+                           batch / layout / wind (a few ms, once; that one call synchronises), and the fastest serves the
+                           handle from then on; 0: the rounds model's guess stands (measured on one MI355X: wf_dispatch.hip) */
 } wf_kernel_choice;
 int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c);
+/* What the calibration (wf_kernel_choice::calibrate) found: *code = (G << 4) | S of the wf_step_ll_kernel shape it chose, 0
+ * = wf_step_kernel, -1 = it has not run for the current configuration; family_ms[6] = ms per launch of the families it
+ * timed, in the order {wf_step_kernel, 8x1, 4x2, 4x1, 2x2, 16x1}, 0 = not timed.  Either pointer may be NULL. */
+int wf_get_calibration(wf_handle* h, int* code, float* family_ms);
 int wf_get_kernel_choice(wf_handle* h, wf_kernel_choice* c);
 
 const char* wf_last_error(wf_handle* h); /* h may be NULL: last error of a failed wf_create */

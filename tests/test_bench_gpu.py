@@ -13,8 +13,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(*args, timeout=900):
+def _run(*args, timeout=900, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
                        timeout=timeout, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -56,7 +57,10 @@ def test_eight_rank_dry_run_of_baseline_config4():
     blocks tile the batch, the kernel is the one the rounds model picks for an 8192-farm shard, and ONE line comes out."""
     from wfcrl_env_amd.sharding import shard_bounds
 
-    d = _run("--gpus", "8", "--config", "cfg4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-env-leg", timeout=1500)
+    # (WF_CALIBRATE=0: with eight ranks timing their kernel families on ONE shared GPU the per-handle calibration measures
+    # the other ranks, not the kernels — on a real node every rank has a GPU of its own; here the rounds model's guess is checked)
+    d = _run("--gpus", "8", "--config", "cfg4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-env-leg", timeout=1500,
+             extra_env={"WF_CALIBRATE": "0"})
     c = d["config"]
     assert d["n_gpus"] == 8 and d["scaling"] == "strong" and c["env_batch_per_gpu"] == 8192 and c["env_batch_total"] == 65536
     assert sorted(s[0] for s in c["shards"]) == list(range(8))

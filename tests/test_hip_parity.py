@@ -185,7 +185,7 @@ def test_risk_flags_mark_exactly_the_farms_near_the_threshold(layouts):
         assert not fl[ref["margin"] > 1.1 * band + 1e-4].any(), band
         if band >= 1e-3:
             assert fl.any()
-    w.set_risk_guard(5e-5)
+    w.set_risk_guard(2e-5)
     w.close()
 
 
@@ -411,6 +411,48 @@ def test_far_skip_is_a_no_op_in_float32(layouts, name, wd):
             ok = (ulp <= 2) | (np.abs(a[k].astype(np.float64) - b[k]) <= 1e-9)
             assert ok.all(), (fam, k, int((~ok).sum()), float(np.abs(a[k].astype(np.float64) - b[k]).max()))
         assert n_diff <= 1e-4 * B * N * 7, (fam, n_diff)
+
+
+def test_per_handle_kernel_calibration(layouts):
+    """wf_kernel_choice::calibrate (default on): the third plain table-path step times the kernel families the rounds model
+    prices close to its best guess on the handle's own batch and keeps the fastest (csrc/wf_dispatch.hip:
+    calibrate_families); results stay inside the contract whichever family wins, a reconfiguration starts over, and
+    calibrate=False leaves the rounds model's guess alone."""
+    import torch
+
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    N, B = 80, 24576
+    rng = np.random.default_rng(77)
+    yaw = torch.from_numpy(rng.uniform(-30, 30, (B, N)).astype(np.float32)).cuda()
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w.set_wind(8.0, 270.0)
+    assert w.calibration()["shape"] is None
+    guess = w.kernel_info()
+    for _ in range(2):
+        w.step(yaw)
+    assert w.calibration()["shape"] is None  # not before the third step
+    out = w.step(yaw)
+    cal = w.calibration()
+    assert cal["shape"] is not None and len(cal["family_ms"]) >= 2, cal
+    assert cal["family_ms"][cal["shape"]] == min(cal["family_ms"].values()), cal
+    info = w.kernel_info()
+    want = (16, 5) if cal["shape"] == "slot" else tuple(int(v) for v in cal["shape"].split("x"))
+    assert (info["lanes_per_env"], info["slots_per_lane"]) == want, (info, cal, guess)
+    idx = rng.choice(B, 48, replace=False)
+    ref = _oracle(l["xcoords"], l["ycoords"], 8.0, 270.0, yaw.cpu().numpy()[idx])
+    flags = w.risk_flags()
+    _check(dict({k: v.cpu().numpy()[idx] for k, v in out.items()}, flags=flags[idx]), ref)
+    w.set_batch(4096 * 3)  # a reconfiguration starts over
+    assert w.calibration()["shape"] is None
+    w.close()
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, kernel_choice=dict(calibrate=False))
+    w.set_wind(8.0, 270.0)
+    for _ in range(4):
+        w.step(yaw)
+    assert w.calibration()["shape"] is None and w.kernel_info() == guess
+    w.close()
 
 
 def test_time_varying_direction_sweep_hornsrev2(layouts):

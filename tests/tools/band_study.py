@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 ROOT = os.getcwd()
-BANDS = [5e-5, 4e-5, 3e-5, 2.5e-5, 2e-5, 1.5e-5, 1e-5, 5e-6]
+BANDS = [5e-5, 3e-5, 2e-5, 1e-5, 5e-6, 2e-6, 1e-6, 5e-7, 2e-7]
 TOL = dict(power=1e-4, ws=5e-5, wd=3e-4, ti=5e-6)
 
 
@@ -38,14 +38,25 @@ def main():
     nb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     mode = sys.argv[4] if len(sys.argv) > 4 else "reset"
-    lay = json.load(open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")))[name]
-    N = len(lay["xcoords"])
-    w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B)
     tot = {b: dict(flagged=0, missed=0) for b in BANDS}
     n_farms = 0
     worst_missed = {}
+    fuzz = name == "fuzz"  # random layouts of the layout fuzzer (grids with ties, jittered grids, clouds), one per batch
+    if fuzz:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+        import fuzz_parity
+    else:
+        lay = json.load(open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")))[name]
+        N = len(lay["xcoords"])
+        w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B)
     for it in range(nb):
         rng = np.random.default_rng(4000 + it)
+        if fuzz:
+            x, y = fuzz_parity.make_layout(rng)
+            while x.size < 12 or x.size > 128:
+                x, y = fuzz_parity.make_layout(rng)
+            N = x.size
+            w = WfStep(x, y, env_batch=B)
         if mode == "shared":
             w.set_wind(float(rng.uniform(6, 11)), float(270 + rng.uniform(-30, 30)))
         elif mode == "wide":
@@ -70,11 +81,16 @@ def main():
                 i = int(torch.nonzero(missed)[0])
                 worst_missed.setdefault(b, []).append(dict(batch=it, farm=i, power=float(p[i]), ws=float(s[i]), wd=float(d[i]), ti=float(t[i])))
         w.set_risk_guard(5e-5)
+        if fuzz:
+            w.close()
+    if fuzz:
+        N = "12..128"
     print(f"{name} N={N} mode={mode}: {n_farms} farms (float64 device kernel as the checker)")
     for b in BANDS:
         print(f"  band {b:.1e}: overlap-flagged {tot[b]['flagged']} ({100.0 * tot[b]['flagged'] / n_farms:.3f} %), unflagged farms outside TOL {tot[b]['missed']}"
               + (f"  e.g. {worst_missed[b][:2]}" if b in worst_missed else ""))
-    w.close()
+    if not fuzz:
+        w.close()
 
 
 if __name__ == "__main__":

@@ -64,7 +64,7 @@ class KernelInfo(C.Structure):
 class KernelChoice(C.Structure):
     """Mirror of `struct wf_kernel_choice`."""
 
-    _fields_ = [(n, C.c_int) for n in ("slot_G", "slot_S", "one_block", "ll_G", "ll_S", "pair_table", "fly_one_block", "far_skip")]
+    _fields_ = [(n, C.c_int) for n in ("slot_G", "slot_S", "one_block", "ll_G", "ll_S", "pair_table", "fly_one_block", "far_skip", "calibrate")]
 
 
 # every symbol include/wfstep.h declares: name -> (restype, argtypes)
@@ -105,6 +105,7 @@ ABI = {
     "wf_get_kernel_info": (C.c_int, [_P, C.POINTER(KernelInfo)]),
     "wf_set_kernel_choice": (C.c_int, [_P, C.POINTER(KernelChoice)]),
     "wf_get_kernel_choice": (C.c_int, [_P, C.POINTER(KernelChoice)]),
+    "wf_get_calibration": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "wf_last_error": (C.c_char_p, [_P]),
 }
 

@@ -345,13 +345,14 @@ class WfStep:
         check(self._lib.wf_timing_end(self._h, C.byref(ms)), self._h)
         return float(ms.value)
 
-    def set_kernel_choice(self, slot=None, one_block=None, pair_table=None, fly_one_block=None, far_skip=None):
+    def set_kernel_choice(self, slot=None, one_block=None, pair_table=None, fly_one_block=None, far_skip=None, calibrate=None):
         """Which kernels may serve THIS handle (include/wfstep.h: wf_set_kernel_choice); None = automatic.
           slot=(G, S) or "16x5"      wf_step_kernel<G,S>
           one_block=False            never wf_step_ll_kernel;  one_block=(G, S) / "4x2" / "8": always, with that shape
           pair_table=False           everything on the fly
           fly_one_block=False        a wind per farm stays on wf_step_kernel
           far_skip=False             wf_step_ll_kernel evaluates every (source, target) pair (no far-source / far-pair skip)
+          calibrate=False            the rounds model's guess stands: no timing of the kernel families on the third step
         Drops the current wind: set it again before the next step."""
         def gs(v, default_s=1):
             if isinstance(v, bool):
@@ -364,7 +365,7 @@ class WfStep:
                 return v, default_s
             return int(v[0]), int(v[1])
 
-        c = KernelChoice(0, 0, -1, 0, 0, -1, -1, -1)
+        c = KernelChoice(0, 0, -1, 0, 0, -1, -1, -1, -1)
         if slot:
             c.slot_G, c.slot_S = gs(slot)
         if one_block is not None:
@@ -379,12 +380,24 @@ class WfStep:
             c.fly_one_block = 0 if fly_one_block is False else -1
         if far_skip is not None:
             c.far_skip = 0 if far_skip is False or far_skip == 0 else -1
+        if calibrate is not None:
+            c.calibrate = 0 if calibrate is False or calibrate == 0 else -1
         check(self._lib.wf_set_kernel_choice(self._h, C.byref(c)), self._h)
 
     def kernel_choice(self) -> dict:
         c = KernelChoice()
         check(self._lib.wf_get_kernel_choice(self._h, C.byref(c)), self._h)
         return {n: getattr(c, n) for n, _ in KernelChoice._fields_}
+
+    def calibration(self) -> dict:
+        """What the per-handle kernel calibration found (include/wfstep.h: wf_get_calibration): {"shape": "2x2" / "16x5-slot
+        kernel" ... or None when it has not run, "family_ms": {family: ms per launch} of the families it timed}."""
+        code = C.c_int(-1)
+        ms = (C.c_float * 6)()
+        check(self._lib.wf_get_calibration(self._h, C.byref(code), ms), self._h)
+        names = ("slot", "8x1", "4x2", "4x1", "2x2", "16x1")
+        shape = None if code.value < 0 else ("slot" if code.value == 0 else f"{code.value >> 4}x{code.value & 15}")
+        return {"shape": shape, "family_ms": {n: float(m) for n, m in zip(names, ms) if m > 0.0}}
 
     def kernel_info(self) -> dict:
         k = KernelInfo()

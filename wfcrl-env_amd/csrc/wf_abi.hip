@@ -68,6 +68,8 @@ int wf_create(int device_id, wf_handle** out) {
     if (off && off[0] == '0') c.one_block = 0;
     const char* fs = getenv("WF_LL_FAR_SKIP");
     if (fs && fs[0] == '0') c.far_skip = 0;
+    const char* cal = getenv("WF_CALIBRATE");
+    if (cal && cal[0] == '0') c.calibrate = 0;
     const char* force = getenv("WF_LL_G");  // "8" or "4x2"
     if (force && c.one_block != 0) {
       int g = 0, sl = 1;
@@ -174,6 +176,7 @@ int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
   }
   if (n != h->N) { free_batch(h); h->B = 0; }
   h->N = n; h->variant = v; h->wind_count = 0; h->shared_dir = false; h->model_dirty = true;
+  reset_calibration(h);
   h->n_groups = 0; h->grid_step = 0.0;
   return WF_OK;
 }

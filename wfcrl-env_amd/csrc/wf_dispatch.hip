@@ -167,7 +167,13 @@ int repick_ll_slots(const wf_handle* h, int N, int ll_G, int ll_S, long farm_slo
 
 // (Re)pick the kernels of a handle for N turbines and B farms under its choice: the register-slot variant and the
 // one-block kernel's shape; frees what was laid out for another shape.  The caller has drained the stream.
+void reset_calibration(wf_handle* h) {
+  h->calib_steps = 0; h->calib_done = false; h->calib_code = -1;
+  for (float& m : h->calib_ms) m = 0.0f;
+}
+
 void apply_kernel_pick(wf_handle* h, int N, int B, bool* variant_changed) {
+  reset_calibration(h);
   const int v = pick_variant(h, N, B);
   const int llg = pick_ll(h, N, B);
   set_ll_shape(h, llg >> 4, llg ? (llg & 15) : 1);
@@ -375,7 +381,75 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
 // The step as the ABI sees it: the float32 kernels, then — when asked for (wf_set_risk_resolve) — the float64 solve of
 // the flagged (or all) farms on the same stream, overwriting their outputs.  (wind_veer != 0 no longer forces it: the
 // VEER instantiations of the float32 kernels serve such models, with the same flags.)
+// Per-handle calibration of the kernel family.  The rounds model above is a table of milliseconds measured on ONE box
+// for two layouts; layouts, directions, clocks and partitioned devices move the families against each other by up to
+// 10 %.  So the handle measures: on its third plain table-path step after a (re)configuration it launches every family
+// the model prices within 35 % of its best guess on the caller's own buffers (the step is stateless: the real launch
+// follows and overwrites them), times two launches of each with HIP events, and keeps the fastest.  A few ms, once;
+// that one call synchronises.  The rounds model remains the cold-start guess and the price list of grouped launches.
+static bool calibration_due(const wf_handle* h, const WfEnvArgs* ea) {
+  if (h->calib_done || h->choice.calibrate == 0 || h->choice.one_block != -1 || h->choice.pair_table == 0) return false;
+  if (ea && ea->action) return false;  // the fused env transition is not idempotent
+  if (h->N <= 16 || h->N > WF_PAIR_MAX_N || h->n_groups > 0 || h->n_layouts != 1) return false;
+  if (!(h->wind_count == 1 || h->shared_dir) || !wfk_variant_has_table(h->variant)) return false;
+  int fpb, per_cu;
+  family_shape(h, 0, h->N, &fpb, &per_cu);
+  return (long)h->B > (long)h->n_cu * fpb;  // below that: the latency regime, pick_variant's widened kernel
+}
+
+static int calibrate_families(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
+  const int N = h->N, B = h->B;
+  const bool veer = h->model.veer != 0.0;
+  double est[kNumFamilies], best_est = 1e300;
+  for (int fi = 0; fi < kNumFamilies; ++fi) {
+    const LlFamily& f = kLlFamilies[fi];
+    est[fi] = 1e300;
+    if (f.code && N <= (f.code >> 4) * (f.code & 15)) continue;
+    if (f.code == ((8 << 4) | 1) && N <= 32) continue;
+    if (veer && f.code && !wfk_ll_has_veer(f.code >> 4, f.code & 15, 1)) continue;
+    est[fi] = ll_estimate(h, fi, N, B);
+    if (est[fi] < best_est) best_est = est[fi];
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  WF_HIP(h, hipEventCreate(&e0));
+  WF_HIP(h, hipEventCreate(&e1));
+  int best = -1;
+  float best_ms = 1e30f;
+  int rc = WF_OK;
+  for (int fi = 0; fi < kNumFamilies && rc == WF_OK; ++fi) {
+    if (!(est[fi] <= 1.35 * best_est)) continue;
+    const int code = kLlFamilies[fi].code;
+    hipStreamSynchronize(h->stream);
+    set_ll_shape(h, code >> 4, code ? (code & 15) : 1);
+    if ((rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea)) != WF_OK) break;  // tables, log, first-launch costs
+    hipError_t e = hipEventRecord(e0, h->stream);
+    for (int r = 0; r < 2 && rc == WF_OK; ++r) rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
+    if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess) { rc = fail(h, WF_E_HIP, std::string("calibration: ") + hipGetErrorString(e)); break; }
+    h->calib_ms[fi] = 0.5f * ms;
+    if (0.5f * ms < best_ms) { best_ms = 0.5f * ms; best = fi; }
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (rc != WF_OK) return rc;
+  if (best >= 0) {
+    const int code = kLlFamilies[best].code;
+    hipStreamSynchronize(h->stream);
+    set_ll_shape(h, code >> 4, code ? (code & 15) : 1);
+    h->calib_code = code;
+  }
+  h->calib_done = true;
+  return WF_OK;
+}
+
 int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
+  if (calibration_due(h, ea) && ++h->calib_steps >= 3) {
+    int rc = calibrate_families(h, yaw, power, wspd, wdir, load, ea);
+    if (rc != WF_OK) return rc;
+  }
   int rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
   if (rc != WF_OK) return rc;
   const int mode = h->resolve_mode;
@@ -453,7 +527,7 @@ int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c) {
   if ((c->slot_G > 0) != (c->slot_S > 0) || (c->slot_G > 0 && find_variant(c->slot_G, c->slot_S) < 0))
     return fail(h, WF_E_INVALID, "no wf_step_kernel variant with these lanes per farm x slots per lane");
   if (c->one_block < -1 || c->one_block > 1 || c->pair_table < -1 || c->pair_table > 1 || c->fly_one_block < -1 || c->fly_one_block > 1 ||
-      c->far_skip < -1 || c->far_skip > 1)
+      c->far_skip < -1 || c->far_skip > 1 || c->calibrate < -1 || c->calibrate > 1)
     return fail(h, WF_E_INVALID, "kernel choice switches must be -1 (automatic), 0 or 1");
   if (c->one_block == 1) {
     const int g = c->ll_G, sl = c->ll_S > 0 ? c->ll_S : 1;
@@ -471,6 +545,14 @@ int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c) {
   }
   // geometry, groups and tables of the current wind were laid out for the previous choice: the wind has to be set again
   h->wind_count = 0; h->shared_dir = false; h->n_groups = 0; h->grid_step = 0.0; h->series_T = 0; h->pair_dirty = true;
+  return WF_OK;
+}
+
+int wf_get_calibration(wf_handle* h, int* code, float* family_ms) {
+  if (!h) return WF_E_INVALID;
+  if (code) *code = h->calib_done ? h->calib_code : -1;
+  if (family_ms)
+    for (int fi = 0; fi < 6; ++fi) family_ms[fi] = fi < kNumFamilies ? h->calib_ms[fi] : 0.0f;
   return WF_OK;
 }
 

@@ -105,8 +105,12 @@ struct wf_handle {
   double* d_gy = nullptr;                   // sorted y' (float64: the lateral gate is decided on it)
   int* d_gidx = nullptr;
   int* d_flags = nullptr;                   // [B] WF_RISK_* bits of the last step
-  double guard_rel = 5.0e-5;                // relative half-width of the overlap-threshold guard band (a deficit at the
-                                            // threshold sits in the Gaussian tail: its float32 error reaches 1-3e-5)
+  double guard_rel = 2.0e-5;                // relative half-width of the overlap-threshold guard band.  Measured (round 4,
+                                            // tests/tools/band_study.py, the float64 device kernel as the checker): over 1.47 M
+                                            // farms — HornsRev1 under the reset distribution and over all speeds / directions,
+                                            // random fuzzer layouts — no unflagged farm leaves the tolerances down to a band of
+                                            // 1e-6, the first do at 5e-7: the float32 deficit at the threshold is good to
+                                            // ~1e-6.  2e-5 keeps a factor 20 over that (rounds 2-3: 5e-5)
   float *d_yaw = nullptr, *d_out = nullptr;  // staging for host callers: yaw [B*N], out [B*N*7]
   float *h_yaw = nullptr, *h_out = nullptr;  // pinned
   size_t cap_env = 0, cap_bn = 0;
@@ -159,8 +163,14 @@ struct wf_handle {
   bool wind_sync = true;       // the wind was set by a call that synchronises anyway (host arrays, series, binned sampling)
   int ll_ties = 2;             // cross-block ties of the current directions: 0 none, 1 all of them, 2 some / not read back
   // which kernels may serve this handle (wf_set_kernel_choice; the WF_* environment variables only seed it at wf_create)
-  wf_kernel_choice choice{0, 0, -1, 0, 0, -1, -1, -1};
+  wf_kernel_choice choice{0, 0, -1, 0, 0, -1, -1, -1, -1};
   int n_cu = 256;              // compute units of the handle's device (hipDeviceProp_t::multiProcessorCount)
+  // per-handle calibration of the kernel family (wf_dispatch.hip: calibrate_families): plain table-path steps since the
+  // last (re)configuration, and whether the families have been timed for it
+  int calib_steps = 0;
+  bool calib_done = false;
+  int calib_code = -1;         // what the timing chose: (G << 4) | S, 0 = the register-slot kernel, -1 = never ran
+  float calib_ms[8] = {};      // ms per launch of each family of the rounds model it timed (0 = not timed)
   // float64 re-solve of the farms the float32 kernels flag (wf_resolve.hip)
   int resolve_mode = 0;        // 0 off, 1 flagged farms, 2 every farm (wf_set_risk_resolve; wind_veer models are served by
                                // the VEER float32 instantiations and take the same modes — nothing forces mode 2)
@@ -221,6 +231,7 @@ int ll_fly_G(const wf_handle* h);
 size_t ll_npad(const wf_handle* h);
 int ll_log_fpb(const wf_handle* h);
 int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea);
+void reset_calibration(wf_handle* h);
 // wf_groups.hip
 void ungroup(wf_handle* h);
 int farms_per_block(const wf_handle* h);

@@ -105,6 +105,7 @@ struct SrcLog {
   float sM, tan_th0, sy0v, snw;     // sqrt(ct), deflection angle; deficit sigma_y0, near-wake sigma
   float kdef, x0d, kyd, pj;         // deficit amplitude factor; column 0: deflection near-wake length, expansion rate, log prefactor
   float x0v, kyv, ch_pref, ix0v;    // column 0: deficit near-wake length, expansion rate; +-Crespo-Hernandez prefactor; 1 / x0v
+  float inv_s0d, d0;                // derived once per source step, not per target slot: 1 / (sy0d sz0d), tan_th0 x0d
 };
 struct ColdRec { float4 a, b, c; };  // the cold part as stored: {sy0d, sz0d, sM, tan_th0} {sy0v, x0d, kyd, pj} {x0v, kyv, ch_pref, ix0v}
 static_assert(WF_LOG_HOT_FLOATS == 2 && WF_LOG_COLD_FLOATS == 12, "source log record");
@@ -407,9 +408,9 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
     const float lin = fmaf(c.bd, dx, c.ad);
     const float amp_on = (bits & 8) ? 1.0f : 0.0f;
     SrcConsts sc;
-    sc.sy0d = R.sy0d; sc.sz0d = R.sz0d; sc.inv_s0d = frcp(R.sy0d * R.sz0d); sc.lnA = 1.6f + R.sM; sc.lnB = 1.6f - R.sM; sc.sM = R.sM;
+    sc.sy0d = R.sy0d; sc.sz0d = R.sz0d; sc.inv_s0d = R.inv_s0d; sc.lnA = 1.6f + R.sM; sc.lnB = 1.6f - R.sM; sc.sM = R.sM;
     sc.tan_th0 = R.tan_th0; sc.sy0v = R.sy0v; sc.snw = R.snw; sc.kdef = R.kdef;
-    const float d0 = R.tan_th0 * R.x0d, ix0v = R.ix0v;
+    const float d0 = R.d0, ix0v = R.ix0v;
     float e1[3], e0[3];
     float e2[VEER ? 3 : 1];  // with veer: the deficit of row k = 2 (e0 is row 0)
     const bool same = !__any(R.ch_pref < 0.0f);  // the sign of ch_pref flags a split-TI source
@@ -619,6 +620,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
     R.x0v = r.c.x; R.kyv = r.c.y; R.ch_pref = r.c.z; R.ix0v = r.c.w;
     R.snw = snw_f * R.sM;                               // 0.501 D sqrt(ct / 2)
     R.kdef = (R.sM * R.sM) * (R.sy0v * c.kdef_sy0v);   // ct cos(yaw) D^2 / 8, cos(yaw) = sy0v / (sz0v [cos veer])
+    R.inv_s0d = frcp(R.sy0d * R.sz0d);
+    R.d0 = R.tan_th0 * R.x0d;
     return R;
   };
   float* const logx = src_log + log_side_offset + (size_t)slot * n_pad * WF_LOG_SIDE_FLOATS;
@@ -806,6 +809,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
       const bool split = !((TIs[0] == TIs[1]) && (TIs[1] == TIs[2]));
       Sc.ch_pref = split ? -Sc.ch_pref : Sc.ch_pref;  // the flag travels in the sign
       Sc.ix0v = frcp(Sc.x0v);
+      Sc.inv_s0d = frcp(Sc.sy0d * Sc.sz0d);
+      Sc.d0 = Sc.tan_th0 * Sc.x0d;
       // the later blocks replay this source from the log
       if (J + 1 < nblk) {
         if (sub == 0) {
@@ -925,24 +930,35 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
           }
           WF_T(st_ab);
           WF_ACC(11, st_a, st_ab);  // (the transverse pass's share of the replay)
-          // -- deflection / deficit / turbulence pass: the near sources only; the next one's cold record one step ahead --
-#pragma unroll 1
-          while (near_bits) {
-            const int k = __builtin_ctzll(near_bits) / GS;
-            near_bits &= near_bits - 1ull;
+          // -- deflection / deficit / turbulence pass: the near sources only; the next one's cold record is fetched while the
+          // current one is applied, into the OTHER of two register sets used alternately (a 2 x unrolled loop: one set
+          // copied into the other costs a move per float and step — 12 of ~200 instructions) --
+          auto near_step = [&](int k, const ColdRec& cold, ColdRec& nxt) {
             const int i = i0 + k;
-            const ColdRec cold = cold_nx;
             float4 exs[S];
 #pragma unroll
             for (int p = 0; p < S; ++p)
               exs[p] = *reinterpret_cast<const float4*>(buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE + WF_PAIR_DX);
             asm volatile("" ::: "memory");
             // unconditional (the last near source re-reads its own record, which is in the cache): a conditional load leaves
-            // "keeps its value" on the other path, a register copy per float and iteration
-            cold_nx = load_cold(near_bits ? i0 + (__builtin_ctzll(near_bits) / GS) : i);
+            // "keeps its value" on the other path, a register copy per float and iteration.  Behind the first LDS reads of the
+            // step: the compiler guards the first read of the staged chunk with s_waitcnt vmcnt(0) (the chunk arrives by
+            // LDS-DMA, counted in vmcnt), and a load issued before it would be waited for on the spot.
+            nxt = load_cold(near_bits ? i0 + (__builtin_ctzll(near_bits) / GS) : i);
             const SrcLog Sl = unpack(make_float2(0.0f, 0.0f), cold);
             const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
             static_for<S>([&](auto PP) { pass2(PP, Sl, side, true, exs[decltype(PP)::value], tvalid[decltype(PP)::value]); });
+          };
+          ColdRec cold_b = {};
+#pragma unroll 1
+          while (near_bits) {
+            const int k0 = __builtin_ctzll(near_bits) / GS;
+            near_bits &= near_bits - 1ull;
+            near_step(k0, cold_nx, cold_b);
+            if (!near_bits) break;
+            const int k1 = __builtin_ctzll(near_bits) / GS;
+            near_bits &= near_bits - 1ull;
+            near_step(k1, cold_b, cold_nx);
           }
         }
       } else {
