@@ -166,7 +166,8 @@ int wf_sync(wf_handle* h);
  * direction 3e-4 deg, TI 5e-6).  A FLAGGED farm left in float32 (wf_set_risk_resolve mode 0 — the C default; the Python
  * envs of this package switch mode 1 on) may differ by the bounded signature of its event, per flag combination
  * (tests/parity.py, measured maxima in brackets):
- *   POWER_KNEE alone        power 5e-2 [1.3e-2 on the cut-out drop]; wind field as an unflagged farm's
+ *   POWER_KNEE alone        power 5e-2 of max(P, 1 kW), or — a turbine ON the cut-out drop, where the power is next to
+ *                           nothing on one side — 2e-2 of the rated power [0.4e-2]; wind field as an unflagged farm's
  *   THRUST_RAMP, no OVERLAP power 1e-2, wind speed 1e-3, direction 1e-2 deg, TI 2e-4
  *   OVERLAP                 power 1e-1 [5.7e-2], wind speed 2e-2, direction 0.1 deg, TI 2e-2   (one overlap count flipped)
  *   OVERLAP | THRUST_RAMP   power 4e-1 [2.7e-1], wind speed 4e-2, direction 0.2 deg [0.13]     (a flip below ~4 m/s, where
@@ -305,7 +306,7 @@ typedef struct wf_kernel_choice {
                            exp2(-27) of the amplitude: no effect on any float32 result); 0: every pair is evaluated (A/B
                            and the bit-identity test, tests/test_hip_parity.py) */
   int calibrate;        /* -1 / 1: with one_block == -1, the third plain step after a (re)configuration times one launch of
-                           every kernel family the rounds model prices within 35 % of its best guess, on the handle's own
+                           every kernel family the rounds model prices within 60 % of its best guess, on the handle's own
                            batch / layout / wind (a few ms, once; that one call synchronises), and the fastest serves the
                            handle from then on; 0: the rounds model's guess stands (measured on one MI355X: wf_dispatch.hip) */
 } wf_kernel_choice;

@@ -43,6 +43,11 @@ RISK_OVERLAP, RISK_POWER_KNEE, RISK_THRUST_RAMP = 1, 2, 4
 # a farm on the thrust ramp without an overlap flag stays within a few TOL (power 7.7e-4, ws 6.9e-5, wd 8.9e-4 deg
 # measured; TI 1.3e-5 on the fixture farm with 48 turbines on the ramp).
 KNEE_ONLY_BOUND = dict(power=5e-2, ws=TOL["ws"], wd=TOL["wd"], ti=TOL["ti"], std=TOL["std"])
+# ... relative to max(P, 1 kW) that holds on the cut-in knee; on the cut-out DROP (nrel_5MW: 5 MW -> 0 between 25 and 25.01 m/s)
+# the power itself is next to nothing on one side, so the error of a turbine that sits on the drop is bounded in units of the
+# RATED power instead: a 3e-6 wind-speed error x 25 m/s on a slope of 5 MW / 0.01 m/s is 3.7e-2 of rated at most, 1.2e-2
+# where the segment is entered (measured: 6.2e-2 of max(P, 1 kW) = 0.4e-2 of rated, fuzz seed 1043 cases 396 / 452, round 4).
+KNEE_POWER_OF_RATED = 2e-2
 RAMP_BOUND = dict(power=1e-2, ws=1e-3, wd=1e-2, ti=2e-4, std=1e-2)
 # Both at once — an overlap-count flip at a turbine on the thrust ramp (below ~4 m/s, where Ct is steep and the power
 # curve amplifies a wind-speed change 6x): the two amplifiers compound.  Measured: power 0.27, ws 2.7e-2, wd 0.13 deg on
@@ -63,10 +68,14 @@ def flagged_within(e, flags, n_turbines):
     ok = np.where(both, within(e, OVERLAP_RAMP_BOUND, n_turbines), within(e, FLAGGED_BOUND, n_turbines))
     f = LARGE_FARM_FACTOR if n_turbines > 128 else 1.0
     ramp_no_overlap = ((flags & RISK_OVERLAP) == 0) & ((flags & RISK_THRUST_RAMP) != 0)
+    knee = (flags & RISK_POWER_KNEE) != 0
     for mask, bound in ((ramp_no_overlap, RAMP_BOUND), (flags == RISK_POWER_KNEE, KNEE_ONLY_BOUND)):
         inside = np.ones_like(ok)
         for k, t in bound.items():  # direction and TI keep their bound on large farms, as within(TOL) keeps them
-            inside &= e[k] <= t * (f if k in _SCALED_FOR_LARGE_FARMS else 1.0)
+            ok_k = e[k] <= t * (f if k in _SCALED_FOR_LARGE_FARMS else 1.0)
+            if k == "power" and "power_of_rated" in e:  # a knee-flagged farm: the cut-out drop is judged against rated power
+                ok_k |= knee & (e["power_of_rated"] <= KNEE_POWER_OF_RATED)
+            inside &= ok_k
         ok &= inside | ~mask
     return ok
 
@@ -76,7 +85,16 @@ def errors(got, ref):
     g = {k: np.asarray(v.cpu().numpy() if hasattr(v, "cpu") else v, dtype=np.float64) for k, v in got.items()
          if k in ("power", "wind_speed", "wind_direction", "load")}
     B = g["power"].shape[0]
+    extra = {}
+    model = getattr(ref, "model", None)
+    if hasattr(ref, "yaw"):  # c_oracle result with margin=True: the turbine table is known -> errors in units of rated power
+        from oracle.floris_gch_numpy import ModelParams
+
+        mp = model if model is not None else ModelParams()
+        rated = float(mp.ref_density * np.max(mp.power_table()))
+        extra["power_of_rated"] = (np.abs(g["power"] - ref["power"]) / rated).reshape(B, -1).max(axis=1)
     return dict(
+        **extra,
         power=(np.abs(g["power"] - ref["power"]) / np.maximum(ref["power"], 1e3)).reshape(B, -1).max(axis=1),
         ws=(np.abs(g["wind_speed"] - ref["wind_speed"]) / np.maximum(ref["wind_speed"], 0.1)).reshape(B, -1).max(axis=1),
         wd=np.abs(g["wind_direction"] - ref["wind_direction"]).reshape(B, -1).max(axis=1),

@@ -44,6 +44,13 @@ def test_a_flag_only_excuses_what_its_event_can_move():
     assert not parity.flagged_within(_e(wd=2e-2), np.array([ramp]), 200).any()
     assert not parity.flagged_within(_e(ti=3e-4), np.array([ramp]), 200).any()
     assert not parity.flagged_within(_e(ti=3e-2), np.array([ovl | ramp | knee]), 42).any()
+    # the cut-out drop of the power table (5 MW -> 0 within 0.01 m/s): a knee-flagged farm is judged against RATED power there
+    drop = _e(power=6.2e-2)
+    drop["power_of_rated"] = np.array([4e-3])
+    assert parity.flagged_within(drop, np.array([knee]), 91).all() and parity.flagged_within(drop, np.array([knee | ramp]), 91).all()
+    drop["power_of_rated"] = np.array([3e-2])
+    assert not parity.flagged_within(drop, np.array([knee]), 91).any()
+    assert not parity.flagged_within(drop, np.array([ramp]), 91).any()  # (no knee flag: no such allowance)
 
 
 def test_check_strict_admits_no_exemption():

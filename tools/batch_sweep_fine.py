@@ -39,10 +39,11 @@ if __name__ == "__main__":
         print(f"# {name} N={lay['num_turbines']}  (ms per step; farm-steps/s of the pick; pick / best family at this batch; pick / envelope)")
         env_best = 0.0
         worst_fam, worst_env = 1.0, 1.0
-        for B in range(4096, 131072 + 1, 4096):
+        step = int(os.environ.get("SWEEP_STEP", 4096))
+        for B in range(step, 131072 + 1, step):
             time_it(lay, B, None)  # (the first handle after a change of batch runs ~5 % slow whatever it is: tools/pick_vs_forced.py)
             ts = {f: time_it(lay, B, c)[0] for f, c in FAMS}
-            t_pick, fam_pick = time_it(lay, B, None)
+            t_pick, fam_pick = time_it(lay, B, None)  # (round 4: the handle calibrates itself on its third step — wf_kernel_choice::calibrate)
             t_best = min(ts.values())
             thr = B / t_pick * 1e3
             env_best = max(env_best, B / min(t_best, t_pick) * 1e3)

@@ -25,6 +25,8 @@ for label, ws, wd in (("shared 8 m/s 270 deg", 8.0, 270.0),
     for mode in (0, 1):
         w.set_risk_resolve(mode)
         out = w.step(yaw)
+        for _ in range(3):  # (the handle times its kernel families on its third table-path step: keep that out of the figures)
+            w.step(yaw, out)
         w.sync()
         w.timing_begin()
         for _ in range(10):

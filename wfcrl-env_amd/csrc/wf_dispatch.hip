@@ -384,8 +384,8 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
 // Per-handle calibration of the kernel family.  The rounds model above is a table of milliseconds measured on ONE box
 // for two layouts; layouts, directions, clocks and partitioned devices move the families against each other by up to
 // 10 %.  So the handle measures: on its third plain table-path step after a (re)configuration it launches every family
-// the model prices within 35 % of its best guess on the caller's own buffers (the step is stateless: the real launch
-// follows and overwrites them), times two launches of each with HIP events, and keeps the fastest.  A few ms, once;
+// the model prices within 60 % of its best guess on the caller's own buffers (the step is stateless: the real launch
+// follows and overwrites them), times three launches of each one by one with HIP events, and keeps the fastest.  A few ms, once;
 // that one call synchronises.  The rounds model remains the cold-start guess and the price list of grouped launches.
 static bool calibration_due(const wf_handle* h, const WfEnvArgs* ea) {
   if (h->calib_done || h->choice.calibrate == 0 || h->choice.one_block != -1 || h->choice.pair_table == 0) return false;
@@ -417,20 +417,25 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
   float best_ms = 1e30f;
   int rc = WF_OK;
   for (int fi = 0; fi < kNumFamilies && rc == WF_OK; ++fi) {
-    if (!(est[fi] <= 1.35 * best_est)) continue;
+    if (!(est[fi] <= 1.6 * best_est)) continue;
     const int code = kLlFamilies[fi].code;
     hipStreamSynchronize(h->stream);
     set_ll_shape(h, code >> 4, code ? (code & 15) : 1);
     if ((rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea)) != WF_OK) break;  // tables, log, first-launch costs
-    hipError_t e = hipEventRecord(e0, h->stream);
-    for (int r = 0; r < 2 && rc == WF_OK; ++r) rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
-    if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
-    float ms = 0.0f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e != hipSuccess) { rc = fail(h, WF_E_HIP, std::string("calibration: ") + hipGetErrorString(e)); break; }
-    h->calib_ms[fi] = 0.5f * ms;
-    if (0.5f * ms < best_ms) { best_ms = 0.5f * ms; best = fi; }
+    float fam_ms = 1e30f;  // the fastest of three launches timed one by one (two handles on one kernel differ by 3-5 %: noise counts)
+    for (int r = 0; r < 3 && rc == WF_OK; ++r) {
+      hipError_t e = hipEventRecord(e0, h->stream);
+      rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
+      if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      float ms = 0.0f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (e != hipSuccess) { rc = fail(h, WF_E_HIP, std::string("calibration: ") + hipGetErrorString(e)); break; }
+      if (ms < fam_ms) fam_ms = ms;
+    }
+    if (rc != WF_OK) break;
+    h->calib_ms[fi] = fam_ms;
+    if (fam_ms < best_ms) { best_ms = fam_ms; best = fi; }
   }
   hipEventDestroy(e0);
   hipEventDestroy(e1);

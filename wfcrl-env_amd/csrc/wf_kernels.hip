@@ -481,16 +481,21 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   // ---- transverse velocities of one source on the targets of register slot p [A.3-4] -------------------
   // table path: geometry-only coefficients of the (source, target) pair, one float4 {aV, bV, aW, bW} per grid
   // point, a grid column (three 16-byte reads) at a time
-  auto apply_tab = [&](int p, const float4* pr, float Gy, float Gwr) {
+  // Ratio form (round 4, as wf_step_ll_kernel's replay): with rho = Gy / Gwr,  max(Gy aW + Gwr bW, 0) = Gwr max(rho aW + bW, 0)
+  // for Gwr > 0 — the wake-rotation circulation gam_wr (a - a^2) ubar is positive — and Gwr min(rho aW + bW, 0) for
+  // Gwr < 0 (a rotor wind speed driven negative by an unphysically tight layout: the reference keeps computing): both are
+  // Gwr med3(rho aW + bW, 0, copysign(inf, Gwr)) — five instead of six instructions per grid point.  Gwr == 0 (transverse
+  // velocities switched off: Gy is 0 too): rho = 0, nothing is added.
+  auto apply_tab = [&](int p, const float4* pr, float rho, float Gwr) {
+    const float lim = copysignf(__builtin_inff(), Gwr);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float4 cf[3] = {pr[3 * j], pr[3 * j + 1], pr[3 * j + 2]};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int q = j * 3 + k;
-        st.V[p][q] = fmaf(Gwr, cf[k].y, fmaf(Gy, cf[k].x, st.V[p][q]));
-        const float ww = fmaf(Gwr, cf[k].w, Gy * cf[k].z);
-        st.W[p][q] += fmaxf(ww, 0.0f);  // W[W<0] = 0, quirk (5)
+        st.V[p][q] = fmaf(Gwr, fmaf(rho, cf[k].x, cf[k].y), st.V[p][q]);
+        st.W[p][q] = fmaf(Gwr, __builtin_amdgcn_fmed3f(fmaf(rho, cf[k].z, cf[k].w), 0.0f, lim), st.W[p][q]);  // W[W<0] = 0, quirk (5)
       }
     }
   };
@@ -605,6 +610,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const float cg = L.cg[eiw][i], sg = L.sg[eiw][i];
 
       // ---- C. pass 1: transverse velocities on every target at or downstream of the source --
+      const float rho_tab = (TAB && Gwt != 0.0f) ? Gy * frcp(Gwt) : 0.0f;  // (apply_tab's ratio form)
       float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
 #pragma unroll
       for (int p = 0; p < S; ++p) {
@@ -626,7 +632,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         }
         if (act) {
          if constexpr (TAB) {
-          apply_tab(p, reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]), Gy, Gwt);
+          apply_tab(p, reinterpret_cast<const float4*>(&prow[i & 1][t * WF_PAIR_STRIDE]), rho_tab, Gwt);
          } else {
           apply_fly(p, dx, (float)(L.yd[eiw][t] - yd_i), Gt, Gb, Gwt);
          }
@@ -894,7 +900,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         if constexpr (TAB) {
           // the source's table row is not staged yet: its (source, target) record comes straight from L2
           const float* rec = pair_tab + (size_t)i2 * WF_PAIR_ROW_FLOATS(NP) + (size_t)t0 * WF_PAIR_STRIDE;
-          if (rec[WF_PAIR_DX] >= 0.0f) apply_tab(0, reinterpret_cast<const float4*>(rec), Gy, Gwt);
+          if (rec[WF_PAIR_DX] >= 0.0f) apply_tab(0, reinterpret_cast<const float4*>(rec), Gwt != 0.0f ? Gy * frcp(Gwt) : 0.0f, Gwt);
         } else {
           if (dx0 >= 0.0f) apply_fly(0, dx0, (float)(L.yd[eiw][t0] - L.yd[eiw][i2]), Gt, Gb, Gwt);
         }

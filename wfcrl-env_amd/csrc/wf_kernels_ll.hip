@@ -186,6 +186,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
   __shared__ TableLds T;
   __shared__ __attribute__((aligned(16))) float prow[2][CHUNK_FLOATS];
   __shared__ unsigned risk_lds[WPB][EPW];
+  __shared__ int env_lds[WPB][EPW];  // farm index of every farm slot of the block (-1 - index: results dropped)
   extern __shared__ __attribute__((aligned(16))) float yaw_lds[];  // [WPB][EPW][n_pad] commanded yaw in sorted order, degrees; then [WPB][n_pad] float4 far bounds
 
   int grp = 0;
@@ -272,37 +273,52 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
 
   const size_t gofs = TAB ? (size_t)grp * N : (size_t)env * N;  // sorted geometry of the direction (group 0 for a shared wind) / of the farm
   const size_t yofs = (size_t)env * N;
-  float* yawL = yaw_lds + ((size_t)wave * EPW + eiw) * n_pad;
-  // commanded yaw of every turbine, in sorted order; fused MDP transition as in wf_step_kernel
+  // Commanded yaw of every turbine of the wave's farms -> LDS, in the CALLER'S turbine order (a block picks its own
+  // turbines through gidx when it starts), with the fused MDP transition as in wf_step_kernel.  The wave walks
+  // the flattened (farm of the wave, turbine) space 64 elements at a time: a wave-instruction reads / writes one or two
+  // contiguous row pieces (rounds 1-3 had lane = farm here: 64 four-byte accesses 320 bytes apart per instruction, in
+  // every array of the env state).
+  float* const yawW = yaw_lds + (size_t)wave * EPW * n_pad;  // [farm of the wave][turbine, caller's order]
+  float* const yawL = yawW + (size_t)eiw * n_pad;
   const bool env_mode = ea.yaw_state != nullptr;
   int moves_new = 0;
   if (env_mode && ea.action) moves_new = ea.moves[env] + 1;
-  for (int kb = 0; kb < nblk * S; ++kb) {
-    const int t = kb * G + sub;
-    const bool ok = t < N;
-    const size_t oi = yofs + gidx[gofs + (ok ? t : 0)];
-    float yw;
-    if (env_mode) {
-      yw = ea.yaw_state[oi];
-      if (ea.action) {
-        float a = ea.action[oi];
-        float acc = ea.acc[oi];
-        const float frac = __fdiv_rn(__fdiv_rn(__fdiv_rn(acc, ea.rate), (float)moves_new), ea.dt);
-        if (frac >= ea.budget) a = 0.0f;
-        if (ea.discrete) a = (a - 1.0f) * ea.yaw_step;
-        if (!ea.discrete) a = fminf(fmaxf(a, -ea.yaw_step), ea.yaw_step);
-        yw = fminf(fmaxf(yw + a, ea.yaw_lo), ea.yaw_hi);
-        acc += fabsf(a);
-        if (ok && env_ok) {
-          ea.yaw_state[oi] = yw;
-          ea.acc[oi] = acc;
+  if (sub == 0) env_lds[wave][eiw] = env_ok ? env : -1 - env;  // (a farm whose results are dropped still has a valid row to read)
+  {
+    int f = 0, o = lane;
+    while (o >= N) { o -= N; ++f; }
+    while (f < EPW) {
+      const int e_raw = env_lds[wave][f];
+      const bool okf = e_raw >= 0;
+      const int e = okf ? e_raw : -1 - e_raw;
+      const size_t oi = (size_t)e * N + o;
+      float yw;
+      if (env_mode) {
+        yw = ea.yaw_state[oi];
+        if (ea.action) {
+          float a = ea.action[oi];
+          float acc = ea.acc[oi];
+          const float frac = __fdiv_rn(__fdiv_rn(__fdiv_rn(acc, ea.rate), (float)(ea.moves[e] + 1)), ea.dt);
+          if (frac >= ea.budget) a = 0.0f;
+          if (ea.discrete) a = (a - 1.0f) * ea.yaw_step;
+          if (!ea.discrete) a = fminf(fmaxf(a, -ea.yaw_step), ea.yaw_step);
+          yw = fminf(fmaxf(yw + a, ea.yaw_lo), ea.yaw_hi);
+          acc += fabsf(a);
+          if (okf) {
+            ea.yaw_state[oi] = yw;
+            ea.acc[oi] = acc;
+          }
         }
+      } else {
+        yw = yaw_in[oi];
       }
-    } else {
-      yw = yaw_in[oi];
+      yawW[(size_t)f * n_pad + o] = yw;
+      o += 64;
+      while (o >= N) { o -= N; ++f; }
     }
-    yawL[t] = yw;
   }
+  // (the move counters are read above by every lane that holds an element of the farm, written here by the farm's first
+  // lane: the same wave, in program order)
   if (env_mode && ea.action && sub == 0 && env_ok) ea.moves[env] = moves_new;
   __syncthreads();
 
@@ -625,6 +641,9 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
     return R;
   };
   float* const logx = src_log + log_side_offset + (size_t)slot * n_pad * WF_LOG_SIDE_FLOATS;
+  int oidx[S], oidx_nx[S];  // caller's (unsorted) index of this lane's turbines: the current block's, the next block's
+#pragma unroll
+  for (int p = 0; p < S; ++p) oidx_nx[p] = gidx[gofs + min(p * G + sub, N - 1)];
   for (int J = 0; J < nblk; ++J) {
     int tt[S];
     bool tvalid[S];
@@ -644,7 +663,11 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
       for (int k = 0; k < NE; ++k) esq[p][k] = 0.0f;
 #pragma unroll
       for (int j = 0; j < 3; ++j) TI[p][j] = amb0;
-      yaw_t[p] = yawL[tvalid[p] ? tt[p] : 0];
+      // (the caller's index of this lane's turbine was fetched a block ahead: a load issued here would be waited for at
+      // the first LDS read of the replay, which the compiler guards with s_waitcnt vmcnt(0))
+      oidx[p] = oidx_nx[p];
+      oidx_nx[p] = gidx[gofs + min(tt[p] + GS, N - 1)];
+      yaw_t[p] = yawL[oidx[p]];
       sincos_yaw(yaw_t[p] * kDeg2Rad, sg_t[p], cg_t[p]);  // this lane's turbines: source constants (own block), power output
     }
 
@@ -1018,7 +1041,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
     for (int p = 0; p < S; ++p) {
       if (!tvalid[p]) continue;
       const int t = tt[p];
-      const int o = gidx[gofs + t];
+      const int o = oidx[p];
       float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
