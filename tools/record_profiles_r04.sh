@@ -5,8 +5,8 @@ R=$GRAFT_REPO_ROOT; cd $R
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 for cfg in cfg5 cfg3b cfg2; do python3 bench.py --config $cfg --steps 20 --cpu-seconds 4 > gpurun_out/${tag}_bench_$cfg.json 2> gpurun_out/${tag}_bench_$cfg.err; done
 python3 bench.py --per-env-wind --steps 20 --no-cpu-baseline --no-env-leg 2>/dev/null | grep "^{" > gpurun_out/${tag}_bench_cfg4_per_env_wind.json
-bash tools/quick_pmc.sh ${tag} > /dev/null 2>&1
-bash tools/quick_pmc.sh ${tag}_fly --per-env-wind > /dev/null 2>&1
+PMC_KERNEL="wf_step_ll_kernel<2, 2" bash tools/quick_pmc.sh ${tag} > /dev/null 2>&1
+PMC_KERNEL="wf_step_ll_kernel<4, 2, false, false" bash tools/quick_pmc.sh ${tag}_fly --per-env-wind > /dev/null 2>&1
 (python3 tools/resolve_cost.py HornsRev1_ 65536; python3 tools/resolve_cost.py HornsRev2_ 131072) 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_resolve_cost.txt
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_rocprof -- python3 $R/bench.py --no-cpu-baseline --no-env-leg > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/${tag}_rocprof.err
