@@ -113,6 +113,14 @@ int wf_set_batch(wf_handle* h, int env_batch);
  * serve the batch; series playback and binned sampling fall back to a geometry per farm.  The layouts may lie anywhere
  * (every lateral offset is taken from the float64 coordinates).  n_layouts == 1 equals wf_set_layout. */
 int wf_set_layouts(wf_handle* h, int n_layouts, const double* x, const double* y, const int* layout_of);
+/* ... of DIFFERENT turbine counts (the reference's registry builds `Turb<N>_Row1` for any N, registration.py:43-68; a
+ * learner trained across it needs several N in one batch): counts[l] in 1..n_turbines is the number of turbines layout l
+ * really has — its row of x / y holds them first, the rest is ignored.  The missing turbines become placeholders that
+ * the geometry kernel puts 10 000 km and more DOWNSTREAM of the farm for whatever direction it is rotated to: last in
+ * the sorted order, outside every reach and gate — they receive wakes and give none, so the real turbines' results are
+ * those of the unpadded farm.  Their outputs (columns counts[l] .. n_turbines-1 of a farm's rows, caller's order) are
+ * written as 0, and the fused reward averages over the real turbines.  counts == NULL: wf_set_layouts. */
+int wf_set_layouts_counts(wf_handle* h, int n_layouts, const double* x, const double* y, const int* counts, const int* layout_of);
 
 /* Replaces FlorisInterface.update_wind -> fi.reinitialize (interface.py:663-671).
  * count == 1: one (ws, wd) shared by the whole batch; count == env_batch: one per instance.

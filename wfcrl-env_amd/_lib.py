@@ -82,6 +82,7 @@ ABI = {
     "wf_set_layout": (C.c_int, [_P, C.c_int, _P, _P]),
     "wf_set_batch": (C.c_int, [_P, C.c_int]),
     "wf_set_layouts": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "wf_set_layouts_counts": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "wf_set_wind": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "wf_set_wind_counts": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int]),
     "wf_wind_sample_binned": (C.c_int, [_P, C.c_ulonglong, C.POINTER(WindDist), C.c_double]),

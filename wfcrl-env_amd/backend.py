@@ -52,6 +52,17 @@ class WfStep:
         self.env_batch = 0
         if model is not None:
             self.set_model(model)
+        ragged = (not isinstance(xcoords, np.ndarray) and len(xcoords) > 0 and hasattr(xcoords[0], "__len__")
+                  and len({len(r) for r in xcoords}) > 1)
+        if ragged:  # layouts of different turbine counts: the handle holds the largest, shorter rows are padded (set_layouts)
+            n = max(len(r) for r in xcoords)
+            big = max(range(len(xcoords)), key=lambda l: len(xcoords[l]))
+            self.set_layout(np.asarray(xcoords[big], np.float64), np.asarray(ycoords[big], np.float64))
+            self.set_batch(env_batch)
+            self.set_layouts(xcoords, ycoords, layout_of)
+            if kernel_choice:
+                self.set_kernel_choice(**kernel_choice)
+            return
         xy = np.asarray(xcoords, dtype=np.float64), np.asarray(ycoords, dtype=np.float64)
         if xy[0].ndim == 2:  # several layouts in the batch: [n_layouts][n_turbines], layout_of[env_batch] (set_layouts)
             self.set_layout(xy[0][0], xy[1][0])
@@ -99,20 +110,36 @@ class WfStep:
         check(self._lib.wf_set_layout(self._h, x.size, x.ctypes.data, y.ctypes.data), self._h)
         self.num_turbines = int(x.size)
 
-    def set_layouts(self, xcoords, ycoords, layout_of=None):
+    def set_layouts(self, xcoords, ycoords, layout_of=None, counts=None):
         """Several layouts in one batch (include/wfstep.h: wf_set_layouts): xcoords / ycoords [n_layouts][n_turbines],
         layout_of [env_batch] the layout of each farm (None: n_layouts == env_batch, farm b has layout b).  After
-        set_batch; the wind has to be set again."""
+        set_batch; the wind has to be set again.
+        Layouts of DIFFERENT turbine counts (wf_set_layouts_counts): `counts[l]` turbines of row l are real, or pass
+        ragged lists of coordinates — rows are padded to the handle's turbine count; the outputs of the padding are 0."""
+        if counts is None and not isinstance(xcoords, np.ndarray) and len({len(r) for r in xcoords}) > 1:
+            counts = [len(r) for r in xcoords]  # ragged lists
+            n = self.num_turbines
+            if max(counts) > n or any(len(a) != len(b) for a, b in zip(xcoords, ycoords)):
+                raise ValueError("every layout needs as many x as y coordinates, at most the handle's turbine count")
+            xcoords = [list(r) + [0.0] * (n - len(r)) for r in xcoords]
+            ycoords = [list(r) + [0.0] * (n - len(r)) for r in ycoords]
         x = np.ascontiguousarray(xcoords, dtype=np.float64)
         y = np.ascontiguousarray(ycoords, dtype=np.float64)
         if x.ndim != 2 or x.shape != y.shape or x.shape[1] != self.num_turbines:
             raise ValueError("xcoords and ycoords must both be [n_layouts][num_turbines]")
+        cn = None
+        if counts is not None:
+            cn = np.ascontiguousarray(counts, dtype=np.int32)
+            if cn.shape != (x.shape[0],):
+                raise ValueError("counts must have one entry per layout")
         lo = None
         if layout_of is not None:
             lo = np.ascontiguousarray(layout_of, dtype=np.int32)
             if lo.shape != (self.env_batch,):
                 raise ValueError("layout_of must have one entry per env")
-        check(self._lib.wf_set_layouts(self._h, x.shape[0], x.ctypes.data, y.ctypes.data, lo.ctypes.data if lo is not None else None), self._h)
+        check(self._lib.wf_set_layouts_counts(self._h, x.shape[0], x.ctypes.data, y.ctypes.data, cn.ctypes.data if cn is not None else None,
+                                              lo.ctypes.data if lo is not None else None), self._h)
+        self.turbine_counts = None if cn is None else cn.copy()  # per layout; None: every layout has num_turbines
 
     def set_batch(self, env_batch: int):
         check(self._lib.wf_set_batch(self._h, int(env_batch)), self._h)

@@ -125,12 +125,14 @@ int wf_set_stream(wf_handle* h, void* s, int external) {
 void* wf_get_stream(wf_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 // Layout data of the handle: K layouts of n turbines, their centres of rotation [A.1-1] and the farm -> layout map.
-static int upload_layouts(wf_handle* h, int n, int K, const double* x, const double* y, const int* layout_of) {
+// counts (or null): turbines each layout really has, 1..n — the rest of its row are placeholders (wf_set_layouts_counts)
+static int upload_layouts(wf_handle* h, int n, int K, const double* x, const double* y, const int* layout_of, const int* counts = nullptr) {
   std::vector<double> centre(2 * (size_t)K);
   for (int l = 0; l < K; ++l) {
     const double *xl = x + (size_t)l * n, *yl = y + (size_t)l * n;
     double xmin = xl[0], xmax = xl[0], ymin = yl[0], ymax = yl[0];
-    for (int i = 0; i < n; ++i) {
+    const int n_l = counts ? counts[l] : n;  // the centre of rotation is that of the REAL turbines' bounding box [A.1-1]
+    for (int i = 0; i < n_l; ++i) {
       if (!std::isfinite(xl[i]) || !std::isfinite(yl[i])) return fail(h, WF_E_INVALID, "turbine coordinates must be finite");
       xmin = std::fmin(xmin, xl[i]); xmax = std::fmax(xmax, xl[i]);
       ymin = std::fmin(ymin, yl[i]); ymax = std::fmax(ymax, yl[i]);
@@ -138,8 +140,9 @@ static int upload_layouts(wf_handle* h, int n, int K, const double* x, const dou
     centre[2 * l] = (xmin + xmax) / 2.0; centre[2 * l + 1] = (ymin + ymax) / 2.0;  // centre of rotation [A.1-1]
   }
   WF_HIP(h, hipStreamSynchronize(h->stream));
-  hipFree(h->d_lx); hipFree(h->d_ly); hipFree(h->d_centre); hipFree(h->d_layout_of);
-  h->d_lx = h->d_ly = h->d_centre = nullptr; h->d_layout_of = nullptr;
+  hipFree(h->d_lx); hipFree(h->d_ly); hipFree(h->d_centre); hipFree(h->d_layout_of); hipFree(h->d_layout_n); hipFree(h->d_nreal);
+  h->d_lx = h->d_ly = h->d_centre = nullptr; h->d_layout_of = h->d_layout_n = h->d_nreal = nullptr;
+  h->layout_n.clear();
   const size_t kn = (size_t)K * n;
   WF_HIP(h, hipMalloc(&h->d_lx, sizeof(double) * kn));
   WF_HIP(h, hipMalloc(&h->d_ly, sizeof(double) * kn));
@@ -152,6 +155,19 @@ static int upload_layouts(wf_handle* h, int n, int K, const double* x, const dou
     h->layout_of.assign(layout_of, layout_of + h->B);
     WF_HIP(h, hipMalloc(&h->d_layout_of, sizeof(int) * h->B));
     WF_HIP(h, hipMemcpy(h->d_layout_of, layout_of, sizeof(int) * h->B, hipMemcpyHostToDevice));
+  }
+  if (counts) {
+    bool ragged = false;
+    for (int l = 0; l < K; ++l) ragged = ragged || counts[l] != n;
+    if (ragged) {
+      h->layout_n.assign(counts, counts + K);
+      std::vector<int> nreal((size_t)h->B);
+      for (int b = 0; b < h->B; ++b) nreal[b] = counts[layout_of ? layout_of[b] : (K == 1 ? 0 : b)];
+      WF_HIP(h, hipMalloc(&h->d_layout_n, sizeof(int) * K));
+      WF_HIP(h, hipMalloc(&h->d_nreal, sizeof(int) * h->B));
+      WF_HIP(h, hipMemcpy(h->d_layout_n, counts, sizeof(int) * K, hipMemcpyHostToDevice));
+      WF_HIP(h, hipMemcpy(h->d_nreal, nreal.data(), sizeof(int) * h->B, hipMemcpyHostToDevice));
+    }
   }
   h->lx.assign(x, x + kn); h->ly.assign(y, y + kn);
   h->n_layouts = K;
@@ -215,6 +231,10 @@ int wf_set_batch(wf_handle* h, int B) {
   return WF_OK;
 }
 int wf_set_layouts(wf_handle* h, int n_layouts, const double* x, const double* y, const int* layout_of) {
+  return wf_set_layouts_counts(h, n_layouts, x, y, nullptr, layout_of);
+}
+
+int wf_set_layouts_counts(wf_handle* h, int n_layouts, const double* x, const double* y, const int* counts, const int* layout_of) {
   if (!h || !x || !y) return WF_E_INVALID;
   if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_layout and wf_set_batch must be called before wf_set_layouts");
   if (n_layouts < 1 || n_layouts > h->B) return fail(h, WF_E_INVALID, "n_layouts must be in 1..env_batch");
@@ -223,9 +243,12 @@ int wf_set_layouts(wf_handle* h, int n_layouts, const double* x, const double* y
   if (layout_of)
     for (int b = 0; b < h->B; ++b)
       if (layout_of[b] < 0 || layout_of[b] >= n_layouts) return fail(h, WF_E_INVALID, "layout_of entry out of range");
+  if (counts)
+    for (int l = 0; l < n_layouts; ++l)
+      if (counts[l] < 1 || counts[l] > h->N) return fail(h, WF_E_INVALID, "turbine count of a layout must be in 1..n_turbines of the handle");
   WF_ON_DEVICE(h);
   {
-    int rc = upload_layouts(h, h->N, n_layouts, x, y, n_layouts > 1 ? layout_of : nullptr);
+    int rc = upload_layouts(h, h->N, n_layouts, x, y, n_layouts > 1 ? layout_of : nullptr, counts);
     if (rc != WF_OK) return rc;
   }
   h->wind_count = 0; h->shared_dir = false; h->pair_dirty = true;

@@ -113,6 +113,9 @@ struct WfGroupArgs {
                          // are served by wf_step_ll_kernel, launched with the opposite predicate)
   const int* farm_pred;  // [B] the same per farm (a wind per farm): wf_step_kernel serves the farms with farm_pred[b] != 0
   int* risk_flags;       // [B] out: WF_RISK_* bits of each farm; null = not written
+  const int* n_real;     // [B] turbines the farm really has (wf_set_layouts_counts: layouts of fewer than N turbines are
+                         // padded with placeholders far downstream, which nothing real can see); null = N.  Outputs of
+                         // the placeholders are written as 0 and stay out of the reward.
 };
 #define WF_RISK_OVERLAP 1
 #define WF_RISK_POWER_KNEE 2

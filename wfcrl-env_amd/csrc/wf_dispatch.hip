@@ -269,7 +269,7 @@ int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
   const bool per_farm = n_env == h->B && h->B > 1 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h));
   // several layouts in the batch (wf_set_layouts): a geometry per farm whatever the wind (the callers pass n_env == B)
   WF_HIP(h, wfk_launch_geometry(n_env, h->N, h->d_lx, h->d_ly, h->d_centre, h->n_layouts == 1 ? 0 : (h->d_layout_of ? 2 : 1),
-                                h->d_layout_of, d_wd, 1, h->d_gx, h->d_gy, h->d_gidx,
+                                h->d_layout_of, h->d_layout_n, d_wd, 1, h->d_gx, h->d_gy, h->d_gidx,
                                 per_farm ? ll_fly_G(h) * ll_fly_S(h) : 0, h->d_farm_tie, h->d_farm_tie ? h->d_farm_tie + h->B : nullptr,
                                 h->stream));
   h->farm_ties = 2;
@@ -330,6 +330,7 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
   WfGroupArgs ga{};
   ga.mod = 1;
   ga.risk_flags = h->d_flags;
+  ga.n_real = h->d_nreal;
   ga.blk_unit = 1;
   if (h->n_groups > 0) {
     ga.perm = h->d_perm; ga.blk_group = h->d_blk_group; ga.n_blocks = h->n_blocks;
@@ -474,6 +475,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
     ra.shift = h->group_shift; ra.mod = h->n_groups;
   }
   ra.ws = h->d_ws; ra.wd = h->d_wd; ra.wind_stride = h->wind_count == 1 ? 0 : 1;
+  ra.n_real = h->d_nreal;
   ra.yaw_in = yaw;
   ra.o_power = power; ra.o_ws = wspd; ra.o_wd = wdir; ra.o_load = load;
   if (ea) {

@@ -13,6 +13,7 @@ void ungroup(wf_handle* h) {
     if (llg && ((llg >> 4) != h->ll_G || (llg & 15) != h->ll_S)) {
       hipStreamSynchronize(h->stream);
       set_ll_shape(h, llg >> 4, llg & 15);
+      reset_calibration(h);  // (back on the rounds model's guess: the plain batch is timed again on its third step)
     }
   }
   h->n_groups = 0;
@@ -112,7 +113,7 @@ int build_groups(wf_handle* h, const int* group_of_farm, int K, const double* d_
   }
   if (rebuild_geometry) {
     // group g: direction g of the one layout, or layout g under its direction (wf_set_layouts: groups are the layouts)
-    WF_HIP(h, wfk_launch_geometry(K, h->N, h->d_lx, h->d_ly, h->d_centre, h->n_layouts == 1 ? 0 : 1, nullptr, d_wd_groups, 1, h->d_gx, h->d_gy,
+    WF_HIP(h, wfk_launch_geometry(K, h->N, h->d_lx, h->d_ly, h->d_centre, h->n_layouts == 1 ? 0 : 1, nullptr, h->d_layout_n, d_wd_groups, 1, h->d_gx, h->d_gy,
                                   h->d_gidx, 0, nullptr, nullptr, h->stream));
     h->pair_dirty = true;
   }

@@ -32,7 +32,7 @@ extern "C" int wfk_variant_has_table(int i);
 extern "C" int wfk_tab_waves();
 extern "C" const void* wfk_variant_fn(int i, int kind);
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, const double* centre,
-                                          int layout_mode, const int* layout_of, const double* wd, int wd_stride, double* gx,
+                                          int layout_mode, const int* layout_of, const int* layout_n, const double* wd, int wd_stride, double* gx,
                                           double* gy, int* gidx, int tie_block, int* farm_tie, int* any_tie, hipStream_t s);
 extern "C" int wfk_ll_has_fly(int G, int S);
 extern "C" int wfk_ll_has_veer(int G, int S, int table);
@@ -91,6 +91,11 @@ struct wf_handle {
   std::vector<int> layout_of;
   int* d_layout_of = nullptr;
   double* d_centre = nullptr;  // [n_layouts][2] centres of rotation
+  // wf_set_layouts_counts: layouts of fewer than N turbines, padded with placeholders (wf_geometry_kernel puts them far
+  // downstream of the real ones): turbines per layout, and per farm (null: every farm has all N)
+  std::vector<int> layout_n;
+  int* d_layout_n = nullptr;   // [n_layouts]
+  int* d_nreal = nullptr;      // [B]
   int B = 0;
   int wind_count = 0;  // 0 = not set
   int variant = -1;

@@ -63,6 +63,7 @@
 // by layout_of[e] (2) — wf_set_layouts; centre[2 l], centre[2 l + 1] is the centre of rotation of layout l.
 __global__ void wf_geometry_kernel(int N, const double* __restrict__ lx, const double* __restrict__ ly,
                                    const double* __restrict__ centre, int layout_mode, const int* __restrict__ layout_of,
+                                   const int* __restrict__ layout_n,
                                    const double* __restrict__ wd, int wd_stride, double* __restrict__ gx,
                                    double* __restrict__ gy, int* __restrict__ gidx, int tie_block, int* __restrict__ farm_tie,
                                    int* __restrict__ any_tie) {
@@ -81,12 +82,25 @@ __global__ void wf_geometry_kernel(int N, const double* __restrict__ lx, const d
   const double a = dev * (M_PI / 180.0);
   const double ca = cos(a), sa = sin(a);
   double xr = 0.0, yr = 0.0;
-  if (t < N) {
+  const int n_l = layout_n ? layout_n[l] : N;  // turbines layout l really has (wf_set_layouts_counts), the rest are placeholders
+  if (t < n_l) {
     const double xo = lx[t] - xc, yo = ly[t] - yc;
     xr = xo * ca - yo * sa + xc;
     yr = xo * sa + yo * ca + yc;
     sx[t] = xr;
   }
+  __syncthreads();
+  if (t >= n_l && t < N) {
+    // A placeholder sits 10 000 km and more DOWNSTREAM of every real turbine, each further than the last, whatever the wind
+    // direction: last in the sorted order, out of every reach and gate, no x' tie — it receives (negligible) wakes and
+    // gives none to a real turbine, so the real turbines' results are those of the unpadded farm.
+    double mx = sx[0];
+    for (int u = 1; u < n_l; ++u) mx = fmax(mx, sx[u]);
+    xr = mx + 1.0e7 * (double)(t - n_l + 1);
+    yr = yc;
+  }
+  __syncthreads();
+  if (t >= n_l && t < N) sx[t] = xr;
   __syncthreads();
   if (t < N) {
     int rank = 0;
@@ -575,6 +589,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
 
   const int nblk = (N + G - 1) / G;
   float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
+  const int n_real = ga.n_real ? ga.n_real[env] : N;  // turbines the farm really has (padded layouts: WfGroupArgs)
   // Register slot p holds turbine block blk + p: once a block's own sources are done nothing downstream in the
   // recurrence touches it again, so its outputs are written and the slots shift down by one (static indices).
   for (int blk = 0; blk < nblk; ++blk) {
@@ -967,14 +982,15 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
         l.y = fsqrt(su * (1.0f / 9.0f));
         l.z = fsqrt(sv * (1.0f / 9.0f));
         l.w = fsqrt(sw * (1.0f / 9.0f));
-        psum += pwr;
-        lsum += (l.x + l.y) + (l.z + l.w);  // loads are non-negative: |.| is the identity
+        const bool real = o < n_real;  // (a placeholder of a padded layout: zeros out, nothing into the reward)
+        psum += real ? pwr : 0.0f;
+        lsum += real ? (l.x + l.y) + (l.z + l.w) : 0.0f;  // loads are non-negative: |.| is the identity
         if (env_ok) {
           const size_t oo = yofs + o;
-          if (o_power) o_power[oo] = pwr;
-          if (o_ws) o_ws[oo] = wsp;
-          if (o_wd) o_wd[oo] = wd - adir * (kRad2Deg / 9.0f);
-          if (o_load) reinterpret_cast<float4*>(o_load)[oo] = l;
+          if (o_power) o_power[oo] = real ? pwr : 0.0f;
+          if (o_ws) o_ws[oo] = real ? wsp : 0.0f;
+          if (o_wd) o_wd[oo] = real ? wd - adir * (kRad2Deg / 9.0f) : 0.0f;
+          if (o_load) reinterpret_cast<float4*>(o_load)[oo] = real ? l : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
       }
     }
@@ -999,7 +1015,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       lsum += __shfl_xor(lsum, w);
     }
     if (sub == 0 && env_ok) {
-      const float invN = __fdiv_rn(1.0f, (float)N);
+      const float invN = __fdiv_rn(1.0f, (float)n_real);
       const float wr = ea.ws_prev ? (float)ea.ws_prev[env] : ws;  // normalised by the PREVIOUS state's free wind
       const float r = psum * invN * 1.0e-3f * frcp(wr * wr * wr) - ea.load_coef * lsum * invN * 0.25f;
       ea.reward[env] = r;
@@ -1132,14 +1148,14 @@ extern "C" const void* wfk_variant_fn(int i, int kind) {
 }
 
 extern "C" hipError_t wfk_launch_geometry(int n_env, int N, const double* lx, const double* ly, const double* centre,
-                                          int layout_mode, const int* layout_of, const double* wd, int wd_stride, double* gx,
+                                          int layout_mode, const int* layout_of, const int* layout_n, const double* wd, int wd_stride, double* gx,
                                           double* gy, int* gidx, int tie_block, int* farm_tie, int* any_tie, hipStream_t s) {
   const int threads = ((N + 63) / 64) * 64;
   if (tie_block > 0) {
     hipError_t e = hipMemsetAsync(any_tie, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(wf_geometry_kernel, dim3(n_env), dim3(threads), 0, s, N, lx, ly, centre, layout_mode, layout_of, wd,
+  hipLaunchKernelGGL(wf_geometry_kernel, dim3(n_env), dim3(threads), 0, s, N, lx, ly, centre, layout_mode, layout_of, layout_n, wd,
                      wd_stride, gx, gy, gidx, tie_block, farm_tie, any_tie);
   return hipGetLastError();
 }

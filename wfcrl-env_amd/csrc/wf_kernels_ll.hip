@@ -601,6 +601,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
   };
 
   float psum = 0.0f, lsum = 0.0f;  // per-lane partial sums for the fused reward
+  const int n_real = ga.n_real ? ga.n_real[env] : N;  // turbines the farm really has (padded layouts: WfGroupArgs)
 #ifdef WF_LL_STAMP
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   WF_T(st_begin);
@@ -1092,14 +1093,15 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
       l.y = fsqrt(su * (1.0f / 9.0f));
       l.z = fsqrt(sv * (1.0f / 9.0f));
       l.w = fsqrt(sw * (1.0f / 9.0f));
-      psum += pwr;
-      lsum += (l.x + l.y) + (l.z + l.w);
+      const bool real = o < n_real;  // (a placeholder of a padded layout: zeros out, nothing into the reward)
+      psum += real ? pwr : 0.0f;
+      lsum += real ? (l.x + l.y) + (l.z + l.w) : 0.0f;
       if (env_ok) {
         const size_t oo = yofs + o;
-        if (o_power) o_power[oo] = pwr;
-        if (o_ws) o_ws[oo] = wsp;
-        if (o_wd) o_wd[oo] = wd - adir * (kRad2Deg / 9.0f);
-        if (o_load) reinterpret_cast<float4*>(o_load)[oo] = l;
+        if (o_power) o_power[oo] = real ? pwr : 0.0f;
+        if (o_ws) o_ws[oo] = real ? wsp : 0.0f;
+        if (o_wd) o_wd[oo] = real ? wd - adir * (kRad2Deg / 9.0f) : 0.0f;
+        if (o_load) reinterpret_cast<float4*>(o_load)[oo] = real ? l : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
     }
     WF_T(st_f);
@@ -1122,7 +1124,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
       lsum += __shfl_xor(lsum, w);
     }
     if (sub == 0 && env_ok) {
-      const float invN = __fdiv_rn(1.0f, (float)N);
+      const float invN = __fdiv_rn(1.0f, (float)n_real);
       const float wr = ea.ws_prev ? (float)ea.ws_prev[env] : ws;
       const float r = psum * invN * 1.0e-3f * frcp(wr * wr * wr) - ea.load_coef * lsum * invN * 0.25f;
       ea.reward[env] = r;

@@ -40,6 +40,7 @@ struct WfResolveArgs {
   int shift, mod;       // geometry index of group g = (g + shift) % mod
   const double *ws, *wd;
   int wind_stride;
+  const int* n_real;       // [B] turbines the farm really has (padded layouts, wf_device.h: WfGroupArgs::n_real), or null
   const float* yaw_in;     // [B][N] commanded yaw (plain step)
   const float* yaw_state;  // [B][N] env state after the transition (fused env step), or null
   float *o_power, *o_ws, *o_wd, *o_load;  // caller's outputs, each may be null

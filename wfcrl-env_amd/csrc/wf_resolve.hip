@@ -424,6 +424,7 @@ __device__ __noinline__ void res_outputs(const WfResolveArgs& a, int b, size_t g
   const int lane = threadIdx.x, N = R.N;
   const double wd = R.wd;
   double psum = 0.0, lsum = 0.0;
+  const int n_real = a.n_real ? a.n_real[b] : N;  // turbines the farm really has (padded layouts)
   for (int t = lane; t < N; t += 64) {
     const int o = a.gidx[gofs + t];
     double m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0, dir = 0.0;
@@ -458,13 +459,14 @@ __device__ __noinline__ void res_outputs(const WfResolveArgs& a, int b, size_t g
     const double veff = c.dens_cbrt * (wsp * exp(c.pP3 * log(RES_CG(t))));
     const double pw = c.rho_ref * interp_fill(veff, c.n_table, R.tws, R.tpw, 0.0, 0.0);
     const double l0 = (RES_ST(27, t) + RES_ST(28, t) + RES_ST(29, t)) / 3.0, l1 = sqrt(su / 9.0), l2 = sqrt(sv / 9.0), l3 = sqrt(sw / 9.0);
-    psum += pw;
-    lsum += fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3);
+    const bool real = o < n_real;  // (a placeholder of a padded layout: zeros out, nothing into the reward)
+    psum += real ? pw : 0.0;
+    lsum += real ? fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3) : 0.0;
     const size_t oo = (size_t)b * N + o;
-    if (a.o_power) a.o_power[oo] = (float)pw;
-    if (a.o_ws) a.o_ws[oo] = (float)wsp;
-    if (a.o_wd) a.o_wd[oo] = (float)(dir / 9.0);
-    if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = make_float4((float)l0, (float)l1, (float)l2, (float)l3);
+    if (a.o_power) a.o_power[oo] = real ? (float)pw : 0.0f;
+    if (a.o_ws) a.o_ws[oo] = real ? (float)wsp : 0.0f;
+    if (a.o_wd) a.o_wd[oo] = real ? (float)(dir / 9.0) : 0.0f;
+    if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = real ? make_float4((float)l0, (float)l1, (float)l2, (float)l3) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   if (a.reward) {  // reference simple_env.py:78-84 on the float64 values
 #pragma unroll
@@ -474,7 +476,7 @@ __device__ __noinline__ void res_outputs(const WfResolveArgs& a, int b, size_t g
     }
     if (lane == 0) {
       const double wr = a.ws_prev ? a.ws_prev[b] : R.ws;
-      a.reward[b] = (float)(psum / N / 1.0e6 * 1.0e3 / (wr * wr * wr) - (double)a.load_coef * lsum / (4.0 * N));
+      a.reward[b] = (float)(psum / n_real / 1.0e6 * 1.0e3 / (wr * wr * wr) - (double)a.load_coef * lsum / (4.0 * n_real));
     }
   }
 }
@@ -886,6 +888,7 @@ __device__ __noinline__ void res4_outputs(const WfResolveArgs& a, int b, size_t 
   const int N = R4.N;
   const double wd = R4.wd;
   double psum = 0.0, lsum = 0.0;
+  const int n_real = a.n_real ? a.n_real[b] : N;  // turbines the farm really has (padded layouts)
   for (int t = threadIdx.x; t < N; t += 256) {
     const int o = a.gidx[gofs + t];
     double m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0, dir = 0.0;
@@ -920,13 +923,14 @@ __device__ __noinline__ void res4_outputs(const WfResolveArgs& a, int b, size_t 
     const double veff = c.dens_cbrt * (wsp * exp(c.pP3 * log(RES4_CG(t))));
     const double pw = c.rho_ref * interp_fill(veff, c.n_table, R4.tws, R4.tpw, 0.0, 0.0);
     const double l0 = (RES4_ST(27, t) + RES4_ST(28, t) + RES4_ST(29, t)) / 3.0, l1 = sqrt(su / 9.0), l2 = sqrt(sv / 9.0), l3 = sqrt(sw / 9.0);
-    psum += pw;
-    lsum += fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3);
+    const bool real = o < n_real;  // (a placeholder of a padded layout: zeros out, nothing into the reward)
+    psum += real ? pw : 0.0;
+    lsum += real ? fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3) : 0.0;
     const size_t oo = (size_t)b * N + o;
-    if (a.o_power) a.o_power[oo] = (float)pw;
-    if (a.o_ws) a.o_ws[oo] = (float)wsp;
-    if (a.o_wd) a.o_wd[oo] = (float)(dir / 9.0);
-    if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = make_float4((float)l0, (float)l1, (float)l2, (float)l3);
+    if (a.o_power) a.o_power[oo] = real ? (float)pw : 0.0f;
+    if (a.o_ws) a.o_ws[oo] = real ? (float)wsp : 0.0f;
+    if (a.o_wd) a.o_wd[oo] = real ? (float)(dir / 9.0) : 0.0f;
+    if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = real ? make_float4((float)l0, (float)l1, (float)l2, (float)l3) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   if (a.reward) {  // reference simple_env.py:78-84 on the float64 values
 #pragma unroll
@@ -940,7 +944,7 @@ __device__ __noinline__ void res4_outputs(const WfResolveArgs& a, int b, size_t 
       double ps = 0.0, ls = 0.0;
       for (int w = 0; w < 4; ++w) { ps += R4.red[w][0]; ls += R4.red[w][1]; }
       const double wr = a.ws_prev ? a.ws_prev[b] : R4.ws;
-      a.reward[b] = (float)(ps / N / 1.0e6 * 1.0e3 / (wr * wr * wr) - (double)a.load_coef * ls / (4.0 * N));
+      a.reward[b] = (float)(ps / n_real / 1.0e6 * 1.0e3 / (wr * wr * wr) - (double)a.load_coef * ls / (4.0 * n_real));
     }
   }
 }

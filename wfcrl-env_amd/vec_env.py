@@ -64,10 +64,11 @@ class VecWindFarmEnv:
         # opt-out for throughput runs that accept the per-flag bounds of include/wfstep.h on flagged farms.
         self.fi.set_risk_resolve(1 if risk_resolve else 0)
         # layouts: several layouts in the batch — dict(xcoords=[K][N], ycoords=[K][N], layout_of=[env_batch] or None for
-        # K == env_batch), each with the case's number of turbines (backend.WfStep.set_layouts); the case's own layout is
-        # then only the default the handle returns to
+        # K == env_batch[, counts=[K]]), each with the case's number of turbines or — with `counts`, or ragged lists of
+        # coordinates — fewer (backend.WfStep.set_layouts: observations, powers and loads of the missing turbines are 0,
+        # the reward averages over the real ones); the case's own layout is then only the default the handle returns to
         if layouts is not None:
-            self.fi.set_layouts(layouts["xcoords"], layouts["ycoords"], layouts.get("layout_of"))
+            self.fi.set_layouts(layouts["xcoords"], layouts["ycoords"], layouts.get("layout_of"), layouts.get("counts"))
         self.fi.env_config(yaw_lo=spec[0], yaw_hi=spec[1], yaw_step=spec[2],
                            actuator_rate=WindFarmMDP.ACTUATORS_RATE["yaw"], dt=self.dt, budget=actuation_budget,
                            load_coef=load_coef, discrete=not continuous_control)
