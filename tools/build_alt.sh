@@ -6,7 +6,8 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 make -s -C wfcrl-env_amd/csrc > /dev/null
-F="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -fno-fast-math -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
+SCHED=${SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp}  # SCHED="" for the default scheduler
+F="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -fno-fast-math -ffp-contract=off -fno-slp-vectorize $SCHED"
 mkdir -p build/alt
 /opt/rocm/bin/hipcc $F "$@" -c -o build/alt/ll_$name.o wfcrl-env_amd/csrc/wf_kernels_ll.hip
 C=wfcrl-env_amd/csrc
