@@ -76,3 +76,26 @@ def test_graft_entry_build_passes():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.build()
+
+
+def test_pmc_index_points_at_committed_counter_files():
+    """bench.py quotes roofline.traffic / valu_roofline from the rocprofv3 --pmc collection profiles/pmc_index.json names for
+    the kernel it launched: every entry's file is committed and carries the counters bench.py reads, and the entry bench.py
+    looks up for the headline (cfg4 at 65536 farms) is this round's."""
+    import json
+    import os
+
+    from conftest import ROOT
+
+    idx = json.load(open(os.path.join(ROOT, "profiles", "pmc_index.json")))
+    for key, e in idx.items():
+        if key.startswith("_"):
+            continue
+        path = os.path.join(ROOT, e["file"])
+        assert os.path.isfile(path), (key, e["file"])
+        pmc = json.load(open(path))
+        assert "SQ_INSTS_VALU" in pmc, key
+        assert "TCC_EA0_RDREQ_128B_sum" in pmc or ("FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc), key
+        assert set(e["kernel"]) <= {"lanes_per_env", "slots_per_lane", "one_block_kernel", "pair_table"}, key
+    head = idx["cfg4_B65536"]
+    assert head["file"].startswith("profiles/r04_") and head["kernel"] == dict(lanes_per_env=2, slots_per_lane=2, one_block_kernel=1, pair_table=1)

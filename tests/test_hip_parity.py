@@ -373,9 +373,10 @@ def test_full_size_properties_hornsrev2_sweep(layouts):
     w.close()
 
 
-@pytest.mark.parametrize("name,wd", [("HornsRev1_", 270.0), ("HornsRev1_", 283.0), ("HornsRev1_", 231.0),
-                                     ("HornsRev2_", 270.0), ("HornsRev2_", 255.0), ("HornsRev2_", 300.0)])
-def test_far_skip_is_a_no_op_in_float32(layouts, name, wd):
+@pytest.mark.parametrize("name,wd,veer", [("HornsRev1_", 270.0, 0.0), ("HornsRev1_", 283.0, 0.0), ("HornsRev1_", 231.0, 0.0),
+                                          ("HornsRev2_", 270.0, 0.0), ("HornsRev2_", 255.0, 0.0), ("HornsRev2_", 300.0, 0.0),
+                                          ("HornsRev1_", 270.0, 4.0), ("HornsRev2_", 291.0, -6.0)])
+def test_far_skip_is_a_no_op_in_float32(layouts, name, wd, veer):
     """The far-source / far-pair skip of the one-block kernel (csrc/wf_kernels_ll.hip: far_bound, pass2) claims that what
     it leaves out cannot change a float32 result.  Same farms with the skip on and off (wf_kernel_choice::far_skip) on
     every table-path family: identical risk flags; outputs bit-identical on all but a handful of values, and those within
@@ -390,10 +391,14 @@ def test_far_skip_is_a_no_op_in_float32(layouts, name, wd):
     rng = np.random.default_rng(int(wd) * 7 + N)
     yaw = torch.from_numpy(rng.uniform(-40, 40, (B, N)).astype(np.float32)).cuda()
     ws = np.where(rng.random(B) < 0.5, rng.uniform(3.2, 6.0, B), rng.uniform(6.0, 12.0, B))
-    for fam, wsx in (("2x2", 8.0), ("2x2", ws), ("4x2", ws), ("4", 8.0), ("8", ws)):  # one speed (constants in SGPRs) / a speed per farm
+    fams = (("2x2", 8.0), ("2x2", ws), ("4x2", ws), ("4", 8.0), ("8", ws))  # one speed (constants in SGPRs) / a speed per farm
+    if veer:  # wind veer: the rotated Gaussian, bounded through its larger width; the families instantiated with it
+        fams = (("2x2", 8.0), ("4x2", ws), ("4", ws))
+    for fam, wsx in fams:
         res = {}
         for skip in (True, False):
-            w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, kernel_choice=dict(one_block=fam, far_skip=skip))
+            w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, model=dict(veer=veer) if veer else None,
+                       kernel_choice=dict(one_block=fam, far_skip=skip))
             w.set_wind(wsx, wd)
             assert w.kernel_info()["one_block_kernel"] == 1
             d = w.step(yaw)

@@ -854,22 +854,26 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
         //        is <= 2.115 for sM = sqrt(ct) <= 1 — ct is clipped to 0.9999 — and the wake only widens: kyd >= 0]
         // hold; with per-column constants (split TI) the growth rate is taken at the largest column TI, the near-wake
         // length and the log prefactor at the smallest (both fall with TI), and the near-wake credit is dropped.
-        float kyv_m = Sc.kyv, bb = fmaf(-Sc.kyv, Sc.x0v, Sc.sy0v);
+        // (wind veer: the Gaussian is rotated — r = a yy^2 - 2 b yy zz + c zz^2 >= yy^2 / (2 sigma_max^2), the smaller
+        // eigenvalue of the form — so the bound takes the larger of the two widths: sigma_z, which starts from sz0v >= sy0v and
+        // grows at the same rate)
+        const float s0 = VEER ? c.sz0v : Sc.sy0v;
+        float kyv_m = Sc.kyv, bb = fmaf(-Sc.kyv, Sc.x0v, s0);
         float db = fabsf(Sc.tan_th0 * Sc.x0d) + 2.2f * fabsf(Sc.pj);
         if (__any(split)) {
           const float TImax = fmaxf(TIs[0], fmaxf(TIs[1], TIs[2])), TImin = fminf(TIs[0], fminf(TIs[1], TIs[2]));
           const float x0d_m = x0num_d * frcp(fmaf(c.alpha4_d, TImin, b2om_d));
           const float pj_m = pfac * frcp(fmaf(c.ka_d, TImin, c.kb_d));
           kyv_m = fmaf(c.ka, TImax + X.dTI, c.kb);
-          bb = split ? Sc.sy0v : bb;
+          bb = split ? s0 : bb;
           db = fabsf(Sc.tan_th0 * x0d_m) + 2.2f * fabsf(pj_m);
         }
         const float dbo = db + c.off[2];
-        float k6 = c.far_k * kyv_m, b6 = fmaf(c.far_k, bb, dbo), n6 = fmaf(c.far_k, fmaxf(Sc.snw, Sc.sy0v), dbo);
+        float k6 = c.far_k * kyv_m, b6 = fmaf(c.far_k, bb, dbo), n6 = fmaf(c.far_k, fmaxf(Sc.snw, s0), dbo);
         k6 = wave_max<G>(k6);
         b6 = wave_max<G>(b6);
         n6 = wave_max<G>(n6);
-        if (!c.far_on || VEER) { k6 = 0.0f; b6 = 0.0f; n6 = 3.0e38f; }  // never far (the rotated Gaussian of a veer model is not bounded this way)
+        if (!c.far_on) { k6 = 0.0f; b6 = 0.0f; n6 = 3.0e38f; }  // never far
         if (lane == 0) bndL[i] = make_float4(k6, b6, n6, 0.0f);
       }
       WF_T(so_4);
