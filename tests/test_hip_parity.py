@@ -379,9 +379,8 @@ def test_full_size_properties_hornsrev2_sweep(layouts):
 def test_far_skip_is_a_no_op_in_float32(layouts, name, wd, veer):
     """The far-source / far-pair skip of the one-block kernel (csrc/wf_kernels_ll.hip: far_bound, pass2) claims that what
     it leaves out cannot change a float32 result.  Same farms with the skip on and off (wf_kernel_choice::far_skip) on
-    every table-path family: identical risk flags; outputs bit-identical on all but a handful of values, and those within
-    2 ulp (a skipped pair would have added ~1e-17 of a deficit^2 to a sum of ~1e-4: the bits can only differ where the
-    exact sum sits within 1e-12 of a rounding boundary).  |yaw| up to 40 deg, wind speeds from cut-in to rated."""
+    every table-path family: identical risk flags and BIT-IDENTICAL outputs (a skipped pair would have added ~1e-17 of a
+    deficit^2 to a sum of ~1e-4: less than half an ulp).  |yaw| up to 40 deg, wind speeds from cut-in to rated."""
     import torch
 
     from wfcrl_env_amd.backend import WfStep
@@ -415,7 +414,10 @@ def test_far_skip_is_a_no_op_in_float32(layouts, name, wd, veer):
             # (std values near zero are differences of nearly equal numbers: held to an absolute 1e-9 m/s instead)
             ok = (ulp <= 2) | (np.abs(a[k].astype(np.float64) - b[k]) <= 1e-9)
             assert ok.all(), (fam, k, int((~ok).sum()), float(np.abs(a[k].astype(np.float64) - b[k]).max()))
-        assert n_diff <= 1e-4 * B * N * 7, (fam, n_diff)
+        print(f"far skip on / off, {name} wd {wd} veer {veer} family {fam}: {n_diff} of {B * N * 7} output values differ")
+        # measured on the round's final build (profiles/r04_far_skip_identity.txt): 0 of 1.1-1.3 M values in every case — a
+        # skipped pair would add less than half an ulp to any sum that is not itself negligible — so the claim is held to that
+        assert n_diff == 0, (fam, n_diff)
 
 
 def test_per_handle_kernel_calibration(layouts):
