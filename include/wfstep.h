@@ -176,7 +176,9 @@ int wf_sync(wf_handle* h);
  * (tests/parity.py, measured maxima in brackets):
  *   POWER_KNEE alone        power 5e-2 of max(P, 1 kW), or — a turbine ON the cut-out drop, where the power is next to
  *                           nothing on one side — 2e-2 of the rated power [0.4e-2]; wind field as an unflagged farm's
- *   THRUST_RAMP, no OVERLAP power 1e-2, wind speed 1e-3, direction 1e-2 deg, TI 2e-4
+ *   THRUST_RAMP, no OVERLAP power 1e-2, wind speed 1e-3, direction 1e-2 deg, TI 2e-4 — on the cut-in ramp / cut-out drop; raised
+ *                           for Ct > 0.995 (user tables) there is NO float32 bound: velocities behind such turbines approach
+ *                           zero (TI off by 0.7 seen on a dense farm behind a table clipped at 0.9999) — use the re-solve
  *   OVERLAP                 power 1e-1 [5.7e-2], wind speed 2e-2, direction 0.1 deg, TI 2e-2   (one overlap count flipped)
  *   OVERLAP | THRUST_RAMP   power 4e-1 [2.7e-1], wind speed 4e-2, direction 0.2 deg [0.13]     (a flip below ~4 m/s, where
  *                           the thrust ramp and the power curve both amplify it: 1.5 x the one measured case)

@@ -145,6 +145,17 @@ def table_flag_conditions(ref, slack=0.05, near=2e-4):
     return cond(veff, tpw, "knee"), cond(wsd, tct, "ramp")
 
 
+def ct_near_unity(ref, lim=0.995 - 1e-4):
+    """(B,) bool: SOME turbine of the farm has, in float64, a thrust coefficient above 0.995 — only a user table gets there
+    (nrel_5MW peaks at 0.99).  The kernels raise WF_RISK_THRUST_RAMP for it (csrc/wf_kernel_common.h: table_ct): behind such a
+    turbine the velocity is a small difference of O(1) numbers (deficit ~ 1), rotor speeds approach zero, and the float32
+    result carries NO bound (layout fuzzer, round 4: TI off by 0.7 on a farm of 108 turbines in 60 m spacing behind a table
+    clipped at 0.9999) — the float64 re-solve, on by default in the envs, is the answer there.  Needs ref.model."""
+    p = ref.model
+    ct = np.interp(np.asarray(ref["wind_speed"], float), np.asarray(p.table_ws, float), np.asarray(p.table_ct, float))
+    return (ct > lim).reshape(ct.shape[0], -1).any(axis=1)
+
+
 def summarize(got, ref, flags, guard_rel=2e-5):
     """Classification of a batch: dict with
       n, n_flagged, n_bad_unflagged (must be 0), n_bad_flagged (beyond FLAGGED_BOUND: must be 0),
@@ -156,6 +167,11 @@ def summarize(got, ref, flags, guard_rel=2e-5):
     n_turbines = np.asarray(ref["power"]).shape[-1]
     strict = within(e, TOL, n_turbines)
     bounded = flagged_within(e, flags, n_turbines)  # a flip deep inside a 256-turbine farm moves more behind it: 3x there too
+    if getattr(ref, "model", None) is not None and hasattr(ref, "yaw"):
+        # a thrust-flagged farm with Ct > 0.995 somewhere: no float32 bound (ct_near_unity) beyond finite outputs
+        finite = np.all([np.isfinite(np.asarray(v.cpu().numpy() if hasattr(v, "cpu") else v, dtype=np.float64)).reshape(fl.size, -1).all(axis=1)
+                         for k, v in got.items() if k in ("power", "wind_speed", "wind_direction", "load")], axis=0)
+        bounded = bounded | (((flags & RISK_THRUST_RAMP) != 0) & ct_near_unity(ref) & finite)
     out = dict(n=int(fl.size), n_flagged=int(fl.sum()), n_bad_unflagged=int((~strict & ~fl).sum()),
                n_bad_flagged=int((~bounded & fl).sum()), n_mismatch_flagged=int((~strict & fl).sum()),
                worst_unflagged={k: float(v[~fl].max()) if (~fl).any() else 0.0 for k, v in e.items()},

@@ -420,6 +420,56 @@ def test_far_skip_is_a_no_op_in_float32(layouts, name, wd, veer):
         assert n_diff == 0, (fam, n_diff)
 
 
+def test_per_farm_launch_order_follows_the_kernel_shape():
+    """The geometry pass of a wind per farm lays out the tie flags and the direction-sorted launch order for ONE block
+    shape of the on-the-fly kernel.  The shape changing afterwards — a grouped launch (wind series) that had moved the
+    handle from the 128-farm blocks of G = 2 to G = 4, left again by the next wf_set_wind; a veer model switched on and
+    off — must not leave the launch reading an order laid out for other blocks (round 4: farm slots past the end of the
+    list read as farm 0, whose env state was then stepped once per such slot).  Fused env steps of a batch that is not
+    a multiple of any block size, against the float32 transition of the reference and a handle configured in one go."""
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    from fuzz_api import mdp_step_f32
+    from wfcrl_env_amd.backend import WfStep
+
+    rng = np.random.default_rng(5)
+    N, B = 43, 1537
+    x, y = rng.uniform(0, 4000, N), rng.uniform(0, 4000, N)
+    envp = dict(yaw_lo=-30.0, yaw_hi=40.0, yaw_step=4.0, actuator_rate=0.3, dt=60.0, budget=0.02, load_coef=0.1, discrete=True)
+    ws, wd = rng.uniform(4, 20, B), rng.uniform(0, 360, B)
+    series = np.stack([rng.uniform(4, 20, 5), rng.uniform(0, 360, 5)], axis=1)
+    for fam in ("2x2", "4x2", "8"):
+        w = WfStep(x, y, env_batch=B, kernel_choice=dict(one_block=fam))
+        w.env_config(**envp)
+        w.set_wind_series(series, start=rng.integers(0, 5, B).astype(np.int32))  # direction groups: may change the block shape
+        w.env_reset()
+        w.env_step(rng.integers(0, 3, (B, N)).astype(np.float32))
+        ref = WfStep(x, y, env_batch=B, kernel_choice=dict(one_block=fam))
+        ref.env_config(**envp)
+        for leg, veer in (("after a series", None), ("veer on", 3.0), ("veer off", 0.0)):
+            if veer is not None:
+                w.set_model(dict(veer=veer))
+                ref.set_model(dict(veer=veer))
+            w.set_wind(torch.from_numpy(ws).cuda(), torch.from_numpy(wd).cuda())  # (a veer toggle asks for the wind again)
+            ref.set_wind(ws, wd)  # (the reference handle lays its geometry out after every change)
+            st = w.env_get_state()
+            ref.env_set_state(st)
+            act = rng.integers(0, 3, (B, N)).astype(np.float32)
+            got = w.env_step(torch.from_numpy(act).cuda())
+            exp = ref.env_step(act)
+            yaw_new = mdp_step_f32(st, act, envp)
+            assert np.array_equal(got["yaw"].cpu().numpy(), yaw_new), (fam, leg)
+            st2 = w.env_get_state()
+            assert np.array_equal(st2["moves"], st["moves"] + 1), (fam, leg)
+            for k in ("power", "wind_speed", "reward"):
+                assert np.array_equal(got[k].cpu().numpy(), np.asarray(exp[k])), (fam, leg, k)
+        w.close()
+        ref.close()
+
+
 def test_per_handle_kernel_calibration(layouts):
     """wf_kernel_choice::calibrate (default on): the third plain table-path step times the kernel families the rounds model
     prices close to its best guess on the handle's own batch and keeps the fastest (csrc/wf_dispatch.hip:
@@ -1061,8 +1111,8 @@ def test_one_block_kernel_on_the_fly_with_a_wind_per_farm(layouts, name, G, monk
     # the table path and the on-the-fly path of one handle share the source log; at G = 4 they use different block
     # sizes (one slot per lane on the table path, two on the fly): alternate them
     lanes = int(G.split("x")[0])
-    k = w.kernel_info()  # on the fly: two slots at G = 4, and G = 4 x 2 stands in for G = 2
-    assert (k["lanes_per_env"], k["slots_per_lane"]) == ((4, 2) if lanes <= 4 else (lanes, 1))
+    k = w.kernel_info()  # on the fly: two slots at G = 4 whatever the table path uses; G = 2 x 2 as on the table path
+    assert (k["lanes_per_env"], k["slots_per_lane"]) == ((lanes, 2) if lanes <= 4 else (lanes, 1))
     w.set_wind(9.0, 281.0)
     assert w.kernel_info()["pair_table"] == 1 and w.kernel_info()["one_block_kernel"] == (1 if N > lanes * (2 if "x2" in G else 1) else 0)
     _check(_with_flags(w, w.step(yaw)), _oracle(l["xcoords"], l["ycoords"], 9.0, 281.0, yaw))

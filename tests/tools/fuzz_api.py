@@ -198,6 +198,18 @@ def run(n_sessions, n_ops, seed):
                 if not np.array_equal(got["yaw"], yaw_new):
                     nbad += 1
                     print("BAD yaw transition", dict(session=sess, seed=seed, N=N, B=B, envp=envp), np.abs(got["yaw"] - yaw_new).max(), log[-12:], flush=True)
+                    where = np.argwhere(got["yaw"] != yaw_new)
+                    print("   (farm, turbine) got / expected / state before / action:",
+                          [(int(b), int(t), float(got["yaw"][b, t]), float(yaw_new[b, t]), float(st["yaw"][b, t]), float(act[b, t])) for b, t in where[:8]],
+                          "of", len(where), w.kernel_info(), flush=True)
+                    st2 = w.env_get_state()
+                    b0 = int(where[0][0])
+                    print("   farm", b0, "acc before", st["acc"][b0][:12], "after", st2["acc"][b0][:12], "moves", int(st["moves"][b0]), "->", int(st2["moves"][b0]),
+                          "yaw after", st2["yaw"][b0][:12], flush=True)
+                    if os.environ.get("FUZZ_DUMP"):
+                        ws_, wd_ = w.get_wind()
+                        np.savez(os.environ["FUZZ_DUMP"], x=x, y=y, ws=ws_, wd=wd_, yaw=st["yaw"], acc=st["acc"], moves=st["moves"], act=act,
+                                 got_yaw=got["yaw"], got_power=got["power"], got_wd=got["wind_direction"], envp=np.array(repr(envp)), llg=np.array(llg))
                 ref, ws = oracle(yaw_new.astype(np.float64))
                 last_yaw = yaw_new
                 check("env_step", got, ref)

@@ -274,6 +274,7 @@ int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
                                 h->stream));
   h->farm_ties = 2;
   h->dir_slots = 0;
+  h->geo_tie_block = per_farm ? ll_fly_G(h) * ll_fly_S(h) : 0;
   if (per_farm && h->n_layouts == 1 && h->choice.fly_one_block != 0 && h->choice.far_skip != 0) {
     // launch order of the on-the-fly one-block kernel: ascending wind direction (wf_sort.hip), padded to its whole blocks
     const int fpb = wfk_ll_farms_per_block(ll_fly_G(h));
@@ -305,9 +306,14 @@ int run_geometry(wf_handle* h, int n_env, const double* d_wd, bool sync_ok) {
 // Target slots per lane of the one-block kernel ON THE FLY (a wind per farm): two at G = 4 whatever the table path
 // uses — there the second slot halves the per-source geometry work as well (HornsRev1 x 65536: 3.48 ms against 4.14).
 int ll_fly_S(const wf_handle* h) { return h->ll_G <= 4 ? 2 : h->ll_S; }
-// ... and its lane-group width: the table path's, except that G = 2 and G = 16 have no on-the-fly instantiation
-// (G = 4 x 2 / G = 8 serve)
-int ll_fly_G(const wf_handle* h) { return h->ll_G == 2 ? 4 : (h->ll_G == 16 ? 8 : h->ll_G); }
+// ... and its lane-group width: the table path's where an on-the-fly instantiation exists
+int ll_fly_G(const wf_handle* h) {
+  // G = 2 x 2 on the fly too where the table path runs it (round 4: with the farms of a wave sorted by direction its
+  // 4-turbine blocks make the wave-level far test take — 3.31 against 3.49 ms at HornsRev1 x 65536; round 3, before the
+  // skips: 3.43 against 3.40); a veer model has no such instantiation, and neither has G = 16: G = 4 x 2 / G = 8 serve
+  if (h->ll_G == 2) return h->model.veer != 0.0 ? 4 : 2;
+  return h->ll_G == 16 ? 8 : h->ll_G;
+}
 
 // turbines per farm in the source log of the one-block kernel: whole lane-group blocks (of the larger of the two
 // block sizes: the table path and the on-the-fly path share the buffer)
@@ -365,6 +371,11 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
       hipFree(h->d_src_log); h->d_src_log = nullptr; h->log_slots_cap = 0;
       WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * ll_npad(h) * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
       h->log_slots_cap = slots;
+    }
+    // The tie flags and the launch order were laid out by the geometry pass for ONE block shape; a change of shape
+    // since (leaving a grouped launch, a veer model switched on or off) means another pass over the same wind first.
+    if (h->geo_tie_block != ll_fly_G(h) * ll_fly_S(h)) {
+      if ((rc = run_geometry(h, h->B, h->d_wd, false)) != WF_OK) return rc;
     }
     WfGroupArgs gf = ga;
     if (h->dir_slots > 0 && h->n_groups == 0) gf.perm = h->d_dir_perm;  // farms of like direction share a wave (run_geometry)

@@ -164,6 +164,7 @@ struct wf_handle {
   void* d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0, dir_perm_cap = 0;
   int dir_slots = 0;           // 0 = no direction order (identity)
+  int geo_tie_block = 0;       // turbines per block the per-farm tie flags / launch order of the last geometry pass were laid out for
   int farm_ties = 2;           // a wind per farm: 0 no farm has such a tie, 1 some have, 2 not read back
   bool wind_sync = true;       // the wind was set by a call that synchronises anyway (host arrays, series, binned sampling)
   int ll_ties = 2;             // cross-block ties of the current directions: 0 none, 1 all of them, 2 some / not read back

@@ -1208,7 +1208,7 @@ extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const 
 // (G, S) shapes instantiated with wind veer: table path 4x1, 4x2, 2x2; on the fly 4x2
 extern "C" int wfk_ll_has_veer(int G, int S, int table) { return table ? ((G == 4 && S <= 2) || (G == 2 && S == 2)) : (G == 4 && S == 2); }
 
-extern "C" int wfk_ll_has_fly(int G, int S) { return (G == 4 && S <= 2) || (G == 8 && S == 1); }
+extern "C" int wfk_ll_has_fly(int G, int S) { return (G == 4 && S <= 2) || (G == 8 && S == 1) || (G == 2 && S == 2); }
 
 // a wind per farm: gx / gy [B][N] sorted coordinates of every farm, farm_tie [B] the per-farm cross-block-tie flags
 extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, const WfTables* tab, const int* gidx, const double* gx,
@@ -1229,6 +1229,7 @@ extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, co
     return hipErrorInvalidValue;
   }
   WF_LL_DISPATCH(4, 2, WF_LL_LAUNCH_FLY);
+  WF_LL_DISPATCH(2, 2, WF_LL_LAUNCH_FLY);
   WF_LL_DISPATCH(4, 1, WF_LL_LAUNCH_FLY);
   WF_LL_DISPATCH(8, 1, WF_LL_LAUNCH_FLY);
   return hipErrorInvalidValue;
@@ -1247,6 +1248,7 @@ extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int
 #define WF_LL_ATTR_FLY(G_, S_) hipFuncGetAttributes(a, (const void*)&wf_step_ll_kernel<G_, S_, false, false, true, kLLWaves>)
   if (!table) {
     WF_LL_DISPATCH(4, 2, WF_LL_ATTR_FLY);
+    WF_LL_DISPATCH(2, 2, WF_LL_ATTR_FLY);
     WF_LL_DISPATCH(4, 1, WF_LL_ATTR_FLY);
     WF_LL_DISPATCH(8, 1, WF_LL_ATTR_FLY);
     return hipErrorInvalidValue;

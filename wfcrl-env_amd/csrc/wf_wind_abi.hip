@@ -62,6 +62,7 @@ int wf_set_wind_counts(wf_handle* h, const double* ws, int n_ws, const double* w
     WF_HIP(h, wfk_launch_fill(h->B, h->d_wd, h->stream));
   if (h->n_layouts > 1) return set_wind_layouts(h, n_ws, n_ws == 1 || same_dir, on_device);
   const int count = n_ws;
+  ungroup(h);  // (first: the geometry pass lays out tie flags and launch order for the kernel shape of the plain batch)
   {
     int rc = run_geometry(h, same_dir ? 1 : count, h->d_wd, !on_device);
     if (rc != WF_OK) return rc;
@@ -71,7 +72,6 @@ int wf_set_wind_counts(wf_handle* h, const double* ws, int n_ws, const double* w
   h->wind_sync = !on_device;
   h->wind_count = count;
   h->series_T = 0;
-  ungroup(h);
   h->ws_prev_valid = false;
   h->pair_dirty = true;
   return WF_OK;
@@ -90,6 +90,7 @@ int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* di
     return fail(h, WF_E_INVALID, "invalid wind distribution parameters");
   const double dv[8] = {d.ws_scale, d.ws_shape, d.ws_lo, d.ws_hi, d.wd_mean, d.wd_std, d.wd_lo, d.wd_hi};
   WF_HIP(h, wfk_launch_wind_sample(h->B, seed, dv, h->d_ws, h->d_wd, h->stream));
+  ungroup(h);  // (before the geometry pass: see wf_set_wind_counts)
   {
     int rc = run_geometry(h, h->B, h->d_wd, false);
     if (rc != WF_OK) return rc;
@@ -98,7 +99,6 @@ int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* di
   h->shared_dir = false;
   h->wind_sync = false;
   h->series_T = 0;
-  ungroup(h);
   h->ws_prev_valid = false;
   h->pair_dirty = true;  // env_batch 1: "one wind per farm" is also "one wind for the batch" (table path)
   return WF_OK;
