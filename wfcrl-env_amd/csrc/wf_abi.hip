@@ -25,7 +25,7 @@ void free_batch(wf_handle* h) {
   hipFree(h->d_series_ws); hipFree(h->d_series_wd); hipFree(h->d_series_start); hipFree(h->d_ws_prev);
   hipFree(h->d_pair_tab); hipFree(h->d_pair_first); h->d_pair_tab = nullptr; h->d_pair_first = nullptr; h->pair_dirty = true;
   hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
-  h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
+  h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_records_cap = 0;
   hipFree(h->d_perm); hipFree(h->d_blk_group); hipFree(h->d_group_wd); hipFree(h->d_bins);
   h->d_perm = h->d_blk_group = h->d_bins = nullptr; h->d_group_wd = nullptr;
   h->perm_cap = h->blk_cap = h->pair_groups_cap = 0; h->n_groups = 0; h->grid_step = 0.0;

@@ -190,7 +190,7 @@ void apply_kernel_pick(wf_handle* h, int N, int B, bool* variant_changed) {
 void set_ll_shape(wf_handle* h, int G, int S) {
   if (G == h->ll_G && S == h->ll_S) return;
   hipFree(h->d_ll_tab); hipFree(h->d_ll_flag); hipFree(h->d_src_log);
-  h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_slots_cap = 0;
+  h->d_ll_tab = h->d_src_log = nullptr; h->d_ll_flag = nullptr; h->ll_groups_cap = h->log_records_cap = 0;
   h->ll_G = G; h->ll_S = S; h->pair_dirty = true;
 }
 // Shared wind: (re)build the geometry-only pair table after the geometry kernel (same stream).  Returns the table
@@ -326,6 +326,19 @@ int ll_log_fpb(const wf_handle* h) {
   const int a = wfk_ll_farms_per_block(h->ll_G), b = wfk_ll_farms_per_block(ll_fly_G(h));
   return a > b ? a : b;
 }
+// The source log of the one-block kernel: `slots` farm slots x ll_npad(h) records of WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS
+// floats.  Both factors can grow under an unchanged (G, S) — the batch, and the block size of the on-the-fly kernel with a
+// veer model (ll_fly_G) — so the capacity is kept in records and checked at every launch.
+static int ensure_log(wf_handle* h, size_t slots, size_t* records) {
+  *records = slots * ll_npad(h);
+  if (*records > h->log_records_cap) {
+    WF_HIP(h, hipStreamSynchronize(h->stream));
+    hipFree(h->d_src_log); h->d_src_log = nullptr; h->log_records_cap = 0;
+    WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * *records * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
+    h->log_records_cap = *records;
+  }
+  return WF_OK;
+}
 // One launch of the step kernel on the handle's stream with the handle's current geometry / wind / table state.
 int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
   const int gstride = (h->wind_count == 1 || h->shared_dir) ? 0 : h->N;
@@ -348,16 +361,12 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
     // behind it, serves the others (device-side predicate, no host round trip)
     const int fpb = ll_log_fpb(h);  // (farm slots of the log: whole blocks of the wider of the two paths' blocks)
     const size_t slots = h->n_groups > 0 ? (size_t)h->n_slots : (size_t)((h->B + fpb - 1) / fpb) * fpb;
-    if (slots > h->log_slots_cap) {
-      WF_HIP(h, hipStreamSynchronize(h->stream));
-      hipFree(h->d_src_log); h->d_src_log = nullptr; h->log_slots_cap = 0;
-      WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * ll_npad(h) * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
-      h->log_slots_cap = slots;
-    }
+    size_t log_records = 0;
+    if ((rc = ensure_log(h, slots, &log_records)) != WF_OK) return rc;
     if (h->ll_ties != 1)
       WF_HIP(h, wfk_launch_step_ll(h->ll_G, h->ll_S, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
                                    load, h->B, ea, h->d_ll_tab, h->d_ll_flag, h->d_src_log,
-                                   h->log_slots_cap * ll_npad(h), &ga, h->stream));
+                                   log_records, &ga, h->stream));
     if (h->ll_ties == 0) return WF_OK;
     ga.pred = h->d_ll_flag;
   }
@@ -366,12 +375,8 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
     // an x' tie across a block boundary (per-farm device flags from the geometry kernel)
     const int fpb = ll_log_fpb(h);
     const size_t slots = (size_t)((h->B + fpb - 1) / fpb) * fpb;
-    if (slots > h->log_slots_cap) {
-      WF_HIP(h, hipStreamSynchronize(h->stream));
-      hipFree(h->d_src_log); h->d_src_log = nullptr; h->log_slots_cap = 0;
-      WF_HIP(h, hipMalloc(&h->d_src_log, sizeof(float) * slots * ll_npad(h) * (WF_LOG_FLOATS + WF_LOG_SIDE_FLOATS)));
-      h->log_slots_cap = slots;
-    }
+    size_t log_records = 0;
+    if ((rc = ensure_log(h, slots, &log_records)) != WF_OK) return rc;
     // The tie flags and the launch order were laid out by the geometry pass for ONE block shape; a change of shape
     // since (leaving a grouped launch, a veer model switched on or off) means another pass over the same wind first.
     if (h->geo_tie_block != ll_fly_G(h) * ll_fly_S(h)) {
@@ -381,7 +386,7 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
     if (h->dir_slots > 0 && h->n_groups == 0) gf.perm = h->d_dir_perm;  // farms of like direction share a wave (run_geometry)
     WF_HIP(h, wfk_launch_step_ll_fly(ll_fly_G(h), ll_fly_S(h), &h->consts, h->d_tab, h->d_gidx, h->d_gx, h->d_gy, h->d_ws, h->d_wd, yaw,
                                      power, wspd, wdir, load, h->B, ea, h->d_farm_tie, h->d_src_log,
-                                     h->log_slots_cap * ll_npad(h), &gf, h->stream));
+                                     log_records, &gf, h->stream));
     if (h->farm_ties == 0) return WF_OK;
     ga.farm_pred = h->d_farm_tie;
   }

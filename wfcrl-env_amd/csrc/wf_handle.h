@@ -154,7 +154,7 @@ struct wf_handle {
   float* d_ll_tab = nullptr;   // [groups][wfk_ll_table_floats]
   int* d_ll_flag = nullptr;    // [groups] 1 = cross-block tie
   float* d_src_log = nullptr;  // R = launch slots x padded N records: [R][2] hot, [R][12] cold, [R][4] side (wf_device.h)
-  size_t ll_groups_cap = 0, log_slots_cap = 0;
+  size_t ll_groups_cap = 0, log_records_cap = 0;
   int* d_farm_tie = nullptr;   // [B] + 1: per-farm cross-block-tie flag of the per-farm geometry, then the "any" flag
   // a wind per farm: launch slots of the on-the-fly one-block kernel in ascending wind direction (wf_sort.hip), so that the
   // farms of a wave nearly share their geometry and the kernel's wave-uniform skips take

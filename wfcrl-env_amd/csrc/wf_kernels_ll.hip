@@ -1045,7 +1045,6 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
 #pragma unroll
     for (int p = 0; p < S; ++p) {
       if (!tvalid[p]) continue;
-      const int t = tt[p];
       const int o = oidx[p];
       float U[9], m3 = 0.0f, mu = 0.0f, mv = 0.0f, mw = 0.0f, adir = 0.0f;
 #pragma unroll
