@@ -332,7 +332,8 @@ def main():
         r = {}
         for mode, key in ((0, "float32_only"), (1, "with_float64_resolve")):
             w.set_risk_resolve(mode)
-            step_fn(0)
+            for _ in range(3):  # (the handle times its kernels once on the third plain step of a configuration: not in the timed region)
+                step_fn(0)
             w.sync()
             w.timing_begin()
             for i in range(nst):

@@ -315,7 +315,8 @@ typedef struct wf_kernel_choice {
                            more than 6.12 sigma_y + D/4 off the wake's centre line (the nearest rotor-grid column would get
                            exp2(-27) of the amplitude: no effect on any float32 result); 0: every pair is evaluated (A/B
                            and the bit-identity test, tests/test_hip_parity.py) */
-  int calibrate;        /* -1 / 1: with one_block == -1, the third plain step after a (re)configuration times one launch of
+  int calibrate;        /* -1 / 1: with one_block == -1, the third step after a (re)configuration (a fused env step is timed
+                           without its action: a solve at the current yaw state, no transition) times one launch of
                            every kernel family the rounds model prices within 60 % of its best guess, on the handle's own
                            batch / layout / wind (a few ms, once; that one call synchronises), and the fastest serves the
                            handle from then on; 0: the rounds model's guess stands (measured on one MI355X: wf_dispatch.hip) */
@@ -325,6 +326,10 @@ int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c);
  * = wf_step_kernel, -1 = it has not run for the current configuration; family_ms[6] = ms per launch of the families it
  * timed, in the order {wf_step_kernel, 8x1, 4x2, 4x1, 2x2, 16x1}, 0 = not timed.  Either pointer may be NULL. */
 int wf_get_calibration(wf_handle* h, int* code, float* family_ms);
+/* The same for the on-the-fly path (a wind per farm: the third plain step there times wf_step_ll_kernel of the table
+ * path's family against wf_step_kernel, which has to win by 3 %): *choice = 0 not timed yet, 1 wf_step_ll_kernel, 2
+ * wf_step_kernel; ms[2] = ms per launch of the two.  Either pointer may be NULL. */
+int wf_get_fly_calibration(wf_handle* h, int* choice, float* ms);
 int wf_get_kernel_choice(wf_handle* h, wf_kernel_choice* c);
 
 const char* wf_last_error(wf_handle* h); /* h may be NULL: last error of a failed wf_create */

@@ -512,6 +512,48 @@ def test_per_handle_kernel_calibration(layouts):
     w.close()
 
 
+def test_on_the_fly_calibration(layouts):
+    """A wind per farm (the reference's resets, mdp.py:237-258): the third plain step times the one-block kernel of the
+    table path's family against the register-slot kernel on the handle's own batch and keeps the slot kernel only when it
+    wins by 3 % (csrc/wf_dispatch.hip: calibrate_fly); the step that follows is inside the contract whichever runs, a
+    forced family or calibrate=False is left alone, and a reconfiguration starts over."""
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    N, B = 80, 16384
+    rng = np.random.default_rng(78)
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    ws, wd = np.clip(8 * rng.weibull(8, B), 3, 28), rng.normal(270, 20, B) % 360
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w.set_wind(ws, wd)
+    assert w.kernel_info()["one_block_kernel"] == 1 and w.calibration()["on_the_fly"] is None
+    for _ in range(2):
+        w.step(yaw)
+    assert w.calibration()["on_the_fly"] is None  # not before the third step
+    out = w.step(yaw)
+    cal = w.calibration()
+    ms = cal["on_the_fly_ms"]
+    assert cal["on_the_fly"] in ("one_block", "slot") and set(ms) == {"one_block", "slot"}, cal
+    assert cal["on_the_fly"] == ("slot" if ms["slot"] < 0.97 * ms["one_block"] else "one_block"), cal
+    assert w.kernel_info()["one_block_kernel"] == (0 if cal["on_the_fly"] == "slot" else 1)
+    idx = rng.choice(B, 48, replace=False)
+    ref = _oracle(l["xcoords"], l["ycoords"], ws[idx], wd[idx], yaw[idx])
+    _check(dict({k: v[idx] for k, v in out.items()}, flags=w.risk_flags()[idx]), ref)
+    print(f"on the fly, HornsRev1 x {B}: {cal}")
+    w.set_wind(ws[::-1].copy(), wd[::-1].copy())  # another draw of winds: the choice stands
+    assert w.calibration()["on_the_fly"] == cal["on_the_fly"]
+    w.set_batch(8192 * 3)  # a reconfiguration starts over
+    assert w.calibration()["on_the_fly"] is None
+    w.close()
+    for choice in (dict(calibrate=False), dict(one_block="4x2")):
+        w = WfStep(l["xcoords"], l["ycoords"], env_batch=B, kernel_choice=choice)
+        w.set_wind(ws, wd)
+        for _ in range(4):
+            w.step(yaw)
+        assert w.calibration()["on_the_fly"] is None and w.kernel_info()["one_block_kernel"] == 1
+        w.close()
+
+
 def test_time_varying_direction_sweep_hornsrev2(layouts):
     """BASELINE config 5: wd(t) = 270 + 30 sin(2 pi t/200), shared and per-env (+U(-10,10))."""
     from oracle import c_oracle

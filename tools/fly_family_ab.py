@@ -11,7 +11,7 @@ L = json.load(open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.
 
 def time_it(lay, B, fam):
     N = lay["num_turbines"]
-    w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B, kernel_choice=dict(one_block=fam))
+    w = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B, kernel_choice=None if fam is None else dict(one_block=fam))
     w.sample_wind(1234)
     yaw = (torch.rand((B, N), device="cuda") * 60 - 30).float()
     out = w.step(yaw)
@@ -29,7 +29,7 @@ def time_it(lay, B, fam):
     return best, f"{k['lanes_per_env']}x{k['slots_per_lane']}" + ("" if k["one_block_kernel"] else "-slot")
 
 
-for name, Bs in (("HornsRev1_", (16384, 65536)), ("HornsRev2_", (65536, 131072)), ("Ormonde_", (65536,)), ("WMR_", (65536,)), ("Turb32_Row5_", (65536,))):
+for name, Bs in () if __name__ != "__main__" else (("HornsRev1_", (16384, 65536)), ("HornsRev2_", (65536, 131072)), ("Ormonde_", (65536,)), ("WMR_", (65536,)), ("Turb32_Row5_", (65536,))):
     lay = L[name]
     for B in Bs:
         row = []

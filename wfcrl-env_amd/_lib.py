@@ -107,6 +107,7 @@ ABI = {
     "wf_set_kernel_choice": (C.c_int, [_P, C.POINTER(KernelChoice)]),
     "wf_get_kernel_choice": (C.c_int, [_P, C.POINTER(KernelChoice)]),
     "wf_get_calibration": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "wf_get_fly_calibration": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "wf_last_error": (C.c_char_p, [_P]),
 }
 

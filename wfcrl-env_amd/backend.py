@@ -418,13 +418,17 @@ class WfStep:
 
     def calibration(self) -> dict:
         """What the per-handle kernel calibration found (include/wfstep.h: wf_get_calibration): {"shape": "2x2" / "16x5-slot
-        kernel" ... or None when it has not run, "family_ms": {family: ms per launch} of the families it timed}."""
+        kernel" ... or None when it has not run, "family_ms": {family: ms per launch} of the families it timed; "on_the_fly":
+        which kernel the timing on the on-the-fly path (a wind per farm) kept, None before it ran}."""
         code = C.c_int(-1)
         ms = (C.c_float * 6)()
         check(self._lib.wf_get_calibration(self._h, C.byref(code), ms), self._h)
         names = ("slot", "8x1", "4x2", "4x1", "2x2", "16x1")
         shape = None if code.value < 0 else ("slot" if code.value == 0 else f"{code.value >> 4}x{code.value & 15}")
-        return {"shape": shape, "family_ms": {n: float(m) for n, m in zip(names, ms) if m > 0.0}}
+        fly, fms = C.c_int(0), (C.c_float * 2)()
+        check(self._lib.wf_get_fly_calibration(self._h, C.byref(fly), fms), self._h)
+        return {"shape": shape, "family_ms": {n: float(m) for n, m in zip(names, ms) if m > 0.0},
+                "on_the_fly": (None, "one_block", "slot")[fly.value], "on_the_fly_ms": {n: float(m) for n, m in zip(("one_block", "slot"), fms) if m > 0.0}}
 
     def kernel_info(self) -> dict:
         k = KernelInfo()

@@ -170,6 +170,7 @@ int repick_ll_slots(const wf_handle* h, int N, int ll_G, int ll_S, long farm_slo
 void reset_calibration(wf_handle* h) {
   h->calib_steps = 0; h->calib_done = false; h->calib_code = -1;
   for (float& m : h->calib_ms) m = 0.0f;
+  h->fly_calib = 0; h->fly_calib_steps = 0; h->fly_calib_ms[0] = h->fly_calib_ms[1] = 0.0f;
 }
 
 void apply_kernel_pick(wf_handle* h, int N, int B, bool* variant_changed) {
@@ -370,7 +371,8 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
     if (h->ll_ties == 0) return WF_OK;
     ga.pred = h->d_ll_flag;
   }
-  if (!ptab && gstride != 0 && h->B > 1 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && h->choice.fly_one_block != 0) {
+  if (!ptab && gstride != 0 && h->B > 1 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && h->choice.fly_one_block != 0 &&
+      h->fly_calib != 2) {
     // a wind per farm: the one-block kernel on the fly; wf_step_kernel behind it for the farms whose own geometry has
     // an x' tie across a block boundary (per-farm device flags from the geometry kernel)
     const int fpb = ll_log_fpb(h);
@@ -406,7 +408,6 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
 // that one call synchronises.  The rounds model remains the cold-start guess and the price list of grouped launches.
 static bool calibration_due(const wf_handle* h, const WfEnvArgs* ea) {
   if (h->calib_done || h->choice.calibrate == 0 || h->choice.one_block != -1 || h->choice.pair_table == 0) return false;
-  if (ea && ea->action) return false;  // the fused env transition is not idempotent
   if (h->N <= 16 || h->N > WF_PAIR_MAX_N || h->n_groups > 0 || h->n_layouts != 1) return false;
   if (!(h->wind_count == 1 || h->shared_dir) || !wfk_variant_has_table(h->variant)) return false;
   int fpb, per_cu;
@@ -467,9 +468,60 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
   return WF_OK;
 }
 
+// The same question on the on-the-fly path (a wind per farm).  The family comes from the table path's pick; what the rounds
+// model cannot know is how the register-slot kernel compares there — on the fly it evaluates every pair once, the
+// one-block kernel re-reads its log per block, and between one and three rounds of the slot kernel (HornsRev1 x 16384,
+// Ormonde x 16384 ... 24576) the slot kernel is 10-15 % faster (profiles/r04_fly_pick_sweep.txt).  Third plain step with a
+// wind per farm: both timed on the caller's buffers, the slot kernel has to win by 3 %.
+static bool fly_calibration_due(const wf_handle* h, const WfEnvArgs* ea) {
+  if (h->fly_calib != 0 || h->choice.calibrate == 0 || h->choice.one_block != -1 || h->choice.fly_one_block != -1) return false;
+  if (h->wind_count == 1 || h->shared_dir || h->n_groups > 0 || h->B <= 1 || !h->ll_G) return false;
+  return wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h));
+}
+
+static int calibrate_fly(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  WF_HIP(h, hipEventCreate(&e0));
+  WF_HIP(h, hipEventCreate(&e1));
+  int rc = WF_OK;
+  for (int opt = 1; opt <= 2 && rc == WF_OK; ++opt) {
+    h->fly_calib = opt;
+    if ((rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea)) != WF_OK) break;  // log, first-launch costs
+    float best = 1e30f;
+    for (int r = 0; r < 3 && rc == WF_OK; ++r) {
+      hipError_t e = hipEventRecord(e0, h->stream);
+      rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
+      if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      float ms = 0.0f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (e != hipSuccess) { rc = fail(h, WF_E_HIP, std::string("calibration: ") + hipGetErrorString(e)); break; }
+      if (ms < best) best = ms;
+    }
+    h->fly_calib_ms[opt - 1] = best;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  h->fly_calib = (rc == WF_OK && h->fly_calib_ms[1] < 0.97f * h->fly_calib_ms[0]) ? 2 : 1;
+  return rc;
+}
+
 int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
+  // The timed launches must leave no trace: a plain step is stateless, and a fused env step is timed WITHOUT its action —
+  // a solve at the yaw the env state holds now (no transition, no reward), whose outputs the real launch overwrites.
+  WfEnvArgs probe_args;
+  const WfEnvArgs* probe = ea;
+  if (ea && ea->action) {
+    probe_args = *ea;
+    probe_args.action = nullptr; probe_args.reward = nullptr;
+    probe = &probe_args;
+  }
   if (calibration_due(h, ea) && ++h->calib_steps >= 3) {
-    int rc = calibrate_families(h, yaw, power, wspd, wdir, load, ea);
+    int rc = calibrate_families(h, yaw, power, wspd, wdir, load, probe);
+    if (rc != WF_OK) return rc;
+  }
+  if (fly_calibration_due(h, ea) && ++h->fly_calib_steps >= 3) {
+    int rc = calibrate_fly(h, yaw, power, wspd, wdir, load, probe);
     if (rc != WF_OK) return rc;
   }
   int rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
@@ -528,7 +580,8 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   info->envs_per_block = wpb * (64 / G); info->threads_per_block = 64 * wpb;
   info->grid_blocks = h->n_groups > 0 ? (h->n_slots + info->envs_per_block - 1) / info->envs_per_block
                                       : (h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0);
-  const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && h->choice.fly_one_block != 0;
+  const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && h->choice.fly_one_block != 0 &&
+                      h->fly_calib != 2;
   info->one_block_kernel = ((tab && h->ll_G) || ll_fly) ? 1 : 0;
   if (info->one_block_kernel) {
     // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
@@ -576,6 +629,13 @@ int wf_get_calibration(wf_handle* h, int* code, float* family_ms) {
   if (code) *code = h->calib_done ? h->calib_code : -1;
   if (family_ms)
     for (int fi = 0; fi < 6; ++fi) family_ms[fi] = fi < kNumFamilies ? h->calib_ms[fi] : 0.0f;
+  return WF_OK;
+}
+
+int wf_get_fly_calibration(wf_handle* h, int* choice, float* ms) {
+  if (!h) return WF_E_INVALID;
+  if (choice) *choice = h->fly_calib;
+  if (ms) { ms[0] = h->fly_calib_ms[0]; ms[1] = h->fly_calib_ms[1]; }
   return WF_OK;
 }
 

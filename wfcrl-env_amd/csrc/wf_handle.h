@@ -177,6 +177,11 @@ struct wf_handle {
   bool calib_done = false;
   int calib_code = -1;         // what the timing chose: (G << 4) | S, 0 = the register-slot kernel, -1 = never ran
   float calib_ms[8] = {};      // ms per launch of each family of the rounds model it timed (0 = not timed)
+  // ... and of the on-the-fly path (a wind per farm; calibrate_fly): the one-block kernel the table path's family stands
+  // for against the register-slot kernel
+  int fly_calib = 0;           // 0 = not timed yet (the one-block kernel runs), 1 = the one-block kernel, 2 = wf_step_kernel
+  int fly_calib_steps = 0;
+  float fly_calib_ms[2] = {};  // {one-block kernel + wf_step_kernel for its tied farms, wf_step_kernel alone}
   // float64 re-solve of the farms the float32 kernels flag (wf_resolve.hip)
   int resolve_mode = 0;        // 0 off, 1 flagged farms, 2 every farm (wf_set_risk_resolve; wind_veer models are served by
                                // the VEER float32 instantiations and take the same modes — nothing forces mode 2)
