@@ -554,6 +554,45 @@ def test_on_the_fly_calibration(layouts):
         w.close()
 
 
+@pytest.mark.parametrize("per_farm", [False, True])
+def test_calibration_inside_env_steps_leaves_no_trace(layouts, per_farm):
+    """A handle that only ever sees fused env steps calibrates too — on its third step, with probes that carry no action (a
+    solve at the current yaw state: no transition, no reward, no move counted).  Every step of the sequence, the calibrating
+    one included, must advance the env state exactly once: yaw against the reference's float32 transition, `moves`, the
+    actuation accumulator, and the outputs of the last step against the oracle."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    from fuzz_api import mdp_step_f32
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    N, B = 80, 16384 if per_farm else 24576
+    rng = np.random.default_rng(79)
+    envp = dict(yaw_lo=-40.0, yaw_hi=40.0, yaw_step=5.0, actuator_rate=0.3, dt=60.0, budget=0.1, load_coef=0.1, discrete=False)
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w.env_config(**envp)
+    if per_farm:
+        ws, wd = np.clip(8 * rng.weibull(8, B), 3, 28), rng.normal(270, 20, B) % 360
+    else:
+        ws, wd = 8.0, 270.0
+    w.set_wind(ws, wd)
+    w.env_reset()
+    key = "on_the_fly" if per_farm else "shape"
+    for k in range(4):
+        st = w.env_get_state()
+        act = rng.uniform(-8, 8, (B, N)).astype(np.float32)
+        got = w.env_step(act)
+        assert np.array_equal(got["yaw"], mdp_step_f32(st, act, envp)), k
+        st2 = w.env_get_state()
+        assert np.array_equal(st2["moves"], st["moves"] + 1), k
+        assert (w.calibration()[key] is None) == (k < 2), (k, w.calibration())
+    idx = rng.choice(B, 32, replace=False)
+    ref = _oracle(l["xcoords"], l["ycoords"], ws[idx] if per_farm else ws, wd[idx] if per_farm else wd, got["yaw"][idx])
+    _check(dict({k: np.asarray(got[k])[idx] for k in ("power", "wind_speed", "wind_direction", "load")}, flags=w.risk_flags()[idx]), ref)
+    w.close()
+
+
 def test_time_varying_direction_sweep_hornsrev2(layouts):
     """BASELINE config 5: wd(t) = 270 + 30 sin(2 pi t/200), shared and per-env (+U(-10,10))."""
     from oracle import c_oracle
