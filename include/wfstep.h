@@ -319,7 +319,9 @@ typedef struct wf_kernel_choice {
                            without its action: a solve at the current yaw state, no transition) times one launch of
                            every kernel family the rounds model prices within 60 % of its best guess, on the handle's own
                            batch / layout / wind (a few ms, once; that one call synchronises), and the fastest serves the
-                           handle from then on; 0: the rounds model's guess stands (measured on one MI355X: wf_dispatch.hip) */
+                           handle from then on — unless the guess is within 4 % of it: near-ties are not left to noise; 0: the rounds model's guess stands (measured on one MI355X: wf_dispatch.hip).
+                           Kernel families agree within the parity tolerances, not bit for bit (another summation order):
+                           a caller that needs the first two steps bit-identical to the later ones sets 0 */
 } wf_kernel_choice;
 int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c);
 /* What the calibration (wf_kernel_choice::calibrate) found: *code = (G << 4) | S of the wf_step_ll_kernel shape it chose, 0
@@ -327,7 +329,7 @@ int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c);
  * timed, in the order {wf_step_kernel, 8x1, 4x2, 4x1, 2x2, 16x1}, 0 = not timed.  Either pointer may be NULL. */
 int wf_get_calibration(wf_handle* h, int* code, float* family_ms);
 /* The same for the on-the-fly path (a wind per farm: the third plain step there times wf_step_ll_kernel of the table
- * path's family against wf_step_kernel, which has to win by 3 %): *choice = 0 not timed yet, 1 wf_step_ll_kernel, 2
+ * path's family against wf_step_kernel, which has to win by 4 %): *choice = 0 not timed yet, 1 wf_step_ll_kernel, 2
  * wf_step_kernel; ms[2] = ms per launch of the two.  Either pointer may be NULL. */
 int wf_get_fly_calibration(wf_handle* h, int* choice, float* ms);
 int wf_get_kernel_choice(wf_handle* h, wf_kernel_choice* c);

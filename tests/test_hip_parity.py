@@ -493,7 +493,9 @@ def test_per_handle_kernel_calibration(layouts):
     out = w.step(yaw)
     cal = w.calibration()
     assert cal["shape"] is not None and len(cal["family_ms"]) >= 2, cal
-    assert cal["family_ms"][cal["shape"]] == min(cal["family_ms"].values()), cal
+    fastest = min(cal["family_ms"].values())  # the rounds model's guess stands within 4 % of the fastest (near-ties are not left to noise)
+    guess_shape = f"{guess['lanes_per_env']}x{guess['slots_per_lane']}" if guess["one_block_kernel"] else "slot"
+    assert cal["family_ms"][cal["shape"]] == fastest or (cal["shape"] == guess_shape and cal["family_ms"][cal["shape"]] <= 1.04 * fastest), (cal, guess)
     info = w.kernel_info()
     want = (16, 5) if cal["shape"] == "slot" else tuple(int(v) for v in cal["shape"].split("x"))
     assert (info["lanes_per_env"], info["slots_per_lane"]) == want, (info, cal, guess)
@@ -515,7 +517,7 @@ def test_per_handle_kernel_calibration(layouts):
 def test_on_the_fly_calibration(layouts):
     """A wind per farm (the reference's resets, mdp.py:237-258): the third plain step times the one-block kernel of the
     table path's family against the register-slot kernel on the handle's own batch and keeps the slot kernel only when it
-    wins by 3 % (csrc/wf_dispatch.hip: calibrate_fly); the step that follows is inside the contract whichever runs, a
+    wins by 4 % (csrc/wf_dispatch.hip: calibrate_fly); the step that follows is inside the contract whichever runs, a
     forced family or calibrate=False is left alone, and a reconfiguration starts over."""
     from wfcrl_env_amd.backend import WfStep
 
@@ -534,7 +536,7 @@ def test_on_the_fly_calibration(layouts):
     cal = w.calibration()
     ms = cal["on_the_fly_ms"]
     assert cal["on_the_fly"] in ("one_block", "slot") and set(ms) == {"one_block", "slot"}, cal
-    assert cal["on_the_fly"] == ("slot" if ms["slot"] < 0.97 * ms["one_block"] else "one_block"), cal
+    assert cal["on_the_fly"] == ("slot" if ms["slot"] < 0.96 * ms["one_block"] else "one_block"), cal
     assert w.kernel_info()["one_block_kernel"] == (0 if cal["on_the_fly"] == "slot" else 1)
     idx = rng.choice(B, 48, replace=False)
     ref = _oracle(l["xcoords"], l["ycoords"], ws[idx], wd[idx], yaw[idx])

@@ -35,6 +35,9 @@ def run():
         tot += r
     torch.cuda.synchronize()
     return tot, obs, time.perf_counter() - t, trunc
+env.reset(seed=5, options={"wind_speed": 8.0, "wind_direction": 270.0})
+for _ in range(3):  # (the handle settles on its kernel family on the third step: both runs on the family it kept)
+    env.step({"yaw": torch.zeros((16384, 80), device="cuda")})
 t1, o1, dt, trunc = run()
 t2, o2, _, _ = run()
 assert torch.isfinite(t1).all() and torch.equal(t1, t2) and torch.equal(o1["wind_speed"], o2["wind_speed"])
@@ -70,6 +73,8 @@ def run2():
             nres += w.resolve_stats()["n_resolved"]
     w.sync()
     return acc, out, yaw, nres
+for _ in range(3):  # (the handle times its kernels on the third step and may change family: families agree within the
+    w.step(torch.zeros((B, 80), device="cuda"))  # parity tolerances, not bit for bit — both runs on the kernel it kept)
 a1, o1, y1, n1 = run2()
 a2, o2, y2, n2 = run2()
 assert torch.isfinite(a1).all() and torch.equal(a1, a2) and n1 == n2 and n1 > 0 and not w.risk_flags().any()
