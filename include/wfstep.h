@@ -328,7 +328,7 @@ int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c);
  * = wf_step_kernel, -1 = it has not run for the current configuration; family_ms[6] = ms per launch of the families it
  * timed, in the order {wf_step_kernel, 8x1, 4x2, 4x1, 2x2, 16x1}, 0 = not timed.  Either pointer may be NULL. */
 int wf_get_calibration(wf_handle* h, int* code, float* family_ms);
-/* The same for the on-the-fly path (a wind per farm: the third plain step there times wf_step_ll_kernel of the table
+/* The same for the on-the-fly path (a wind per farm: the third step there times wf_step_ll_kernel of the table
  * path's family against wf_step_kernel, which has to win by 4 %): *choice = 0 not timed yet, 1 wf_step_ll_kernel, 2
  * wf_step_kernel; ms[2] = ms per launch of the two.  Either pointer may be NULL. */
 int wf_get_fly_calibration(wf_handle* h, int* choice, float* ms);

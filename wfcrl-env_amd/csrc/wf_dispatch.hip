@@ -402,7 +402,7 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
 // VEER instantiations of the float32 kernels serve such models, with the same flags.)
 // Per-handle calibration of the kernel family.  The rounds model above is a table of milliseconds measured on ONE box
 // for two layouts; layouts, directions, clocks and partitioned devices move the families against each other by up to
-// 10 %.  So the handle measures: on its third plain table-path step after a (re)configuration it launches every family
+// 10 %.  So the handle measures: on its third table-path step (plain or fused env step: launch_step) after a (re)configuration it launches every family
 // the model prices within 60 % of its best guess on the caller's own buffers (the step is stateless: the real launch
 // follows and overwrites them), times three launches of each one by one with HIP events, and keeps the fastest.  A few ms, once;
 // that one call synchronises.  The rounds model remains the cold-start guess and the price list of grouped launches.
@@ -476,7 +476,7 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
 // The same question on the on-the-fly path (a wind per farm).  The family comes from the table path's pick; what the rounds
 // model cannot know is how the register-slot kernel compares there — on the fly it evaluates every pair once, the
 // one-block kernel re-reads its log per block, and between one and three rounds of the slot kernel (HornsRev1 x 16384,
-// Ormonde x 16384 ... 24576) the slot kernel is 10-15 % faster (profiles/r04_fly_pick_sweep.txt).  Third plain step with a
+// Ormonde x 16384 ... 24576) the slot kernel is 10-15 % faster (profiles/r04_fly_pick_sweep.txt).  Third step with a
 // wind per farm: both timed on the caller's buffers, the slot kernel has to win by 4 % (near-ties stay where they are).
 static bool fly_calibration_due(const wf_handle* h, const WfEnvArgs* ea) {
   if (h->fly_calib != 0 || h->choice.calibrate == 0 || h->choice.one_block != -1 || h->choice.fly_one_block != -1) return false;

@@ -171,7 +171,7 @@ struct wf_handle {
   // which kernels may serve this handle (wf_set_kernel_choice; the WF_* environment variables only seed it at wf_create)
   wf_kernel_choice choice{0, 0, -1, 0, 0, -1, -1, -1, -1};
   int n_cu = 256;              // compute units of the handle's device (hipDeviceProp_t::multiProcessorCount)
-  // per-handle calibration of the kernel family (wf_dispatch.hip: calibrate_families): plain table-path steps since the
+  // per-handle calibration of the kernel family (wf_dispatch.hip: calibrate_families): table-path steps since the
   // last (re)configuration, and whether the families have been timed for it
   int calib_steps = 0;
   bool calib_done = false;
