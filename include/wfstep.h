@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 5
+#define WF_ABI_VERSION 6
 
 /* status codes (0 = ok, negative = error; text via wf_last_error) */
 #define WF_OK 0
@@ -167,18 +167,21 @@ int wf_sync(wf_handle* h);
  *                       (Ct 0 -> 0.99 between 2.5 and 3 m/s, 20x steeper than anywhere in the operating range) and its
  *                       cut-out drop.  With a row of turbines on the ramp the float64 result itself moves by 7e-5 in
  *                       power for 1e-5 deg of wind direction (tests/golden/README: case bad_512_56); float32 wind
- *                       speeds (3e-7 relative each) are amplified the same way.  Also raised for a turbine whose thrust
- *                       coefficient exceeds 0.995 (user tables only: nrel_5MW peaks at 0.99): 1 - Ct cancels in float32
- *                       and the velocity behind such a turbine is a small difference of O(1) numbers.
+ *                       speeds (3e-7 relative each) are amplified the same way;
+ *   WF_RISK_THRUST_UNITY a turbine whose thrust coefficient exceeds 0.995 (user tables only: nrel_5MW peaks at 0.99): 1 - Ct
+ *                       cancels in float32 and the velocity behind such a turbine is a small difference of O(1) numbers —
+ *                       there is no float32 bound (TI off by 0.7 seen on a dense farm behind a table clipped at 0.9999).
+ *                       Such farms are ALWAYS solved again in float64 and the flag cleared, in every wf_set_risk_resolve
+ *                       mode (round 5; round 4 exempted them from every bound on the float32-only path): a caller never
+ *                       sees this flag after a step, only in wf_get_resolve_stats' raw flags.
  * Farms with flag 0 match the float64 path within the parity tolerances (power 1e-4 of max(P, 1 kW), wind speed 5e-5,
- * direction 3e-4 deg, TI 5e-6).  A FLAGGED farm left in float32 (wf_set_risk_resolve mode 0 — the C default; the Python
- * envs of this package switch mode 1 on) may differ by the bounded signature of its event, per flag combination
+ * direction 3e-4 deg, TI 5e-6).  By default (wf_set_risk_resolve mode 1) the flagged farms are solved again in float64 behind
+ * every step and no flag is left.  A FLAGGED farm left in float32 (mode 0, the opt-out) may differ by the bounded signature of
+ * its event, per flag combination
  * (tests/parity.py, measured maxima in brackets):
  *   POWER_KNEE alone        power 5e-2 of max(P, 1 kW), or — a turbine ON the cut-out drop, where the power is next to
  *                           nothing on one side — 2e-2 of the rated power [0.4e-2]; wind field as an unflagged farm's
- *   THRUST_RAMP, no OVERLAP power 1e-2, wind speed 1e-3, direction 1e-2 deg, TI 2e-4 — on the cut-in ramp / cut-out drop; raised
- *                           for Ct > 0.995 (user tables) there is NO float32 bound: velocities behind such turbines approach
- *                           zero (TI off by 0.7 seen on a dense farm behind a table clipped at 0.9999) — use the re-solve
+ *   THRUST_RAMP, no OVERLAP power 1e-2, wind speed 1e-3, direction 1e-2 deg, TI 2e-4 — on the cut-in ramp / cut-out drop
  *   OVERLAP                 power 1e-1 [5.7e-2], wind speed 2e-2, direction 0.1 deg, TI 2e-2   (one overlap count flipped)
  *   OVERLAP | THRUST_RAMP   power 4e-1 [2.7e-1], wind speed 4e-2, direction 0.2 deg [0.13]     (a flip below ~4 m/s, where
  *                           the thrust ramp and the power curve both amplify it: 1.5 x the one measured case)
@@ -189,6 +192,7 @@ int wf_sync(wf_handle* h);
 #define WF_RISK_OVERLAP 1
 #define WF_RISK_POWER_KNEE 2
 #define WF_RISK_THRUST_RAMP 4
+#define WF_RISK_THRUST_UNITY 8
 int wf_set_risk_guard(wf_handle* h, double rel_band); /* default 2e-5 (20 x the float32 deficit error measured at the
                                                          threshold); 0 disables WF_RISK_OVERLAP */
 int wf_get_risk_flags(wf_handle* h, int* flags, int on_device);
@@ -201,12 +205,16 @@ int wf_get_risk_flags(wf_handle* h, int* flags, int on_device);
  * afterwards EVERY farm of the batch matches the float64 path within the parity tolerances.  Cost: nothing measurable
  * when no farm is flagged (three tiny launches); otherwise the latency of one farm's float64 chain — 0.7 to 1.4 ms for up
  * to ~1400 flagged 80-turbine farms.
+ * mode 1 is the DEFAULT of a new handle (ABI 6; ABI <= 5 started in mode 0): a binding that calls nothing but wf_create ...
+ * wf_step gets what the reference computes — every farm within the tolerances of the float64 path, every flag 0.
  * mode 2 solves every farm in float64 (validation: 1.2e6 farm-steps/s on HornsRev1).
- * mode 0 (the C default; `VecWindFarmEnv` and `HipFlorisInterface` set mode 1 unless told risk_resolve=False): float32
- * results with flags, flagged farms within the per-flag bounds listed above.
+ * mode 0 is the opt-out: float32 results with flags, flagged farms within the per-flag bounds listed above (only farms with
+ * WF_RISK_THRUST_UNITY are still re-solved — a thrust table that reaches 0.995; costs nothing with nrel_5MW).
+ * wf_get_risk_resolve: the handle's current mode.
  * wf_get_resolve_stats: number of farms the last step solved in float64, and (raw_flags != NULL, env_batch ints) the
  * flags as the float32 kernels raised them before they were cleared. */
 int wf_set_risk_resolve(wf_handle* h, int mode);
+int wf_get_risk_resolve(wf_handle* h, int* mode);
 int wf_get_resolve_stats(wf_handle* h, int* n_resolved, int* raw_flags, int on_device);
 
 /* ---- Fused env step (not in the reference, which does this in Python per farm) ----
@@ -315,24 +323,38 @@ typedef struct wf_kernel_choice {
                            more than 6.12 sigma_y + D/4 off the wake's centre line (the nearest rotor-grid column would get
                            exp2(-27) of the amplitude: no effect on any float32 result); 0: every pair is evaluated (A/B
                            and the bit-identity test, tests/test_hip_parity.py) */
-  int calibrate;        /* -1 / 1: with one_block == -1, the third step after a (re)configuration (a fused env step is timed
-                           without its action: a solve at the current yaw state, no transition) times one launch of
+  int calibrate;        /* -1 / 1: with one_block == -1, the FIRST step after a (re)configuration (a fused env step is probed
+                           without its action: a solve at the current yaw state, no transition) first times three launches of
                            every kernel family the rounds model prices within 60 % of its best guess, on the handle's own
-                           batch / layout / wind (a few ms, once; that one call synchronises), and the fastest serves the
-                           handle from then on — unless the guess is within 4 % of it: near-ties are not left to noise; 0: the rounds model's guess stands (measured on one MI355X: wf_dispatch.hip).
-                           Kernel families agree within the parity tolerances, not bit for bit (another summation order):
-                           a caller that needs the first two steps bit-identical to the later ones sets 0 */
+                           batch / layout / wind (a few ms, once; that one call synchronises — or call wf_calibrate at a point
+                           of your choosing), and the fastest serves the handle from its first real launch on — unless the
+                           guess is within 4 % of it: near-ties are not left to noise.  Every step of a handle therefore comes
+                           from ONE family.  The result is cached per process under (device, turbines, batch, layout, model):
+                           a re-created handle neither times again nor changes family; wf_get_calibration +
+                           wf_set_calibration carry it across processes (kernel families agree within the parity tolerances,
+                           not bit for bit: another summation order).  0: the rounds model's guess stands (measured on one
+                           MI355X: wf_dispatch.hip) */
 } wf_kernel_choice;
 int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c);
 /* What the calibration (wf_kernel_choice::calibrate) found: *code = (G << 4) | S of the wf_step_ll_kernel shape it chose, 0
  * = wf_step_kernel, -1 = it has not run for the current configuration; family_ms[6] = ms per launch of the families it
  * timed, in the order {wf_step_kernel, 8x1, 4x2, 4x1, 2x2, 16x1}, 0 = not timed.  Either pointer may be NULL. */
 int wf_get_calibration(wf_handle* h, int* code, float* family_ms);
-/* The same for the on-the-fly path (a wind per farm: the third step there times wf_step_ll_kernel of the table
+/* The same for the on-the-fly path (a wind per farm: the first step there times wf_step_ll_kernel of the table
  * path's family against wf_step_kernel, which has to win by 4 %): *choice = 0 not timed yet, 1 wf_step_ll_kernel, 2
  * wf_step_kernel; ms[2] = ms per launch of the two.  Either pointer may be NULL. */
 int wf_get_fly_calibration(wf_handle* h, int* choice, float* ms);
 int wf_get_kernel_choice(wf_handle* h, wf_kernel_choice* c);
+/* Time the kernel families NOW for the handle's current layout / batch / wind (after wf_set_wind*), on scratch buffers with
+ * zero yaw, ignoring and then refreshing the process cache; synchronises.  Lets a caller keep the timing out of its first
+ * step (stream capture, asynchronous pipelines).  A configuration that has nothing to calibrate (forced kernel choice,
+ * N <= 16, the latency regime, grouped launches) returns WF_OK and does nothing. */
+int wf_calibrate(wf_handle* h);
+/* Take a saved calibration as is — nothing is timed for this configuration afterwards: code as wf_get_calibration returned
+ * it (-1: leave the table path to the timing), fly_choice as wf_get_fly_calibration returned it (0: leave it to the timing).
+ * After wf_set_batch; a later wf_set_batch / wf_set_layout / wf_set_kernel_choice starts over.  With it a run can be
+ * replayed on exactly the kernels of the run that saved it. */
+int wf_set_calibration(wf_handle* h, int code, int fly_choice);
 
 const char* wf_last_error(wf_handle* h); /* h may be NULL: last error of a failed wf_create */
 

@@ -37,6 +37,7 @@ LARGE_FARM_FACTOR = 3.0  # N > 128, see above
 # genuine flip, float64 margin 9.8e-6 — fuzz_api seed 802, session 15
 FLAGGED_BOUND = dict(power=1e-1, ws=2e-2, wd=0.1, ti=2e-2, std=5e-2)
 RISK_OVERLAP, RISK_POWER_KNEE, RISK_THRUST_RAMP = 1, 2, 4
+RISK_THRUST_UNITY = 8  # Ct > 0.995 (user tables): never left in float32 — re-solved in float64 in every mode, so never seen after a step
 # A flag only excuses what its event can move (round 3; tests/tools/flag_stats.py on 10 x 4096 farms,
 # profiles/r03_flag_stats.txt): a farm flagged for the power knee ALONE has a wind field as good as an unflagged farm's —
 # only the power read off the steep segment moves (1.3e-2 measured on the cut-out drop, condition number 2500) — and
@@ -139,21 +140,9 @@ def table_flag_conditions(ref, slack=0.05, near=2e-4):
                 out |= inside & (p.ref_density * np.abs(slope) * vv > 30.0 * (1 - slack) * np.maximum(p.ref_density * val, 1e3))
             else:
                 out |= inside & (val > 0.0001 * (1 - slack)) & (val < 0.9999 * (1 + slack)) & (np.abs(slope) * vv > 5.0 * (1 - slack))
-                out |= inside & (val > 0.995 - 1e-4)  # thrust coefficient within 0.005 of 1 (user tables): 1 - Ct cancels in float32
         return out.reshape(out.shape[0], -1).any(axis=1)
 
     return cond(veff, tpw, "knee"), cond(wsd, tct, "ramp")
-
-
-def ct_near_unity(ref, lim=0.995 - 1e-4):
-    """(B,) bool: SOME turbine of the farm has, in float64, a thrust coefficient above 0.995 — only a user table gets there
-    (nrel_5MW peaks at 0.99).  The kernels raise WF_RISK_THRUST_RAMP for it (csrc/wf_kernel_common.h: table_ct): behind such a
-    turbine the velocity is a small difference of O(1) numbers (deficit ~ 1), rotor speeds approach zero, and the float32
-    result carries NO bound (layout fuzzer, round 4: TI off by 0.7 on a farm of 108 turbines in 60 m spacing behind a table
-    clipped at 0.9999) — the float64 re-solve, on by default in the envs, is the answer there.  Needs ref.model."""
-    p = ref.model
-    ct = np.interp(np.asarray(ref["wind_speed"], float), np.asarray(p.table_ws, float), np.asarray(p.table_ct, float))
-    return (ct > lim).reshape(ct.shape[0], -1).any(axis=1)
 
 
 def summarize(got, ref, flags, guard_rel=2e-5):
@@ -167,11 +156,6 @@ def summarize(got, ref, flags, guard_rel=2e-5):
     n_turbines = np.asarray(ref["power"]).shape[-1]
     strict = within(e, TOL, n_turbines)
     bounded = flagged_within(e, flags, n_turbines)  # a flip deep inside a 256-turbine farm moves more behind it: 3x there too
-    if getattr(ref, "model", None) is not None and hasattr(ref, "yaw"):
-        # a thrust-flagged farm with Ct > 0.995 somewhere: no float32 bound (ct_near_unity) beyond finite outputs
-        finite = np.all([np.isfinite(np.asarray(v.cpu().numpy() if hasattr(v, "cpu") else v, dtype=np.float64)).reshape(fl.size, -1).all(axis=1)
-                         for k, v in got.items() if k in ("power", "wind_speed", "wind_direction", "load")], axis=0)
-        bounded = bounded | (((flags & RISK_THRUST_RAMP) != 0) & ct_near_unity(ref) & finite)
     out = dict(n=int(fl.size), n_flagged=int(fl.sum()), n_bad_unflagged=int((~strict & ~fl).sum()),
                n_bad_flagged=int((~bounded & fl).sum()), n_mismatch_flagged=int((~strict & fl).sum()),
                worst_unflagged={k: float(v[~fl].max()) if (~fl).any() else 0.0 for k, v in e.items()},

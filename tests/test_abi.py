@@ -1,6 +1,7 @@
 """CPU: libwfstep.so builds, loads, and exports every symbol include/wfstep.h declares.
 No compute calls here (no GPU); with no device wf_create must fail loudly, not fall back."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -30,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"libwfstep.so does not export {s}"
         assert s in _lib.ABI, f"ctypes binding table lacks {s}"
     assert set(_lib.ABI) == set(declared_symbols())
-    assert lib.wf_version() == 5
+    assert lib.wf_version() == 6
 
 
 def test_default_model_matches_oracle_defaults():
@@ -99,3 +100,23 @@ def test_pmc_index_points_at_committed_counter_files():
         assert set(e["kernel"]) <= {"lanes_per_env", "slots_per_lane", "one_block_kernel", "pair_table"}, key
     head = idx["cfg4_B65536"]
     assert head["file"].startswith("profiles/r04_") and head["kernel"] == dict(lanes_per_env=2, slots_per_lane=2, one_block_kernel=1, pair_table=1)
+
+
+def test_last_fuzz_campaign_ran_on_these_kernels():
+    """the round closes on a FUZZED head.  tools/round_close.sh (GPU box) runs the short fuzz campaign and
+    records the sha256 of the kernel / host sources it ran on in profiles/fuzz_head.json; any later change of csrc/*.hip,
+    csrc/*.h or include/wfstep.h makes this test fail until the campaign has been run again and its record committed."""
+    import glob
+    import hashlib
+
+    rec = json.load(open(os.path.join(ROOT, "profiles", "fuzz_head.json")))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "wfcrl-env_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "wfcrl-env_amd", "csrc", "*.h")))
+    files.append(os.path.join(ROOT, "include", "wfstep.h"))
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    assert [os.path.relpath(f, ROOT) for f in files] == rec["files"]
+    assert h.hexdigest() == rec["sources_sha256"], "kernel sources changed after the last recorded fuzz campaign: run tools/round_close.sh on the GPU box and commit profiles/fuzz_head.json"
+    assert rec["violations_total"] == 0 and not rec["legs_without_a_summary"], rec
+    assert any("FUZZ_API_BIG=1" in l["leg"] for l in rec["legs"])  # (the leg in which the kernel calibration fires mid-session)

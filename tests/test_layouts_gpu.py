@@ -12,6 +12,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _float32_unless_asked(monkeypatch):
+    """The tests of this file hold the FLOAT32 kernels to their flag contract (tests/parity.py) and switch the float64
+    re-solve on themselves where they test it: new handles start with it off here (WF_RISK_RESOLVE seeds wf_create; the
+    library's own default — on — is what test_default_mode_is_the_reference_contract checks)."""
+    monkeypatch.setenv("WF_RISK_RESOLVE", "0")
+
+
 def _oracle_layouts(X, Y, layout_of, ws, wd, yaw, mp=None):
     """The oracle on each layout's farms, scattered back to batch order."""
     from oracle import c_oracle
@@ -411,4 +419,59 @@ def test_layout_counts_error_behaviour():
     w.set_wind(8.0, 270.0)
     out = w.step(np.zeros((4, 7), np.float32))
     assert (out["power"] > 0).all()
+    w.close()
+
+
+def test_set_batch_after_layouts_of_different_turbine_counts():
+    """wf_set_batch carries the per-layout turbine counts across a batch change.  (a) ONE layout with fewer
+    turbines than the handle holds: a LARGER batch must see the placeholders as placeholders in every farm (rounds 3-4 kept
+    the per-farm counts of the old batch: an out-of-bounds device read for the new farms).  (b) Several ragged layouts:
+    wf_set_batch returns every farm to the FIRST layout — with the turbine count that layout really has, not with its
+    padding stacked at (0, 0) as real turbines.  Checker: the CPU oracle on the unpadded first layout."""
+    import parity
+    from oracle import c_oracle
+    from wfcrl_env_amd.backend import WfStep
+
+    rng = np.random.default_rng(515)
+    N, n0 = 12, 7
+    Xf, Yf = _cloud(rng, 3, N, extent=14.0)
+    x0, y0 = Xf[0, :n0], Yf[0, :n0]
+
+    def check_first_layout(w, B):
+        yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
+        for ws, wd in ((9.0, 263.0), (np.clip(8 * rng.weibull(8, B), 4, 20), rng.normal(270, 20, B) % 360)):
+            w.set_wind(ws, wd)
+            got = w.step(yaw)
+            assert not w.risk_flags().any()  # (the library's default mode: flagged farms re-solved in float64)
+            ref = c_oracle.farm_step_batch(x0, y0, ws, wd, yaw[:, :n0].astype(np.float64))
+            for k, v in got.items():
+                assert not np.asarray(v)[:, n0:].any(), k
+            parity.check_strict({k: np.asarray(v)[:, :n0] for k, v in got.items()}, ref)
+            w.env_config(load_coef=0.1)
+            w.env_reset()
+            st = w.env_get_state()
+            st["yaw"][:] = yaw
+            w.env_set_state(st)
+            e = w.env_step(None, want=("reward",))
+            wsb = np.broadcast_to(np.atleast_1d(ws), (B,))
+            r_ref = ref["power"].sum(1) / n0 / 1e6 * 1e3 / wsb ** 3 - 0.1 * np.abs(ref["load"]).sum((1, 2)) / (4 * n0)
+            assert np.abs(e["reward"] - r_ref).max() < 5e-5 * np.abs(r_ref).max()
+
+    # (a) one short layout, then a larger and a smaller batch
+    w = WfStep(np.concatenate([x0, np.zeros(N - n0)]), np.concatenate([y0, np.zeros(N - n0)]), env_batch=64)
+    w.set_risk_resolve(1)
+    w.set_layouts(np.concatenate([x0, np.zeros(N - n0)])[None], np.concatenate([y0, np.zeros(N - n0)])[None], counts=[n0])
+    check_first_layout(w, 64)
+    for B in (1500, 40):
+        w.set_batch(B)
+        check_first_layout(w, B)
+    w.close()
+    # (b) ragged layouts whose FIRST row is a short one
+    counts = [n0, N, 9]
+    X = [list(Xf[l, :counts[l]]) for l in range(3)]
+    Y = [list(Yf[l, :counts[l]]) for l in range(3)]
+    w = WfStep(X, Y, env_batch=96, layout_of=rng.integers(0, 3, 96).astype(np.int32))
+    w.set_risk_resolve(1)
+    w.set_batch(700)
+    check_first_layout(w, 700)
     w.close()

@@ -16,6 +16,14 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _float32_unless_asked(monkeypatch):
+    """The tests of this file hold the FLOAT32 kernels to their flag contract (tests/parity.py) and switch the float64
+    re-solve on themselves where they test it: new handles start with it off here (WF_RISK_RESOLVE seeds wf_create; the
+    library's own default — on — is what test_default_mode_is_the_reference_contract checks)."""
+    monkeypatch.setenv("WF_RISK_RESOLVE", "0")
+
+
 def _oracle(x, y, ws, wd, yaw, mp=None):
     from oracle import c_oracle
 
@@ -399,3 +407,84 @@ def test_env_surface_switches(layouts):
     fast.step({"yaw": torch.zeros((512, 80), device="cuda")})
     assert fast.fi.risk_flags().any()
     fast.close()
+
+
+@pytest.mark.parametrize("name", ["thrust_ramp", "overlap_flip"])
+def test_default_mode_is_the_reference_contract(name, monkeypatch):
+    """ABI 6: a new handle starts in wf_set_risk_resolve mode 1 — a binding that calls nothing but wf_create ... wf_step gets
+    what the reference computes in float64 (interface.py:564): on the two farms float32 cannot decide, no flag is left and
+    every turbine is inside the tolerances, on the host path and on the device path, plain step and fused env step."""
+    import parity
+    import torch
+    from wfcrl_env_amd.backend import WfStep
+
+    monkeypatch.delenv("WF_RISK_RESOLVE", raising=False)  # (this file's fixture seeds mode 0 for the float32-contract tests)
+    i, ref = _regime(name)
+    B = 32
+    w = WfStep(i["x"], i["y"], env_batch=B)
+    assert w.risk_resolve() == 1
+    w.set_wind(float(i["ws"][0]), float(i["wd"][0]))
+    yaw = np.repeat(i["yaw"], B, axis=0).astype(np.float32)
+    want = {k: np.repeat(v, B, axis=0) for k, v in ref.items()}
+    out = w.step(yaw)
+    assert not w.risk_flags().any() and w.resolve_stats()["n_resolved"] == B
+    parity.check_strict(out, want)
+    out = w.step(torch.from_numpy(yaw).cuda())
+    assert not w.risk_flags().any()
+    parity.check_strict({k: v.cpu().numpy() for k, v in out.items()}, want)
+    w.env_config(load_coef=0.1)
+    w.env_reset()
+    st = w.env_get_state()
+    st["yaw"][:] = yaw
+    w.env_set_state(st)
+    e = w.env_step(None, want=("power", "wind_speed", "wind_direction", "load"))
+    assert not w.risk_flags().any()
+    parity.check_strict(e, want)
+    w.set_risk_resolve(0)  # the opt-out: the float32 kernel on its own raises its flag
+    w.step(yaw)
+    assert w.risk_resolve() == 0 and w.risk_flags().all()
+    w.close()
+
+
+@pytest.mark.parametrize("kernel", ["", "4x2", "slot"])
+def test_thrust_coefficient_near_one_is_never_left_in_float32(kernel, monkeypatch):
+    """a thrust table that reaches 0.9999 (a user table; nrel_5MW peaks at 0.99).  Behind a turbine with
+    Ct > 0.995 float32 has no bound (1 - Ct cancels, velocities approach zero) — round 4 exempted such farms from every
+    bound on the float32-only path.  Now the kernels raise WF_RISK_THRUST_UNITY for them and they are re-solved in float64 in
+    EVERY mode: with the library's default every farm is strict; with wf_set_risk_resolve(0) the unity farms are strict
+    too (their flag is gone), the other flagged farms stay within their per-flag bounds, nothing is exempt."""
+    import parity
+    from oracle.floris_gch_numpy import ModelParams
+    from wfcrl_env_amd.backend import WfStep
+
+    monkeypatch.delenv("WF_RISK_RESOLVE", raising=False)
+    rng = np.random.default_rng(995)
+    D = 126.0
+    gx, gy = np.meshgrid(np.arange(7) * 3.0 * D, np.arange(6) * 2.5 * D)  # a dense farm: 42 turbines, 3 D x 2.5 D
+    x, y = (gx + 0.07 * D * rng.standard_normal(gx.shape)).ravel(), (gy + 0.07 * D * rng.standard_normal(gy.shape)).ravel()
+    N, B = x.size, 384
+    mp = ModelParams()
+    tct = np.clip(np.asarray(mp.table_ct) * 1.35, 0.0, 0.9999)
+    mp.table_ct = list(tct)
+    model = dict(table_ws=list(mp.table_ws), table_ct=list(tct), table_cp=list(mp.table_cp))
+    choice = None if not kernel else (dict(one_block=False) if kernel == "slot" else dict(one_block=kernel))
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    w = WfStep(x, y, env_batch=B, model=model, kernel_choice=choice)
+    assert w.risk_resolve() == 1
+    for ws, wd in ((rng.uniform(3.5, 12.0, B), np.full(B, 268.0)), (rng.uniform(3.5, 12.0, B), rng.normal(270, 20, B) % 360)):
+        ref = _oracle(x, y, ws, wd, yaw, mp)
+        w.set_risk_resolve(1)
+        w.set_wind(ws, wd)
+        out = w.step(yaw)
+        raw = w.resolve_stats()["raw_flags"]
+        assert (raw & parity.RISK_THRUST_UNITY).any() and not w.risk_flags().any()
+        parity.check_strict(out, ref)
+        w.set_risk_resolve(0)  # the float32-only opt-out: unity farms are re-solved all the same
+        out0 = {k: v.copy() for k, v in w.step(yaw).items()}
+        fl0 = w.risk_flags()
+        assert not (fl0 & parity.RISK_THRUST_UNITY).any()
+        unity = (raw & parity.RISK_THRUST_UNITY) != 0
+        assert not fl0[unity].any()  # solved in float64, flags cleared
+        parity.check_strict({k: v[unity] for k, v in out0.items()}, {k: v[unity] for k, v in ref.items()})
+        parity.check(out0, ref, fl0, max_flagged_frac=1.0)
+    w.close()

@@ -14,6 +14,7 @@ and, independent of the band, the smallest band that would have caught every far
 width at which a wrong farm is still unflagged, from the sweep).
 usage: python tests/tools/band_study.py [layout] [n_batches] [B] [mode: reset|shared|wide]"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import torch

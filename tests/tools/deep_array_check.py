@@ -2,6 +2,7 @@
 Reports every unflagged farm outside the strict tolerances with the turbine that is worst and its oracle-side state.
 usage: python tests/tools/deep_array_check.py [n_cases] [seed] [B]"""
 import os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd())
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np

@@ -3,6 +3,7 @@ to past cut-out, every direction), plain float32 step vs the C oracle: for every
 how many of them miss TOL, their worst errors per output family, spurious flags; then the same batch with the float64
 re-solve on (must be 0 farms outside TOL).  python tests/tools/flag_stats.py [B] [layouts]"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

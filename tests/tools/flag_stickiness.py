@@ -5,6 +5,7 @@ moves it (random walk, dyaw ~ U(-5, 5) clipped to +-40): per step, the flagged f
 the previous step, by flag type.
 usage: python tests/tools/flag_stickiness.py [layout] [B] [steps]"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import torch

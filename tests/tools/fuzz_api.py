@@ -3,8 +3,13 @@ wf_set_model / wf_set_wind (shared, per farm, device pointers) / wf_wind_sample 
 wf_env_reset interleaved with wf_step (host and device buffers) and wf_env_step, every result checked against the
 float64 oracle evaluated on the state the sequence should have produced (stale geometry, a stale pair table, a stale
 kernel variant or stale env state all show up as a mismatch).
-usage: python tests/tools/fuzz_api.py [n_sessions] [ops_per_session] [seed]"""
+usage: python tests/tools/fuzz_api.py [n_sessions] [ops_per_session] [seed]
+FUZZ_API_BIG=1: farms of 33+ turbines in batches of 4200-9000 — beyond the latency regime, so that the handle's own timing of
+the kernel families (wf_kernel_choice::calibrate: before the first launch of a configuration, table path and on the fly) fires
+inside the sessions, also inside fused env steps and after every reconfiguration; a sample of 192 farms per check goes to the
+oracle (tools/round_close.sh runs one such seed on every round's HEAD)."""
 import os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd())
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
@@ -36,12 +41,27 @@ def run(n_sessions, n_ops, seed):
 
     rng = np.random.default_rng(seed)
     nbad = nflip = nchecks = 0
+    BIG = bool(os.environ.get("FUZZ_API_BIG"))
+
+    def new_layout():
+        while True:
+            xx, yy = make_layout(rng)
+            if not BIG or 33 <= xx.size <= 100:
+                return xx, yy
+
+    def new_batch(small_hi=20):
+        return int(rng.integers(4200, 9000)) if BIG else int(rng.integers(1, small_hi))
+
+    ncal = 0
     for sess in range(n_sessions):
-        x, y = make_layout(rng)
-        B = int(rng.integers(1, 20))
+        x, y = new_layout()
+        B = new_batch()
+        sub = rng.choice(B, 192, replace=False) if BIG else None  # farms whose results go to the oracle (None: all)
         # every other session forces the one-block-at-a-time kernel (table path and on the fly) where the farm has more
         # than one of its blocks; the batch sizes of this fuzzer would never pick it by themselves
         llg = str(rng.choice(["", "", "8", "4x2", "4", "2x2"]))
+        if BIG:
+            llg = str(rng.choice(["", "", "", "4x2"]))  # mostly the handle's own pick + calibration
         w = WfStep(x, y, env_batch=B, kernel_choice=dict(one_block=llg) if llg else None)
         resolve_on = False
         mp, model = None, {}
@@ -53,13 +73,18 @@ def run(n_sessions, n_ops, seed):
 
         multi = None  # (X [K][N], Y, layout_of [B]) after wf_set_layouts; None: the one layout (x, y)
 
+        def S(a):
+            return a if sub is None else a[sub]
+
         def oracle(yaw64):
+            """reference of the farms `sub` (all of them unless FUZZ_API_BIG)"""
             ws, wd = w.get_wind()
+            ws, wd, yaw64 = S(ws), S(wd), S(yaw64)
             if multi is None:
                 return c_oracle.farm_step_batch(x, y, ws, wd, yaw64, mp, margin=True), ws
             out = None
             for l in range(multi[0].shape[0]):
-                idx = np.flatnonzero(multi[2] == l)
+                idx = np.flatnonzero(S(multi[2]) == l)
                 if idx.size == 0:
                     continue
                 r = c_oracle.farm_step_batch(multi[0][l], multi[1][l], ws[idx], wd[idx], yaw64[idx], mp, margin=True)
@@ -74,8 +99,8 @@ def run(n_sessions, n_ops, seed):
         def check(tag, got, ref):
             nonlocal nbad, nflip, nchecks
             nchecks += 1
-            got = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in got.items()}
-            flags_now = w.risk_flags()
+            got = {k: S(v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in got.items()}
+            flags_now = S(w.risk_flags())
             r = worst(got, ref, flags_now)
             k = classify(r)
             if resolve_on:  # the float64 re-solve is on: every farm strict, no flag left — anything else is a violation
@@ -114,15 +139,18 @@ def run(n_sessions, n_ops, seed):
                 w._ws_prev = None
                 w.set_wind(float(rng.uniform(4, 15)), float(rng.choice([270.0, rng.uniform(0, 360)])))
             elif op == "layout":
-                x, y = make_layout(rng)
+                x, y = new_layout()
                 w.set_layout(x, y)
-                B = int(rng.integers(1, 20))
+                B = new_batch()
+                sub = rng.choice(B, 192, replace=False) if BIG else None
                 w.set_batch(B)
                 w.env_batch = B
                 w.set_wind(float(rng.uniform(4, 15)), float(rng.choice([270.0, 90.0, rng.uniform(0, 360)])))
                 w.env_reset()
             elif op == "layouts":  # several layouts in the batch (wf_set_layouts): shifted / jittered copies of the current one
-                K = B if (rng.random() < 0.3 and B <= 64) else int(rng.integers(1, min(B, 4) + 1))  # (the oracle runs layout by layout)
+                K = B if (rng.random() < 0.3 and B <= 64) else int(rng.integers(1, min(B, 4) + 1))
+                if BIG:
+                    K = int(rng.integers(1, 4))  # (the oracle runs layout by layout)
                 X = np.repeat(x[None, :], K, axis=0) + rng.choice([0.0, 126.0, -378.0], (K, 1))
                 Y = np.repeat(y[None, :], K, axis=0) + rng.choice([0.0, 252.0, -126.0], (K, 1))
                 jit = rng.random(K) < 0.5
@@ -136,7 +164,8 @@ def run(n_sessions, n_ops, seed):
                 multi = None if K == 1 else (X, Y, np.arange(B) if lof is None else lof)
                 w.set_wind(float(rng.uniform(4, 15)), float(rng.choice([270.0, 90.0, rng.uniform(0, 360)])))
             elif op == "batch":
-                B = int(rng.choice([1, rng.integers(1, 40), rng.integers(200, 3000)]))
+                B = new_batch() if BIG else int(rng.choice([1, rng.integers(1, 40), rng.integers(200, 3000)]))
+                sub = rng.choice(B, 192, replace=False) if BIG else None
                 w.set_batch(B)
                 w.env_batch = B
                 w.set_wind(float(rng.uniform(4, 15)), float(rng.uniform(0, 360)))
@@ -188,6 +217,8 @@ def run(n_sessions, n_ops, seed):
                 ref, _ = oracle(yaw.astype(np.float64))
                 last_yaw = yaw
                 check(op, got, ref)
+                cal = w.calibration()
+                ncal += (cal["shape"] is not None) + (cal["on_the_fly"] is not None)
             elif op == "env_step":
                 st = w.env_get_state()
                 act = (rng.integers(0, 3, (B, N)) if envp["discrete"] else rng.uniform(-8, 8, (B, N))).astype(np.float32)
@@ -215,15 +246,16 @@ def run(n_sessions, n_ops, seed):
                 check("env_step", got, ref)
                 # the wind of the state before the step: the one before the last series tick, ONCE (a second env step without
                 # a new tick starts from the current wind; include/wfstep.h: wf_env_set_prev_wind)
-                wsn = w._ws_prev if getattr(w, "_ws_prev", None) is not None else ws
+                prev = getattr(w, "_ws_prev", None)
+                wsn = S(prev) if prev is not None else ws  # (ws: the sample's already)
                 w._ws_prev = None
                 r_ref = (ref["power"] / 1e6 * 1e3 / wsn[:, None] ** 3).mean(axis=1) - envp["load_coef"] * np.abs(ref["load"]).mean(axis=(1, 2))
-                bad_r = np.abs(got["reward"] - r_ref) > 5e-5 * np.abs(r_ref) + 1e-7
-                if (bad_r & (w.risk_flags() == 0)).any():  # a reward may only differ where the kernel flagged the farm
+                bad_r = np.abs(S(got["reward"]) - r_ref) > 5e-5 * np.abs(r_ref) + 1e-7
+                if (bad_r & (S(w.risk_flags()) == 0)).any():  # a reward may only differ where the kernel flagged the farm
                     nbad += 1
-                    print("BAD reward", dict(session=sess, seed=seed, N=N, B=B, envp=envp), float(np.abs(got["reward"] / r_ref - 1).max()), log[-12:], flush=True)
+                    print("BAD reward", dict(session=sess, seed=seed, N=N, B=B, envp=envp), float(np.abs(S(got["reward"]) / r_ref - 1).max()), log[-12:], flush=True)
         w.close()
-    print(f"api fuzz: {n_sessions} sessions x {n_ops} ops, {nchecks} oracle checks: {nflip} threshold flips, {nbad} violations")
+    print(f"api fuzz{' (big batches: ' + str(ncal) + ' checks behind a kernel calibration)' if BIG else ''}: {n_sessions} sessions x {n_ops} ops, {nchecks} oracle checks: {nflip} threshold flips, {nbad} violations")
     return nflip, nbad
 
 

@@ -4,6 +4,7 @@ single-farm envs with the reference's semantics (simple_env / mdp mirror) runnin
 (host-side draws in the reference's order) or by options, actions that overshoot the step and trip the actuation
 budget.  usage: python tests/tools/fuzz_env.py [n_episodes] [seed]"""
 import os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd())
 sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np

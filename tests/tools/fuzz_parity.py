@@ -3,6 +3,7 @@ exact ties, jittered grids, random clouds with a minimum spacing), wind directio
 every kernel variant that can hold the farm, shared and per-farm wind, plain step and fused env step outputs.
 usage: python tests/tools/fuzz_parity.py [n_cases] [seed]      (exit code 1 on the first violation)"""
 import os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd())
 import numpy as np
 

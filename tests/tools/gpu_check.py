@@ -1,5 +1,6 @@
 """Dev script (GPU box): parity of the HIP step against the C oracle on seeded random inputs + rough timing."""
 import json, os, sys, time
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

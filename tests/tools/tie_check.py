@@ -1,6 +1,7 @@
 """GPU box: exact x' ties across kernel blocks (axis-aligned grids at wd = 270) on forced multi-slot variants,
 all outputs against the float64 oracle.  usage: python tests/tools/tie_check.py [GxS]"""
 import os, json, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd())
 import numpy as np
 os.environ["WF_KERNEL_GS"] = sys.argv[1] if len(sys.argv) > 1 else "4x4"

@@ -2,6 +2,7 @@
 the table path (float64 oracle as the reference) — how the core-factor cancellation of DESIGN.md §5 showed up: a bias
 growing by one step per upstream row.  usage: python tests/tools/wd_error_map.py [zero]   (zero: all yaw angles 0)"""
 import os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
 from oracle import c_oracle

@@ -2,6 +2,7 @@
 8 x 14 grid at 5 D x 4 D, exact x' ties at 360 deg) over hub height, shear, direction and veer — worst error over the
 batch against the float64 oracle, register-slot kernel on the fly, one-block kernel on the fly, and the table path."""
 import os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd())
 sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np

@@ -2,6 +2,7 @@
 table path, over num_eps, rotor diameter, hub height, shear and wind speed — the error scaled with 1 / num_eps and
 changed sign with D: the float32 cancellation of 1 - exp(-r^2 / eps^2) at r^2 = 2 num_eps^2."""
 import os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
 from oracle import c_oracle

@@ -1,6 +1,7 @@
 """GPU box: HornsRev1 (or LAYOUT=...), shared wind, over env-batch sizes — which kernel `pick_ll` chooses and what it delivers, against the
 register-slot kernel (WF_LL=0) and the forced one-block variants.  usage: python tools/batch_sweep.py"""
 import json, os, subprocess, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 code = r'''
 import os, sys, json, torch
 sys.path.insert(0, os.getcwd())

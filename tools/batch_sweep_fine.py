@@ -3,6 +3,7 @@ forced family delivers, and where the pick stands against the best family at tha
 (the "envelope": the highest farm-steps/s of any family at any batch up to this one).
   python tools/batch_sweep_fine.py [layout ...] > gpurun_out/r03_batch_sweep_fine.txt"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

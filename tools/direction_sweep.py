@@ -2,6 +2,7 @@
 depends on it) — the yardstick for the grouped modes, whose groups spread over directions.
   python tools/direction_sweep.py [layout] [B]"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from wfcrl_env_amd.backend import WfStep

@@ -1,6 +1,7 @@
 """GPU box: is the first handle of a process slower than later ones at the same batch (buffer placement)?
   python tools/first_handle.py [B]"""
 import json, os, sys, torch
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 sys.path.insert(0, os.getcwd())
 from wfcrl_env_amd.backend import WfStep
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536

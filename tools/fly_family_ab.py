@@ -1,6 +1,7 @@
 """GPU box: a wind per farm (reset distribution, mdp.py:237-258) on the on-the-fly one-block kernel, family by family:
 which lane-group width serves which layout / batch.   python tools/fly_family_ab.py > gpurun_out/r04_fly_family_ab.txt"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

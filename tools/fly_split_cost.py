@@ -2,6 +2,7 @@
 sector where HornsRev1 has none (262..276 deg) against the reference's reset distribution N(270, 20).
   python tools/fly_split_cost.py [B]"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from wfcrl_env_amd.backend import WfStep

@@ -3,6 +3,7 @@ the directions themselves: (a) T series rows all inside a sector where no turbin
 (262..276 deg on HornsRev1: tools/direction_sweep.py), (b) rows spread over 240..300 deg, (c) the plain launch at the
 slowest direction of (b).   python tools/group_overhead.py [T] [B]"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from wfcrl_env_amd.backend import WfStep

@@ -1,6 +1,7 @@
 """GPU box: time alternative (lanes per farm, slots per lane) variants of the step kernel on the same layout
 (WF_KERNEL_GS override), 65536 farms, shared wind — the occupancy-vs-instruction-count evidence of DESIGN.md §3/§4."""
 import os, subprocess, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 code = r'''
 import os, sys, json, torch
 from wfcrl_env_amd.backend import WfStep

@@ -3,6 +3,7 @@ round-robin; one wind for the batch (layouts = groups of a grouped launch, pair-
 and a layout per farm.  Also the cost of setting the wind (a geometry per farm).
   python tools/layouts_rate.py [layout] [B]"""
 import json, os, sys, time
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -4,6 +4,7 @@
 Phases (s_memtime cycles summed over the waves of one launch, divided by the wave count): replay of logged sources,
 this block's own sources, the chunk barrier, outputs; the rest is the prologue (yaw staging, tables)."""
 import ctypes, json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 from pathlib import Path
 
 import torch

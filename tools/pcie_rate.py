@@ -1,6 +1,7 @@
 """GPU box: farm-steps/s when the boundary hands over HOST buffers (wf_step on_device=0: pinned staging, H2D yaw,
 kernel, D2H of the 7 outputs, synchronous) — the PCIe-inclusive rate DESIGN.md quotes beside the HBM-resident one."""
 import json, os, sys, time
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,7 @@
 """GPU box: where a wave of the float64 re-solve kernel spends its cycles (a -DWF_RES_STAMP build of wf_resolve.hip:
 s_memtime deltas per phase, summed over the farms of the launch).  bash tools/res_stamps.sh"""
 import ctypes as C, json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -3,6 +3,7 @@ at 1, 2, 3 blocks per CU, for farms of 32, 48, 64, 80, 91 turbines (the first N 
 no x' ties), on the pair-table path.  A round = (CUs x blocks per CU) blocks = that many x farms-per-block farms.
   python tools/rounds_table.py > gpurun_out/r03_rounds_table.txt"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,5 @@
 import json, os, subprocess, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 code = r'''
 import os, sys, json, torch
 sys.path.insert(0, os.getcwd())

@@ -1,6 +1,7 @@
 """GPU box: HornsRev1 x 65536 — shared wind vs series playback (grouped tables) vs binned reset directions vs a continuous
 direction per farm.  usage: python tools/time_series_mode.py [T] [step_deg] [B]"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from wfcrl_env_amd.backend import WfStep

@@ -1,5 +1,6 @@
 """GPU box: time alternative builds of libwfstep (WFSTEP_LIB=path) on HornsRev1 65536, interleaved rounds."""
 import json, os, subprocess, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 libs = sys.argv[1:]
 code = r'''
 import os, sys, json, torch

@@ -2,6 +2,7 @@
 one-block kernel's families), shared wind and a wind per farm, beside veer 0 and the float64 kernel on every farm.
   python tools/veer_rate.py [layout] [B]"""
 import json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -91,6 +91,7 @@ ABI = {
     "wf_set_risk_guard": (C.c_int, [_P, C.c_double]),
     "wf_get_risk_flags": (C.c_int, [_P, _P, C.c_int]),
     "wf_set_risk_resolve": (C.c_int, [_P, C.c_int]),
+    "wf_get_risk_resolve": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "wf_get_resolve_stats": (C.c_int, [_P, C.POINTER(C.c_int), _P, C.c_int]),
     "wf_wind_sample": (C.c_int, [_P, C.c_ulonglong, C.POINTER(WindDist)]),
     "wf_wind_series": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_ulonglong]),
@@ -108,6 +109,8 @@ ABI = {
     "wf_get_kernel_choice": (C.c_int, [_P, C.POINTER(KernelChoice)]),
     "wf_get_calibration": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "wf_get_fly_calibration": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "wf_calibrate": (C.c_int, [_P]),
+    "wf_set_calibration": (C.c_int, [_P, C.c_int, C.c_int]),
     "wf_last_error": (C.c_char_p, [_P]),
 }
 

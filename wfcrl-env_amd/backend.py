@@ -332,18 +332,24 @@ class WfStep:
         check(self._lib.wf_set_risk_guard(self._h, float(rel_band)), self._h)
 
     def set_risk_resolve(self, mode: int | bool = 1):
-        """Float64 re-solve of the farms the float32 kernels flag (include/wfstep.h: wf_set_risk_resolve): 0 / False off,
-        1 / True the flagged farms, 2 every farm.  Afterwards every farm meets the parity tolerances and its flag is 0."""
+        """Float64 re-solve of the farms the float32 kernels flag (include/wfstep.h: wf_set_risk_resolve): 1 / True the
+        flagged farms (the DEFAULT of a new handle: every farm then meets the parity tolerances and its flag is 0), 2 every
+        farm, 0 / False off (float32 only: flagged farms within the per-flag bounds of include/wfstep.h)."""
         check(self._lib.wf_set_risk_resolve(self._h, int(mode)), self._h)
-        self._resolve_mode = int(mode)
+
+    def risk_resolve(self) -> int:
+        """The handle's re-solve mode (wf_get_risk_resolve): 0 off, 1 flagged farms, 2 every farm."""
+        m = C.c_int(0)
+        check(self._lib.wf_get_risk_resolve(self._h, C.byref(m)), self._h)
+        return int(m.value)
 
     def resolve_stats(self) -> dict:
         """{"n_resolved": farms the last step solved in float64, "raw_flags": int32 (B,) flags before they were cleared}.
         Only meaningful after a step with the re-solve on: with it off (set_risk_resolve(0)) nothing is recorded and
         this raises instead of returning stale flags — read risk_flags() there."""
-        if not getattr(self, "_resolve_mode", 0):
-            raise RuntimeError("resolve_stats() needs the float64 re-solve on (set_risk_resolve(1)); with it off the flags "
-                               "of the last step are risk_flags()")
+        if not self.risk_resolve():
+            raise RuntimeError("resolve_stats() needs the float64 re-solve on (set_risk_resolve(1), the default); with it off "
+                               "the flags of the last step are risk_flags()")
         n = C.c_int(0)
         raw = np.empty(self.env_batch, np.int32)
         check(self._lib.wf_get_resolve_stats(self._h, C.byref(n), raw.ctypes.data, 0), self._h)
@@ -379,7 +385,7 @@ class WfStep:
           pair_table=False           everything on the fly
           fly_one_block=False        a wind per farm stays on wf_step_kernel
           far_skip=False             wf_step_ll_kernel evaluates every (source, target) pair (no far-source / far-pair skip)
-          calibrate=False            the rounds model's guess stands: no timing of the kernel families on the third step
+          calibrate=False            the rounds model's guess stands: no timing of the kernel families before the first step
         Drops the current wind: set it again before the next step."""
         def gs(v, default_s=1):
             if isinstance(v, bool):
@@ -429,6 +435,20 @@ class WfStep:
         check(self._lib.wf_get_fly_calibration(self._h, C.byref(fly), fms), self._h)
         return {"shape": shape, "family_ms": {n: float(m) for n, m in zip(names, ms) if m > 0.0},
                 "on_the_fly": (None, "one_block", "slot")[fly.value], "on_the_fly_ms": {n: float(m) for n, m in zip(("one_block", "slot"), fms) if m > 0.0}}
+
+    def calibrate(self):
+        """Time the kernel families NOW for the current layout / batch / wind (include/wfstep.h: wf_calibrate; synchronises) —
+        otherwise the first step of a configuration does it (or takes the process-wide cached result)."""
+        check(self._lib.wf_calibrate(self._h), self._h)
+
+    _FAMILY_CODES = {"slot": 0, "8x1": (8 << 4) | 1, "4x2": (4 << 4) | 2, "4x1": (4 << 4) | 1, "2x2": (2 << 4) | 2, "16x1": (16 << 4) | 1}
+
+    def set_calibration(self, shape=None, on_the_fly=None):
+        """Take a saved calibration as is — `shape` and `on_the_fly` as calibration() returned them (None: leave that one
+        to the timing); nothing is timed for this configuration afterwards (wf_set_calibration)."""
+        code = -1 if shape is None else self._FAMILY_CODES[shape]
+        fly = {None: 0, "one_block": 1, "slot": 2}[on_the_fly]
+        check(self._lib.wf_set_calibration(self._h, code, fly), self._h)
 
     def kernel_info(self) -> dict:
         k = KernelInfo()

@@ -68,6 +68,8 @@ int wf_create(int device_id, wf_handle** out) {
     if (off && off[0] == '0') c.one_block = 0;
     const char* fs = getenv("WF_LL_FAR_SKIP");
     if (fs && fs[0] == '0') c.far_skip = 0;
+    const char* rr = getenv("WF_RISK_RESOLVE");  // "0": float32 only (the tests that hold the float32 kernels to their flag contract)
+    if (rr && rr[0] >= '0' && rr[0] <= '2' && rr[1] == 0) h->resolve_mode = rr[0] - '0';
     const char* cal = getenv("WF_CALIBRATE");
     if (cal && cal[0] == '0') c.calibrate = 0;
     const char* force = getenv("WF_LL_G");  // "8" or "4x2"
@@ -204,12 +206,6 @@ int wf_set_batch(wf_handle* h, int B) {
   WF_ON_DEVICE(h);
   WF_HIP(h, hipStreamSynchronize(h->stream));
   if (pick_variant(h, h->N, B) < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
-  if (h->n_layouts > 1) {  // the farm -> layout map was for the old batch: back to the first layout for every farm
-    std::vector<double> x0(h->lx.begin(), h->lx.begin() + h->N), y0(h->ly.begin(), h->ly.begin() + h->N);
-    int rc = upload_layouts(h, h->N, 1, x0.data(), y0.data(), nullptr);
-    if (rc != WF_OK) return rc;
-    h->model_dirty = true;
-  }
   apply_kernel_pick(h, h->N, B, nullptr);
   if ((size_t)B != h->cap_env) {
     free_batch(h);
@@ -228,6 +224,16 @@ int wf_set_batch(wf_handle* h, int B) {
   }
   h->B = B; h->wind_count = 0; h->shared_dir = false; h->ws_prev_valid = false;
   h->n_groups = 0; h->grid_step = 0.0;
+  if (h->n_layouts > 1 || !h->layout_n.empty()) {
+    // The farm -> layout map and the per-farm turbine counts were laid out for the old batch: every farm goes back to the
+    // first layout — with the turbine count that layout really has (wf_set_layouts_counts), so that its placeholders stay
+    // placeholders and d_nreal has one entry per farm of the NEW batch.
+    std::vector<double> x0(h->lx.begin(), h->lx.begin() + h->N), y0(h->ly.begin(), h->ly.begin() + h->N);
+    const int n0 = h->layout_n.empty() ? h->N : h->layout_n[0];
+    int rc = upload_layouts(h, h->N, 1, x0.data(), y0.data(), nullptr, n0 < h->N ? &n0 : nullptr);
+    if (rc != WF_OK) return rc;
+    h->model_dirty = true;
+  }
   return WF_OK;
 }
 int wf_set_layouts(wf_handle* h, int n_layouts, const double* x, const double* y, const int* layout_of) {
@@ -300,11 +306,17 @@ int wf_set_risk_resolve(wf_handle* h, int mode) {
   return WF_OK;
 }
 
+int wf_get_risk_resolve(wf_handle* h, int* mode) {
+  if (!h || !mode) return WF_E_INVALID;
+  *mode = h->resolve_mode;
+  return WF_OK;
+}
+
 int wf_get_resolve_stats(wf_handle* h, int* n_resolved, int* raw_flags, int on_device) {
   if (!h) return WF_E_INVALID;
   if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called first");
   WF_ON_DEVICE(h);
-  if (!h->d_res_list || h->resolve_mode == 0) {  // nothing is being resolved on this batch
+  if (!h->d_res_list || !h->res_last) {  // the last step had no re-solve behind it
     if (n_resolved) *n_resolved = 0;
     if (raw_flags) return wf_get_risk_flags(h, raw_flags, on_device);
     return WF_OK;
@@ -312,7 +324,7 @@ int wf_get_resolve_stats(wf_handle* h, int* n_resolved, int* raw_flags, int on_d
   if (raw_flags)
     WF_HIP(h, hipMemcpyAsync(raw_flags, h->d_flags_raw, sizeof(int) * h->B, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                              h->stream));
-  if (n_resolved) WF_HIP(h, hipMemcpyAsync(n_resolved, h->d_res_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (n_resolved) WF_HIP(h, hipMemcpyAsync(n_resolved, h->d_res_count + h->res_parity, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (n_resolved || (raw_flags && !on_device)) WF_HIP(h, hipStreamSynchronize(h->stream));
   return WF_OK;
 }

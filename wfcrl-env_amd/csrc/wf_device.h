@@ -113,6 +113,14 @@ struct WfGroupArgs {
                          // are served by wf_step_ll_kernel, launched with the opposite predicate)
   const int* farm_pred;  // [B] the same per farm (a wind per farm): wf_step_kernel serves the farms with farm_pred[b] != 0
   int* risk_flags;       // [B] out: WF_RISK_* bits of each farm; null = not written
+  // Compaction for the float64 re-solve (wf_resolve.hip), folded into the step kernel's epilogue (round 5: one memset and one
+  // launch fewer behind every step): a farm whose flags meet res_mask appends itself to res_list; the raw flags are kept in
+  // flags_raw; block 0 zeroes the counter the NEXT step will use (two counters used alternately).  All null: no re-solve.
+  int* res_list;         // [B]
+  int* res_count;        // this step's counter
+  int* res_zero;         // the other counter
+  int* flags_raw;        // [B]
+  int res_mask;          // WF_RISK_* bits that select a farm
   const int* n_real;     // [B] turbines the farm really has (wf_set_layouts_counts: layouts of fewer than N turbines are
                          // padded with placeholders far downstream, which nothing real can see); null = N.  Outputs of
                          // the placeholders are written as 0 and stay out of the reward.
@@ -120,6 +128,7 @@ struct WfGroupArgs {
 #define WF_RISK_OVERLAP 1
 #define WF_RISK_POWER_KNEE 2
 #define WF_RISK_THRUST_RAMP 4
+#define WF_RISK_THRUST_UNITY 8
 
 // Pair-coefficient table (shared wind only): for source i and target t (sorted indices) the
 // transverse-velocity contribution is linear in the source's circulations.  The tip vortices' circulations share

@@ -3,6 +3,10 @@
 // kernel introspection.
 #include "wf_handle.h"
 
+#include <cstddef>
+#include <map>
+#include <tuple>
+
 namespace wfi {
 
 // Kernel variant for N turbines and B farms: G lanes per farm, S target slots per lane, G*S >= N.
@@ -168,9 +172,9 @@ int repick_ll_slots(const wf_handle* h, int N, int ll_G, int ll_S, long farm_slo
 // (Re)pick the kernels of a handle for N turbines and B farms under its choice: the register-slot variant and the
 // one-block kernel's shape; frees what was laid out for another shape.  The caller has drained the stream.
 void reset_calibration(wf_handle* h) {
-  h->calib_steps = 0; h->calib_done = false; h->calib_code = -1;
+  h->calib_done = false; h->calib_code = -1; h->tab_slot = false;
   for (float& m : h->calib_ms) m = 0.0f;
-  h->fly_calib = 0; h->fly_calib_steps = 0; h->fly_calib_ms[0] = h->fly_calib_ms[1] = 0.0f;
+  h->fly_calib = 0; h->fly_calib_ms[0] = h->fly_calib_ms[1] = 0.0f;
 }
 
 void apply_kernel_pick(wf_handle* h, int N, int B, bool* variant_changed) {
@@ -351,13 +355,17 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
   ga.mod = 1;
   ga.risk_flags = h->d_flags;
   ga.n_real = h->d_nreal;
+  if (h->res_mask) {  // the real launch of a step with the re-solve behind it (not a calibration probe): launch_step
+    ga.res_list = h->d_res_list; ga.flags_raw = h->d_flags_raw; ga.res_mask = h->res_mask;
+    ga.res_count = h->d_res_count + h->res_parity; ga.res_zero = h->d_res_count + (h->res_parity ^ 1);
+  }
   ga.blk_unit = 1;
   if (h->n_groups > 0) {
     ga.perm = h->d_perm; ga.blk_group = h->d_blk_group; ga.n_blocks = h->n_blocks;
     ga.shift = h->group_shift; ga.mod = h->n_groups;
     ga.blk_unit = group_unit(h); ga.n_slots = h->n_slots;
   }
-  if (ptab && h->ll_G) {
+  if (ptab && h->ll_G && !(h->tab_slot && h->n_groups == 0)) {
     // the one-block-at-a-time kernel serves every direction without a cross-block tie; wf_step_kernel, enqueued right
     // behind it, serves the others (device-side predicate, no host round trip)
     const int fpb = ll_log_fpb(h);  // (farm slots of the log: whole blocks of the wider of the two paths' blocks)
@@ -397,16 +405,18 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
   return WF_OK;
 }
 
-// The step as the ABI sees it: the float32 kernels, then — when asked for (wf_set_risk_resolve) — the float64 solve of
-// the flagged (or all) farms on the same stream, overwriting their outputs.  (wind_veer != 0 no longer forces it: the
-// VEER instantiations of the float32 kernels serve such models, with the same flags.)
 // Per-handle calibration of the kernel family.  The rounds model above is a table of milliseconds measured on ONE box
 // for two layouts; layouts, directions, clocks and partitioned devices move the families against each other by up to
-// 10 %.  So the handle measures: on its third table-path step (plain or fused env step: launch_step) after a (re)configuration it launches every family
-// the model prices within 60 % of its best guess on the caller's own buffers (the step is stateless: the real launch
-// follows and overwrites them), times three launches of each one by one with HIP events, and keeps the fastest.  A few ms, once;
-// that one call synchronises.  The rounds model remains the cold-start guess and the price list of grouped launches.
-static bool calibration_due(const wf_handle* h, const WfEnvArgs* ea) {
+// 10 %.  So the handle measures — BEFORE its first real launch of a configuration (round 5; rounds 3-4 waited for the third
+// step, so that steps 1-2 and 3+ could come from two families with different summation orders): every family the model
+// prices within 60 % of its best guess is launched on the caller's own buffers (the step is stateless: the real launch
+// follows and overwrites them; each probe carries its own warm launch), three launches of each are timed one by one with
+// HIP events, and the fastest is kept — the guess itself when it is within 4 % of it.  A few ms, once; that one call
+// synchronises (wf_calibrate does the same at a point of the caller's choosing).  The result is cached per process under
+// (device, turbines, batch, layout, model, skip switch): a re-created handle of the same configuration does not time
+// again and is served by the same family; wf_get_calibration / wf_set_calibration save and restore it across processes.
+// The rounds model remains the cold-start guess and the price list of grouped launches.
+static bool calibration_due(const wf_handle* h) {
   if (h->calib_done || h->choice.calibrate == 0 || h->choice.one_block != -1 || h->choice.pair_table == 0) return false;
   if (h->N <= 16 || h->N > WF_PAIR_MAX_N || h->n_groups > 0 || h->n_layouts != 1) return false;
   if (!(h->wind_count == 1 || h->shared_dir) || !wfk_variant_has_table(h->variant)) return false;
@@ -415,16 +425,70 @@ static bool calibration_due(const wf_handle* h, const WfEnvArgs* ea) {
   return (long)h->B > (long)h->n_cu * fpb;  // below that: the latency regime, pick_variant's widened kernel
 }
 
+// ---- process-wide cache of calibration results ----
+struct CalibKey {
+  int device, N, B, n_cu, far_skip;
+  unsigned long long layout_hash, model_hash;
+  bool operator<(const CalibKey& o) const {
+    return std::tie(device, N, B, n_cu, far_skip, layout_hash, model_hash) <
+           std::tie(o.device, o.N, o.B, o.n_cu, o.far_skip, o.layout_hash, o.model_hash);
+  }
+};
+struct CalibVal {
+  bool have_tab = false, have_fly = false;
+  int code = -1, fly = 0;
+  float ms[8] = {}, fly_ms[2] = {};
+};
+static std::mutex g_calib_mu;
+static std::map<CalibKey, CalibVal> g_calib;
+
+static unsigned long long fnv(const void* p, size_t n, unsigned long long hsh = 1469598103934665603ull) {
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  for (size_t i = 0; i < n; ++i) hsh = (hsh ^ b[i]) * 1099511628211ull;
+  return hsh;
+}
+static CalibKey calib_key(const wf_handle* h) {
+  CalibKey k{};
+  k.device = h->device; k.N = h->N; k.B = h->B; k.n_cu = h->n_cu; k.far_skip = h->choice.far_skip;
+  k.layout_hash = fnv(h->ly.data(), sizeof(double) * h->ly.size(), fnv(h->lx.data(), sizeof(double) * h->lx.size()));
+  const wf_model_params& m = h->model;  // every scalar up to the table (the pointers behind it are this handle's own copies)
+  unsigned long long mh = fnv(&m, offsetof(wf_model_params, n_table));
+  const int sw[3] = {m.enable_secondary_steering, m.enable_yaw_added_recovery, m.enable_transverse_velocities};
+  mh = fnv(sw, sizeof(sw), mh);
+  mh = fnv(h->tws.data(), sizeof(double) * h->tws.size(), mh);
+  mh = fnv(h->tct.data(), sizeof(double) * h->tct.size(), mh);
+  k.model_hash = fnv(h->tcp.data(), sizeof(double) * h->tcp.size(), mh);
+  return k;
+}
+
+// the family `code` ((G << 4) | S, 0 = the register-slot kernel) serves the handle's ungrouped table path from now on.
+// The caller has drained the stream.
+static void apply_family(wf_handle* h, int code, int guess_code) {
+  if (code == 0) {
+    // ll_G / ll_S keep the rounds model's shape: grouped launches and the on-the-fly path (a wind per farm) go on using it
+    set_ll_shape(h, guess_code >> 4, guess_code ? (guess_code & 15) : 1);
+    h->tab_slot = guess_code != 0;
+  } else {
+    set_ll_shape(h, code >> 4, code & 15);
+    h->tab_slot = false;
+  }
+}
+
+static bool family_valid(const wf_handle* h, int fi) {
+  const LlFamily& f = kLlFamilies[fi];
+  const bool veer = h->model.veer != 0.0;
+  if (f.code && h->N <= (f.code >> 4) * (f.code & 15)) return false;
+  if (f.code == ((8 << 4) | 1) && h->N <= 32) return false;
+  if (veer && f.code && !wfk_ll_has_veer(f.code >> 4, f.code & 15, 1)) return false;
+  return true;
+}
+
 static int calibrate_families(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
   const int N = h->N, B = h->B;
-  const bool veer = h->model.veer != 0.0;
   double est[kNumFamilies], best_est = 1e300;
   for (int fi = 0; fi < kNumFamilies; ++fi) {
-    const LlFamily& f = kLlFamilies[fi];
     est[fi] = 1e300;
-    if (f.code && N <= (f.code >> 4) * (f.code & 15)) continue;
-    if (f.code == ((8 << 4) | 1) && N <= 32) continue;
-    if (veer && f.code && !wfk_ll_has_veer(f.code >> 4, f.code & 15, 1)) continue;
+    if (!family_valid(h, fi)) continue;
     est[fi] = ll_estimate(h, fi, N, B);
     if (est[fi] < best_est) best_est = est[fi];
   }
@@ -434,13 +498,12 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
   int best = -1, guess = -1;
   float best_ms = 1e30f;
   int rc = WF_OK;
-  const int code0 = h->ll_G ? ((h->ll_G << 4) | h->ll_S) : 0;  // the rounds model's guess: what has served the handle so far
+  const int code0 = h->ll_G ? ((h->ll_G << 4) | h->ll_S) : 0;  // the rounds model's guess
   for (int fi = 0; fi < kNumFamilies && rc == WF_OK; ++fi) {
     if (kLlFamilies[fi].code == code0 && est[fi] < 1e300) guess = fi;
     if (!(est[fi] <= 1.6 * best_est) && fi != guess) continue;
-    const int code = kLlFamilies[fi].code;
     hipStreamSynchronize(h->stream);
-    set_ll_shape(h, code >> 4, code ? (code & 15) : 1);
+    apply_family(h, kLlFamilies[fi].code, code0);
     if ((rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea)) != WF_OK) break;  // tables, log, first-launch costs
     float fam_ms = 1e30f;  // the fastest of three launches timed one by one (two handles on one kernel differ by 3-5 %: noise counts)
     for (int r = 0; r < 3 && rc == WF_OK; ++r) {
@@ -459,16 +522,17 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
   }
   hipEventDestroy(e0);
   hipEventDestroy(e1);
-  if (rc != WF_OK) return rc;
+  hipStreamSynchronize(h->stream);
+  if (rc != WF_OK) {  // a failed probe leaves the handle on the rounds model's guess, not on a candidate
+    apply_family(h, code0, code0);
+    return rc;
+  }
   // The guess stands unless another family beats it by 4 %: near-ties would otherwise be decided by timing noise, and two
   // runs of one program would be served by different families (which agree within the parity tolerances, not bit for bit).
   if (guess >= 0 && h->calib_ms[guess] > 0.0f && h->calib_ms[guess] <= 1.04f * best_ms) best = guess;
-  if (best >= 0) {
-    const int code = kLlFamilies[best].code;
-    hipStreamSynchronize(h->stream);
-    set_ll_shape(h, code >> 4, code ? (code & 15) : 1);
-    h->calib_code = code;
-  }
+  const int code = best >= 0 ? kLlFamilies[best].code : code0;
+  apply_family(h, code, code0);
+  h->calib_code = code;
   h->calib_done = true;
   return WF_OK;
 }
@@ -476,9 +540,9 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
 // The same question on the on-the-fly path (a wind per farm).  The family comes from the table path's pick; what the rounds
 // model cannot know is how the register-slot kernel compares there — on the fly it evaluates every pair once, the
 // one-block kernel re-reads its log per block, and between one and three rounds of the slot kernel (HornsRev1 x 16384,
-// Ormonde x 16384 ... 24576) the slot kernel is 10-15 % faster (profiles/r04_fly_pick_sweep.txt).  Third step with a
-// wind per farm: both timed on the caller's buffers, the slot kernel has to win by 4 % (near-ties stay where they are).
-static bool fly_calibration_due(const wf_handle* h, const WfEnvArgs* ea) {
+// Ormonde x 16384 ... 24576) the slot kernel is 10-15 % faster (profiles/r04_fly_pick_sweep.txt).  Before the first step
+// with a wind per farm: both timed on the caller's buffers, the slot kernel has to win by 4 % (near-ties stay where they are).
+static bool fly_calibration_due(const wf_handle* h) {
   if (h->fly_calib != 0 || h->choice.calibrate == 0 || h->choice.one_block != -1 || h->choice.fly_one_block != -1) return false;
   if (h->wind_count == 1 || h->shared_dir || h->n_groups > 0 || h->B <= 1 || !h->ll_G) return false;
   return wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h));
@@ -511,35 +575,110 @@ static int calibrate_fly(wf_handle* h, const float* yaw, float* power, float* ws
   return rc;
 }
 
+// Whatever calibration the handle's current configuration and wind regime still owe, now (the stream is drained on the
+// way).  use_cache: take / leave the process-wide result for this configuration instead of timing again.
+int calibrate_now(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* probe, bool use_cache) {
+  const bool tab_due = calibration_due(h), fly_due = fly_calibration_due(h);
+  if (!tab_due && !fly_due) return WF_OK;
+  const CalibKey key = calib_key(h);
+  CalibVal cv;
+  {
+    std::lock_guard<std::mutex> lk(g_calib_mu);
+    auto it = g_calib.find(key);
+    if (it != g_calib.end()) cv = it->second;
+  }
+  int rc = WF_OK;
+  if (tab_due) {
+    const int code0 = h->ll_G ? ((h->ll_G << 4) | h->ll_S) : 0;
+    if (use_cache && cv.have_tab) {
+      const int cur = h->tab_slot ? 0 : code0;
+      if (cv.code != cur) {
+        WF_HIP(h, hipStreamSynchronize(h->stream));
+        apply_family(h, cv.code, code0);
+      }
+      h->calib_code = cv.code; h->calib_done = true;
+      for (int k = 0; k < 8; ++k) h->calib_ms[k] = cv.ms[k];
+    } else {
+      if ((rc = calibrate_families(h, yaw, power, wspd, wdir, load, probe)) != WF_OK) return rc;
+      cv.have_tab = true; cv.code = h->calib_code;
+      for (int k = 0; k < 8; ++k) cv.ms[k] = h->calib_ms[k];
+    }
+  }
+  if (fly_due) {
+    if (use_cache && cv.have_fly) {
+      h->fly_calib = cv.fly; h->fly_calib_ms[0] = cv.fly_ms[0]; h->fly_calib_ms[1] = cv.fly_ms[1];
+    } else {
+      if ((rc = calibrate_fly(h, yaw, power, wspd, wdir, load, probe)) != WF_OK) return rc;
+      cv.have_fly = true; cv.fly = h->fly_calib; cv.fly_ms[0] = h->fly_calib_ms[0]; cv.fly_ms[1] = h->fly_calib_ms[1];
+    }
+  }
+  std::lock_guard<std::mutex> lk(g_calib_mu);
+  g_calib[key] = cv;
+  return WF_OK;
+}
+
+// A calibration saved from another handle / process (wf_get_calibration, wf_get_fly_calibration): taken as is, nothing is timed.
+int apply_saved_calibration(wf_handle* h, int code, int fly_choice) {
+  if (code >= 0) {
+    int fi = -1;
+    for (int k = 0; k < kNumFamilies; ++k)
+      if (kLlFamilies[k].code == code) fi = k;
+    if (fi < 0 || !family_valid(h, fi)) return fail(h, WF_E_INVALID, "wf_set_calibration: not a kernel family of this turbine count / model");
+    if (h->choice.one_block != -1 || h->choice.pair_table == 0) return fail(h, WF_E_INVALID, "wf_set_calibration: the kernel choice of this handle is forced");
+    WF_HIP(h, hipStreamSynchronize(h->stream));
+    apply_family(h, code, pick_ll(h, h->N, h->B));  // (tables and log are laid out per shape: rebuilt by the next launch)
+    h->calib_code = code; h->calib_done = true;
+  }
+  if (fly_choice == 1 || fly_choice == 2) h->fly_calib = fly_choice;
+  return WF_OK;
+}
+
+// The step as the ABI sees it: the float32 kernels, then — unless switched off (wf_set_risk_resolve) — the float64 solve of
+// the flagged (or all) farms on the same stream, overwriting their outputs.  (wind_veer != 0 no longer forces it: the
+// VEER instantiations of the float32 kernels serve such models, with the same flags.)
 int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
   // The timed launches must leave no trace: a plain step is stateless, and a fused env step is timed WITHOUT its action —
   // a solve at the yaw the env state holds now (no transition, no reward), whose outputs the real launch overwrites.
-  WfEnvArgs probe_args;
-  const WfEnvArgs* probe = ea;
-  if (ea && ea->action) {
-    probe_args = *ea;
-    probe_args.action = nullptr; probe_args.reward = nullptr;
-    probe = &probe_args;
-  }
-  if (calibration_due(h, ea) && ++h->calib_steps >= 3) {
-    int rc = calibrate_families(h, yaw, power, wspd, wdir, load, probe);
+  if (calibration_due(h) || fly_calibration_due(h)) {
+    WfEnvArgs probe_args;
+    const WfEnvArgs* probe = ea;
+    if (ea && ea->action) {
+      probe_args = *ea;
+      probe_args.action = nullptr; probe_args.reward = nullptr;
+      probe = &probe_args;
+    }
+    int rc = calibrate_now(h, yaw, power, wspd, wdir, load, probe, true);
     if (rc != WF_OK) return rc;
   }
-  if (fly_calibration_due(h, ea) && ++h->fly_calib_steps >= 3) {
-    int rc = calibrate_fly(h, yaw, power, wspd, wdir, load, probe);
-    if (rc != WF_OK) return rc;
-  }
-  int rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
-  if (rc != WF_OK) return rc;
+  // Which farms are solved again in float64 behind this launch: mode 1 every flagged farm, mode 2 all of them, mode 0 only
+  // the farms with WF_RISK_THRUST_UNITY — a thrust coefficient above 0.995, where float32 carries no bound at all
+  // (wf_kernel_common.h: table_ct) — and that only when the handle's thrust table gets there (nrel_5MW does not: nothing
+  // is enqueued for it).
   const int mode = h->resolve_mode;
-  if (mode == 0) return WF_OK;
-  if (!h->d_res_list) {
-    WF_HIP(h, hipMalloc(&h->d_res_list, sizeof(int) * h->cap_env));
-    WF_HIP(h, hipMalloc(&h->d_res_count, sizeof(int)));
-    WF_HIP(h, hipMalloc(&h->d_flags_raw, sizeof(int) * h->cap_env));
+  int mask = mode == 1 ? 0xF : 0;
+  if (mode == 0) {
+    double ct_max = 0.0;
+    for (double v : h->tct) ct_max = v > ct_max ? v : ct_max;
+    if (ct_max > 0.994) mask = WF_RISK_THRUST_UNITY;
   }
+  if (mode != 0 || mask) {
+    if (!h->d_res_list) {
+      WF_HIP(h, hipMalloc(&h->d_res_list, sizeof(int) * h->cap_env));
+      WF_HIP(h, hipMalloc(&h->d_res_count, sizeof(int) * 2));
+      WF_HIP(h, hipMalloc(&h->d_flags_raw, sizeof(int) * h->cap_env));
+      WF_HIP(h, hipMemsetAsync(h->d_res_count, 0, sizeof(int) * 2, h->stream));
+      h->res_parity = 0;
+    }
+  }
+  h->res_last = mode != 0 || mask != 0;
+  if (mask) h->res_parity ^= 1;  // this step's counter; the step kernels zero the other one for the next step
+  h->res_mask = mask;
+  int rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
+  h->res_mask = 0;
+  if (rc != WF_OK) return rc;
+  if (mode == 0 && !mask) return WF_OK;
   WfResolveArgs ra{};
-  ra.tab64 = h->d_tab64; ra.list = h->d_res_list; ra.count = h->d_res_count; ra.flags = h->d_flags;
+  ra.tab64 = h->d_tab64; ra.list = h->d_res_list; ra.count = h->d_res_count + h->res_parity; ra.flags = h->d_flags;
   ra.gx = h->d_gx; ra.gy = h->d_gy; ra.gidx = h->d_gidx;
   ra.geom_stride = (h->wind_count == 1 || h->shared_dir) ? 0 : (size_t)h->N;
   ra.mod = 1;
@@ -587,7 +726,7 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
                                       : (h->B > 0 ? (h->B + info->envs_per_block - 1) / info->envs_per_block : 0);
   const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && h->choice.fly_one_block != 0 &&
                       h->fly_calib != 2;
-  info->one_block_kernel = ((tab && h->ll_G) || ll_fly) ? 1 : 0;
+  info->one_block_kernel = ((tab && h->ll_G && !(h->tab_slot && h->n_groups == 0)) || ll_fly) ? 1 : 0;
   if (info->one_block_kernel) {
     // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
     // fields above would describe) is enqueued behind it for the directions that have one
@@ -627,6 +766,37 @@ int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c) {
   // geometry, groups and tables of the current wind were laid out for the previous choice: the wind has to be set again
   h->wind_count = 0; h->shared_dir = false; h->n_groups = 0; h->grid_step = 0.0; h->series_T = 0; h->pair_dirty = true;
   return WF_OK;
+}
+
+int wf_calibrate(wf_handle* h) {
+  if (!h) return WF_E_INVALID;
+  if (h->wind_count == 0) return fail(h, WF_E_INVALID, "wf_set_wind must be called before wf_calibrate");
+  WF_ON_DEVICE(h);
+  if (h->model_dirty) {
+    int rc = build_consts(h);
+    if (rc != WF_OK) return rc;
+  }
+  WF_HIP(h, hipStreamSynchronize(h->stream));
+  apply_kernel_pick(h, h->N, h->B, nullptr);  // start over from the rounds model's guess
+  if (h->variant < 0) return fail(h, WF_E_UNSUPPORTED, "no kernel variant for this turbine count");
+  // probes on scratch buffers: zero yaw in, outputs dropped
+  const size_t bn = (size_t)h->B * h->N;
+  float* d = nullptr;
+  WF_HIP(h, hipMalloc(&d, sizeof(float) * bn * 8));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(float) * bn, h->stream);
+  int rc = e == hipSuccess ? calibrate_now(h, d, d + bn, d + 2 * bn, d + 3 * bn, d + 4 * bn, nullptr, false)
+                           : fail(h, WF_E_HIP, std::string("wf_calibrate: ") + hipGetErrorString(e));
+  hipStreamSynchronize(h->stream);
+  hipFree(d);
+  return rc;
+}
+
+int wf_set_calibration(wf_handle* h, int code, int fly_choice) {
+  if (!h) return WF_E_INVALID;
+  if (h->N <= 0 || h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_layout and wf_set_batch must be called before wf_set_calibration");
+  if (code < -1 || fly_choice < 0 || fly_choice > 2) return fail(h, WF_E_INVALID, "wf_set_calibration: code is -1 or a family code, fly_choice 0, 1 or 2");
+  WF_ON_DEVICE(h);
+  return apply_saved_calibration(h, code, fly_choice);
 }
 
 int wf_get_calibration(wf_handle* h, int* code, float* family_ms) {

@@ -171,23 +171,27 @@ struct wf_handle {
   // which kernels may serve this handle (wf_set_kernel_choice; the WF_* environment variables only seed it at wf_create)
   wf_kernel_choice choice{0, 0, -1, 0, 0, -1, -1, -1, -1};
   int n_cu = 256;              // compute units of the handle's device (hipDeviceProp_t::multiProcessorCount)
-  // per-handle calibration of the kernel family (wf_dispatch.hip: calibrate_families): table-path steps since the
-  // last (re)configuration, and whether the families have been timed for it
-  int calib_steps = 0;
+  // per-handle calibration of the kernel family (wf_dispatch.hip: calibrate_families): whether the families have been
+  // timed (or taken from the process cache / wf_set_calibration) for the current configuration
   bool calib_done = false;
   int calib_code = -1;         // what the timing chose: (G << 4) | S, 0 = the register-slot kernel, -1 = never ran
+  bool tab_slot = false;       // the calibration kept the register-slot kernel for the UNGROUPED shared-wind table path; ll_G / ll_S
+                               // keep the rounds model's shape, which grouped launches and the on-the-fly path go on using
   float calib_ms[8] = {};      // ms per launch of each family of the rounds model it timed (0 = not timed)
   // ... and of the on-the-fly path (a wind per farm; calibrate_fly): the one-block kernel the table path's family stands
   // for against the register-slot kernel
   int fly_calib = 0;           // 0 = not timed yet (the one-block kernel runs), 1 = the one-block kernel, 2 = wf_step_kernel
-  int fly_calib_steps = 0;
   float fly_calib_ms[2] = {};  // {one-block kernel + wf_step_kernel for its tied farms, wf_step_kernel alone}
   // float64 re-solve of the farms the float32 kernels flag (wf_resolve.hip)
-  int resolve_mode = 0;        // 0 off, 1 flagged farms, 2 every farm (wf_set_risk_resolve; wind_veer models are served by
-                               // the VEER float32 instantiations and take the same modes — nothing forces mode 2)
+  int resolve_mode = 1;        // 0 off, 1 flagged farms (the default: the reference computes every step in float64), 2 every farm
+                               // (wf_set_risk_resolve; wind_veer models are served by the VEER float32 instantiations and take
+                               // the same modes — nothing forces mode 2)
   WfResolveConsts rconsts{};
   double* d_tab64 = nullptr;   // [3][WF_TABLE_PAD] wind speed, Ct, power in float64
-  int *d_res_list = nullptr, *d_res_count = nullptr, *d_flags_raw = nullptr;  // [B], [1], [B]
+  int *d_res_list = nullptr, *d_res_count = nullptr, *d_flags_raw = nullptr;  // [B], [2] (used alternately: res_parity), [B]
+  int res_parity = 0;          // which of the two counters the last step with a re-solve used
+  bool res_last = false;       // the last step had a re-solve behind it (its list, counter and raw flags are current)
+  int res_mask = 0;            // nonzero only while launch_step enqueues the real launch: WF_RISK_* bits that put a farm on the list
 };
 
 namespace wfi {
@@ -243,6 +247,8 @@ size_t ll_npad(const wf_handle* h);
 int ll_log_fpb(const wf_handle* h);
 int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea);
 void reset_calibration(wf_handle* h);
+int calibrate_now(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* probe, bool use_cache);
+int apply_saved_calibration(wf_handle* h, int code, int fly_choice);
 // wf_groups.hip
 void ungroup(wf_handle* h);
 int farms_per_block(const wf_handle* h);

@@ -63,16 +63,19 @@ __device__ __forceinline__ int table_segment(const WfConsts& c, const TableLds& 
 }
 
 // scipy interp1d(linear, fill_value=(lo,hi)) on the LDS copy of the table
-// steep: the turbine sits on a segment of the thrust table with v |dCt/dv| > ct_kappa (WF_RISK_THRUST_RAMP)
-__device__ __forceinline__ float table_ct(const WfConsts& c, const TableLds& T, float v, bool& steep) {
+// risk: WF_RISK_THRUST_RAMP when the turbine sits on a segment of the thrust table with v |dCt/dv| > ct_kappa;
+//       WF_RISK_THRUST_UNITY when its thrust coefficient is within 0.005 of 1 (a user table; nrel_5MW peaks at 0.99): the wake
+//       amplitude Ct / (1 + sqrt(1 - Ct)) then loses 1e-5 to the cancellation in 1 - Ct, and behind such a turbine the velocity
+//       u = Uinit (1 - deficit) is a tenth or less of the deficit — the error reaches 1e-4 of u and there is no float32 bound
+//       (layout fuzzer, round 4: a table clipped at 0.9999 over 3-11 m/s; TI off by 0.7 on a dense farm).  Farms with this
+//       flag are ALWAYS solved again in float64, whatever wf_set_risk_resolve says (wf_dispatch.hip: launch_step).
+__device__ __forceinline__ float table_ct(const WfConsts& c, const TableLds& T, float v, unsigned& risk) {
   int j = table_segment(c, T, v);
   float r = fmaf(T.cts[j], v - T.knot[j], T.ct[j]);
-  const bool inside = v >= T.knot[0] && v <= T.knot[c.n_table - 1] && r > 0.0001f && r < 0.9999f;
-  // ... or the thrust coefficient is within 0.005 of 1 (a user table; nrel_5MW peaks at 0.99): the wake amplitude
-  // Ct / (1 + sqrt(1 - Ct)) then loses 1e-5 to the cancellation in 1 - Ct, and behind such a turbine the velocity
-  // u = Uinit (1 - deficit) is a tenth or less of the deficit — the error reaches 1e-4 of u (layout fuzzer, round 4:
-  // a table clipped at 0.9999 over 3-11 m/s)
-  steep = (inside && fabsf(T.cts[j]) * v > c.ct_kappa) || (v >= T.knot[0] && v <= T.knot[c.n_table - 1] && r > 0.995f);
+  const bool in_range = v >= T.knot[0] && v <= T.knot[c.n_table - 1];
+  const bool inside = in_range && r > 0.0001f && r < 0.9999f;
+  risk = ((inside && fabsf(T.cts[j]) * v > c.ct_kappa) ? (unsigned)WF_RISK_THRUST_RAMP : 0u) |
+         ((in_range && r > 0.995f) ? (unsigned)WF_RISK_THRUST_UNITY : 0u);
   r = (v < T.knot[0]) ? 0.0001f : r;
   r = (v > T.knot[c.n_table - 1]) ? 0.9999f : r;
   return fminf(fmaxf(r, 0.0001f), 0.9999f);

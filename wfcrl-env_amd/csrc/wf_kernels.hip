@@ -327,6 +327,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   __shared__ unsigned risk_lds[WPB][EPW];  // per farm: WF_RISK_* bits raised during the solve
   // Direction groups (a pair table + sorted geometry per distinct wind direction): all farms of a block belong to one
   // group; blocks beyond the padded farm list carry group -1.
+  if (ga.res_zero && blockIdx.x == 0 && threadIdx.x == 0) *ga.res_zero = 0;  // the re-solve counter of the NEXT step (before any early return)
   int grp = 0;
   if (ga.blk_group) {
     grp = ga.blk_group[(blockIdx.x * (WPB * EPW)) / ga.blk_unit];
@@ -572,9 +573,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
                           float& a, float& gt, float& gb) {
     ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
     const float cg = L.cg[eiw][i], sg = L.sg[eiw][i];
-    bool steep;
-    ct = table_ct(c, T, ubar, steep) * cg;
-    if (steep) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_THRUST_RAMP);
+    unsigned trisk;
+    ct = table_ct(c, T, ubar, trisk) * cg;
+    if (trisk) atomicOr(&risk_lds[wave][eiw], trisk);
     const float sq1 = fsqrt(1.0f - ct * cg);
     a = 0.5f * ct * frcp(1.0f + sq1);  // == 0.5/cg*(1 - sqrt(1 - ct*cg))
     Gwr = c.gam_wr * (a - a * a) * ubar;
@@ -1006,7 +1007,14 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
     }
   }  // blk
 
-  if (ga.risk_flags && sub == 0 && env_ok) ga.risk_flags[env] = (int)risk_lds[wave][eiw];
+  if (ga.risk_flags && sub == 0 && env_ok) {
+    const int rf = (int)risk_lds[wave][eiw];
+    ga.risk_flags[env] = rf;
+    if (ga.res_list) {  // the float64 re-solve's work list (wf_device.h: WfGroupArgs)
+      ga.flags_raw[env] = rf;
+      if (rf & ga.res_mask) ga.res_list[atomicAdd(ga.res_count, 1)] = env;
+    }
+  }
   if (ea.reward) {
     // r = mean_j(P_j[MW] * 1e3 / ws^3) - load_coef * mean|loads|      (simple_env.py:78-84)
 #pragma unroll

@@ -1,4 +1,4 @@
-// wf_kernels_ll.hip — the farm step on the pair-table path, one target block at a time ("left-looking").
+// wf_kernels_ll.hip — the farm step, one target block at a time ("left-looking"): the kernel the headline runs on.
 //
 // Same model, same arithmetic and the same discontinuity handling as wf_step_kernel (wf_kernels.hip; references and
 // [A.x] tags there); what differs is the order in which the (source, target) pairs of the triangular recurrence are
@@ -6,23 +6,40 @@
 //   * wf_step_kernel ("right-looking") applies a source to ALL downstream targets at once: the state of S target slots
 //     (27 S floats) lives in VGPRs for the whole solve, which pins the S >= 4 variants at two waves per SIMD;
 //   * here ONE target block of G S turbines (27 S floats per lane, S = 1 or 2) is in registers at a time.  Block J is first
-//     swept by all sources of the earlier blocks, whose constants (16 floats per source and farm: circulations,
-//     deflection / deficit / turbulence constants) are replayed from a per-farm SOURCE LOG in device memory, written when
-//     that source had its turn; then the block's own sources run the sequential recurrence exactly as wf_step_kernel's
-//     slot 0 does (source phase, transverse pass, yaw-added recovery, deficit pass), appending to the log; then the
-//     block's outputs are written.  The lane group can be narrow — G = 4: sixteen farms per wave share every per-source
-//     instruction — because the block, not the farm, has to fit the registers; with S = 1 the kernel runs three waves
-//     per SIMD (168 VGPRs), with G = 4, S = 2 two (223 VGPRs; 24 % fewer instructions per farm than G = 8, S = 1, the
-//     same log traffic), and no register slots have to be shifted.  Which of them runs is decided per batch size by
-//     the rounds model in wf_dispatch.hip::pick_ll.
-//   * the replay loop's memory order is pinned by hand (compiler barriers; DESIGN.md §4 "what the replay loop was
-//     actually waiting for"): {dx, dy, tipow, bits} reads, the prefetch of the next log record, the deficit / TI bodies of
-//     all slots, and only then the 9 coefficient float4 per slot and the transverse pass.
+//     swept by all sources of the earlier blocks, REPLAYED from a per-wave source log in device memory; then the block's own
+//     sources run the sequential recurrence exactly as wf_step_kernel's slot 0 does (source phase, transverse pass, yaw-added
+//     recovery, deficit pass) and append to the log; then the block's outputs are written.  The lane group can be narrow —
+//     G = 2: thirty-two farms per wave share every per-source instruction — because the block, not the farm, has to fit the
+//     registers.  Families: 2x2 (the headline: 4-turbine blocks, two waves per SIMD), 4x2, 4x1, 8x1, 16x1 (three waves per
+//     SIMD with one slot); wf_dispatch.hip picks by batch size (rounds model + the handle's own timing).
+//   * The source log is split by who reads it (round 4; struct SrcLog below has the field list):
+//       HOT   8 B per source and farm  {Gy / Gwt, Gwt}: all the transverse pass needs — read by EVERY later block; sources
+//             2m and 2m + 1 share one float4;
+//       COLD  48 B per source and farm (three float4): what deflection / deficit / turbulence need — read only by the
+//             blocks the source's wake can reach;
+//       BOUND 16 B per source in wave-private LDS {k6, b6, n6}: a bound on 6.12 sigma_y(dx) + D/4 + |deflection| over the
+//             farms of the wave (far_bound arithmetic in own_source); beyond it the nearest rotor-grid column gets exp2(-27)
+//             of the amplitude — no effect on any float32 result (tests/test_hip_parity.py: skip on / off bit-identical);
+//       SIDE  16 B, written and read only for split-TI sources (the three column TIs and dTI).
+//     Both global parts are wave-major ([wave][source][farm]): a wave-instruction reads one contiguous run and a block's
+//     records are whole 128-byte lines (no line is shared between a block being written and one being read).
+//   * Replay of a staged chunk of 64 / (G S) sources (table path): one lane per (source, target) pair tests the pair against
+//     the source's bound — the ballot, folded to a bit per source, is the chunk's NEAR LIST (farm-independent: the farms of a
+//     wave share geometry); then the transverse pass over ALL sources of the chunk, two per iteration (5 instructions per grid
+//     point, the next pair's hot record fetched one iteration ahead); then the deflection / deficit / turbulence pass over
+//     the near sources only, the next near source's cold record fetched a step ahead into the other of two register sets.
+//     The two passes touch disjoint state and keep their own source order: bit for bit the result of one loop.
 //   * pair-table records are laid out per target block, [J][source i][target of J], so that the 64 records of a chunk
-//     (64 / G consecutive sources of one block) are one contiguous 11-KiB piece, staged into a double-buffered LDS slab
-//     with global_load_lds_dwordx4 one chunk ahead (one __syncthreads() per chunk);
-//   * the price is the log traffic: 64 B written per source and farm, re-read once per later block (it does not fit the
-//     L2: DESIGN.md §4).
+//     (64 / (G S) consecutive sources of one block) are one contiguous 11-KiB piece, staged into a double-buffered LDS slab
+//     with global_load_lds_dwordx4 one chunk ahead (one __syncthreads() per chunk).  The compiler guards the first LDS read
+//     of an iteration with s_waitcnt vmcnt(0) — the chunk arrives by LDS-DMA, counted in vmcnt — so log prefetches are
+//     issued BEHIND the first LDS reads of an iteration and no load stays in flight across one.
+//   * A wind per farm (TAB = false): no pair table — the transverse pass is evaluated on the fly from the farm's own float64
+//     coordinates (apply_fly), same log, one loop; wf_set_wind sorts the launch slots by direction so that the farms of a
+//     wave lie within a fraction of a degree and the wave-uniform skips take.
+//   * the price of the order is the log traffic: 56 B written per source and farm, the hot part re-read once per later
+//     block, the cold part once per later block in reach (2.4 GB per launch at HornsRev1 x 65536 = 14 x the algorithmic
+//     bytes; it does not fit the L2 — DESIGN.md section 4).
 // Precondition: no x' tie across a block boundary (a later block's source at dx = 0 from an earlier block's target owes
 // that target its transverse velocities [A.3-4], which this order cannot deliver).  wf_pair_table_ll_kernel detects it
 // per wind direction and raises a device flag; this kernel then leaves the launch to wf_step_kernel, which is always
@@ -189,6 +206,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
   __shared__ int env_lds[WPB][EPW];  // farm index of every farm slot of the block (-1 - index: results dropped)
   extern __shared__ __attribute__((aligned(16))) float yaw_lds[];  // [WPB][EPW][n_pad] commanded yaw in sorted order, degrees; then [WPB][n_pad] float4 far bounds
 
+  if (ga.res_zero && blockIdx.x == 0 && threadIdx.x == 0) *ga.res_zero = 0;  // the re-solve counter of the NEXT step (before any early return)
   int grp = 0;
   if (ga.blk_group) {
     grp = ga.blk_group[(blockIdx.x * (WPB * EPW)) / ga.blk_unit];
@@ -728,9 +746,9 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
       WF_ACC(6, so_0, so_1);
       SrcLog Sc;
       const float ubar = fcbrt_pos(m3 * (1.0f / 9.0f));
-      bool steep;
-      const float ct = table_ct(c, T, ubar, steep) * cg;
-      if (steep) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_THRUST_RAMP);
+      unsigned trisk;
+      const float ct = table_ct(c, T, ubar, trisk) * cg;
+      if (trisk) atomicOr(&risk_lds[wave][eiw], trisk);
       const float sq1 = fsqrt(1.0f - ct * cg);
       const float a = 0.5f * ct * frcp(1.0f + sq1);
       const float Gwr = c.gam_wr * (a - a * a) * ubar;
@@ -1119,7 +1137,14 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
   }
 #endif
 
-  if (ga.risk_flags && sub == 0 && env_ok) ga.risk_flags[env] = (int)risk_lds[wave][eiw];
+  if (ga.risk_flags && sub == 0 && env_ok) {
+    const int rf = (int)risk_lds[wave][eiw];
+    ga.risk_flags[env] = rf;
+    if (ga.res_list) {  // the float64 re-solve's work list (wf_device.h: WfGroupArgs)
+      ga.flags_raw[env] = rf;
+      if (rf & ga.res_mask) ga.res_list[atomicAdd(ga.res_count, 1)] = env;
+    }
+  }
   if (ea.reward) {
 #pragma unroll
     for (int w = G / 2; w >= 1; w >>= 1) {

@@ -58,14 +58,15 @@ __device__ inline double interp_fill_uniform(double xq, int n, const double* xs,
 
 }  // namespace
 
-// farms with a nonzero risk flag -> list (any order), count; raw = copy of the flags as the float32 kernels raised them
-__global__ void wf_compact_flagged_kernel(const int* __restrict__ flags, int B, int all, int* __restrict__ list,
-                                          int* __restrict__ count, int* __restrict__ raw) {
+// every farm -> list, count = B; raw = copy of the flags as the float32 kernels raised them (mode 2: the flagged-farms list of
+// modes 0 / 1 is written by the step kernels themselves, wf_device.h: WfGroupArgs::res_list)
+__global__ void wf_list_all_kernel(const int* __restrict__ flags, int B, int* __restrict__ list, int* __restrict__ count,
+                                   int* __restrict__ raw) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) *count = B;
   if (b >= B) return;
-  const int f = flags[b];
-  raw[b] = f;
-  if (f != 0 || all) list[atomicAdd(count, 1)] = b;
+  raw[b] = flags[b];
+  list[b] = b;
 }
 
 // 1 / x to float64 accuracy from the hardware estimate and two Newton steps (6 instructions; the compiler's IEEE division
@@ -1033,10 +1034,11 @@ extern "C" int wfk_res_stamps(unsigned long long* out, int reset) {
 
 extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags,
                                          int n_cu, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(a->count, 0, sizeof(int), s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wf_compact_flagged_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a->flags, B, all, a->list, a->count, raw_flags);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipError_t e = hipSuccess;
+  if (all) {
+    hipLaunchKernelGGL(wf_list_all_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a->flags, B, a->list, a->count, raw_flags);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
   // Which kernel serves the list depends on how many farms it holds, and that number exists on the device only (no host
   // round trip): up to kRes4MaxFarms — one residency of the four-wave kernel at WF_RES4_OCC farms per CU, where the
   // re-solve is a single farm's latency — the four-wave kernel, beyond it the one-wave kernel (four times the farms per

@@ -137,8 +137,8 @@ class HipFlorisInterface(BaseInterface):
             raise ValueError("xcoords and ycoords layout coordinates must have num_turbines entries")
         self.num_turbines = num_turbines
         self.fi = self._make_backend(xcoords, ycoords, device_id, model)
-        if risk_resolve and hasattr(self.fi, "set_risk_resolve"):
-            self.fi.set_risk_resolve(1)
+        if hasattr(self.fi, "set_risk_resolve"):  # (on is also the default of the handle itself)
+            self.fi.set_risk_resolve(1 if risk_resolve else 0)
         self.measure_map = self.DEFAULT_MEASURE_MAP
         self._num_measures = sum(len(v) if isinstance(v, list) else 1 for v in self.measure_map.values()) - 1
         self.dt = 60

@@ -31,7 +31,7 @@ class VecWindFarmEnv:
                  reward_shaper=None, start_iter: int = 0, max_num_steps: int = 500, load_coef: float = 0.1,
                  device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None,
                  wind_sampling: str = "host", reuse_buffers: bool = False, wind_direction_step: float = None,
-                 actuation_budget: float = 0.1, kernel_choice: dict = None, risk_resolve: bool = True,
+                 actuation_budget: float = 0.1, kernel_choice: dict = None, risk_resolve: bool = None,
                  layouts: dict = None):
         controls = {"yaw": (-40, 40, 5)} if controls is None else dict(controls)
         if list(controls) != ["yaw"]:
@@ -57,12 +57,15 @@ class VecWindFarmEnv:
         p = self.farm_case.simul_params
         self.fi = backend if backend is not None else WfStep(p["xcoords"], p["ycoords"], env_batch=self.num_envs,
                                                               device_id=device_id, model=model, kernel_choice=kernel_choice)
-        # risk_resolve (default ON since round 4): every farm the float32 kernel flags is solved again in float64 behind
-        # each step (wf_set_risk_resolve) — the reference computes every step in float64 (interface.py:564), and north_star's
-        # 1e-4 holds on EVERY farm only with it.  Nothing measurable where no farm is flagged (a shared 270 deg wind on
-        # HornsRev1); about +1 ms per step where a wind per farm flags ~2 % of the batch.  risk_resolve=False is the
-        # opt-out for throughput runs that accept the per-flag bounds of include/wfstep.h on flagged farms.
-        self.fi.set_risk_resolve(1 if risk_resolve else 0)
+        # risk_resolve: every farm the float32 kernel flags is solved again in float64 behind each step (wf_set_risk_resolve)
+        # — the reference computes every step in float64 (interface.py:564), and north_star's 1e-4 holds on EVERY farm only
+        # with it.  ON unless told otherwise (it is the default of the handle itself, ABI 6); a caller's own `backend=` is left as
+        # it was configured unless risk_resolve is given — one set up for mode 2 (every farm in float64) stays in mode 2.  Nothing measurable where no
+        # farm is flagged (a shared 270 deg wind on HornsRev1); about +1 ms per step where a wind per farm flags ~1 % of the
+        # batch.  risk_resolve=False is the opt-out for throughput runs that accept the per-flag bounds of
+        # include/wfstep.h on flagged farms.
+        if risk_resolve is not None or backend is None:
+            self.fi.set_risk_resolve(0 if risk_resolve is False else 1)
         # layouts: several layouts in the batch — dict(xcoords=[K][N], ycoords=[K][N], layout_of=[env_batch] or None for
         # K == env_batch[, counts=[K]]), each with the case's number of turbines or — with `counts`, or ragged lists of
         # coordinates — fewer (backend.WfStep.set_layouts: observations, powers and loads of the missing turbines are 0,
