@@ -120,3 +120,23 @@ def test_last_fuzz_campaign_ran_on_these_kernels():
     assert h.hexdigest() == rec["sources_sha256"], "kernel sources changed after the last recorded fuzz campaign: run tools/round_close.sh on the GPU box and commit profiles/fuzz_head.json"
     assert rec["violations_total"] == 0 and not rec["legs_without_a_summary"], rec
     assert any("FUZZ_API_BIG=1" in l["leg"] for l in rec["legs"])  # (the leg in which the kernel calibration fires mid-session)
+
+
+def test_float64_kernels_have_no_private_segment(tmp_path):
+    """Round 5: a kernel with a private segment (a stack for out-of-line calls, callee-saved register saves, spills) costs
+    ~20 us per LAUNCH on MI355X against ~2.6 us without one (tools/ubench/scratch_switch.hip, profiles/r05_scratch_switch.txt);
+    two such launches followed every step of the default configuration.  The float64 re-solve kernels — and the headline
+    float32 kernel — must stay free of scratch: compiled here with the Makefile's flags, metadata read from the listing."""
+    import subprocess
+
+    src = os.path.join(ROOT, "wfcrl-env_amd", "csrc")
+    flags = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-fast-math", "-ffp-contract=off", "-fno-slp-vectorize", "-S", "--cuda-device-only"]
+    out = tmp_path / "res.s"
+    subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-o", str(out), os.path.join(src, "wf_resolve.hip")], check=True, capture_output=True)
+    text = out.read_text()
+    kernels = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
+    seen = {n: (int(p), int(v)) for n, p, v in kernels if "wf_resolve" in n}
+    assert len(seen) == 2, seen
+    for name, (private, spills) in seen.items():
+        assert private == 0 and spills == 0, (name, private, spills)
+    assert "s_swappc_b64" not in text  # no out-of-line call anywhere in the file

@@ -2,6 +2,7 @@
 for a shared wind (no farm flagged) and the reference's reset distribution per farm (about 2 % flagged).
   python tools/resolve_cost.py [layout] [B]"""
 import sys
+import os
 os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import json
 import os

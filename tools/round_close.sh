@@ -32,7 +32,7 @@ for line in open("gpurun_out/fuzz_head.txt"):
     elif line.startswith("BAD"):
         cur["bad_lines"] += 1
     else:
-        m = re.search(r"(\d+) violations", line)
+        m = re.search(r"(\d+) violations", line) or re.search(r"violations: (\d+)", line)
         if m:
             cur["summary"], cur["violations"] = line.strip(), int(m.group(1))
 json.dump({"sources_sha256": h.hexdigest(), "files": files, "legs": legs,

@@ -932,12 +932,13 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
           // the pair geometry and the bound is the wave's own, so the answer does not depend on the farm: ONE lane per
           // (source, target of the block) pair of the chunk — 64 / GS sources x GS targets = 64 lanes — tests its pair;
           // the ballot, folded to one bit per source (at bit k GS), is the whole chunk's answer.
-          unsigned long long near_bits;
+          unsigned long long near_bits, pair_bits;  // per source (at bit k GS) / per (source, target of the block) pair
           {
             const int kk = lane / GS, rr = lane % GS;
             const float2 e = *reinterpret_cast<const float2*>(buf + (kk * GS + rr) * WF_PAIR_STRIDE + WF_PAIR_DX);
             const float4 bnd = bndL[min(i0 + kk, n_pad - 1)];
-            near_bits = __ballot(kk < k_log && (J * GS + rr) < N && within_bound(bnd, e.x, e.y));
+            pair_bits = __ballot(kk < k_log && (J * GS + rr) < N && within_bound(bnd, e.x, e.y));
+            near_bits = pair_bits;
 #pragma unroll
             for (int sh = 1; sh < GS; sh <<= 1) near_bits |= near_bits >> sh;
             unsigned long long rep = 0ull;
@@ -965,7 +966,11 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
               for (int qq = 0; qq < 9; ++qq)
                 cf[p][qq] = *reinterpret_cast<const float4*>(buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE + 4 * qq);
             asm volatile("" ::: "memory");
+#ifdef WF_EXP_NOHOT  // timing experiment only (wrong results): what the transverse pass costs without its log load
+            hot2_nx = make_float4(0.1f, 0.2f, 0.1f, 0.2f);
+#else
             hot2_nx = load_hot2(min(i0 + k + 2, first_own - 2));
+#endif
             static_for<S>([&](auto PP) { apply_tab_ratio(PP, cf[decltype(PP)::value], hot2.x, hot2.y); });
 #pragma unroll
             for (int p = 0; p < S; ++p)
@@ -990,10 +995,20 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
             // "keeps its value" on the other path, a register copy per float and iteration.  Behind the first LDS reads of the
             // step: the compiler guards the first read of the staged chunk with s_waitcnt vmcnt(0) (the chunk arrives by
             // LDS-DMA, counted in vmcnt), and a load issued before it would be waited for on the spot.
+#ifdef WF_EXP_NOCOLD  // timing experiment only (wrong results): the deficit pass without its cold-record loads
+            nxt = cold;
+#else
             nxt = load_cold(near_bits ? i0 + (__builtin_ctzll(near_bits) / GS) : i);
+#endif
             const SrcLog Sl = unpack(make_float2(0.0f, 0.0f), cold);
             const float* side = logx + (size_t)i * WF_LOG_SIDE_FLOATS;
-            static_for<S>([&](auto PP) { pass2(PP, Sl, side, true, exs[decltype(PP)::value], tvalid[decltype(PP)::value]); });
+            // ... on the slots that hold a target within the source's bound (round 5: the pair test already knows which; a near
+            // source usually reaches ONE of a block's slots — a wake is a row wide, a slot's turbines sit in two rows — and the
+            // other slot used to pay the deflection arithmetic (root, reciprocal, logarithm) just to find itself out of reach)
+            static_for<S>([&](auto PP) {
+              constexpr int p = decltype(PP)::value;
+              if ((pair_bits >> (k * GS + p * G)) & ((1ull << G) - 1ull)) pass2(PP, Sl, side, true, exs[p], tvalid[p]);
+            });
           };
           ColdRec cold_b = {};
 #pragma unroll 1

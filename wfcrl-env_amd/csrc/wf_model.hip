@@ -182,6 +182,7 @@ int build_consts(wf_handle* h) {
     r.sw_steer = m.enable_secondary_steering ? 1 : 0; r.sw_yar = m.enable_yaw_added_recovery ? 1 : 0;
     r.sw_tv = m.enable_transverse_velocities ? 1 : 0;
     r.D = D; r.HH = HH; r.TSR = m.tsr; r.amb = m.ambient_ti; r.eps2 = eps2; r.num_eps = m.num_eps; r.sqrt2 = std::sqrt(2.0);
+    r.inv_D = 1.0 / D; r.inv_TSR = 1.0 / m.tsr; r.inv_eps2 = 1.0 / eps2;
     r.uinf1 = 0.0;
     for (int k = 0; k < 3; ++k) {
       r.off[k] = off[k];

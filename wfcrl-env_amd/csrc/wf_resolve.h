@@ -8,6 +8,7 @@ struct WfResolveConsts {
   int sw_steer, sw_yar, sw_tv;  // solver switches of case.yaml:46-50
   int mirror_core;              // some exp(-zm^2 / eps^2) >= 1e-17: the ground mirrors' core factors differ from 1.0 in float64
   double D, HH, TSR, amb, eps2, num_eps, sqrt2;
+  double inv_D, inv_TSR, inv_eps2;  // reciprocals of the three above (the kernels' per-stage chains hold no division by a constant)
   double off[3];       // rotor-grid offsets -D/4, 0, +D/4 (lateral and vertical) [A.1-3]
   double shearf[3];    // (z_k / HH)^shear [A.2]
   double uinf1;        // mean shearf: Uinf = ws * uinf1

@@ -19,17 +19,14 @@
 
 #include "wf_device.h"
 #include "wf_resolve.h"
+#include "wf_f64_math.h"
 
 namespace {
 
-constexpr double kDeg = 3.14159265358979323846 / 180.0;
-constexpr double kTwoPi = 2.0 * 3.14159265358979323846;
 
-__device__ __forceinline__ double cosd(double a) { return cos(a * kDeg); }
-__device__ __forceinline__ double sind(double a) { return sin(a * kDeg); }
 
-// scipy interp1d(linear, bounds_error=False, fill_value=(lo, hi)) on the LDS copy of a table column
-__device__ inline double interp_fill(double xq, int n, const double* xs, const double* ys, double lo, double hi) {
+// scipy interp1d(linear, bounds_error=False, fill_value=(lo, hi)) on the LDS copy of a table column; sl: the segment slopes
+__device__ inline double interp_fill(double xq, int n, const double* xs, const double* ys, const double* sl, double lo, double hi) {
   if (xq < xs[0]) return lo;
   if (xq > xs[n - 1]) return hi;
   if (xq == xs[n - 1]) return ys[n - 1];
@@ -38,13 +35,12 @@ __device__ inline double interp_fill(double xq, int n, const double* xs, const d
     const int k = j + step;
     if (k <= n - 2 && xq >= xs[k]) j = k;
   }
-  const double slope = (ys[j + 1] - ys[j]) / (xs[j + 1] - xs[j]);
-  return slope * (xq - xs[j]) + ys[j];
+  return sl[j] * (xq - xs[j]) + ys[j];
 }
 
 // the same for a query that is uniform over the wave (the source's rotor wind speed): every lane tests one knot, the
 // segment index is the population count of the ballot — one LDS read instead of six dependent ones
-__device__ inline double interp_fill_uniform(double xq, int n, const double* xs, const double* ys, double lo, double hi) {
+__device__ inline double interp_fill_uniform(double xq, int n, const double* xs, const double* ys, const double* sl, double lo, double hi) {
   const int l = threadIdx.x & 63;
   const unsigned long long m = __ballot(l < n && xq >= xs[l < n ? l : 0]);
   if (xq < xs[0]) return lo;
@@ -52,8 +48,7 @@ __device__ inline double interp_fill_uniform(double xq, int n, const double* xs,
   if (xq == xs[n - 1]) return ys[n - 1];
   int j = __popcll(m) - 1;
   j = j < 0 ? 0 : (j > n - 2 ? n - 2 : j);
-  const double slope = (ys[j + 1] - ys[j]) / (xs[j + 1] - xs[j]);
-  return slope * (xq - xs[j]) + ys[j];
+  return sl[j] * (xq - xs[j]) + ys[j];
 }
 
 }  // namespace
@@ -69,68 +64,43 @@ __global__ void wf_list_all_kernel(const int* __restrict__ flags, int B, int* __
   list[b] = b;
 }
 
-// 1 / x to float64 accuracy from the hardware estimate and two Newton steps (6 instructions; the compiler's IEEE division
-// sequence is 11): the quotients here are all between normal, finite, nonzero operands
-__device__ __forceinline__ double rcp64(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  return fma(r, e, r);
+// The kernels below contain NO function call and no register spill: a kernel with a private segment (a stack for out-of-line
+// library routines, callee-saved register saves, spills) costs ~20 us per LAUNCH on this chip against ~2.6 us without one
+// (tools/ubench/scratch_switch.hip, profiles/r05_scratch_switch.txt) — two such launches behind every step were the whole
+// price of the re-solve on small farms.  So the rare out-of-range arguments (a yaw beyond 45 deg, a steering term beyond 0.3,
+// velocities driven negative by an unphysically tight layout) are served by inline general-range routines built on the lean
+// ones, chosen wave-uniformly.
+// A phase of a source step starts behind a compiler barrier: with the phases inlined into one loop body, the model constants
+// and the per-source record (all in LDS) would otherwise be loaded once, ahead of the loop, and held in registers across every
+// phase — ~370 live values
+#ifndef RES_SCHED_LIMIT
+#define RES_SCHED_LIMIT 0  // 1: the 14 reciprocal chains of a rotor-grid column are interleaved two at a time instead of all at once (30 registers
+                           // less; 3 % slower: profiles/r05_resolve_ab.txt)
+#endif
+#define RES_PHASE_FENCE asm volatile("" ::: "memory")
+// ... and with its own opaque copy of the thread index: everything derived from it (wave, lane, a dozen LDS addresses per phase)
+// is recomputed where it is used instead of being hoisted out of the source loop and held — or spilled — across it
+__device__ __forceinline__ int res_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
 }
+#define LOG_F64(x) log_any(x)
+#define POW_F64(x, y) pow_any(x, y)
 
-// The transcendental functions of the per-source chain on the argument ranges this model produces, as short branch-free
-// polynomials (the device library's general-range tan / asin / atan2 / cbrt each keep 60-90 registers live: they set the
-// kernel's register count); callers fall back to the library outside the range, wave-uniformly.
-// tan(x), |x| <= 0.5: sin and cos by Taylor series (terms below 1e-19), one division
-__device__ __forceinline__ double tan_small(double x) {
-  const double x2 = x * x;
-  double sn = 1.0 / 51090942171709440000.0, cs = 1.0 / 2432902008176640000.0;  // 1/21!, 1/20!
-  const double fs[10] = {1.0 / 121645100408832000.0, 1.0 / 355687428096000.0, 1.0 / 1307674368000.0, 1.0 / 6227020800.0,
-                         1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0, 1.0};
-  const double fc[10] = {1.0 / 6402373705728000.0, 1.0 / 20922789888000.0, 1.0 / 87178291200.0, 1.0 / 479001600.0,
-                         1.0 / 3628800.0, 1.0 / 40320.0, 1.0 / 720.0, 1.0 / 24.0, 1.0 / 2.0, 1.0};
-#pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    sn = fma(-x2, sn, fs[k]);
-    cs = fma(-x2, cs, fc[k]);
-  }
-  return x * sn * rcp64(cs);
-}
-// asin(x), |x| <= 0.3: odd series, coefficients (2k)! / (4^k (k!)^2 (2k + 1)), 17 terms (0.3^36 / 37 = 4e-21)
-__device__ __forceinline__ double asin_small(double x) {
-  const double x2 = x * x;
-  double cf[18];
-  cf[0] = 1.0;
-  double b = 1.0;
-#pragma unroll
-  for (int k = 1; k < 18; ++k) {
-    b *= (2.0 * k - 1.0) / (2.0 * k);
-    cf[k] = b / (2.0 * k + 1.0);
-  }
-  double p = cf[17];
-#pragma unroll
-  for (int k = 16; k >= 0; --k) p = fma(p, x2, cf[k]);
-  return x * p;
-}
-// atan(r), |r| <= 0.1: odd series, 10 terms (0.1^20 / 21 = 5e-22)
-__device__ __forceinline__ double atan_small(double r) {
-  const double r2 = r * r;
-  double p = -1.0 / 19.0;
-#pragma unroll
-  for (int k = 8; k >= 0; --k) p = fma(p, r2, ((k & 1) ? -1.0 : 1.0) / (2.0 * k + 1.0));
-  return r * p;
-}
-// cbrt(x), x > 0: float estimate, two Newton steps in float64
-__device__ __forceinline__ double cbrt_pos(double x) {
-  double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (1.0f / 3.0f));
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const double y2 = y * y;
-    y = y - (y2 * y - x) * rcp64(3.0 * y2);
-  }
-  return y;
-}
+// which phase functions are real functions (A/B builds: -DRES_PASS_INLINE=1 / -DRES_SRC_INLINE=1)
+#ifndef RES_PASS_INLINE
+#define RES_PASS_INLINE 1
+#endif
+#ifndef RES_SRC_INLINE
+#define RES_SRC_INLINE 1
+#endif
+#if RES_PASS_INLINE
+#define RES_PASS_FN __device__ __forceinline__
+#else
+#define RES_PASS_FN __device__ __noinline__
+#endif
+
 
 
 // One farm per WAVE (64-thread blocks).  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column
@@ -149,7 +119,13 @@ __device__ __forceinline__ double cbrt_pos(double x) {
 // re-deriving the source constants: 1.95 ms for 1394 HornsRev1 farms; the inlined one-wave version 1.42 ms; this one 1.37 ms.
 // The four-wave kernel further down has the lower latency per farm (0.73 against 1.04 ms) but takes four wave slots per
 // farm: this kernel serves the counts beyond half a residency of that one.)
-#define WF_RES_OCC 2  // waves per SIMD the register allocator is asked to make room for (three / four spill: 1.48 / 1.76 ms)
+#ifndef WF_RES_OCC
+// ONE wave per SIMD (round 5; rounds 3-4: two).  The kernel is a single wave's dependent float64 chain: a second wave on the
+// SIMD buys ~1.3 x, not 2 x, and the hardware does not spread 64-thread blocks evenly — with 813 farms on 1024 SIMDs some SIMDs
+// got two farms and the launch took their time: 1.08 ms against 0.70 with one wave per SIMD enforced (profiles/r05_resolve_ab.txt).
+// Beyond 4 farms per CU the persistent blocks take their next farm: 3 rounds of 0.8 ms for 3000 farms against 3.9 ms before.
+#define WF_RES_OCC 1
+#endif
 struct SrcShared {  // what a source leaves for the two passes over its targets
   double x_i, y_i, ct, ai, ubar, Vmean, TIs[3], dTI;
   double Gt, Gb, Gw;  // circulations / (2 pi): top, bottom, wake rotation (commanded yaw)
@@ -159,64 +135,80 @@ struct SrcShared {  // what a source leaves for the two passes over its targets
 struct ResShared {
   WfResolveConsts c;
   double tws[WF_TABLE_PAD], tct[WF_TABLE_PAD], tpw[WF_TABLE_PAD];
+  double tcs[WF_TABLE_PAD], tps[WF_TABLE_PAD];  // segment slopes of the thrust / power columns (one division per segment and launch)
   double ws, wd, Uinf, Uinit[3];
+  double dec_a[3];  // 4 nu_k ws / Uinf: decay_k = eps^2 / (dec_a[k] dx + eps^2)  [A.3-4]
   int N, n_pad, veer_on, mcore;
+  WfResolveArgs a;  // the launch arguments (read from here inside the farm loop: a dozen pointers less to keep in registers)
   SrcShared s;
 };
 __shared__ ResShared R;
-extern __shared__ double res_dyn[];  // per sorted turbine: x', y', cos / sin / radians of the commanded yaw, the 30 state values, tie start
+extern __shared__ double res_dyn[];  // per sorted turbine: x', y', cos / sin / radians of the commanded yaw, the 30 state values; then the int arrays
+// Turbine-major (round 5; rounds 3-4: one array per quantity at stride n_pad): a quantity of turbine t is at a CONSTANT offset
+// from t's record, so a phase's dozens of state addresses are one base plus immediates — with the run-time stride the compiler
+// hoisted every (5 + q) n_pad product out of the source loop and spilled them.  The record is 35 doubles padded to 38 = 304
+// bytes: a multiple of 16 (the compiler merges neighbouring doubles into ds_read / ds_write_b128, which this runtime serves
+// only at 16-byte alignment — a 280-byte record put every odd turbine's merged accesses 8 bytes off) and 76 words = 12 banks
+// mod 64: sixteen consecutive turbines cover 32 banks with their 8-byte accesses, the full LDS rate.
+#define RES_TS 38
 
-#define RES_XS(t) res_dyn[(t)]
-#define RES_YS(t) res_dyn[R.n_pad + (t)]
-#define RES_CG(t) res_dyn[2 * R.n_pad + (t)]
-#define RES_SG(t) res_dyn[3 * R.n_pad + (t)]
-#define RES_GR(t) res_dyn[4 * R.n_pad + (t)]
-#define RES_ST(q, t) res_dyn[(5 + (q)) * R.n_pad + (t)]  // wake2 q = 0..8, V 9..17, W 18..26, TI 27..29
-#define RES_TIE(t) (reinterpret_cast<int*>(res_dyn + 35 * R.n_pad)[(t)])
+#define RES_XS(t) res_dyn[(t) * RES_TS]
+#define RES_YS(t) res_dyn[(t) * RES_TS + 1]
+#define RES_CG(t) res_dyn[(t) * RES_TS + 2]
+#define RES_SG(t) res_dyn[(t) * RES_TS + 3]
+#define RES_GR(t) res_dyn[(t) * RES_TS + 4]
+#define RES_ST(q, t) res_dyn[(t) * RES_TS + 5 + (q)]  // wake2 q = 0..8, V 9..17, W 18..26, TI 27..29
+#define RES_TIE(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R.n_pad)[(t)])
 
 // ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
 // (the source-only phases stay out of line: inlined, the loop body carries their live ranges across the calls — 5.18
 // against 4.78 ms per step with 1394 farms re-solved)
+#if RES_SRC_INLINE
+#define RES_SRC_FN __device__ __forceinline__
+#else
 #define RES_SRC_FN __device__ __noinline__
+#endif
 RES_SRC_FN void res_source_begin(int i) {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R.c;
   const double cg = RES_CG(i), sg = RES_SG(i);
   double m3 = 0.0, vs = 0.0;
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
-    const double u = R.Uinit[q % 3] - sqrt(RES_ST(q, i));
+    const double u = R.Uinit[q % 3] - sqrt_nn(RES_ST(q, i));
     m3 += u * u * u;
     vs += RES_ST(9 + q, i);
   }
-  const double m3m = m3 / 9.0;
-  const double ubar = __any(!(m3m > 1.0e-6)) ? cbrt(m3m) : cbrt_pos(m3m);
-  double ct_tab = interp_fill_uniform(ubar, c.n_table, R.tws, R.tct, 0.0001, 0.9999);
+  const double m3m = m3 * (1.0 / 9.0);
+  const double ubar = __any(!(m3m > 1.0e-6)) ? cbrt_any(m3m) : cbrt_pos(m3m);
+  double ct_tab = interp_fill_uniform(ubar, c.n_table, R.tws, R.tct, R.tcs, 0.0001, 0.9999);
   ct_tab = fmin(fmax(ct_tab, 0.0001), 0.9999);
   const double ct = ct_tab * cg;
-  const double ai = 0.5 / cg * (1.0 - sqrt(1.0 - ct * cg));
-  const double G_wr = 0.25 * kTwoPi * c.D * (ai - ai * ai) * ubar / c.TSR;
+  const double ai = 0.5 * rcp64(cg) * (1.0 - sqrt_nn(1.0 - ct * cg));
+  const double G_wr = (0.25 * kTwoPi) * c.D * (ai - ai * ai) * ubar * c.inv_TSR;
   const double gam_top = (kTwoPi / 16.0) * c.D * c.vel_top * R.Uinf * ct;
   const double gam_bot = (kTwoPi / 16.0) * c.D * c.vel_bot * R.Uinf * ct;
   const double sc = sg * cg;
-  if (threadIdx.x == 0) {
+  if (res_tid() == 0) {
     SrcShared& s = R.s;
-    s.x_i = RES_XS(i); s.y_i = RES_YS(i); s.ct = ct; s.ai = ai; s.ubar = ubar; s.Vmean = vs / 9.0;
+    s.x_i = RES_XS(i); s.y_i = RES_YS(i); s.ct = ct; s.ai = ai; s.ubar = ubar; s.Vmean = vs * (1.0 / 9.0);
     s.TIs[0] = RES_ST(27, i); s.TIs[1] = RES_ST(28, i); s.TIs[2] = RES_ST(29, i);
-    s.Gt = sc * gam_top / kTwoPi; s.Gb = -sc * gam_bot / kTwoPi; s.Gw = G_wr / kTwoPi;
+    s.Gt = sc * gam_top * (1.0 / kTwoPi); s.Gb = -sc * gam_bot * (1.0 / kTwoPi); s.Gw = G_wr * (1.0 / kTwoPi);
     s.first_tv = RES_TIE(i);
     // secondary steering [A.3-2]: the three means on the source's own grid are geometry constants
     const double v_top = gam_top * c.k_top, v_bot = -gam_bot * c.k_bot, v_core = G_wr * c.k_core;
-    s.cgv = 2.0 * (s.Vmean - v_core) / (v_top + v_bot);  // (val: parked here until res_source_finish overwrites it)
+    s.cgv = 2.0 * (s.Vmean - v_core) * rcp64(v_top + v_bot);  // (val: parked here until res_source_finish overwrites it)
   }
 }
 
 // ---- 4. transverse velocities (commanded yaw) on every turbine at or downstream of the source, ties included; per grid
 // column the 7 + 7 distinct vertical offsets of the three vortices and their ground mirrors ----
-__device__ __noinline__ void res_transverse_pass() {
+RES_PASS_FN void res_transverse_pass() {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R.c;
-  const int lane = threadIdx.x, N = R.N;
+  const int lane = res_tid(), N = R.N;
   const double x_i = R.s.x_i, y_i = R.s.y_i, Gt = R.s.Gt, Gb = R.s.Gb, Gw = R.s.Gw;
-  const double qd = c.off[2], neps = c.num_eps, twoHH = 2.0 * c.HH, eps2 = c.eps2, ieps2 = 1.0 / c.eps2;
+  const double qd = c.off[2], neps = c.num_eps, twoHH = 2.0 * c.HH, eps2 = c.eps2, ieps2 = c.inv_eps2;
   const bool mcore = R.mcore != 0;
   for (int base = R.s.first_tv; base < N; base += 64) {
     const int t = base + lane;
@@ -224,7 +216,7 @@ __device__ __noinline__ void res_transverse_pass() {
     const double dx = RES_XS(t) - x_i, y_t = RES_YS(t);
     double dec[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) dec[k] = eps2 * rcp64(4.0 * (c.nu1[k] * R.ws) * dx / R.Uinf + eps2);
+    for (int k = 0; k < 3; ++k) dec[k] = eps2 * rcp64(fma(R.dec_a[k], dx, eps2));
 #pragma unroll 1
     for (int j = 0; j < 3; ++j) {  // (a real loop: the state is addressed in LDS, nothing needs a static index; the three columns interleaved gained nothing)
       double Vj[3], Wj[3];
@@ -232,7 +224,7 @@ __device__ __noinline__ void res_transverse_pass() {
       for (int k = 0; k < 3; ++k) { Vj[k] = RES_ST(9 + j * 3 + k, t); Wj[k] = RES_ST(18 + j * 3 + k, t); }
       const double yL = (y_t + c.off[j] - y_i) + neps;
       const double yL2 = yL * yL;
-      const double Ey = exp(-yL2 * ieps2);
+      const double Ey = exp_lean(-yL2 * ieps2);
       double Av[3] = {0.0, 0.0, 0.0}, Bw[3] = {0.0, 0.0, 0.0};
 #pragma unroll
       for (int m = 0; m < 7; ++m) {
@@ -255,7 +247,7 @@ __device__ __noinline__ void res_transverse_pass() {
         }
         // (the scheduler interleaves all 14 reciprocal chains of a column otherwise: 250 registers; the other waves of
         // the SIMD hide the latency of one chain at a time)
-        if (WF_RES_OCC > 2 && (m & 1)) __builtin_amdgcn_sched_barrier(0);
+        if (RES_SCHED_LIMIT && (m & 1)) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -269,12 +261,13 @@ __device__ __noinline__ void res_transverse_pass() {
 
 // ---- 2, 5 and the source-only part of 3 + 6: steering, yaw-added recovery, deflection / deficit constants ----
 RES_SRC_FN void res_source_finish(int i) {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R.c;
   const SrcShared& s0 = R.s;
   const double cg = RES_CG(i), sg = RES_SG(i), ct = s0.ct, ubar = s0.ubar, D = c.D;
   double val = s0.cgv;  // parked by res_source_begin
   val = fmin(fmax(val, -1.0), 1.0);
-  const double asv = __any(fabs(val) > 0.3) ? asin(val) : asin_small(val);
+  const double asv = __any(fabs(val) > 0.3) ? asin_any(val) : asin_small(val);
   const double g_off = c.sw_steer ? 0.5 * asv : 0.0;  // radians added to the commanded yaw
   double dTI = 0.0;
   {  // 5. yaw-added recovery [A.3-5] (the source's own transverse contribution is in V / W now)
@@ -282,33 +275,34 @@ RES_SRC_FN void res_source_finish(int i) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) { vsum += RES_ST(9 + q, i); wsum += RES_ST(18 + q, i); }
     const double I = s0.TIs[0];
-    const double k_tke = (ubar * I) * (ubar * I) / (2.0 / 3.0);
-    const double vbar = vsum / 9.0, wbar = wsum / 9.0;
-    const double I_tot = sqrt((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) / ubar;
+    const double k_tke = (ubar * I) * (ubar * I) * 1.5;
+    const double vbar = vsum * (1.0 / 9.0), wbar = wsum * (1.0 / 9.0);
+    const double I_tot = sqrt_nn((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) * rcp64(ubar);
     if (c.sw_yar) dTI = c.gch_gain * (I_tot - I);
   }
   // cosd(-g_eff) = cos(g + d), d = asin(val) / 2: half-angle formulas instead of a second cosine
-  const double c2d = sqrt(fmax(1.0 - val * val, 0.0)), cd = sqrt(0.5 * (1.0 + c2d)), sd = 0.5 * val / cd;
+  const double c2d = sqrt_nn(fmax(1.0 - val * val, 0.0)), cd = sqrt_pos(0.5 * (1.0 + c2d)), sd = 0.5 * val * rcp64(cd);
   const double cgd = c.sw_steer ? cg * cd - sg * sd : cg;
   const double gd_rad = -(RES_GR(i) + g_off);  // -(g + d) in radians
-  const double s_cc = sqrt(1.0 - ct * cgd), s_c = sqrt(1.0 - ct);
-  const double th0 = c.dm * (0.3 * gd_rad / cgd) * (1.0 - s_cc);
-  const double tan_th0 = __any(fabs(th0) > 0.5) ? tan(th0) : tan_small(th0);
+  const double s_cc = sqrt_nn(1.0 - ct * cgd), s_c = sqrt_nn(1.0 - ct);
+  const double th0 = c.dm * (0.3 * gd_rad * rcp64(cgd)) * (1.0 - s_cc);
+  const double tan_th0 = __any(fabs(th0) > 0.5) ? tan_any(th0) : tan_small(th0);
   const double C0 = 1.0 - s_c;
   const double M0 = C0 * (2.0 - C0);
-  const double sz0d = D * 0.5 * sqrt((ct * cgd / (2.0 * (1.0 - s_cc))) / (1.0 + s_c));
+  const double i1sc = rcp64(1.0 + s_c);
+  const double sz0d = D * 0.5 * sqrt_pos((ct * cgd * rcp64(2.0 * (1.0 - s_cc))) * i1sc);
   const double sy0d = sz0d * cgd * c.cos_veer;
-  const double sM = sqrt(M0);
-  const double sz0v = D * 0.5 * sqrt((ct / (2.0 * (1.0 - s_c))) / (1.0 + s_c));
-  const int lane = threadIdx.x;
+  const double sM = sqrt_pos(M0);
+  const double sz0v = D * 0.5 * sqrt_pos((ct * rcp64(2.0 * (1.0 - s_c))) * i1sc);
+  const int lane = res_tid();
   if (lane < 3) RES_ST(27 + lane, i) = s0.TIs[lane] + dTI;
   if (lane == 0) {
     SrcShared& s = R.s;
     s.dTI = dTI; s.cgd = cgd; s.s_cc = s_cc; s.s_c = s_c; s.th0 = th0; s.tan_th0 = tan_th0; s.M0 = M0;
     s.E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
-    s.sM = sM; s.sz0d = sz0d; s.sy0d = sy0d; s.is0d = 1.0 / (sy0d * sz0d); s.lnAB = (1.6 + sM) / (1.6 - sM);
-    s.sz0v = sz0v; s.sy0v = sz0v * cg * c.cos_veer; s.snw = c.near_c * sqrt(ct / 2.0); s.kdef = ct * cg * D * D / 8.0;
-    s.ch_pref = c.ch_constant * exp(c.ch_ai * log(s0.ai)) * c.ch_amb_pow;
+    s.sM = sM; s.sz0d = sz0d; s.sy0d = sy0d; s.is0d = rcp64(sy0d * sz0d); s.lnAB = (1.6 + sM) * rcp64(1.6 - sM);
+    s.sz0v = sz0v; s.sy0v = sz0v * cg * c.cos_veer; s.snw = c.near_c * sqrt_pos(ct * 0.5); s.kdef = ct * cg * D * D * 0.125;
+    s.ch_pref = c.ch_constant * POW_F64(s0.ai, c.ch_ai) * c.ch_amb_pow;
     s.cgv = cg;  // cosd(-g)
     s.same = (s0.TIs[0] == s0.TIs[1]) && (s0.TIs[1] == s0.TIs[2]);
   }
@@ -316,10 +310,11 @@ RES_SRC_FN void res_source_finish(int i) {
 
 // ---- 3 + 6 + 7 + 8 on the turbines behind the source: deflection (TI before mixing, effective yaw), deficit (TI after
 // mixing, commanded yaw), SOSFS, Crespo-Hernandez with the overlap count taken as FLORIS takes it ----
-__device__ __noinline__ void res_deficit_pass(int i) {
+RES_PASS_FN void res_deficit_pass(int i) {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R.c;
   const SrcShared& s = R.s;
-  const int lane = threadIdx.x, N = R.N;
+  const int lane = res_tid(), N = R.N;
   const bool veer_on = R.veer_on != 0, same = s.same != 0;
   const double x_i = s.x_i, y_i = s.y_i, D = c.D;
   const double q2 = c.off[2] * c.off[2];
@@ -336,24 +331,26 @@ __device__ __noinline__ void res_deficit_pass(int i) {
       if (j == 0 || !same) {  // (one column serves all three when the source's TIs agree)
         // source-side constants of this column [A.3-3, A.3-6]
         const double TIpre = s.TIs[j];
-        const double x0d = c.D * s.cgd * (1.0 + s.s_cc) / (c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - s.s_c))) + x_i;
-        const double ix0d_rel = 1.0 / (x0d - x_i);
+        const double x0d_rel = c.D * s.cgd * (1.0 + s.s_cc) * rcp64(c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - s.s_c)));
+        const double x0d = x0d_rel + x_i;
+        const double ix0d_rel = rcp64(x0d_rel);
         const double kyd = c.defl_ka * TIpre + c.defl_kb;
-        const double d0 = s.tan_th0 * (x0d - x_i);
+        const double d0 = s.tan_th0 * x0d_rel;
         const double TIq = TIpre + s.dTI;
-        const double x0v = c.D * s.cgv * (1.0 + s.s_c) / (c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - s.s_c))) + x_i;
-        const double ix0v_rel = 1.0 / (x0v - x_i);
+        const double x0v_rel = c.D * s.cgv * (1.0 + s.s_c) * rcp64(c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - s.s_c)));
+        const double x0v = x0v_rel + x_i;
+        const double ix0v_rel = rcp64(x0v_rel);
         const double kyv = c.ka * TIq + c.kb;
         // this turbine's column: deflection -> delta; deficit -> amplitude and the Gaussian's 1 / (2 sigma^2)
         double d_near = (dx * ix0d_rel) * d0 + lin;
         if (!(x_t <= x0d)) d_near = 0.0;  // [x >= x_i] holds here
         double d_far = 0.0;
         if (x_t > x0d) {
-          const double pfar = s.th0 * s.E0 / 5.2 * sqrt(s.sy0d * s.sz0d / (kyd * kyd * s.M0));
+          const double pfar = s.th0 * s.E0 * (1.0 / 5.2) * sqrt_pos(s.sy0d * s.sz0d * rcp64(kyd * kyd * s.M0));
           const double sy = kyd * (x_t - x0d) + s.sy0d, sz = kyd * (x_t - x0d) + s.sz0d;
-          const double sg_ = sqrt(sy * sz * s.is0d);
+          const double sg_ = sqrt_pos(sy * sz * s.is0d);
           const double ln_arg = s.lnAB * (1.6 * sg_ - s.sM) * rcp64(1.6 * sg_ + s.sM);
-          d_far = d0 + pfar * log(ln_arg) + lin;
+          d_far = d0 + pfar * LOG_F64(ln_arg) + lin;
         }
         delta = d_near + d_far;
         amp = 0.0; isy2 = 0.0; isz2 = 0.0;
@@ -373,7 +370,7 @@ __device__ __noinline__ void res_deficit_pass(int i) {
           const double isy = rcp64(sy), isz = rcp64(sz);
           double dd = 1.0 - s.kdef * isy * isz;
           dd = fmin(fmax(dd, 0.0), 1.0);
-          amp = 1.0 - sqrt(dd);
+          amp = 1.0 - sqrt_nn(dd);
           isy2 = 0.5 * isy * isy;
           isz2 = 0.5 * isz * isz;
         }
@@ -381,8 +378,8 @@ __device__ __noinline__ void res_deficit_pass(int i) {
       const double yy = (y_t + c.off[j]) - y_i - delta;
       double def[3];
       if (!veer_on) {  // r = yy^2 / (2 sy^2) + zz^2 / (2 sz^2), zz = -q, 0, +q
-        const double e1 = amp * exp(-(yy * yy) * isy2);
-        const double e0 = e1 * exp(-q2 * isz2);
+        const double e1 = amp * exp_lean(-(yy * yy) * isy2);
+        const double e0 = e1 * exp_lean(-q2 * isz2);
         def[0] = e0; def[1] = e1; def[2] = e0;
       } else {  // FLORIS rCalt [gauss.py]: the Gaussian rotated by the veer angle
         const double ca = c.cos2_veer * isy2 + c.sin2_veer * isz2;
@@ -391,7 +388,7 @@ __device__ __noinline__ void res_deficit_pass(int i) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const double zz = c.off[k];
-          def[k] = amp * exp(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
+          def[k] = amp * exp_lean(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
         }
       }
 #pragma unroll
@@ -408,10 +405,10 @@ __device__ __noinline__ void res_deficit_pass(int i) {
     for (int j = 0; j < 3; ++j) gate[j] = reach && (fabs(y_i - (y_t + c.off[j])) < 2.0 * D);
     if (gate[0] || gate[1] || gate[2]) {
       const double dxp = (dx <= 0.1) ? dx + 1.0 : dx;  // dx > -0.1 holds for every downstream turbine
-      double ti = s.ch_pref * exp(c.ch_down * log(dxp / D));
+      double ti = s.ch_pref * POW_F64(dxp * c.inv_D, c.ch_down);
       if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
-      const double ti_added = ((double)cnt / 9.0) * ti;
-      const double cand = sqrt(ti_added * ti_added + c.amb * c.amb);
+      const double ti_added = ((double)cnt * (1.0 / 9.0)) * ti;
+      const double cand = sqrt_pos(ti_added * ti_added + c.amb * c.amb);
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         if (gate[j] && cand > RES_ST(27 + j, t)) RES_ST(27 + j, t) = cand;
@@ -419,55 +416,61 @@ __device__ __noinline__ void res_deficit_pass(int i) {
   }
 }
 
+// ---- outputs [A.4] of one turbine (sorted index t, caller's index o) from the farm's state in LDS ----
+// (tb: the turbine's record in LDS; the nine rotor-grid velocities are kept in registers: one root per grid point)
+__device__ __forceinline__ void res_turbine_outputs(const WfResolveConsts& c, const WfResolveArgs& a, const double* tb,
+                                                    size_t oo, bool real, const double* Uinit, double wd, double cg_t, const double* tws,
+                                                    const double* tpw, const double* tps, double& psum, double& lsum) {
+  double u[9], m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0;
+  bool small = true;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    u[q] = Uinit[q % 3] - sqrt_nn(tb[5 + q]);
+    const double v = tb[14 + q];
+    m3 += u[q] * u[q] * u[q];
+    mu += u[q]; mv += v; mw += tb[23 + q];
+    small = small && (u[q] > 0.0) && (fabs(v) <= 0.1 * u[q]);
+  }
+  double dir = 0.0;
+  if (__all(small)) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dir += wd - atan_small(tb[14 + q] * rcp64(u[q])) * (1.0 / kDeg);
+  } else {
+#pragma unroll 1
+    for (int q = 0; q < 9; ++q) dir += wd - atan2_any(tb[14 + q], u[q]) * (1.0 / kDeg);
+  }
+  mu *= (1.0 / 9.0); mv *= (1.0 / 9.0); mw *= (1.0 / 9.0);
+  double su = 0.0, sv = 0.0, sw = 0.0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const double du = u[q] - mu, dv = tb[14 + q] - mv, dw = tb[23 + q] - mw;
+    su = fma(du, du, su); sv = fma(dv, dv, sv); sw = fma(dw, dw, sw);
+  }
+  const double m3m = m3 * (1.0 / 9.0);
+  const double wsp = __any(!(m3m > 1.0e-6)) ? cbrt_any(m3m) : cbrt_pos(m3m);
+  const double veff = c.dens_cbrt * (wsp * POW_F64(cg_t, c.pP3));
+  const double pw = c.rho_ref * interp_fill(veff, c.n_table, tws, tpw, tps, 0.0, 0.0);
+  const double l0 = (tb[32] + tb[33] + tb[34]) * (1.0 / 3.0);
+  const double l1 = sqrt_nn(su * (1.0 / 9.0)), l2 = sqrt_nn(sv * (1.0 / 9.0)), l3 = sqrt_nn(sw * (1.0 / 9.0));
+  psum += real ? pw : 0.0;
+  lsum += real ? fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3) : 0.0;
+  if (a.o_power) a.o_power[oo] = real ? (float)pw : 0.0f;
+  if (a.o_ws) a.o_ws[oo] = real ? (float)wsp : 0.0f;
+  if (a.o_wd) a.o_wd[oo] = real ? (float)(dir * (1.0 / 9.0)) : 0.0f;
+  if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = real ? make_float4((float)l0, (float)l1, (float)l2, (float)l3) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
 // ---- outputs [A.4] in the caller's turbine order; the farm's reward ----
-__device__ __noinline__ void res_outputs(const WfResolveArgs& a, int b, size_t gofs) {
+RES_PASS_FN void res_outputs(const WfResolveArgs& a, int b, size_t gofs) {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R.c;
-  const int lane = threadIdx.x, N = R.N;
-  const double wd = R.wd;
+  const int lane = res_tid(), N = R.N;
   double psum = 0.0, lsum = 0.0;
   const int n_real = a.n_real ? a.n_real[b] : N;  // turbines the farm really has (padded layouts)
   for (int t = lane; t < N; t += 64) {
     const int o = a.gidx[gofs + t];
-    double m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0, dir = 0.0;
-    bool small = true;
-#pragma unroll 1
-    for (int q = 0; q < 9; ++q) {  // (runtime loops over the grid points: the state is read from LDS where it is needed)
-      const double u = R.Uinit[q % 3] - sqrt(RES_ST(q, t)), v = RES_ST(9 + q, t);
-      m3 += u * u * u;
-      mu += u; mv += v; mw += RES_ST(18 + q, t);
-      small = small && (u > 0.0) && (fabs(v) <= 0.1 * u);
-    }
-    if (__all(small)) {
-#pragma unroll 1
-      for (int q = 0; q < 9; ++q) {
-        const double u = R.Uinit[q % 3] - sqrt(RES_ST(q, t));
-        dir += wd - atan_small(RES_ST(9 + q, t) * rcp64(u)) / kDeg;
-      }
-    } else {
-#pragma unroll 1
-      for (int q = 0; q < 9; ++q) dir += wd - atan2(RES_ST(9 + q, t), R.Uinit[q % 3] - sqrt(RES_ST(q, t))) / kDeg;
-    }
-    mu /= 9.0; mv /= 9.0; mw /= 9.0;
-    double su = 0.0, sv = 0.0, sw = 0.0;
-#pragma unroll 1
-    for (int q = 0; q < 9; ++q) {
-      const double u = R.Uinit[q % 3] - sqrt(RES_ST(q, t)), v = RES_ST(9 + q, t), w = RES_ST(18 + q, t);
-      su += (u - mu) * (u - mu);
-      sv += (v - mv) * (v - mv);
-      sw += (w - mw) * (w - mw);
-    }
-    const double wsp = cbrt(m3 / 9.0);
-    const double veff = c.dens_cbrt * (wsp * exp(c.pP3 * log(RES_CG(t))));
-    const double pw = c.rho_ref * interp_fill(veff, c.n_table, R.tws, R.tpw, 0.0, 0.0);
-    const double l0 = (RES_ST(27, t) + RES_ST(28, t) + RES_ST(29, t)) / 3.0, l1 = sqrt(su / 9.0), l2 = sqrt(sv / 9.0), l3 = sqrt(sw / 9.0);
-    const bool real = o < n_real;  // (a placeholder of a padded layout: zeros out, nothing into the reward)
-    psum += real ? pw : 0.0;
-    lsum += real ? fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3) : 0.0;
-    const size_t oo = (size_t)b * N + o;
-    if (a.o_power) a.o_power[oo] = real ? (float)pw : 0.0f;
-    if (a.o_ws) a.o_ws[oo] = real ? (float)wsp : 0.0f;
-    if (a.o_wd) a.o_wd[oo] = real ? (float)(dir / 9.0) : 0.0f;
-    if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = real ? make_float4((float)l0, (float)l1, (float)l2, (float)l3) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    res_turbine_outputs(c, a, res_dyn + t * RES_TS, (size_t)b * N + o, o < n_real, R.Uinit, R.wd, RES_CG(t), R.tws, R.tpw, R.tps,
+                        psum, lsum);  // (a placeholder of a padded layout: zeros out, nothing into the reward)
   }
   if (a.reward) {  // reference simple_env.py:78-84 on the float64 values
 #pragma unroll
@@ -490,43 +493,52 @@ __device__ unsigned long long wf_res_stamp[8];
 #define RES_T(v)
 #define RES_ACC(k, a, b)
 #endif
-__global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a, int n_pad, int min_count) {
+__global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a_arg, int n_pad, int min_count) {
   const int lane = threadIdx.x;
   const int N = c_arg.N;
   if (lane == 0) {
     R.c = c_arg;
+    R.a = a_arg;
     R.N = N; R.n_pad = n_pad; R.veer_on = c_arg.sin2_veer != 0.0; R.mcore = c_arg.mirror_core;
   }
   for (int k = lane; k < c_arg.n_table; k += 64) {
-    R.tws[k] = a.tab64[k];
-    R.tct[k] = a.tab64[WF_TABLE_PAD + k];
-    R.tpw[k] = a.tab64[2 * WF_TABLE_PAD + k];
+    R.tws[k] = a_arg.tab64[k];
+    R.tct[k] = a_arg.tab64[WF_TABLE_PAD + k];
+    R.tpw[k] = a_arg.tab64[2 * WF_TABLE_PAD + k];
+    if (k + 1 < c_arg.n_table) {  // segment slopes (scipy interp1d: slope * (x - x_lo) + y_lo)
+      const double dxk = a_arg.tab64[k + 1] - a_arg.tab64[k];
+      R.tcs[k] = (a_arg.tab64[WF_TABLE_PAD + k + 1] - a_arg.tab64[WF_TABLE_PAD + k]) / dxk;
+      R.tps[k] = (a_arg.tab64[2 * WF_TABLE_PAD + k + 1] - a_arg.tab64[2 * WF_TABLE_PAD + k]) / dxk;
+    }
   }
-  const int n_list = *a.count;
+  const int n_list = *a_arg.count;
   if (n_list < min_count) return;  // (few enough farms for one residency of the four-wave kernel below: it serves them)
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
-    const int b = a.list[li];
+    const int b = a_arg.list[li];
+    RES_T(t_farm);
+    __syncthreads();  // (one wave: orders the constants / the previous farm's last reads before the new contents)
+    RES_PHASE_FENCE;
+    const WfResolveArgs& a = R.a;
     size_t gofs = 0;
     if (a.farm_group) gofs = (size_t)((a.farm_group[b] + a.shift) % a.mod) * N;
     else gofs = (size_t)b * a.geom_stride;
     const float* yaw_b = (a.yaw_state ? a.yaw_state : a.yaw_in) + (size_t)b * N;
-    RES_T(t_farm);
-    __syncthreads();  // (one wave: orders the constants / the previous farm's last reads before the new contents)
     if (lane == 0) {
       const double ws = a.ws[(size_t)b * a.wind_stride];
       double wd = fmod(a.wd[(size_t)b * a.wind_stride], 360.0);  // reference interface.py:664 (Python's %)
       if (wd < 0.0) wd += 360.0;
       R.ws = ws; R.wd = wd; R.Uinf = ws * c_arg.uinf1;  // inflow [A.2]
-      for (int k = 0; k < 3; ++k) R.Uinit[k] = ws * c_arg.shearf[k];
+      for (int k = 0; k < 3; ++k) { R.Uinit[k] = ws * c_arg.shearf[k]; R.dec_a[k] = 4.0 * (c_arg.nu1[k] * ws) / R.Uinf; }
     }
     for (int t = lane; t < N; t += 64) {
       const double g = (double)yaw_b[a.gidx[gofs + t]];
       double sg, cg;
-      sincos(g * kDeg, &sg, &cg);
+      if (__any(fabs(g) > 45.0)) sincos_any(g * kDeg, sg, cg);  // (never an admissible yaw command)
+      else sincos_small(g * kDeg, sg, cg);
       RES_XS(t) = a.gx[gofs + t]; RES_YS(t) = a.gy[gofs + t]; RES_CG(t) = cg; RES_SG(t) = sg; RES_GR(t) = g * kDeg;
 #pragma unroll 1
-      for (int q = 0; q < 27; ++q) res_dyn[(5 + q) * n_pad + t] = 0.0;
-      for (int j = 0; j < 3; ++j) res_dyn[(32 + j) * n_pad + t] = c_arg.amb;
+      for (int q = 0; q < 27; ++q) res_dyn[t * RES_TS + 5 + q] = 0.0;
+      for (int j = 0; j < 3; ++j) res_dyn[t * RES_TS + 32 + j] = c_arg.amb;
     }
     __syncthreads();
     for (int t = lane; t < N; t += 64) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
@@ -571,8 +583,10 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
 // the re-solve is pure latency — one farm's 80-stage chain, whatever the count — and spreading a source step over four
 // waves shortens it (HornsRev1: 1.04 -> 0.73 ms per farm).  Both kernels are enqueued behind the compaction; each reads
 // the count on the device and the one it is not meant for returns at once.
-#define WF_RES_GRID_PER_CU 8  // persistent one-wave blocks per CU
-#define WF_RES4_OCC 4          // waves per SIMD = resident farms per CU
+#define WF_RES_GRID_PER_CU 4  // persistent one-wave blocks per CU: one per SIMD (WF_RES_OCC)
+#ifndef WF_RES4_OCC
+#define WF_RES4_OCC 2          // blocks per CU the register allocator makes room for (256 VGPRs: the inlined source step fits without a spill; at 3 or 4 it spills 57 / 113 values and the kernel gets a private segment)
+#endif
 // One farm per 256-thread block.  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column TIs,
 // float64 — lives in LDS, structure-of-arrays over the sorted turbine index; a lane is not tied to a turbine: for source i
 // the lanes take the turbines the source can reach, t = first + lane (first = the start of the source's x' tie group for
@@ -603,7 +617,10 @@ struct Fin4Shared {  // the source-only constants of deflection, deficit and wak
 struct Res4Shared {
   WfResolveConsts c;
   double tws[WF_TABLE_PAD], tct[WF_TABLE_PAD], tpw[WF_TABLE_PAD];
+  double tcs[WF_TABLE_PAD], tps[WF_TABLE_PAD];  // segment slopes of the thrust / power columns
   double ws, wd, Uinf, Uinit[3];
+  double dec_a[3];  // 4 nu_k ws / Uinf
+  WfResolveArgs a;  // the launch arguments (read from here inside the farm loop)
   double red[4][2];
   int N, n_pad, veer_on, mcore;
   Src4Shared s[4];
@@ -612,46 +629,52 @@ struct Res4Shared {
 };
 __shared__ Res4Shared R4;
 
-#define RES4_XS(t) res_dyn[(t)]
-#define RES4_YS(t) res_dyn[R4.n_pad + (t)]
-#define RES4_CG(t) res_dyn[2 * R4.n_pad + (t)]
-#define RES4_SG(t) res_dyn[3 * R4.n_pad + (t)]
-#define RES4_GR(t) res_dyn[4 * R4.n_pad + (t)]
-#define RES4_ST(q, t) res_dyn[(5 + (q)) * R4.n_pad + (t)]  // wake2 q = 0..8, V 9..17, W 18..26, TI 27..29
-#define RES4_TIE(t) (reinterpret_cast<int*>(res_dyn + 35 * R4.n_pad)[(t)])
-#define RES4_CNT(j, t) (reinterpret_cast<int*>(res_dyn + 35 * R4.n_pad)[(1 + (j)) * R4.n_pad + (t)])  // overlap count of column j
+#define RES4_XS(t) res_dyn[(t) * RES_TS]
+#define RES4_YS(t) res_dyn[(t) * RES_TS + 1]
+#define RES4_CG(t) res_dyn[(t) * RES_TS + 2]
+#define RES4_SG(t) res_dyn[(t) * RES_TS + 3]
+#define RES4_GR(t) res_dyn[(t) * RES_TS + 4]
+#define RES4_ST(q, t) res_dyn[(t) * RES_TS + 5 + (q)]  // wake2 q = 0..8, V 9..17, W 18..26, TI 27..29
+#define RES4_TIE(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(t)])
+#define RES4_CNT(j, t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(1 + (j)) * R4.n_pad + (t)])  // overlap count of column j
 
 // ---- the source's state and circulations [A.3-1, A.3-2, A.3-4]: every wave, into its own copy ----
-__device__ __noinline__ void res4_source_begin(int i) {
+RES_SRC_FN void res4_source_begin(int tid, int i) {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const int wave = threadIdx.x >> 6;
+  const int wave = tid >> 6;
   const double cg = RES4_CG(i), sg = RES4_SG(i);
   double m3 = 0.0, vs = 0.0;
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
-    const double u = R4.Uinit[q % 3] - sqrt(RES4_ST(q, i));
+    const double u = R4.Uinit[q % 3] - sqrt_nn(RES4_ST(q, i));
     m3 += u * u * u;
     vs += RES4_ST(9 + q, i);
   }
-  const double m3m = m3 / 9.0;
-  const double ubar = __any(!(m3m > 1.0e-6)) ? cbrt(m3m) : cbrt_pos(m3m);
-  double ct_tab = interp_fill_uniform(ubar, c.n_table, R4.tws, R4.tct, 0.0001, 0.9999);
+  const double m3m = m3 * (1.0 / 9.0);
+  const double ubar = __any(!(m3m > 1.0e-6)) ? cbrt_any(m3m) : cbrt_pos(m3m);
+  double ct_tab = interp_fill_uniform(ubar, c.n_table, R4.tws, R4.tct, R4.tcs, 0.0001, 0.9999);
   ct_tab = fmin(fmax(ct_tab, 0.0001), 0.9999);
   const double ct = ct_tab * cg;
-  const double ai = 0.5 / cg * (1.0 - sqrt(1.0 - ct * cg));
-  const double G_wr = 0.25 * kTwoPi * c.D * (ai - ai * ai) * ubar / c.TSR;
+  const double ai = 0.5 * rcp64(cg) * (1.0 - sqrt_nn(1.0 - ct * cg));
+  const double G_wr = (0.25 * kTwoPi) * c.D * (ai - ai * ai) * ubar * c.inv_TSR;
   const double gam_top = (kTwoPi / 16.0) * c.D * c.vel_top * R4.Uinf * ct;
   const double gam_bot = (kTwoPi / 16.0) * c.D * c.vel_bot * R4.Uinf * ct;
   const double sc = sg * cg;
-  if ((threadIdx.x & 63) == 0) {
+  if ((tid & 63) == 0) {
     Src4Shared& s = R4.s[wave];
-    s.x_i = RES4_XS(i); s.y_i = RES4_YS(i); s.ct = ct; s.ai = ai; s.ubar = ubar; s.Vmean = vs / 9.0;
+    s.x_i = RES4_XS(i); s.y_i = RES4_YS(i); s.ct = ct; s.ai = ai; s.ubar = ubar; s.Vmean = vs * (1.0 / 9.0);
     s.TIs[0] = RES4_ST(27, i); s.TIs[1] = RES4_ST(28, i); s.TIs[2] = RES4_ST(29, i);
-    s.Gt = sc * gam_top / kTwoPi; s.Gb = -sc * gam_bot / kTwoPi; s.Gw = G_wr / kTwoPi;
+    s.Gt = sc * gam_top * (1.0 / kTwoPi); s.Gb = -sc * gam_bot * (1.0 / kTwoPi); s.Gw = G_wr * (1.0 / kTwoPi);
     s.first_tv = RES4_TIE(i);
     // secondary steering [A.3-2]: the three means on the source's own grid are geometry constants
     const double v_top = gam_top * c.k_top, v_bot = -gam_bot * c.k_bot, v_core = G_wr * c.k_core;
-    s.val = 2.0 * (s.Vmean - v_core) / (v_top + v_bot);
+    s.val = 2.0 * (s.Vmean - v_core) * rcp64(v_top + v_bot);
+#ifdef RES_DEBUG
+    if (tid == 0 && blockIdx.x == 0 && i < 2)
+      printf("dbg i=%d cg=%g sg=%g m3m=%g ubar=%g ct_tab=%g ct=%g ai=%g Gwr=%g gam_top=%g Gt=%g val=%g tws0=%g tws1=%g tct1=%g tcs1=%g n_table=%d invTSR=%g invD=%g ieps2=%g Uinf=%g dec_a0=%g x=%g y=%g TI=%g\n",
+             i, cg, sg, m3m, ubar, ct_tab, ct, ai, G_wr, gam_top, s.Gt, s.val, R4.tws[0], R4.tws[1], R4.tct[1], R4.tcs[1], c.n_table, c.inv_TSR, c.inv_D, c.inv_eps2, R4.Uinf, R4.dec_a[0], s.x_i, s.y_i, s.TIs[0]);
+#endif
   }
 }
 
@@ -659,12 +682,13 @@ __device__ __noinline__ void res4_source_begin(int i) {
 // included; the 7 + 7 distinct vertical offsets of the three vortices and their ground mirrors ----
 // The new V / W of the SOURCE's own turbine go to a side buffer, not into the state: the other waves may still be reading
 // that turbine's V in res4_source_begin (its rotor mean feeds the steering) — res4_recovery commits them after the barrier.
-__device__ __noinline__ void res4_transverse_pass(int i, int j) {
+RES_PASS_FN void res4_transverse_pass(int tid, int i, int j) {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const Src4Shared& s = R4.s[threadIdx.x >> 6];
-  const int lane = threadIdx.x & 63, N = R4.N;
+  const Src4Shared& s = R4.s[tid >> 6];
+  const int lane = tid & 63, N = R4.N;
   const double x_i = s.x_i, y_i = s.y_i, Gt = s.Gt, Gb = s.Gb, Gw = s.Gw;
-  const double qd = c.off[2], neps = c.num_eps, twoHH = 2.0 * c.HH, eps2 = c.eps2, ieps2 = 1.0 / c.eps2;
+  const double qd = c.off[2], neps = c.num_eps, twoHH = 2.0 * c.HH, eps2 = c.eps2, ieps2 = c.inv_eps2;
   const bool mcore = R4.mcore != 0;
   for (int base = s.first_tv; base < N; base += 64) {
     const int t = base + lane;
@@ -673,13 +697,13 @@ __device__ __noinline__ void res4_transverse_pass(int i, int j) {
     double dec[3], Vj[3], Wj[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      dec[k] = eps2 * rcp64(4.0 * (c.nu1[k] * R4.ws) * dx / R4.Uinf + eps2);
+      dec[k] = eps2 * rcp64(fma(R4.dec_a[k], dx, eps2));
       Vj[k] = RES4_ST(9 + j * 3 + k, t);
       Wj[k] = RES4_ST(18 + j * 3 + k, t);
     }
     const double yL = (y_t + c.off[j] - y_i) + neps;
     const double yL2 = yL * yL;
-    const double Ey = exp(-yL2 * ieps2);
+    const double Ey = exp_lean(-yL2 * ieps2);
     double Av[3] = {0.0, 0.0, 0.0}, Bw[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int m = 0; m < 7; ++m) {
@@ -701,7 +725,7 @@ __device__ __noinline__ void res4_transverse_pass(int i, int j) {
         Bw[m - 2] += Gw * (tr - tm);
       }
       // (above two waves per SIMD the 14 interleaved reciprocal chains of a column would not fit the registers)
-      if (WF_RES4_OCC > 2 && (m & 1)) __builtin_amdgcn_sched_barrier(0);
+      if (RES_SCHED_LIMIT && (m & 1)) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -720,55 +744,58 @@ __device__ __noinline__ void res4_transverse_pass(int i, int j) {
 
 // ---- 2 and the source-only part of 3 + 6 + 8: steering, deflection / deficit / turbulence constants (wave 3, beside the
 // transverse pass) ----
-__device__ __noinline__ void res4_source_chain(int i) {
+RES_SRC_FN void res4_source_chain(int tid, int i) {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const Src4Shared& s0 = R4.s[threadIdx.x >> 6];
+  const Src4Shared& s0 = R4.s[tid >> 6];
   const double cg = RES4_CG(i), sg = RES4_SG(i), ct = s0.ct, D = c.D;
   double val = s0.val;
   val = fmin(fmax(val, -1.0), 1.0);
-  const double asv = __any(fabs(val) > 0.3) ? asin(val) : asin_small(val);
+  const double asv = __any(fabs(val) > 0.3) ? asin_any(val) : asin_small(val);
   const double g_off = c.sw_steer ? 0.5 * asv : 0.0;  // radians added to the commanded yaw
   // cosd(-g_eff) = cos(g + d), d = asin(val) / 2: half-angle formulas instead of a second cosine
-  const double c2d = sqrt(fmax(1.0 - val * val, 0.0)), cd = sqrt(0.5 * (1.0 + c2d)), sd = 0.5 * val / cd;
+  const double c2d = sqrt_nn(fmax(1.0 - val * val, 0.0)), cd = sqrt_pos(0.5 * (1.0 + c2d)), sd = 0.5 * val * rcp64(cd);
   const double cgd = c.sw_steer ? cg * cd - sg * sd : cg;
   const double gd_rad = -(RES4_GR(i) + g_off);  // -(g + d) in radians
-  const double s_cc = sqrt(1.0 - ct * cgd), s_c = sqrt(1.0 - ct);
-  const double th0 = c.dm * (0.3 * gd_rad / cgd) * (1.0 - s_cc);
-  const double tan_th0 = __any(fabs(th0) > 0.5) ? tan(th0) : tan_small(th0);
+  const double s_cc = sqrt_nn(1.0 - ct * cgd), s_c = sqrt_nn(1.0 - ct);
+  const double th0 = c.dm * (0.3 * gd_rad * rcp64(cgd)) * (1.0 - s_cc);
+  const double tan_th0 = __any(fabs(th0) > 0.5) ? tan_any(th0) : tan_small(th0);
   const double C0 = 1.0 - s_c;
   const double M0 = C0 * (2.0 - C0);
-  const double sz0d = D * 0.5 * sqrt((ct * cgd / (2.0 * (1.0 - s_cc))) / (1.0 + s_c));
+  const double i1sc = rcp64(1.0 + s_c);
+  const double sz0d = D * 0.5 * sqrt_pos((ct * cgd * rcp64(2.0 * (1.0 - s_cc))) * i1sc);
   const double sy0d = sz0d * cgd * c.cos_veer;
-  const double sM = sqrt(M0);
-  const double sz0v = D * 0.5 * sqrt((ct / (2.0 * (1.0 - s_c))) / (1.0 + s_c));
-  if ((threadIdx.x & 63) == 0) {
+  const double sM = sqrt_pos(M0);
+  const double sz0v = D * 0.5 * sqrt_pos((ct * rcp64(2.0 * (1.0 - s_c))) * i1sc);
+  if ((tid & 63) == 0) {
     Fin4Shared& f = R4.f;
     f.cgd = cgd; f.s_cc = s_cc; f.s_c = s_c; f.th0 = th0; f.tan_th0 = tan_th0; f.M0 = M0;
     f.E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
-    f.sM = sM; f.sz0d = sz0d; f.sy0d = sy0d; f.is0d = 1.0 / (sy0d * sz0d); f.lnAB = (1.6 + sM) / (1.6 - sM);
-    f.sz0v = sz0v; f.sy0v = sz0v * cg * c.cos_veer; f.snw = c.near_c * sqrt(ct / 2.0); f.kdef = ct * cg * D * D / 8.0;
-    f.ch_pref = c.ch_constant * exp(c.ch_ai * log(s0.ai)) * c.ch_amb_pow;
+    f.sM = sM; f.sz0d = sz0d; f.sy0d = sy0d; f.is0d = rcp64(sy0d * sz0d); f.lnAB = (1.6 + sM) * rcp64(1.6 - sM);
+    f.sz0v = sz0v; f.sy0v = sz0v * cg * c.cos_veer; f.snw = c.near_c * sqrt_pos(ct * 0.5); f.kdef = ct * cg * D * D * 0.125;
+    f.ch_pref = c.ch_constant * POW_F64(s0.ai, c.ch_ai) * c.ch_amb_pow;
     f.cgv = cg;  // cosd(-g)
   }
 }
 
 // ---- 5. yaw-added recovery [A.3-5]: the source's own transverse contribution is in V / W now (every wave; returns the
 // increment of the source's TI, which waves 0-2 apply to their column) ----
-__device__ __noinline__ double res4_recovery(int i) {
+RES_SRC_FN double res4_recovery(int tid, int i) {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const int wave = threadIdx.x >> 6;
+  const int wave = tid >> 6;
   const Src4Shared& s0 = R4.s[wave];
   double vsum = 0.0, wsum = 0.0;
 #pragma unroll
   for (int q = 0; q < 9; ++q) { vsum += R4.own[q]; wsum += R4.own[9 + q]; }
   const double I = s0.TIs[0], ubar = s0.ubar;
-  const double k_tke = (ubar * I) * (ubar * I) / (2.0 / 3.0);
-  const double vbar = vsum / 9.0, wbar = wsum / 9.0;
-  const double I_tot = sqrt((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) / ubar;
+  const double k_tke = (ubar * I) * (ubar * I) * 1.5;
+  const double vbar = vsum * (1.0 / 9.0), wbar = wsum * (1.0 / 9.0);
+  const double I_tot = sqrt_nn((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) * rcp64(ubar);
   const double dTI = c.sw_yar ? c.gch_gain * (I_tot - I) : 0.0;
-  if (wave < 3 && (threadIdx.x & 63) == 0) RES4_ST(27 + wave, i) = s0.TIs[wave] + dTI;
-  if (wave < 3 && (threadIdx.x & 63) < 3) {  // commit the source's own column (nothing reads it before the next barrier)
-    const int q = wave * 3 + (threadIdx.x & 63);
+  if (wave < 3 && (tid & 63) == 0) RES4_ST(27 + wave, i) = s0.TIs[wave] + dTI;
+  if (wave < 3 && (tid & 63) < 3) {  // commit the source's own column (nothing reads it before the next barrier)
+    const int q = wave * 3 + (tid & 63);
     RES4_ST(9 + q, i) = R4.own[q];
     RES4_ST(18 + q, i) = R4.own[9 + q];
   }
@@ -777,24 +804,27 @@ __device__ __noinline__ double res4_recovery(int i) {
 
 // ---- 3 + 6 + 7 of grid column j on the turbines behind the source: deflection (TI before mixing, effective yaw), deficit
 // (TI after mixing, commanded yaw), SOSFS; the column's part of the overlap count, taken as FLORIS takes it ----
-__device__ __noinline__ void res4_deficit_pass(int i, int j, double dTI) {
+RES_PASS_FN void res4_deficit_pass(int tid, int i, int j, double dTI) {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const Src4Shared& s = R4.s[threadIdx.x >> 6];
+  const Src4Shared& s = R4.s[tid >> 6];
   const Fin4Shared& f = R4.f;
-  const int lane = threadIdx.x & 63, N = R4.N;
+  const int lane = tid & 63, N = R4.N;
   const bool veer_on = R4.veer_on != 0;
   const double x_i = s.x_i, y_i = s.y_i;
   const double q2 = c.off[2] * c.off[2];
   // source-side constants of this column [A.3-3, A.3-6]
   const double TIpre = s.TIs[j];
-  const double x0d = c.D * f.cgd * (1.0 + f.s_cc) / (c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - f.s_c))) + x_i;
-  const double ix0d_rel = 1.0 / (x0d - x_i);
+  const double x0d_rel = c.D * f.cgd * (1.0 + f.s_cc) * rcp64(c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - f.s_c)));
+  const double x0d = x0d_rel + x_i;
+  const double ix0d_rel = rcp64(x0d_rel);
   const double kyd = c.defl_ka * TIpre + c.defl_kb;
-  const double d0 = f.tan_th0 * (x0d - x_i);
-  const double pfar = f.th0 * f.E0 / 5.2 * sqrt(f.sy0d * f.sz0d / (kyd * kyd * f.M0));
+  const double d0 = f.tan_th0 * x0d_rel;
+  const double pfar = f.th0 * f.E0 * (1.0 / 5.2) * sqrt_pos(f.sy0d * f.sz0d * rcp64(kyd * kyd * f.M0));
   const double TIq = TIpre + dTI;
-  const double x0v = c.D * f.cgv * (1.0 + f.s_c) / (c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - f.s_c))) + x_i;
-  const double ix0v_rel = 1.0 / (x0v - x_i);
+  const double x0v_rel = c.D * f.cgv * (1.0 + f.s_c) * rcp64(c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - f.s_c)));
+  const double x0v = x0v_rel + x_i;
+  const double ix0v_rel = rcp64(x0v_rel);
   const double kyv = c.ka * TIq + c.kb;
   for (int base = i + 1; base < N; base += 64) {
     const int t = base + lane;
@@ -808,9 +838,9 @@ __device__ __noinline__ void res4_deficit_pass(int i, int j, double dTI) {
     double d_far = 0.0;
     if (x_t > x0d) {
       const double sy = kyd * (x_t - x0d) + f.sy0d, sz = kyd * (x_t - x0d) + f.sz0d;
-      const double sg_ = sqrt(sy * sz * f.is0d);
+      const double sg_ = sqrt_pos(sy * sz * f.is0d);
       const double ln_arg = f.lnAB * (1.6 * sg_ - f.sM) * rcp64(1.6 * sg_ + f.sM);
-      d_far = d0 + pfar * log(ln_arg) + lin;
+      d_far = d0 + pfar * LOG_F64(ln_arg) + lin;
     }
     const double delta = d_near + d_far;
     double amp = 0.0, isy2 = 0.0, isz2 = 0.0, sy = 0.0, sz = 0.0;
@@ -829,15 +859,15 @@ __device__ __noinline__ void res4_deficit_pass(int i, int j, double dTI) {
       const double isy = rcp64(sy), isz = rcp64(sz);
       double dd = 1.0 - f.kdef * isy * isz;
       dd = fmin(fmax(dd, 0.0), 1.0);
-      amp = 1.0 - sqrt(dd);
+      amp = 1.0 - sqrt_nn(dd);
       isy2 = 0.5 * isy * isy;
       isz2 = 0.5 * isz * isz;
     }
     const double yy = (y_t + c.off[j]) - y_i - delta;
     double def[3];
     if (!veer_on) {  // r = yy^2 / (2 sy^2) + zz^2 / (2 sz^2), zz = -q, 0, +q
-      const double e1 = amp * exp(-(yy * yy) * isy2);
-      const double e0 = e1 * exp(-q2 * isz2);
+      const double e1 = amp * exp_lean(-(yy * yy) * isy2);
+      const double e0 = e1 * exp_lean(-q2 * isz2);
       def[0] = e0; def[1] = e1; def[2] = e0;
     } else {  // FLORIS rCalt [gauss.py]: the Gaussian rotated by the veer angle
       const double ca = c.cos2_veer * isy2 + c.sin2_veer * isz2;
@@ -846,7 +876,7 @@ __device__ __noinline__ void res4_deficit_pass(int i, int j, double dTI) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const double zz = c.off[k];
-        def[k] = amp * exp(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
+        def[k] = amp * exp_lean(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
       }
     }
     int cnt = 0;
@@ -861,10 +891,11 @@ __device__ __noinline__ void res4_deficit_pass(int i, int j, double dTI) {
 }
 
 // ---- 8. Crespo-Hernandez + overlap gating [A.3-8] of grid column j (the overlap count is the sum over the three columns) ----
-__device__ __noinline__ void res4_turbulence_pass(int i, int j) {
+RES_PASS_FN void res4_turbulence_pass(int tid, int i, int j) {
+  RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const Src4Shared& s = R4.s[threadIdx.x >> 6];
-  const int lane = threadIdx.x & 63, N = R4.N;
+  const Src4Shared& s = R4.s[tid >> 6];
+  const int lane = tid & 63, N = R4.N;
   const double x_i = s.x_i, y_i = s.y_i, D = c.D, ch_pref = R4.f.ch_pref;
   for (int base = i + 1; base < N; base += 64) {
     const int t = base + lane;
@@ -875,63 +906,26 @@ __device__ __noinline__ void res4_turbulence_pass(int i, int j) {
     const double dx = x_t - x_i;
     const int cnt = RES4_CNT(0, t) + RES4_CNT(1, t) + RES4_CNT(2, t);
     const double dxp = (dx <= 0.1) ? dx + 1.0 : dx;  // dx > -0.1 holds for every downstream turbine
-    double ti = ch_pref * exp(c.ch_down * log(dxp / D));
+    double ti = ch_pref * POW_F64(dxp * c.inv_D, c.ch_down);
     if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
-    const double ti_added = ((double)cnt / 9.0) * ti;
-    const double cand = sqrt(ti_added * ti_added + c.amb * c.amb);
+    const double ti_added = ((double)cnt * (1.0 / 9.0)) * ti;
+    const double cand = sqrt_pos(ti_added * ti_added + c.amb * c.amb);
     if (cand > RES4_ST(27 + j, t)) RES4_ST(27 + j, t) = cand;
   }
 }
 
 // ---- outputs [A.4] in the caller's turbine order; the farm's reward ----
-__device__ __noinline__ void res4_outputs(const WfResolveArgs& a, int b, size_t gofs) {
+RES_PASS_FN void res4_outputs(int tid, const WfResolveArgs& a, int b, size_t gofs) {
+  RES_PHASE_FENCE;
+  asm volatile("" : "+v"(tid));
   const WfResolveConsts& c = R4.c;
   const int N = R4.N;
-  const double wd = R4.wd;
   double psum = 0.0, lsum = 0.0;
   const int n_real = a.n_real ? a.n_real[b] : N;  // turbines the farm really has (padded layouts)
-  for (int t = threadIdx.x; t < N; t += 256) {
+  for (int t = tid; t < N; t += 256) {
     const int o = a.gidx[gofs + t];
-    double m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0, dir = 0.0;
-    bool small = true;
-#pragma unroll 1
-    for (int q = 0; q < 9; ++q) {  // (runtime loops over the grid points: the state is read from LDS where it is needed)
-      const double u = R4.Uinit[q % 3] - sqrt(RES4_ST(q, t)), v = RES4_ST(9 + q, t);
-      m3 += u * u * u;
-      mu += u; mv += v; mw += RES4_ST(18 + q, t);
-      small = small && (u > 0.0) && (fabs(v) <= 0.1 * u);
-    }
-    if (__all(small)) {
-#pragma unroll 1
-      for (int q = 0; q < 9; ++q) {
-        const double u = R4.Uinit[q % 3] - sqrt(RES4_ST(q, t));
-        dir += wd - atan_small(RES4_ST(9 + q, t) * rcp64(u)) / kDeg;
-      }
-    } else {
-#pragma unroll 1
-      for (int q = 0; q < 9; ++q) dir += wd - atan2(RES4_ST(9 + q, t), R4.Uinit[q % 3] - sqrt(RES4_ST(q, t))) / kDeg;
-    }
-    mu /= 9.0; mv /= 9.0; mw /= 9.0;
-    double su = 0.0, sv = 0.0, sw = 0.0;
-#pragma unroll 1
-    for (int q = 0; q < 9; ++q) {
-      const double u = R4.Uinit[q % 3] - sqrt(RES4_ST(q, t)), v = RES4_ST(9 + q, t), w = RES4_ST(18 + q, t);
-      su += (u - mu) * (u - mu);
-      sv += (v - mv) * (v - mv);
-      sw += (w - mw) * (w - mw);
-    }
-    const double wsp = cbrt(m3 / 9.0);
-    const double veff = c.dens_cbrt * (wsp * exp(c.pP3 * log(RES4_CG(t))));
-    const double pw = c.rho_ref * interp_fill(veff, c.n_table, R4.tws, R4.tpw, 0.0, 0.0);
-    const double l0 = (RES4_ST(27, t) + RES4_ST(28, t) + RES4_ST(29, t)) / 3.0, l1 = sqrt(su / 9.0), l2 = sqrt(sv / 9.0), l3 = sqrt(sw / 9.0);
-    const bool real = o < n_real;  // (a placeholder of a padded layout: zeros out, nothing into the reward)
-    psum += real ? pw : 0.0;
-    lsum += real ? fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3) : 0.0;
-    const size_t oo = (size_t)b * N + o;
-    if (a.o_power) a.o_power[oo] = real ? (float)pw : 0.0f;
-    if (a.o_ws) a.o_ws[oo] = real ? (float)wsp : 0.0f;
-    if (a.o_wd) a.o_wd[oo] = real ? (float)(dir / 9.0) : 0.0f;
-    if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = real ? make_float4((float)l0, (float)l1, (float)l2, (float)l3) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    res_turbine_outputs(c, a, res_dyn + t * RES_TS, (size_t)b * N + o, o < n_real, R4.Uinit, R4.wd, RES4_CG(t), R4.tws, R4.tpw,
+                        R4.tps, psum, lsum);
   }
   if (a.reward) {  // reference simple_env.py:78-84 on the float64 values
 #pragma unroll
@@ -939,9 +933,9 @@ __device__ __noinline__ void res4_outputs(const WfResolveArgs& a, int b, size_t 
       psum += __shfl_xor(psum, w);
       lsum += __shfl_xor(lsum, w);
     }
-    if ((threadIdx.x & 63) == 0) { R4.red[threadIdx.x >> 6][0] = psum; R4.red[threadIdx.x >> 6][1] = lsum; }
+    if ((tid & 63) == 0) { R4.red[tid >> 6][0] = psum; R4.red[tid >> 6][1] = lsum; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       double ps = 0.0, ls = 0.0;
       for (int w = 0; w < 4; ++w) { ps += R4.red[w][0]; ls += R4.red[w][1]; }
       const double wr = a.ws_prev ? a.ws_prev[b] : R4.ws;
@@ -950,42 +944,51 @@ __device__ __noinline__ void res4_outputs(const WfResolveArgs& a, int b, size_t 
   }
 }
 
-__global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfResolveConsts c_arg, const WfResolveArgs a, int n_pad, int max_count) {
-  const int tid = threadIdx.x, wave = tid >> 6;
+__global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfResolveConsts c_arg, const WfResolveArgs a_arg, int n_pad, int max_count) {
+  const int tid = threadIdx.x;
   const int N = c_arg.N;
   if (tid == 0) {
     R4.c = c_arg;
+    R4.a = a_arg;
     R4.N = N; R4.n_pad = n_pad; R4.veer_on = c_arg.sin2_veer != 0.0; R4.mcore = c_arg.mirror_core;
   }
   for (int k = tid; k < c_arg.n_table; k += 256) {
-    R4.tws[k] = a.tab64[k];
-    R4.tct[k] = a.tab64[WF_TABLE_PAD + k];
-    R4.tpw[k] = a.tab64[2 * WF_TABLE_PAD + k];
+    R4.tws[k] = a_arg.tab64[k];
+    R4.tct[k] = a_arg.tab64[WF_TABLE_PAD + k];
+    R4.tpw[k] = a_arg.tab64[2 * WF_TABLE_PAD + k];
+    if (k + 1 < c_arg.n_table) {  // segment slopes (scipy interp1d: slope * (x - x_lo) + y_lo)
+      const double dxk = a_arg.tab64[k + 1] - a_arg.tab64[k];
+      R4.tcs[k] = (a_arg.tab64[WF_TABLE_PAD + k + 1] - a_arg.tab64[WF_TABLE_PAD + k]) / dxk;
+      R4.tps[k] = (a_arg.tab64[2 * WF_TABLE_PAD + k + 1] - a_arg.tab64[2 * WF_TABLE_PAD + k]) / dxk;
+    }
   }
-  const int n_list = *a.count;
+  const int n_list = *a_arg.count;
   if (n_list > max_count) return;  // the one-wave-per-farm kernel serves counts beyond one residency of this one
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
-    const int b = a.list[li];
+    const int b = a_arg.list[li];
+    __syncthreads();  // the constants are in place / the previous farm's last readers are done
+    RES_PHASE_FENCE;
+    const WfResolveArgs& a = R4.a;
     size_t gofs = 0;
     if (a.farm_group) gofs = (size_t)((a.farm_group[b] + a.shift) % a.mod) * N;
     else gofs = (size_t)b * a.geom_stride;
     const float* yaw_b = (a.yaw_state ? a.yaw_state : a.yaw_in) + (size_t)b * N;
-    __syncthreads();  // the constants are in place / the previous farm's last readers are done
     if (tid == 0) {
       const double ws = a.ws[(size_t)b * a.wind_stride];
       double wd = fmod(a.wd[(size_t)b * a.wind_stride], 360.0);  // reference interface.py:664 (Python's %)
       if (wd < 0.0) wd += 360.0;
       R4.ws = ws; R4.wd = wd; R4.Uinf = ws * c_arg.uinf1;  // inflow [A.2]
-      for (int k = 0; k < 3; ++k) R4.Uinit[k] = ws * c_arg.shearf[k];
+      for (int k = 0; k < 3; ++k) { R4.Uinit[k] = ws * c_arg.shearf[k]; R4.dec_a[k] = 4.0 * (c_arg.nu1[k] * ws) / R4.Uinf; }
     }
     for (int t = tid; t < N; t += 256) {
       const double g = (double)yaw_b[a.gidx[gofs + t]];
       double sg, cg;
-      sincos(g * kDeg, &sg, &cg);
+      if (__any(fabs(g) > 45.0)) sincos_any(g * kDeg, sg, cg);  // (never an admissible yaw command)
+      else sincos_small(g * kDeg, sg, cg);
       RES4_XS(t) = a.gx[gofs + t]; RES4_YS(t) = a.gy[gofs + t]; RES4_CG(t) = cg; RES4_SG(t) = sg; RES4_GR(t) = g * kDeg;
 #pragma unroll 1
-      for (int q = 0; q < 27; ++q) res_dyn[(5 + q) * n_pad + t] = 0.0;
-      for (int j = 0; j < 3; ++j) res_dyn[(32 + j) * n_pad + t] = c_arg.amb;
+      for (int q = 0; q < 27; ++q) res_dyn[t * RES_TS + 5 + q] = 0.0;
+      for (int j = 0; j < 3; ++j) res_dyn[t * RES_TS + 32 + j] = c_arg.amb;
     }
     __syncthreads();
     for (int t = tid; t < N; t += 256) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
@@ -995,27 +998,32 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
     }
     __syncthreads();
     for (int i = 0; i < N; ++i) {
-      res4_source_begin(i);
-      if (wave < 3) {
-        if (c_arg.sw_tv) res4_transverse_pass(i, wave);
-        else if ((tid & 63) < 3) {  // (no transverse velocities: the side buffer holds the unchanged — zero — state)
-          const int q = wave * 3 + (tid & 63);
+      // (the thread index is made opaque once per source: everything derived from it — wave, lane, a dozen LDS addresses per
+      // phase — is recomputed where it is used instead of being hoisted out of this loop and held, or spilled, across it)
+      int tq = tid;
+      asm volatile("" : "+v"(tq));
+      const int wq = tq >> 6;
+      res4_source_begin(tq, i);
+      if (wq < 3) {
+        if (R4.c.sw_tv) res4_transverse_pass(tq, i, wq);
+        else if ((tq & 63) < 3) {  // (no transverse velocities: the side buffer holds the unchanged — zero — state)
+          const int q = wq * 3 + (tq & 63);
           R4.own[q] = RES4_ST(9 + q, i);
           R4.own[9 + q] = RES4_ST(18 + q, i);
         }
       } else {
-        res4_source_chain(i);
+        res4_source_chain(tq, i);
       }
       __syncthreads();
-      const double dTI = res4_recovery(i);
+      const double dTI = res4_recovery(tq, i);
       if (i + 1 < N) {
-        if (wave < 3) res4_deficit_pass(i, wave, dTI);
+        if (wq < 3) res4_deficit_pass(tq, i, wq, dTI);
         __syncthreads();
-        if (wave < 3) res4_turbulence_pass(i, wave);
+        if (wq < 3) res4_turbulence_pass(tq, i, wq);
       }
       __syncthreads();
     }
-    res4_outputs(a, b, gofs);
+    res4_outputs(tid, a, b, gofs);
     if (tid == 0) a.flags[b] = 0;
   }
 }
@@ -1045,7 +1053,7 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
   // residency, the same throughput per instruction without the redundant per-wave parts).  Both are enqueued; the one
   // the count is not meant for returns at once.  With `all` the count is B and only the right one is launched.
   const int n_pad = (c->N + 1) & ~1;  // (keeps the int arrays behind the doubles aligned)
-  const size_t dyn4 = sizeof(double) * 35 * (size_t)n_pad + sizeof(int) * 4 * (size_t)n_pad;
+  const size_t dyn4 = sizeof(double) * RES_TS * (size_t)n_pad + sizeof(int) * 4 * (size_t)n_pad;
   const size_t lds4 = dyn4 + sizeof(Res4Shared);
   int per_cu = (int)((160 * 1024) / lds4);
   if (per_cu > WF_RES4_OCC) per_cu = WF_RES4_OCC;
@@ -1065,7 +1073,7 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
     // 73.7 ms at 65536 HornsRev1 farms, tools/gridab.sh; the flagged list is short and an empty launch should be cheap)
     const int per_cu_grid = all ? 4 * WF_RES_GRID_PER_CU : WF_RES_GRID_PER_CU;
     const int grid = B < n_cu * per_cu_grid ? B : n_cu * per_cu_grid;
-    const size_t dyn = sizeof(double) * 35 * (size_t)n_pad + sizeof(int) * (size_t)n_pad;
+    const size_t dyn = sizeof(double) * RES_TS * (size_t)n_pad + sizeof(int) * (size_t)n_pad;
     hipLaunchKernelGGL(wf_resolve_kernel, dim3(grid), dim3(64), dyn, s, *c, *a, n_pad, max4 + 1);
   }
   return hipGetLastError();
