@@ -300,24 +300,29 @@ def main():
             from wfcrl_env_amd import environments as envs
 
             env_id = {"Turb16_TCRWP_": "Turb16_TCRWP_Floris"}.get(layout_name, layout_name + "Floris")
-            env = envs.make(env_id, env_batch=B, max_num_steps=10 ** 9, load_coef=0.1, log=False, reuse_buffers=True)
-            env.reset(seed=0, options={"wind_speed": 8.0, "wind_direction": 270.0})
             acts = [(torch.rand((B, N), device="cuda") * 10 - 5) for _ in range(8)]
             env_level = {}
-            for name, fn in (("step", env.step), ("step_light", env.step_light)):
-                for i in range(3):
-                    fn(acts[i])
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for i in range(args.steps):
-                    fn(acts[i % 8])
-                torch.cuda.synchronize()
-                ms = (time.perf_counter() - t) / args.steps * 1e3
-                env_level[name] = {"ms_per_step": ms, "env_steps_per_sec": B / (ms * 1e-3), "over_kernel": ms / kern_ms - 1.0}
+            # the env object as make() builds it by DEFAULT (fresh output tensors every step) and with reuse_buffers=True
+            # (two preallocated buffer sets used alternately: the opt-in for throughput loops)
+            for label, kw in (("default", {}), ("reuse_buffers", {"reuse_buffers": True})):
+                env = envs.make(env_id, env_batch=B, max_num_steps=10 ** 9, load_coef=0.1, log=False, **kw)
+                env.reset(seed=0, options={"wind_speed": 8.0, "wind_direction": 270.0})
+                for name, fn in (("step", env.step), ("step_light", env.step_light)):
+                    for i in range(3):
+                        fn(acts[i])
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for i in range(args.steps):
+                        fn(acts[i % 8])
+                    torch.cuda.synchronize()
+                    ms = (time.perf_counter() - t) / args.steps * 1e3
+                    key = name if label == "reuse_buffers" else name + "_default_buffers"
+                    env_level[key] = {"ms_per_step": ms, "env_steps_per_sec": B / (ms * 1e-3), "over_kernel": ms / kern_ms - 1.0}
+                env.close()
             env_level["what"] = (f'make("{env_id}", env_batch={B}).step / .step_light with device-resident random actions, '
-                                 "wall clock per step over the same number of steps (asynchronous launches, one sync at the end; "
-                                 "reuse_buffers=True: outputs written into two preallocated buffer sets used alternately)")
-            env.close()
+                                 "wall clock per step over the same number of steps (asynchronous launches, one sync at the end); "
+                                 "*_default_buffers: the env as make() builds it (outputs allocated per step); step / step_light: "
+                                 "reuse_buffers=True (outputs written into two preallocated buffer sets used alternately)")
         except Exception as e:  # pragma: no cover
             print(f"bench.py: env-level leg failed: {e}", file=sys.stderr)
 

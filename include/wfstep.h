@@ -301,6 +301,8 @@ typedef struct wf_kernel_info {
   int vgprs, lds_bytes, scratch_bytes; /* from hipFuncGetAttributes */
   int pair_table; /* 1: shared-wind pair-coefficient table path, 0: per-farm on-the-fly path */
   int direction_groups; /* > 0: farms grouped by that many distinct wind directions, one pair table each */
+  int mixed_main_farms; /* > 0: mixed launch (wf_kernel_choice::mixed) — the figures describe the kernel of the farms [0,
+                           mixed_main_farms); wf_step_kernel serves the rest */
   int one_block_kernel; /* 1: the figures describe wf_step_ll_kernel (one target block of lanes_per_env x slots_per_lane turbines in
                            registers at a time, csrc/wf_kernels_ll.hip), which serves every wind direction without an
                            x' tie across a block boundary; the register-slot kernel is enqueued behind it for the rest */
@@ -334,6 +336,12 @@ typedef struct wf_kernel_choice {
                            wf_set_calibration carry it across processes (kernel families agree within the parity tolerances,
                            not bit for bit: another summation order).  0: the rounds model's guess stands (measured on one
                            MI355X: wf_dispatch.hip) */
+  int mixed;            /* -1 / 1: a batch a little beyond a whole number of ROUNDS of its kernel family (a launch costs whole
+                           rounds: 69 632 HornsRev1 farms are one round of the 2x2 kernel plus 4 096 farms that would take a
+                           second one) is served by two launches on disjoint farm ranges — the whole rounds on the family, the
+                           remainder on wf_step_kernel behind it, same stream — where that is faster (rounds model; measured
+                           by the calibration); 0: always one launch.  Results of a farm do not depend on which range it is in
+                           beyond the family difference stated under `calibrate`. */
 } wf_kernel_choice;
 int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c);
 /* What the calibration (wf_kernel_choice::calibrate) found: *code = (G << 4) | S of the wf_step_ll_kernel shape it chose, 0
@@ -344,6 +352,9 @@ int wf_get_calibration(wf_handle* h, int* code, float* family_ms);
  * path's family against wf_step_kernel, which has to win by 4 %): *choice = 0 not timed yet, 1 wf_step_ll_kernel, 2
  * wf_step_kernel; ms[2] = ms per launch of the two.  Either pointer may be NULL. */
 int wf_get_fly_calibration(wf_handle* h, int* choice, float* ms);
+/* The mixed launch of the current configuration: *main_farms = farms the one-block family keeps (0: one launch), *mixed_ms = ms
+ * per step the calibration measured for it (0: not timed — the rounds model decided).  Either pointer may be NULL. */
+int wf_get_mixed_launch(wf_handle* h, int* main_farms, float* mixed_ms);
 int wf_get_kernel_choice(wf_handle* h, wf_kernel_choice* c);
 /* Time the kernel families NOW for the handle's current layout / batch / wind (after wf_set_wind*), on scratch buffers with
  * zero yaw, ignoring and then refreshing the process cache; synchronises.  Lets a caller keep the timing out of its first

@@ -309,7 +309,7 @@ def test_kernel_choice_round_trip_and_errors(layouts):
 
     l = layouts["HornsRev1_"]
     w = WfStep(l["xcoords"], l["ycoords"], env_batch=256)
-    assert w.kernel_choice() == dict(slot_G=0, slot_S=0, one_block=-1, ll_G=0, ll_S=0, pair_table=-1, fly_one_block=-1, far_skip=-1, calibrate=-1)
+    assert w.kernel_choice() == dict(slot_G=0, slot_S=0, one_block=-1, ll_G=0, ll_S=0, pair_table=-1, fly_one_block=-1, far_skip=-1, calibrate=-1, mixed=-1)
     w.set_wind(8.0, 263.0)
     w.set_kernel_choice(one_block="4x2", slot="16x5")
     c = w.kernel_choice()

@@ -1,7 +1,8 @@
 """GPU box: throughput over the env batch in steps of 4096: what the rounds model picks, what every
 forced family delivers, and where the pick stands against the best family at that batch and against the running best
 (the "envelope": the highest farm-steps/s of any family at any batch up to this one).
-  python tools/batch_sweep_fine.py [layout ...] > gpurun_out/r03_batch_sweep_fine.txt"""
+  python tools/batch_sweep_fine.py [layout ...] > gpurun_out/r03_batch_sweep_fine.txt      (SWEEP_BS=36864,69632: those batches only;
+with SWEEP_BS the envelope is that of the listed batches)"""
 import json, os, sys
 os.environ.setdefault("WF_RISK_RESOLVE", "0")  # float32 kernels on their own unless the script switches the re-solve on (a handle's default is on)
 import torch
@@ -31,7 +32,10 @@ def time_it(lay, B, choice):
         best = min(best, w.timing_end() / 6)
     k = w.kernel_info()
     w.close()
-    return best, ("slot" if not k["one_block_kernel"] else f"{k['lanes_per_env']}x{k['slots_per_lane']}")
+    fam = "slot" if not k["one_block_kernel"] else f"{k['lanes_per_env']}x{k['slots_per_lane']}"
+    if k.get("mixed_main_farms"):  # (round 5: whole rounds on the family + the remainder on the slot kernel)
+        fam += f"+slot@{k['mixed_main_farms']}"
+    return best, fam
 
 
 if __name__ == "__main__":
@@ -41,7 +45,8 @@ if __name__ == "__main__":
         env_best = 0.0
         worst_fam, worst_env = 1.0, 1.0
         step = int(os.environ.get("SWEEP_STEP", 4096))
-        for B in range(step, 131072 + 1, step):
+        Bs = [int(v) for v in os.environ["SWEEP_BS"].split(",")] if os.environ.get("SWEEP_BS") else range(step, 131072 + 1, step)
+        for B in Bs:
             time_it(lay, B, None)  # (the first handle after a change of batch runs ~5 % slow whatever it is: tools/pick_vs_forced.py)
             ts = {f: time_it(lay, B, c)[0] for f, c in FAMS}
             t_pick, fam_pick = time_it(lay, B, None)  # (round 4: the handle calibrates itself on its third step — wf_kernel_choice::calibrate)
@@ -50,6 +55,6 @@ if __name__ == "__main__":
             env_best = max(env_best, B / min(t_best, t_pick) * 1e3)
             r_fam, r_env = min(t_best / t_pick, 1.0), thr / env_best
             worst_fam, worst_env = min(worst_fam, r_fam), min(worst_env, r_env)
-            print(f"B={B:7d} pick {fam_pick:4s} {t_pick:.3f} ms {thr:.3e}  " + " ".join(f"{f}={t:.3f}" for f, t in ts.items())
+            print(f"B={B:7d} pick {fam_pick:16s} {t_pick:.3f} ms {thr:.3e}  " + " ".join(f"{f}={t:.3f}" for f, t in ts.items())
                   + f"  pick/best {r_fam:.3f}  pick/envelope {r_env:.3f}", flush=True)
         print(f"# {name}: worst pick / best family {worst_fam:.3f}, worst pick / envelope {worst_env:.3f}")

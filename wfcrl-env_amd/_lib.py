@@ -58,13 +58,13 @@ class WindDist(C.Structure):
 class KernelInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "lanes_per_env", "slots_per_lane", "envs_per_block", "threads_per_block", "grid_blocks",
-        "vgprs", "lds_bytes", "scratch_bytes", "pair_table", "direction_groups", "one_block_kernel")]
+        "vgprs", "lds_bytes", "scratch_bytes", "pair_table", "direction_groups", "mixed_main_farms", "one_block_kernel")]
 
 
 class KernelChoice(C.Structure):
     """Mirror of `struct wf_kernel_choice`."""
 
-    _fields_ = [(n, C.c_int) for n in ("slot_G", "slot_S", "one_block", "ll_G", "ll_S", "pair_table", "fly_one_block", "far_skip", "calibrate")]
+    _fields_ = [(n, C.c_int) for n in ("slot_G", "slot_S", "one_block", "ll_G", "ll_S", "pair_table", "fly_one_block", "far_skip", "calibrate", "mixed")]
 
 
 # every symbol include/wfstep.h declares: name -> (restype, argtypes)
@@ -109,6 +109,7 @@ ABI = {
     "wf_get_kernel_choice": (C.c_int, [_P, C.POINTER(KernelChoice)]),
     "wf_get_calibration": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "wf_get_fly_calibration": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "wf_get_mixed_launch": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "wf_calibrate": (C.c_int, [_P]),
     "wf_set_calibration": (C.c_int, [_P, C.c_int, C.c_int]),
     "wf_last_error": (C.c_char_p, [_P]),

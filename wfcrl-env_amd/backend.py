@@ -378,7 +378,7 @@ class WfStep:
         check(self._lib.wf_timing_end(self._h, C.byref(ms)), self._h)
         return float(ms.value)
 
-    def set_kernel_choice(self, slot=None, one_block=None, pair_table=None, fly_one_block=None, far_skip=None, calibrate=None):
+    def set_kernel_choice(self, slot=None, one_block=None, pair_table=None, fly_one_block=None, far_skip=None, calibrate=None, mixed=None):
         """Which kernels may serve THIS handle (include/wfstep.h: wf_set_kernel_choice); None = automatic.
           slot=(G, S) or "16x5"      wf_step_kernel<G,S>
           one_block=False            never wf_step_ll_kernel;  one_block=(G, S) / "4x2" / "8": always, with that shape
@@ -386,6 +386,7 @@ class WfStep:
           fly_one_block=False        a wind per farm stays on wf_step_kernel
           far_skip=False             wf_step_ll_kernel evaluates every (source, target) pair (no far-source / far-pair skip)
           calibrate=False            the rounds model's guess stands: no timing of the kernel families before the first step
+          mixed=False                always ONE launch per step (no whole-rounds + remainder split of the batch)
         Drops the current wind: set it again before the next step."""
         def gs(v, default_s=1):
             if isinstance(v, bool):
@@ -398,7 +399,7 @@ class WfStep:
                 return v, default_s
             return int(v[0]), int(v[1])
 
-        c = KernelChoice(0, 0, -1, 0, 0, -1, -1, -1, -1)
+        c = KernelChoice(0, 0, -1, 0, 0, -1, -1, -1, -1, -1)
         if slot:
             c.slot_G, c.slot_S = gs(slot)
         if one_block is not None:
@@ -415,6 +416,8 @@ class WfStep:
             c.far_skip = 0 if far_skip is False or far_skip == 0 else -1
         if calibrate is not None:
             c.calibrate = 0 if calibrate is False or calibrate == 0 else -1
+        if mixed is not None:
+            c.mixed = 0 if mixed is False or mixed == 0 else -1
         check(self._lib.wf_set_kernel_choice(self._h, C.byref(c)), self._h)
 
     def kernel_choice(self) -> dict:
@@ -433,8 +436,11 @@ class WfStep:
         shape = None if code.value < 0 else ("slot" if code.value == 0 else f"{code.value >> 4}x{code.value & 15}")
         fly, fms = C.c_int(0), (C.c_float * 2)()
         check(self._lib.wf_get_fly_calibration(self._h, C.byref(fly), fms), self._h)
+        mixn, mixms = C.c_int(0), C.c_float(0.0)
+        check(self._lib.wf_get_mixed_launch(self._h, C.byref(mixn), C.byref(mixms)), self._h)
         return {"shape": shape, "family_ms": {n: float(m) for n, m in zip(names, ms) if m > 0.0},
-                "on_the_fly": (None, "one_block", "slot")[fly.value], "on_the_fly_ms": {n: float(m) for n, m in zip(("one_block", "slot"), fms) if m > 0.0}}
+                "on_the_fly": (None, "one_block", "slot")[fly.value], "on_the_fly_ms": {n: float(m) for n, m in zip(("one_block", "slot"), fms) if m > 0.0},
+                "mixed_main_farms": int(mixn.value), "mixed_ms": float(mixms.value)}
 
     def calibrate(self):
         """Time the kernel families NOW for the current layout / batch / wind (include/wfstep.h: wf_calibrate; synchronises) —

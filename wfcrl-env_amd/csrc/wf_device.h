@@ -121,6 +121,10 @@ struct WfGroupArgs {
   int* res_zero;         // the other counter
   int* flags_raw;        // [B]
   int res_mask;          // WF_RISK_* bits that select a farm
+  // Mixed launch (round 5, wf_dispatch.hip): the launch serves the farms [env_base, env_end) of the batch (launch slot s holds
+  // farm env_base + s); env_end == 0: all B farms from 0.  Lets one step be served by two kernels on disjoint farm ranges —
+  // whole rounds of the throughput family, the remainder on the register-slot kernel — instead of a nearly empty last round.
+  int env_base, env_end;
   const int* n_real;     // [B] turbines the farm really has (wf_set_layouts_counts: layouts of fewer than N turbines are
                          // padded with placeholders far downstream, which nothing real can see); null = N.  Outputs of
                          // the placeholders are written as 0 and stay out of the reward.

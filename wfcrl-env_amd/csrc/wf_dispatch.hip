@@ -123,6 +123,31 @@ double ll_estimate(const wf_handle* h, int fi, int N, long farms) {
   return t;
 }
 
+// Mixed launch (round 5; priced in round 3, asked for twice since).  A launch costs whole ROUNDS, so a batch a little beyond a
+// whole number of rounds of its family pays a nearly empty last round — 69 632 HornsRev1 farms are one round of the 2x2 kernel
+// (65 536) plus 4 096 farms that take another full round's time on a sixteenth of the chip: 0.66 of the envelope.  Instead the
+// whole rounds run on the family and the remainder on the register-slot kernel, the lowest-latency one, enqueued behind it on
+// the same stream for the farms [main, B) (WfGroupArgs::env_base / env_end): its blocks move in as the last round drains.
+// Returns the number of farms the family keeps (0: no mixing): by the rounds model here, by measurement in calibrate_families.
+int mix_candidate(const wf_handle* h, int fi, int N, long B) {
+  if (kLlFamilies[fi].code == 0 || h->choice.mixed == 0) return 0;
+  int fpb, per_cu;
+  family_shape(h, fi, N, &fpb, &per_cu);
+  const long per_round = (long)h->n_cu * per_cu * fpb;
+  const long full = B / per_round, rem = B % per_round;
+  if (full < 1 || rem == 0) return 0;
+  int fpb0, per_cu0;
+  family_shape(h, 0, N, &fpb0, &per_cu0);
+  if (rem > 2l * h->n_cu * per_cu0 * fpb0) return 0;  // (more than two rounds of the slot kernel: the partial round is well filled)
+  return (int)(full * per_round);
+}
+double mix_estimate(const wf_handle* h, int fi, int N, long B, int main_farms) {
+  int fpb, per_cu;
+  family_shape(h, fi, N, &fpb, &per_cu);
+  const long per_round = (long)h->n_cu * per_cu * fpb;
+  return (main_farms / per_round) * round_ms(fi, N, per_cu) + 0.9 * ll_estimate(h, 0, N, B - main_farms);
+}
+
 // Lane-group width of the one-block-at-a-time kernel for N turbines and B farms, 0 = keep wf_step_kernel.  It pays once
 // the farm spans several blocks (the register-slot kernel is then pinned at two waves per SIMD by its 27 S state
 // registers) and the batch fills the chip.  wf_set_kernel_choice: one_block = 0 disables it, 1 forces (ll_G, ll_S).
@@ -172,9 +197,20 @@ int repick_ll_slots(const wf_handle* h, int N, int ll_G, int ll_S, long farm_slo
 // (Re)pick the kernels of a handle for N turbines and B farms under its choice: the register-slot variant and the
 // one-block kernel's shape; frees what was laid out for another shape.  The caller has drained the stream.
 void reset_calibration(wf_handle* h) {
-  h->calib_done = false; h->calib_code = -1; h->tab_slot = false;
+  h->calib_done = false; h->calib_code = -1; h->tab_slot = false; h->mix_main = 0;
   for (float& m : h->calib_ms) m = 0.0f;
   h->fly_calib = 0; h->fly_calib_ms[0] = h->fly_calib_ms[1] = 0.0f;
+}
+
+// the rounds model's answer to "mix?" for family `code` at B farms: farms the family keeps, 0 = one launch
+int model_mix(const wf_handle* h, int code, int N, int B) {
+  if (!code || h->choice.one_block == 0) return 0;
+  for (int fi = 0; fi < kNumFamilies; ++fi)
+    if (kLlFamilies[fi].code == code) {
+      const int m = mix_candidate(h, fi, N, B);
+      return (m && mix_estimate(h, fi, N, B, m) < 0.93 * ll_estimate(h, fi, N, B)) ? m : 0;
+    }
+  return 0;
 }
 
 void apply_kernel_pick(wf_handle* h, int N, int B, bool* variant_changed) {
@@ -182,6 +218,7 @@ void apply_kernel_pick(wf_handle* h, int N, int B, bool* variant_changed) {
   const int v = pick_variant(h, N, B);
   const int llg = pick_ll(h, N, B);
   set_ll_shape(h, llg >> 4, llg ? (llg & 15) : 1);
+  h->mix_main = model_mix(h, llg, N, B);
   if (variant_changed) *variant_changed = v != h->variant;
   if (v != h->variant) {  // the pair table is laid out for the variant's capacity
     hipFree(h->d_pair_tab); hipFree(h->d_pair_first);
@@ -372,10 +409,25 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
     const size_t slots = h->n_groups > 0 ? (size_t)h->n_slots : (size_t)((h->B + fpb - 1) / fpb) * fpb;
     size_t log_records = 0;
     if ((rc = ensure_log(h, slots, &log_records)) != WF_OK) return rc;
+    // mixed launch (mix_candidate above): the family keeps its whole rounds, the farms [M, B) go to wf_step_kernel behind it
+    const int M = (h->mix_main > 0 && h->mix_main < h->B && h->n_groups == 0) ? h->mix_main : 0;
+    if (M) { ga.env_base = 0; ga.env_end = M; }
     if (h->ll_ties != 1)
       WF_HIP(h, wfk_launch_step_ll(h->ll_G, h->ll_S, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
                                    load, h->B, ea, h->d_ll_tab, h->d_ll_flag, h->d_src_log,
                                    log_records, &ga, h->stream));
+    if (M) {
+      if (h->ll_ties != 0) {  // (a direction with a cross-block tie: the family's share is wf_step_kernel's too)
+        WfGroupArgs gp = ga;
+        gp.pred = h->d_ll_flag;
+        WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
+                                  wstride, yaw, power, wspd, wdir, load, h->B, ea, ptab, h->d_pair_first, &gp, h->stream, &h->grid));
+      }
+      ga.env_base = M; ga.env_end = h->B;
+      WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
+                                wstride, yaw, power, wspd, wdir, load, h->B, ea, ptab, h->d_pair_first, &ga, h->stream, &h->grid));
+      return WF_OK;
+    }
     if (h->ll_ties == 0) return WF_OK;
     ga.pred = h->d_ll_flag;
   }
@@ -436,7 +488,7 @@ struct CalibKey {
 };
 struct CalibVal {
   bool have_tab = false, have_fly = false;
-  int code = -1, fly = 0;
+  int code = -1, fly = 0, mix_main = 0;
   float ms[8] = {}, fly_ms[2] = {};
 };
 static std::mutex g_calib_mu;
@@ -520,10 +572,10 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
     h->calib_ms[fi] = fam_ms;
     if (fam_ms < best_ms) { best_ms = fam_ms; best = fi; }
   }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
   hipStreamSynchronize(h->stream);
   if (rc != WF_OK) {  // a failed probe leaves the handle on the rounds model's guess, not on a candidate
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
     apply_family(h, code0, code0);
     return rc;
   }
@@ -533,6 +585,32 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
   const int code = best >= 0 ? kLlFamilies[best].code : code0;
   apply_family(h, code, code0);
   h->calib_code = code;
+  // ... and the winner's mixed launch (whole rounds on the family, the remainder on wf_step_kernel), where the batch has one:
+  // measured like a family, kept when it beats the single launch by 4 %
+  h->mix_main = 0;
+  h->calib_ms[6] = 0.0f;
+  const int m = (best >= 0 && code) ? mix_candidate(h, best, N, B) : 0;
+  if (m) {
+    h->mix_main = m;
+    float mix_ms = 1e30f;
+    rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
+    for (int r = 0; r < 3 && rc == WF_OK; ++r) {
+      hipError_t e = hipEventRecord(e0, h->stream);
+      rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
+      if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      float ms = 0.0f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (e != hipSuccess) { rc = fail(h, WF_E_HIP, std::string("calibration: ") + hipGetErrorString(e)); break; }
+      if (ms < mix_ms) mix_ms = ms;
+    }
+    hipStreamSynchronize(h->stream);
+    if (rc != WF_OK) { h->mix_main = 0; hipEventDestroy(e0); hipEventDestroy(e1); return rc; }
+    h->calib_ms[6] = mix_ms;
+    if (!(mix_ms < 0.96f * h->calib_ms[best])) h->mix_main = 0;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
   h->calib_done = true;
   return WF_OK;
 }
@@ -596,11 +674,11 @@ int calibrate_now(wf_handle* h, const float* yaw, float* power, float* wspd, flo
         WF_HIP(h, hipStreamSynchronize(h->stream));
         apply_family(h, cv.code, code0);
       }
-      h->calib_code = cv.code; h->calib_done = true;
+      h->calib_code = cv.code; h->calib_done = true; h->mix_main = cv.mix_main;
       for (int k = 0; k < 8; ++k) h->calib_ms[k] = cv.ms[k];
     } else {
       if ((rc = calibrate_families(h, yaw, power, wspd, wdir, load, probe)) != WF_OK) return rc;
-      cv.have_tab = true; cv.code = h->calib_code;
+      cv.have_tab = true; cv.code = h->calib_code; cv.mix_main = h->mix_main;
       for (int k = 0; k < 8; ++k) cv.ms[k] = h->calib_ms[k];
     }
   }
@@ -628,6 +706,7 @@ int apply_saved_calibration(wf_handle* h, int code, int fly_choice) {
     WF_HIP(h, hipStreamSynchronize(h->stream));
     apply_family(h, code, pick_ll(h, h->N, h->B));  // (tables and log are laid out per shape: rebuilt by the next launch)
     h->calib_code = code; h->calib_done = true;
+    h->mix_main = model_mix(h, code, h->N, h->B);  // (deterministic: the rounds model's answer for this family)
   }
   if (fly_choice == 1 || fly_choice == 2) h->fly_calib = fly_choice;
   return WF_OK;
@@ -727,6 +806,7 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && h->choice.fly_one_block != 0 &&
                       h->fly_calib != 2;
   info->one_block_kernel = ((tab && h->ll_G && !(h->tab_slot && h->n_groups == 0)) || ll_fly) ? 1 : 0;
+  info->mixed_main_farms = (tab && info->one_block_kernel && !ll_fly && h->n_groups == 0 && h->mix_main > 0 && h->mix_main < h->B) ? h->mix_main : 0;
   if (info->one_block_kernel) {
     // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
     // fields above would describe) is enqueued behind it for the directions that have one
@@ -747,7 +827,7 @@ int wf_set_kernel_choice(wf_handle* h, const wf_kernel_choice* c) {
   if ((c->slot_G > 0) != (c->slot_S > 0) || (c->slot_G > 0 && find_variant(c->slot_G, c->slot_S) < 0))
     return fail(h, WF_E_INVALID, "no wf_step_kernel variant with these lanes per farm x slots per lane");
   if (c->one_block < -1 || c->one_block > 1 || c->pair_table < -1 || c->pair_table > 1 || c->fly_one_block < -1 || c->fly_one_block > 1 ||
-      c->far_skip < -1 || c->far_skip > 1 || c->calibrate < -1 || c->calibrate > 1)
+      c->far_skip < -1 || c->far_skip > 1 || c->calibrate < -1 || c->calibrate > 1 || c->mixed < -1 || c->mixed > 1)
     return fail(h, WF_E_INVALID, "kernel choice switches must be -1 (automatic), 0 or 1");
   if (c->one_block == 1) {
     const int g = c->ll_G, sl = c->ll_S > 0 ? c->ll_S : 1;
@@ -804,6 +884,13 @@ int wf_get_calibration(wf_handle* h, int* code, float* family_ms) {
   if (code) *code = h->calib_done ? h->calib_code : -1;
   if (family_ms)
     for (int fi = 0; fi < 6; ++fi) family_ms[fi] = fi < kNumFamilies ? h->calib_ms[fi] : 0.0f;
+  return WF_OK;
+}
+
+int wf_get_mixed_launch(wf_handle* h, int* main_farms, float* mixed_ms) {
+  if (!h) return WF_E_INVALID;
+  if (main_farms) *main_farms = (h->mix_main > 0 && h->mix_main < h->B) ? h->mix_main : 0;
+  if (mixed_ms) *mixed_ms = h->calib_ms[6];
   return WF_OK;
 }
 

@@ -169,12 +169,14 @@ struct wf_handle {
   bool wind_sync = true;       // the wind was set by a call that synchronises anyway (host arrays, series, binned sampling)
   int ll_ties = 2;             // cross-block ties of the current directions: 0 none, 1 all of them, 2 some / not read back
   // which kernels may serve this handle (wf_set_kernel_choice; the WF_* environment variables only seed it at wf_create)
-  wf_kernel_choice choice{0, 0, -1, 0, 0, -1, -1, -1, -1};
+  wf_kernel_choice choice{0, 0, -1, 0, 0, -1, -1, -1, -1, -1};
   int n_cu = 256;              // compute units of the handle's device (hipDeviceProp_t::multiProcessorCount)
   // per-handle calibration of the kernel family (wf_dispatch.hip: calibrate_families): whether the families have been
   // timed (or taken from the process cache / wf_set_calibration) for the current configuration
   bool calib_done = false;
   int calib_code = -1;         // what the timing chose: (G << 4) | S, 0 = the register-slot kernel, -1 = never ran
+  int mix_main = 0;            // mixed launch of the ungrouped shared-wind table path: farms [0, mix_main) on the one-block family, the rest
+                               // on wf_step_kernel (0: one launch) — wf_dispatch.hip: mix_candidate
   bool tab_slot = false;       // the calibration kept the register-slot kernel for the UNGROUPED shared-wind table path; ll_G / ll_S
                                // keep the rounds model's shape, which grouped launches and the on-the-fly path go on using
   float calib_ms[8] = {};      // ms per launch of each family of the rounds model it timed (0 = not timed)
@@ -236,6 +238,7 @@ int build_consts(wf_handle* h);
 // wf_dispatch.hip
 int pick_variant(const wf_handle* h, int N, int B);
 int pick_ll(const wf_handle* h, int N, int B);  // (G << 4) | S, 0 = keep wf_step_kernel
+int model_mix(const wf_handle* h, int code, int N, int B);
 int repick_ll_slots(const wf_handle* h, int N, int ll_G, int ll_S, long farm_slots);
 void set_ll_shape(wf_handle* h, int G, int S);
 void apply_kernel_pick(wf_handle* h, int N, int B, bool* variant_changed);

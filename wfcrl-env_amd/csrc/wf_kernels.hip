@@ -372,9 +372,9 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
   const int sub = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
   const int eiw = lane / G;  // env index inside the wave
-  int env_raw = (blockIdx.x * (blockDim.x >> 6) + wave) * EPW + eiw;
+  int env_raw = (blockIdx.x * (blockDim.x >> 6) + wave) * EPW + eiw + ga.env_base;  // (env_base: a mixed launch's farm range)
   if (ga.perm) env_raw = ga.perm[env_raw];  // padded farm list of the grouped launch: -1 = no farm
-  bool env_ok = env_raw >= 0 && env_raw < B;
+  bool env_ok = env_raw >= 0 && env_raw < (ga.env_end ? ga.env_end : B);
   const int env = env_ok ? env_raw : (B - 1);
   if (ga.farm_pred) {  // a wind per farm, behind wf_step_ll_kernel: only the farms it left (x' tie across its blocks)
     const int mine = env_ok ? ga.farm_pred[env] : 0;
@@ -1100,7 +1100,8 @@ static hipError_t local_launch_step(int variant, const WfConsts* c, const WfTabl
   const int envs_per_block = wpb * (64 / v.G);
   WfGroupArgs ga = *grp;
   // grouped launch: the farm list is padded per group to whole blocks (ga.n_blocks of them, some possibly unused)
-  const int grid = ga.blk_group ? (ga.n_slots + envs_per_block - 1) / envs_per_block : (B + envs_per_block - 1) / envs_per_block;
+  const int n_farms = ga.env_end ? ga.env_end - ga.env_base : B;  // (a mixed launch serves a range of the batch)
+  const int grid = ga.blk_group ? (ga.n_slots + envs_per_block - 1) / envs_per_block : (n_farms + envs_per_block - 1) / envs_per_block;
   if (grid_out) *grid_out = grid;
   WfConsts cc = *c;
   WfEnvArgs ea;

@@ -99,6 +99,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// LDS-DMA by hand (round 5): one wave-instruction moves 64 x 16 bytes from global memory (lane's address g) to 1 KiB of LDS at
+// l (wave-uniform).  Issued through inline assembly the transfer is INVISIBLE to the compiler's wait-count bookkeeping — which
+// is the point: the builtin (__builtin_amdgcn_global_load_lds) made it guard the first LDS read after ANY such transfer with
+// s_waitcnt vmcnt(0), so the "prefetch" of the next chunk was waited for at the top of the chunk that issued it, and every
+// register prefetch of a log record at the top of the next loop iteration (rounds 2-4: DESIGN_HISTORY "what the replay loop was
+// actually waiting for").  Now the kernel waits where the data is needed: wf_dma_wait() in front of the chunk's closing barrier.
+// (Compiler-issued loads that are waited for in between may wait for an older transfer with them — in-order counter — never
+// for too little.)  agent: sc1, served by the L2 past the vector L1.
+__device__ __forceinline__ void lds_dma16(const void* g, void* l, bool agent) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)l);
+  if (agent) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "s"(la) : "memory");
+  else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory");
+}
+__device__ __forceinline__ void wf_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // What a source leaves behind for the target blocks after its own, in registers (SrcLog) and in the per-wave source log:
 //   HOT  (8 bytes per farm):   {Gy / Gwt, Gwt} — the two circulations, all the transverse pass needs; read by EVERY later block;
 //   COLD (48 bytes per farm):  three float4 {sy0d, sz0d, sM, tan_th0} {sy0v, x0d, kyd, pj} {x0v, kyv, +-ch_pref, 1 / x0v} —
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
   __shared__ __attribute__((aligned(16))) float prow[2][CHUNK_FLOATS];
   __shared__ unsigned risk_lds[WPB][EPW];
   __shared__ int env_lds[WPB][EPW];  // farm index of every farm slot of the block (-1 - index: results dropped)
-  extern __shared__ __attribute__((aligned(16))) float yaw_lds[];  // [WPB][EPW][n_pad] commanded yaw in sorted order, degrees; then [WPB][n_pad] float4 far bounds
+  extern __shared__ __attribute__((aligned(16))) float yaw_lds[];  // [WPB][n_pad] float4 far bounds, then (table path) [WPB][2][HOT_F4] float4 hot records
 
   if (ga.res_zero && blockIdx.x == 0 && threadIdx.x == 0) *ga.res_zero = 0;  // the re-solve counter of the NEXT step (before any early return)
   int grp = 0;
@@ -223,10 +238,8 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
   auto stage_chunk = [&](int q) {
     const char* g0 = reinterpret_cast<const char*>(ll_tab) + (size_t)q * (CHUNK_FLOATS * 4);
     char* l0 = reinterpret_cast<char*>(&prow[q & 1][0]);
-    for (int ch = (int)(threadIdx.x >> 6); ch < CHUNK_FLOATS * 4 / 1024; ch += WPB) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + ch * 1024 + (threadIdx.x & 63) * 16),
-                                       (__attribute__((address_space(3))) void*)(l0 + ch * 1024), 16, 0, 0);
-    }
+    for (int ch = (int)(threadIdx.x >> 6); ch < CHUNK_FLOATS * 4 / 1024; ch += WPB)
+      lds_dma16(g0 + ch * 1024 + (threadIdx.x & 63) * 16, l0 + ch * 1024, false);
   };
   if constexpr (TAB) stage_chunk(0);
   for (int k = threadIdx.x; k < WF_TABLE_PAD; k += blockDim.x) {
@@ -244,9 +257,9 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
   const int gbase = lane & ~(G - 1);
   const int eiw = lane / G;
   const int slot = (blockIdx.x * WPB + wave) * EPW + eiw;  // launch slot of the farm: indexes the source log
-  int env_raw = slot;
+  int env_raw = slot + ga.env_base;  // (env_base: a mixed launch's farm range; the source log is indexed by the slot)
   if (ga.perm) env_raw = ga.perm[env_raw];
-  bool env_ok = env_raw >= 0 && env_raw < B;
+  bool env_ok = env_raw >= 0 && env_raw < (ga.env_end ? ga.env_end : B);
   const int env = env_ok ? env_raw : (B - 1);
   // a wind per farm: a farm whose own geometry has an x' tie across a block boundary is left to wf_step_kernel, which
   // is enqueued behind this kernel for exactly those farms (its results here are computed and dropped)
@@ -291,18 +304,16 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
 
   const size_t gofs = TAB ? (size_t)grp * N : (size_t)env * N;  // sorted geometry of the direction (group 0 for a shared wind) / of the farm
   const size_t yofs = (size_t)env * N;
-  // Commanded yaw of every turbine of the wave's farms -> LDS, in the CALLER'S turbine order (a block picks its own
-  // turbines through gidx when it starts), with the fused MDP transition as in wf_step_kernel.  The wave walks
-  // the flattened (farm of the wave, turbine) space 64 elements at a time: a wave-instruction reads / writes one or two
-  // contiguous row pieces (rounds 1-3 had lane = farm here: 64 four-byte accesses 320 bytes apart per instruction, in
-  // every array of the env state).
-  float* const yawW = yaw_lds + (size_t)wave * EPW * n_pad;  // [farm of the wave][turbine, caller's order]
-  float* const yawL = yawW + (size_t)eiw * n_pad;
+  // The fused MDP transition as in wf_step_kernel, over the env state of the wave's farms: the wave walks the
+  // flattened (farm of the wave, turbine) space 64 elements at a time — a wave-instruction reads / writes one or two contiguous
+  // row pieces.  The commanded yaw itself is NOT kept in LDS any more (round 5; rounds 2-4: 40 KiB per block at 128 farms x 80
+  // turbines): a block fetches its own turbines' yaw from the caller's array / the env state one block ahead (load_yaw below),
+  // which left room for the hot-record buffers at two blocks per CU.
   const bool env_mode = ea.yaw_state != nullptr;
   int moves_new = 0;
   if (env_mode && ea.action) moves_new = ea.moves[env] + 1;
   if (sub == 0) env_lds[wave][eiw] = env_ok ? env : -1 - env;  // (a farm whose results are dropped still has a valid row to read)
-  {
+  if (env_mode && ea.action) {
     int f = 0, o = lane;
     while (o >= N) { o -= N; ++f; }
     while (f < EPW) {
@@ -310,34 +321,34 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
       const bool okf = e_raw >= 0;
       const int e = okf ? e_raw : -1 - e_raw;
       const size_t oi = (size_t)e * N + o;
-      float yw;
-      if (env_mode) {
-        yw = ea.yaw_state[oi];
-        if (ea.action) {
-          float a = ea.action[oi];
-          float acc = ea.acc[oi];
-          const float frac = __fdiv_rn(__fdiv_rn(__fdiv_rn(acc, ea.rate), (float)(ea.moves[e] + 1)), ea.dt);
-          if (frac >= ea.budget) a = 0.0f;
-          if (ea.discrete) a = (a - 1.0f) * ea.yaw_step;
-          if (!ea.discrete) a = fminf(fmaxf(a, -ea.yaw_step), ea.yaw_step);
-          yw = fminf(fmaxf(yw + a, ea.yaw_lo), ea.yaw_hi);
-          acc += fabsf(a);
-          if (okf) {
-            ea.yaw_state[oi] = yw;
-            ea.acc[oi] = acc;
-          }
-        }
-      } else {
-        yw = yaw_in[oi];
+      float yw = ea.yaw_state[oi];
+      float a = ea.action[oi];
+      float acc = ea.acc[oi];
+      const float frac = __fdiv_rn(__fdiv_rn(__fdiv_rn(acc, ea.rate), (float)(ea.moves[e] + 1)), ea.dt);
+      if (frac >= ea.budget) a = 0.0f;
+      if (ea.discrete) a = (a - 1.0f) * ea.yaw_step;
+      if (!ea.discrete) a = fminf(fmaxf(a, -ea.yaw_step), ea.yaw_step);
+      yw = fminf(fmaxf(yw + a, ea.yaw_lo), ea.yaw_hi);
+      acc += fabsf(a);
+      if (okf) {
+        ea.yaw_state[oi] = yw;
+        ea.acc[oi] = acc;
       }
-      yawW[(size_t)f * n_pad + o] = yw;
       o += 64;
       while (o >= N) { o -= N; ++f; }
     }
   }
+  // the commanded yaw of turbine o (caller's order) of this lane's farm.  After a transition it is read back from the env state
+  // this wave has just written — at agent scope: the transition above READ those lines, the vector L1 is not updated by this
+  // CU's stores, and a plain load could hit the old value.  (A farm whose results are dropped — padding slots — was not written
+  // and solves on the old yaw: nobody sees it.)
+  const float* const yaw_src = (env_mode ? ea.yaw_state : yaw_in) + yofs;
+  const bool yaw_fresh = env_mode && ea.action;
+  auto load_yaw = [&](int o) { return yaw_fresh ? __hip_atomic_load(yaw_src + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : yaw_src[o]; };
   // (the move counters are read above by every lane that holds an element of the farm, written here by the farm's first
   // lane: the same wave, in program order)
   if (env_mode && ea.action && sub == 0 && env_ok) ea.moves[env] = moves_new;
+  if constexpr (TAB) wf_dma_wait();  // (chunk 0 of the table)
   __syncthreads();
 
   // ---- per-turbine state of the ONE target block in registers (as Slots<1> of wf_step_kernel) ----
@@ -635,10 +646,27 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
   // is even, and so is every chunk's count of logged sources)
   float2* const log_hot = reinterpret_cast<float2*>(src_log + wave_rec0 * WF_LOG_HOT_FLOATS);
   float4* const log_cold = reinterpret_cast<float4*>(src_log + log_cold_offset + wave_rec0 * WF_LOG_COLD_FLOATS) + eiw;
-  float4* const bndL = reinterpret_cast<float4*>(yaw_lds + (size_t)WPB * EPW * n_pad) + (size_t)wave * n_pad;  // far bounds
+  float4* const bndL = reinterpret_cast<float4*>(yaw_lds) + (size_t)wave * n_pad;  // far bounds
+  // Table path (round 5): the HOT records of a chunk's logged sources are staged into wave-private LDS by LDS-DMA a whole chunk
+  // (or a block's output phase) ahead of their use, like the chunk's pair records.  Rounds 2-4 fetched them into registers one
+  // loop iteration ahead — all the compiler's s_waitcnt vmcnt(0) in front of every iteration's first LDS read leaves room for —
+  // and the transverse pass waited for the log: 6 % of the launch (profiles/r05_ablate_log.txt: the pass without the load).
+  // A chunk's CH / 2 source pairs x EPW farms x 16 bytes are one contiguous run of the wave-major log: whole 1-KiB
+  // wave-instructions (a run shorter than 1 KiB reads on into the following records, which nobody looks at).
+  constexpr int HOT_INSTR = (CH / 2) * EPW * 16 >= 1024 ? (CH / 2) * EPW * 16 / 1024 : 1;  // wave-instructions per chunk
+  constexpr int HOT_F4 = HOT_INSTR * 64;                                                   // float4 per wave and buffer
+  float4* const hotL = reinterpret_cast<float4*>(yaw_lds) + (size_t)WPB * n_pad + (size_t)wave * (2 * HOT_F4);
+  auto stage_hot = [&](int qq, int i_first) {  // the hot records of sources i_first .. i_first + CH - 1 -> buffer qq & 1
+    const char* g0 = reinterpret_cast<const char*>(reinterpret_cast<const float4*>(log_hot) + (size_t)(i_first >> 1) * EPW);
+    char* l0 = reinterpret_cast<char*>(hotL + (qq & 1) * HOT_F4);
+#pragma unroll
+    for (int ch = 0; ch < HOT_INSTR; ++ch) lds_dma16(g0 + ch * 1024 + lane * 16, l0 + ch * 1024, true);
+    // (agent scope, served by the L2.  The run may hold records that are not written yet — the chunk's own
+    // sources, the records behind a short run — and the vector L1 is not updated by this CU's later stores: a line cached
+    // now would be stale when a later block stages it again.  Every record is read once per block: nothing is lost.)
+  };
   auto hot_index = [&](int i) { return 2 * ((size_t)(i >> 1) * EPW + eiw) + (i & 1); };
   auto load_hot = [&](int i) { return log_hot[hot_index(i)]; };
-  auto load_hot2 = [&](int i) { return reinterpret_cast<const float4*>(log_hot)[(size_t)(i >> 1) * EPW + eiw]; };  // i even: sources i, i + 1
   auto load_cold = [&](int i) {
     const float4* lp = log_cold + (size_t)i * (3 * EPW);
     ColdRec r;
@@ -660,9 +688,17 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
     return R;
   };
   float* const logx = src_log + log_side_offset + (size_t)slot * n_pad * WF_LOG_SIDE_FLOATS;
-  int oidx[S], oidx_nx[S];  // caller's (unsorted) index of this lane's turbines: the current block's, the next block's
+  // caller's (unsorted) index of this lane's turbines — the current block's, the next block's, the one after — and the next
+  // block's commanded yaw: indices are fetched two blocks ahead, the yaw behind them one block ahead
+  int oidx[S], oidx_nx[S], oidx_n2[S];
+  float yaw_nx[S];
 #pragma unroll
-  for (int p = 0; p < S; ++p) oidx_nx[p] = gidx[gofs + min(p * G + sub, N - 1)];
+  for (int p = 0; p < S; ++p) {
+    oidx_nx[p] = gidx[gofs + min(p * G + sub, N - 1)];
+    oidx_n2[p] = gidx[gofs + min(GS + p * G + sub, N - 1)];
+  }
+#pragma unroll
+  for (int p = 0; p < S; ++p) yaw_nx[p] = load_yaw(oidx_nx[p]);
   for (int J = 0; J < nblk; ++J) {
     int tt[S];
     bool tvalid[S];
@@ -685,8 +721,10 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
       // (the caller's index of this lane's turbine was fetched a block ahead: a load issued here would be waited for at
       // the first LDS read of the replay, which the compiler guards with s_waitcnt vmcnt(0))
       oidx[p] = oidx_nx[p];
-      oidx_nx[p] = gidx[gofs + min(tt[p] + GS, N - 1)];
-      yaw_t[p] = yawL[oidx[p]];
+      yaw_t[p] = yaw_nx[p];
+      oidx_nx[p] = oidx_n2[p];
+      oidx_n2[p] = gidx[gofs + min(tt[p] + 2 * GS, N - 1)];
+      yaw_nx[p] = load_yaw(oidx_nx[p]);
       sincos_yaw(yaw_t[p] * kDeg2Rad, sg_t[p], cg_t[p]);  // this lane's turbines: source constants (own block), power output
     }
 
@@ -695,11 +733,9 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
     const int n_chunks = (n_src + CH - 1) / CH;
     // the first logged source's record is fetched ahead; every later one while its predecessor is being applied
     float2 hot_nx = make_float2(0.0f, 0.0f);   // on the fly: the hot record of the next source
-    float4 hot2_nx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // table path: the hot records of the next PAIR of sources
     ColdRec cold_nx = {};             // (on the fly; the table path fetches cold records per chunk, for the near sources only)
     double xs_nx = 0.0, ys_nx = 0.0;  // on the fly: the sorted coordinates of that source come with its record
     if (first_own > 0) {
-      if constexpr (TAB) hot2_nx = load_hot2(0);
       if constexpr (!TAB) {
         hot_nx = load_hot(0);
         cold_nx = load_cold(0);
@@ -910,7 +946,13 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
 
     for (int cq = 0; cq < n_chunks; ++cq, ++q) {
       if constexpr (TAB) {
+        // (a block's first chunk: its hot records were staged behind the previous block's sources, in front of that block's
+        // outputs — long landed; waited for here, before this chunk's own transfers are issued)
+        if (cq == 0 && first_own > 0) wf_dma_wait();
         if (cq + 1 < n_chunks || J + 1 < nblk) stage_chunk(q + 1);  // lands in the other buffer while this chunk is consumed
+        // the next chunk's hot records, when it has logged sources and is a chunk of THIS block (everything it replays was
+        // logged by earlier blocks); the first chunk of the NEXT block replays this block's sources too: staged behind them
+        if (cq + 1 < n_chunks && (cq + 1) * CH < first_own) stage_hot(q + 1, (cq + 1) * CH);
       }
       const float* buf = &prow[q & 1][0];
       const int i0 = cq * CH;
@@ -958,19 +1000,13 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
           static_assert(GS % 2 == 0 && CH % 2 == 0, "logged sources come in pairs");
 #pragma unroll 1
           for (int k = 0; k < k_log; k += 2) {
-            const float4 hot2 = hot2_nx;
+            const float4 hot2 = hotL[(q & 1) * HOT_F4 + (k >> 1) * EPW + eiw];  // {rho, Gwt} of sources i0 + k, i0 + k + 1
             float4 cf[S][9];
 #pragma unroll
             for (int p = 0; p < S; ++p)
 #pragma unroll
               for (int qq = 0; qq < 9; ++qq)
                 cf[p][qq] = *reinterpret_cast<const float4*>(buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE + 4 * qq);
-            asm volatile("" ::: "memory");
-#ifdef WF_EXP_NOHOT  // timing experiment only (wrong results): what the transverse pass costs without its log load
-            hot2_nx = make_float4(0.1f, 0.2f, 0.1f, 0.2f);
-#else
-            hot2_nx = load_hot2(min(i0 + k + 2, first_own - 2));
-#endif
             static_for<S>([&](auto PP) { apply_tab_ratio(PP, cf[decltype(PP)::value], hot2.x, hot2.y); });
 #pragma unroll
             for (int p = 0; p < S; ++p)
@@ -1068,9 +1104,17 @@ __global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_
       }
       WF_T(st_c);
       WF_ACC(1, st_b, st_c);
-      if constexpr (TAB) __syncthreads();  // the next chunk has landed; everyone is done with this one
+      if constexpr (TAB) {
+        wf_dma_wait();    // this wave's transfers for the next chunk (pair records, hot records) have landed ...
+        __syncthreads();  // ... and so have everyone else's; everyone is done with this chunk
+      }
       WF_T(st_d);
       WF_ACC(2, st_c, st_d);
+    }
+    if constexpr (TAB) {
+      // the next block's first chunk replays this block's sources too: its hot records are staged now, behind their log writes
+      // (same wave, program order), and land while this block's outputs are computed
+      if (J + 1 < nblk) stage_hot(q, 0);
     }
     WF_T(st_e);
 
@@ -1187,14 +1231,17 @@ static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* g
                             const WfGroupArgs* grp, const double* gx, const double* gy, hipStream_t s) {
   constexpr int fpb = kLLWaves * (64 / G);
   WfGroupArgs ga = *grp;
-  const int grid = ga.blk_group ? (ga.n_slots + fpb - 1) / fpb : (B + fpb - 1) / fpb;
+  const int n_farms = ga.env_end ? ga.env_end - ga.env_base : B;  // (a mixed launch serves a range of the batch)
+  const int grid = ga.blk_group ? (ga.n_slots + fpb - 1) / fpb : (n_farms + fpb - 1) / fpb;
   WfConsts cc = *c;
   WfEnvArgs ea;
   if (env) ea = *env; else memset(&ea, 0, sizeof(ea));
   size_t group_floats = wfk_ll_table_floats(cc.N, G * S);
   int n_pad = ((cc.N + G * S - 1) / (G * S)) * (G * S);
-  // dynamic LDS: the commanded yaw of every farm of the block, then the far bounds of every wave (16 bytes per source)
-  const size_t dyn_lds = sizeof(float) * (size_t)fpb * n_pad + sizeof(float4) * (size_t)kLLWaves * n_pad;
+  // dynamic LDS: the far bounds of every wave (16 bytes per source)
+  // ... then (table path) two buffers per wave for the hot records of a chunk's logged sources (stage_hot)
+  constexpr int hot_bytes = 32768 / (G * G * S) >= 1024 ? 32768 / (G * G * S) : 1024;  // (CH / 2) x EPW x 16 B, whole 1-KiB DMA instructions
+  const size_t dyn_lds = sizeof(float4) * (size_t)kLLWaves * n_pad + (TAB ? (size_t)kLLWaves * 2 * hot_bytes : 0);
   // the log allocation holds log_records (farm slot, source) records: hot part, cold part, side records (wf_device.h)
   size_t log_cold_offset = log_records * WF_LOG_HOT_FLOATS, log_side_offset = log_records * WF_LOG_FLOATS;
   void* args[] = {&cc, &tab, &gidx, &ws, &wd, &wind_stride, &yaw, &power, &o_ws, &o_wd, &load, &B, &ea, &ll_tab,
