@@ -148,6 +148,18 @@ double mix_estimate(const wf_handle* h, int fi, int N, long B, int main_farms) {
   return (main_farms / per_round) * round_ms(fi, N, per_cu) + 0.9 * ll_estimate(h, 0, N, B - main_farms);
 }
 
+// ms of family fi at B farms in its better form — one launch, or whole rounds + remainder; *mix = the farms the family keeps
+double family_estimate(const wf_handle* h, int fi, int N, long B, int* mix) {
+  double t = ll_estimate(h, fi, N, B);
+  *mix = 0;
+  const int m = mix_candidate(h, fi, N, B);
+  if (m) {
+    const double tm = mix_estimate(h, fi, N, B, m);
+    if (tm < 0.93 * t) { t = tm; *mix = m; }
+  }
+  return t;
+}
+
 // Lane-group width of the one-block-at-a-time kernel for N turbines and B farms, 0 = keep wf_step_kernel.  It pays once
 // the farm spans several blocks (the register-slot kernel is then pinned at two waves per SIMD by its 27 S state
 // registers) and the batch fills the chip.  wf_set_kernel_choice: one_block = 0 disables it, 1 forces (ll_G, ll_S).
@@ -176,7 +188,8 @@ int pick_ll(const wf_handle* h, int N, int B) {  // returns (G << 4) | S, 0 = ke
     if (f.code && N <= (f.code >> 4) * (f.code & 15)) continue;  // needs more than one block
     if (f.code == ((8 << 4) | 1) && N <= 32) continue;           // (not instantiated to pay below that)
     if (veer && f.code && !wfk_ll_has_veer(f.code >> 4, f.code & 15, 1)) continue;
-    double t = ll_estimate(h, fi, N, B);
+    int mix_unused;
+    double t = family_estimate(h, fi, N, B, &mix_unused);
     // G = 16 runs neck and neck with the register-slot kernel up to two blocks per CU (0.290 against 0.294 ms at
     // HornsRev1 x 8192, either way round from layout to layout): it has to win by 4 % — its case is the third block
     if (f.code == ((16 << 4) | 1)) t *= 1.04;
@@ -207,8 +220,9 @@ int model_mix(const wf_handle* h, int code, int N, int B) {
   if (!code || h->choice.one_block == 0) return 0;
   for (int fi = 0; fi < kNumFamilies; ++fi)
     if (kLlFamilies[fi].code == code) {
-      const int m = mix_candidate(h, fi, N, B);
-      return (m && mix_estimate(h, fi, N, B, m) < 0.93 * ll_estimate(h, fi, N, B)) ? m : 0;
+      int m = 0;
+      family_estimate(h, fi, N, B, &m);
+      return m;
     }
   return 0;
 }
@@ -423,6 +437,9 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
         WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                                   wstride, yaw, power, wspd, wdir, load, h->B, ea, ptab, h->d_pair_first, &gp, h->stream, &h->grid));
       }
+      // the remainder, behind the family on the same stream.  (On a side stream beside it — tried: 1.139 against 1.116 ms at
+      // 69 632 farms — it gains nothing: a block of the family lives for the whole round, so the half of them that has to
+      // wait for the remainder's blocks to leave finishes that much later.)
       ga.env_base = M; ga.env_end = h->B;
       WF_HIP(h, wfk_launch_step(h->variant, &h->consts, h->d_tab, h->d_gx, h->d_gy, h->d_gidx, gstride, h->d_ws, h->d_wd,
                                 wstride, yaw, power, wspd, wdir, load, h->B, ea, ptab, h->d_pair_first, &ga, h->stream, &h->grid));
@@ -538,10 +555,12 @@ static bool family_valid(const wf_handle* h, int fi) {
 static int calibrate_families(wf_handle* h, const float* yaw, float* power, float* wspd, float* wdir, float* load, const WfEnvArgs* ea) {
   const int N = h->N, B = h->B;
   double est[kNumFamilies], best_est = 1e300;
+  int mix_f[kNumFamilies];  // every family is timed in the form the rounds model prefers for it: one launch, or whole rounds + remainder
   for (int fi = 0; fi < kNumFamilies; ++fi) {
     est[fi] = 1e300;
+    mix_f[fi] = 0;
     if (!family_valid(h, fi)) continue;
-    est[fi] = ll_estimate(h, fi, N, B);
+    est[fi] = family_estimate(h, fi, N, B, &mix_f[fi]);
     if (est[fi] < best_est) best_est = est[fi];
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -556,6 +575,7 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
     if (!(est[fi] <= 1.6 * best_est) && fi != guess) continue;
     hipStreamSynchronize(h->stream);
     apply_family(h, kLlFamilies[fi].code, code0);
+    h->mix_main = mix_f[fi];
     if ((rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea)) != WF_OK) break;  // tables, log, first-launch costs
     float fam_ms = 1e30f;  // the fastest of three launches timed one by one (two handles on one kernel differ by 3-5 %: noise counts)
     for (int r = 0; r < 3 && rc == WF_OK; ++r) {
@@ -577,6 +597,7 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     apply_family(h, code0, code0);
+    h->mix_main = guess >= 0 ? mix_f[guess] : 0;
     return rc;
   }
   // The guess stands unless another family beats it by 4 %: near-ties would otherwise be decided by timing noise, and two
@@ -585,14 +606,15 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
   const int code = best >= 0 ? kLlFamilies[best].code : code0;
   apply_family(h, code, code0);
   h->calib_code = code;
-  // ... and the winner's mixed launch (whole rounds on the family, the remainder on wf_step_kernel), where the batch has one:
-  // measured like a family, kept when it beats the single launch by 4 %
-  h->mix_main = 0;
+  // ... and the winner's OTHER form, where the batch has a mixed launch for it (whole rounds on the family, the remainder on
+  // wf_step_kernel): measured like a family; the model's preference stands unless the other form beats it by 4 %
+  h->mix_main = best >= 0 ? mix_f[best] : 0;
   h->calib_ms[6] = 0.0f;
   const int m = (best >= 0 && code) ? mix_candidate(h, best, N, B) : 0;
   if (m) {
-    h->mix_main = m;
-    float mix_ms = 1e30f;
+    const int model_form = h->mix_main;
+    h->mix_main = model_form ? 0 : m;
+    float alt_ms = 1e30f;
     rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
     for (int r = 0; r < 3 && rc == WF_OK; ++r) {
       hipError_t e = hipEventRecord(e0, h->stream);
@@ -602,12 +624,12 @@ static int calibrate_families(wf_handle* h, const float* yaw, float* power, floa
       float ms = 0.0f;
       if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
       if (e != hipSuccess) { rc = fail(h, WF_E_HIP, std::string("calibration: ") + hipGetErrorString(e)); break; }
-      if (ms < mix_ms) mix_ms = ms;
+      if (ms < alt_ms) alt_ms = ms;
     }
     hipStreamSynchronize(h->stream);
-    if (rc != WF_OK) { h->mix_main = 0; hipEventDestroy(e0); hipEventDestroy(e1); return rc; }
-    h->calib_ms[6] = mix_ms;
-    if (!(mix_ms < 0.96f * h->calib_ms[best])) h->mix_main = 0;
+    if (rc != WF_OK) { h->mix_main = model_form; hipEventDestroy(e0); hipEventDestroy(e1); return rc; }
+    h->calib_ms[6] = model_form ? h->calib_ms[best] : alt_ms;  // (what the mixed form measured)
+    if (!(alt_ms < 0.96f * h->calib_ms[best])) h->mix_main = model_form;
   }
   hipEventDestroy(e0);
   hipEventDestroy(e1);
