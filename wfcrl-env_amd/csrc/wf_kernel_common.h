@@ -20,6 +20,21 @@ __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
 
+// LDS-DMA by hand (round 5): one wave-instruction moves 64 x 16 bytes from global memory (lane's address g) to 1 KiB of LDS at
+// l (wave-uniform).  Issued through inline assembly the transfer is INVISIBLE to the compiler's wait-count bookkeeping — which
+// is the point: the builtin (__builtin_amdgcn_global_load_lds) made it guard the first LDS read after ANY such transfer with
+// s_waitcnt vmcnt(0), so the "prefetch" of the next chunk was waited for at the top of the chunk that issued it, and every
+// register prefetch of a log record at the top of the next loop iteration (rounds 2-4: DESIGN_HISTORY "what the replay loop was
+// actually waiting for").  Now the kernel waits where the data is needed: wf_dma_wait() in front of the chunk's closing barrier.
+// (Compiler-issued loads that are waited for in between may wait for an older transfer with them — in-order counter — never
+// for too little.)  agent: sc1, served by the L2 past the vector L1.
+__device__ __forceinline__ void lds_dma16(const void* g, void* l, bool agent) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)l);
+  if (agent) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "s"(la) : "memory");
+  else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory");
+}
+__device__ __forceinline__ void wf_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // cube root, sign-aware like np.cbrt (unphysically tight layouts can drive grid velocities negative, and the
 // reference keeps computing): exp2(log2|x|/3) polished by one Newton step (rel. err ~1e-7); cbrt(0) = 0
 __device__ __forceinline__ float fcbrt_pos(float x) {

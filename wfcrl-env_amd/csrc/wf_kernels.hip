@@ -350,11 +350,10 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       char* l0 = reinterpret_cast<char*>(&prow[src_i & 1][0]);
       // targets upstream of the source are never read: start at the 1-KiB piece holding its first active target
       const int ch0 = __builtin_amdgcn_readfirstlane(pfirst[src_i]) * (WF_PAIR_STRIDE * 4) / 1024;
-      for (int ch = ch0 + (int)(threadIdx.x >> 6); ch < row_chunks; ch += WPB) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(g0 + ch * 1024 + (threadIdx.x & 63) * 16),
-            (__attribute__((address_space(3))) void*)(l0 + ch * 1024), 16, 0, 0);
-      }
+      // (hand-issued since round 5 — wf_kernel_common.h: lds_dma16 —: through the builtin the compiler waited for the NEXT row
+      // at this step's first LDS read, the thrust-table probe sixty instructions on)
+      for (int ch = ch0 + (int)(threadIdx.x >> 6); ch < row_chunks; ch += WPB)
+        lds_dma16(g0 + ch * 1024 + (threadIdx.x & 63) * 16, l0 + ch * 1024, false);
     }
   };
   stage_row(0);
@@ -473,6 +472,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
     L.sg[eiw][t] = sy_;
   }
   if (env_mode && ea.action && sub == 0 && env_ok) ea.moves[env] = moves_new;
+  if constexpr (TAB) wf_dma_wait();  // (row 0 of the pair table)
   __syncthreads();
 
   constexpr int NE = VEER ? 9 : 6;
@@ -878,7 +878,10 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           }
         }
       }
-      if constexpr (TAB) __syncthreads();  // next row has landed; everyone is done with the current one
+      if constexpr (TAB) {
+        wf_dma_wait();    // this wave's pieces of the next row have landed ...
+        __syncthreads();  // ... and so have everyone else's; everyone is done with the current one
+      }
     }  // li
 
     // ---- x' ties across the block boundary ------------------------------------------------------

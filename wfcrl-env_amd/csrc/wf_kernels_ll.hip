@@ -99,21 +99,6 @@ __device__ __forceinline__ float wave_max(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// LDS-DMA by hand (round 5): one wave-instruction moves 64 x 16 bytes from global memory (lane's address g) to 1 KiB of LDS at
-// l (wave-uniform).  Issued through inline assembly the transfer is INVISIBLE to the compiler's wait-count bookkeeping — which
-// is the point: the builtin (__builtin_amdgcn_global_load_lds) made it guard the first LDS read after ANY such transfer with
-// s_waitcnt vmcnt(0), so the "prefetch" of the next chunk was waited for at the top of the chunk that issued it, and every
-// register prefetch of a log record at the top of the next loop iteration (rounds 2-4: DESIGN_HISTORY "what the replay loop was
-// actually waiting for").  Now the kernel waits where the data is needed: wf_dma_wait() in front of the chunk's closing barrier.
-// (Compiler-issued loads that are waited for in between may wait for an older transfer with them — in-order counter — never
-// for too little.)  agent: sc1, served by the L2 past the vector L1.
-__device__ __forceinline__ void lds_dma16(const void* g, void* l, bool agent) {
-  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)l);
-  if (agent) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "s"(la) : "memory");
-  else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory");
-}
-__device__ __forceinline__ void wf_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 // What a source leaves behind for the target blocks after its own, in registers (SrcLog) and in the per-wave source log:
 //   HOT  (8 bytes per farm):   {Gy / Gwt, Gwt} — the two circulations, all the transverse pass needs; read by EVERY later block;
 //   COLD (48 bytes per farm):  three float4 {sy0d, sz0d, sM, tan_th0} {sy0v, x0d, kyd, pj} {x0v, kyv, +-ch_pref, 1 / x0v} —
