@@ -38,6 +38,7 @@ extern "C" {
 
 #define WF_MAX_TURBINES 256
 #define WF_MAX_TABLE 64
+#define WF_MAX_TURBINE_TYPES 4
 
 typedef struct wf_handle wf_handle;
 
@@ -100,6 +101,32 @@ int wf_set_model(wf_handle* h, const wf_model_params* p);
 
 /* Replaces farm.layout_x / layout_y of case.yaml (simul_utils.py:39-40). n <= WF_MAX_TURBINES. */
 int wf_set_layout(wf_handle* h, int n_turbines, const double* x, const double* y);
+
+/* Several turbine definitions per farm — farm.turbine_type of case.yaml is a LIST (reference
+ * wfcrl/simulators/floris/inputs/template/case.yaml:27-28; the template writes one entry, FLORIS 3.5 takes one per turbine):
+ * `defs[0 .. n_types-1]` (n_types <= WF_MAX_TURBINE_TYPES) and, per turbine of the layout in the caller's order, the index of
+ * its definition.  A definition carries what FLORIS reads per turbine type on this path: the power_thrust_table (thrust
+ * coefficient of the source's rotor speed, power of the yaw-corrected speed: Turbine.fCt / power_interp), TSR (wake
+ * rotation circulation), pP (yaw exponent of the power), generator_efficiency and ref_density_cp_ct.  The definitions
+ * share the ROTOR — rotor_diameter and hub_height stay those of the model (wf_set_model): the rotor grid, the vortex
+ * geometry and the shear profile are per handle; a caller whose definitions differ there must refuse (the Python host does).
+ * While definitions are set every farm is solved by the float64 kernels (wf_resolve_mt.hip) on every step — mode 2 of
+ * wf_set_risk_resolve, which then refuses mode 0 (the float32 kernels know one table), keeps mode 1 for when the
+ * definitions are cleared, and wf_get_risk_resolve reports 2.  About 1.2e6 farm-steps/s on
+ * HornsRev1 instead of 7.6e7: the feature is for the rare mixed farm, not for the benchmark.  With layouts of different
+ * turbine counts (wf_set_layouts_counts) the index is per turbine SLOT, shared by all layouts.
+ * n_types == 0 clears the definitions (back to the model's single table; the resolve mode set before is in force again).
+ * Call after wf_set_layout; a later layout with another turbine count invalidates them (the next step fails until they are
+ * set again or cleared). */
+typedef struct wf_turbine_def {
+  int n_table; /* 2 .. WF_MAX_TABLE - 1, wind speeds strictly ascending */
+  const double* table_ws;
+  const double* table_ct;
+  const double* table_cp;
+  double tsr, pP, gen_eff, ref_density;
+} wf_turbine_def;
+int wf_set_turbine_types(wf_handle* h, int n_types, const wf_turbine_def* defs, const int* type_of);
+int wf_get_turbine_types(wf_handle* h, int* n_types);
 
 /* Number of independent farm instances evaluated per step (not in the reference: it holds one). */
 int wf_set_batch(wf_handle* h, int env_batch);

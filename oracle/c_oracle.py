@@ -16,6 +16,11 @@ _HERE = Path(__file__).resolve().parent
 _LIB = None
 
 
+class _Type(C.Structure):  # wfo_type
+    _fields_ = [("TSR", C.c_double), ("pP", C.c_double), ("ref_density", C.c_double), ("n_table", C.c_int),
+                ("table_ws", C.POINTER(C.c_double)), ("table_ct", C.POINTER(C.c_double)), ("table_pow", C.POINTER(C.c_double))]
+
+
 class _Params(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "air_density", "ambient_ti", "shear", "veer",
@@ -32,6 +37,9 @@ class _Params(C.Structure):
         ("enable_secondary_steering", C.c_int),
         ("enable_yaw_added_recovery", C.c_int),
         ("enable_transverse_velocities", C.c_int),
+        ("n_types", C.c_int),
+        ("types", C.POINTER(_Type)),
+        ("type_of", C.POINTER(C.c_int)),
     ]
 
 
@@ -96,6 +104,19 @@ def farm_step_batch(x, y, ws, wd, yaw, p: ModelParams | None = None, nthreads: i
         setattr(cp, name, int(bool(getattr(p, name))))
     cp.n_table = len(tws)
     cp.table_ws, cp.table_ct, cp.table_pow = _dp(tws), _dp(tct), _dp(tpw)
+    keep = []  # (the arrays the definitions point into)
+    if p.turbine_defs:  # several turbine definitions per farm (ModelParams.turbine_defs)
+        types = (_Type * len(p.turbine_defs))()
+        for k in range(len(p.turbine_defs)):
+            pk = p.definition(k)
+            cols = [np.ascontiguousarray(c, dtype=np.float64) for c in (pk.table_ws, pk.table_ct, pk.power_table())]
+            keep.append(cols)
+            types[k].TSR, types[k].pP, types[k].ref_density, types[k].n_table = pk.TSR, pk.pP, pk.ref_density, len(cols[0])
+            types[k].table_ws, types[k].table_ct, types[k].table_pow = (_dp(c) for c in cols)
+        type_of = np.ascontiguousarray(p.turbine_type_of, dtype=np.int32)
+        assert type_of.shape == (N,) and type_of.min() >= 0 and type_of.max() < len(p.turbine_defs)
+        keep.append(type_of)
+        cp.n_types, cp.types, cp.type_of = len(p.turbine_defs), types, type_of.ctypes.data_as(C.POINTER(C.c_int))
     out = {
         "power": np.empty((B, N)),
         "wind_speed": np.empty((B, N)),

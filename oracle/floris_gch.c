@@ -37,7 +37,22 @@ typedef struct {
   const double* table_ct;
   const double* table_pow; /* 1/2 A Cp eta ws^3 (W per unit density) */
   int enable_secondary_steering, enable_yaw_added_recovery, enable_transverse_velocities; /* case.yaml:46-50 */
+  /* several turbine definitions per farm (farm.turbine_type of case.yaml:27-28 is a list; FLORIS 3.5 evaluates the
+   * thrust / power tables, TSR, pP and ref_density_cp_ct per turbine through turbine_type_map): n_types > 0 -> turbine o
+   * (caller's order) evaluates with types[type_of[o]] instead of the fields above; the definitions share the rotor (D, HH).
+   * As floris_gch_numpy.py: ModelParams.turbine_defs. */
+  int n_types;
+  const struct wfo_type* types;
+  const int* type_of;
 } wfo_params;
+
+typedef struct wfo_type {
+  double TSR, pP, ref_density;
+  int n_table;
+  const double* table_ws;
+  const double* table_ct;
+  const double* table_pow;
+} wfo_type;
 
 #define DEG2RAD (M_PI / 180.0)
 static inline double cosd(double a) { return cos(a * DEG2RAD); }
@@ -168,12 +183,14 @@ static void farm_step_one(const wfo_params* p, int N, const double* x, const dou
     double m3 = 0.0;
     for (int q = 0; q < 9; ++q) m3 += S->U[q] * S->U[q] * S->U[q];
     const double ubar = cbrt(m3 / 9.0);
-    double ct_tab = interp_fill(ubar, p->n_table, p->table_ws, p->table_ct, 0.0001, 0.9999);
+    wfo_type ty_i = {p->TSR, p->pP, p->ref_density, p->n_table, p->table_ws, p->table_ct, p->table_pow};
+    if (p->n_types > 0) ty_i = p->types[p->type_of[order[i]]]; /* the source's own definition */
+    double ct_tab = interp_fill(ubar, ty_i.n_table, ty_i.table_ws, ty_i.table_ct, 0.0001, 0.9999);
     if (ct_tab < 0.0001) ct_tab = 0.0001;
     if (ct_tab > 0.9999) ct_tab = 0.9999;
     const double ct = ct_tab * cg;
     const double a = 0.5 / cg * (1.0 - sqrt(1.0 - ct * cg));
-    const double G_wr = 0.25 * 2.0 * M_PI * D * (a - a * a) * ubar / p->TSR;
+    const double G_wr = 0.25 * 2.0 * M_PI * D * (a - a * a) * ubar / ty_i.TSR;
     const double gam_top = (M_PI / 8.0) * D * vel_top * Uinf * ct;
     const double gam_bot = (M_PI / 8.0) * D * vel_bot * Uinf * ct;
 
@@ -395,9 +412,11 @@ static void farm_step_one(const wfo_params* p, int N, const double* x, const dou
     const double wsp = cbrt(m3 / 9.0);
     wind_speed[o] = wsp;
     wind_dir[o] = dir / 9.0;
-    double veff = wsp * pow(cosd(yaw[o]), p->pP / 3.0);
-    veff = pow(p->air_density / p->ref_density, 1.0 / 3.0) * veff;
-    power[o] = p->ref_density * interp_fill(veff, p->n_table, p->table_ws, p->table_pow, 0.0, 0.0);
+    wfo_type ty = {p->TSR, p->pP, p->ref_density, p->n_table, p->table_ws, p->table_ct, p->table_pow};
+    if (p->n_types > 0) ty = p->types[p->type_of[o]];
+    double veff = wsp * pow(cosd(yaw[o]), ty.pP / 3.0);
+    veff = pow(p->air_density / ty.ref_density, 1.0 / 3.0) * veff;
+    power[o] = ty.ref_density * interp_fill(veff, ty.n_table, ty.table_ws, ty.table_pow, 0.0, 0.0);
     load[o * 4 + 0] = mti;
     load[o * 4 + 1] = sqrt(su / 9.0);
     load[o * 4 + 2] = sqrt(sv / 9.0);

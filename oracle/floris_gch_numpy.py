@@ -35,7 +35,7 @@ Layout conventions: all per-turbine grids are (N, 3, 3) arrays indexed
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, replace
 
 import numpy as np
 
@@ -146,6 +146,22 @@ class ModelParams:
     table_ws: list = field(default_factory=lambda: list(TABLE_WS))
     table_ct: list = field(default_factory=lambda: list(TABLE_CT))
     table_cp: list = field(default_factory=lambda: list(TABLE_CP))
+    # several turbine definitions per farm (farm.turbine_type of case.yaml:27-28 is a list; FLORIS 3.5 evaluates fCt /
+    # power_interp / TSR / pP / ref_density_cp_ct per turbine through turbine_type_map, floris/simulation/turbine.py Ct(),
+    # axial_induction(), power()): `turbine_defs` = one dict per definition with any of table_ws / table_ct / table_cp /
+    # TSR / pP / gen_eff / ref_density (missing keys: this object's value), `turbine_type_of` = definition index per
+    # turbine in the caller's order.  The definitions share the rotor (D, HH): everything geometric stays per farm.
+    # PARITY UNPINNED like the rest of the oracle beyond the one KAT — and the reference holds no mixed farm at all.
+    turbine_defs: list = None
+    turbine_type_of: list = None
+
+    def definition(self, k: int) -> "ModelParams":
+        """The parameter set turbine definition k evaluates with (this object with the definition's overrides)."""
+        d = dict(self.turbine_defs[k])
+        bad = set(d) - {"table_ws", "table_ct", "table_cp", "TSR", "pP", "gen_eff", "ref_density"}
+        if bad:
+            raise ValueError(f"turbine definition {k}: {sorted(bad)} cannot differ between the definitions of one farm")
+        return replace(self, turbine_defs=None, turbine_type_of=None, **d)
 
     def __post_init__(self):
         for k in ("alpha", "beta", "ka", "kb"):
@@ -230,6 +246,13 @@ def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=Fal
     xr, yr = rotate_layout(x, y, wd)
     order = sort_order(xr, tie_reverse)
     xs, ys, yaws = xr[order], yr[order], yaw[order]
+    if p.turbine_defs:  # several turbine definitions: which one each (sorted) turbine evaluates with
+        pdef = [p.definition(k) for k in range(len(p.turbine_defs))]
+        type_of = np.asarray(p.turbine_type_of, dtype=np.int64)
+        assert type_of.shape == (N,) and type_of.min() >= 0 and type_of.max() < len(pdef)
+    else:
+        pdef, type_of = [p], np.zeros(N, dtype=np.int64)
+    tsorted = type_of[order]
     off = np.linspace(-D / 4.0, D / 4.0, 3)  # radius_ratio 0.5 * R
     X = np.broadcast_to(xs[:, None, None], (N, 3, 3)).copy()
     Y = np.broadcast_to(ys[:, None, None] + off[None, :, None], (N, 3, 3)).copy()
@@ -267,12 +290,13 @@ def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=Fal
 
         # 1. Ct / induction [A.3-1]
         ubar = np.cbrt(np.mean(U[i] ** 3))
-        ct_tab = float(_interp_fill(ubar, p.table_ws, p.table_ct, 0.0001, 0.9999))
+        p_i = pdef[tsorted[i]]  # the source's own definition (one for all unless the farm mixes turbine types)
+        ct_tab = float(_interp_fill(ubar, p_i.table_ws, p_i.table_ct, 0.0001, 0.9999))
         ct_tab = min(max(ct_tab, 0.0001), 0.9999)
         ct = ct_tab * cg
         a = 0.5 / cg * (1.0 - np.sqrt(1.0 - ct * cg))
 
-        G_wr = 0.25 * two_pi * D * (a - a * a) * ubar / p.TSR
+        G_wr = 0.25 * two_pi * D * (a - a * a) * ubar / p_i.TSR
 
         # 2. secondary steering [A.3-2]  (own 9 points, no decay, no mirrors, no sin*cos)
         yL_own = (Y[i] - y_i) + p.num_eps
@@ -415,9 +439,14 @@ def farm_step(x, y, ws, wd, yaw, p: ModelParams | None = None, return_fields=Fal
     U, V, W, TI = U[inv], V[inv], W[inv], TI[inv]
     wind_speed = np.cbrt(np.mean(U**3, axis=(1, 2)))
     wind_direction = np.mean(wd - np.degrees(np.arctan2(V, U)), axis=(1, 2))
-    v_eff = wind_speed * cosd(yaw) ** (p.pP / 3.0)
-    v_eff = (p.air_density / p.ref_density) ** (1.0 / 3.0) * v_eff
-    power = p.ref_density * _interp_fill(v_eff, p.table_ws, p.power_table(), 0.0, 0.0)
+    power = np.empty(N)
+    for k, pk in enumerate(pdef):  # per definition, as FLORIS sums over np.unique(turbine_type_map)
+        sel = type_of == k
+        if not sel.any():
+            continue
+        v_eff = wind_speed[sel] * cosd(yaw[sel]) ** (pk.pP / 3.0)
+        v_eff = (p.air_density / pk.ref_density) ** (1.0 / 3.0) * v_eff
+        power[sel] = pk.ref_density * _interp_fill(v_eff, pk.table_ws, pk.power_table(), 0.0, 0.0)
     load = np.stack(
         [TI.mean(axis=(1, 2)), U.std(axis=(1, 2)), V.std(axis=(1, 2)), W.std(axis=(1, 2))], axis=1
     )

@@ -1,6 +1,6 @@
 """GPU box: randomised fuzz of the handle's state machine — long random sequences of wf_set_layout / wf_set_batch /
 wf_set_model / wf_set_wind (shared, per farm, device pointers) / wf_wind_sample / wf_wind_series(+_step) /
-wf_env_reset interleaved with wf_step (host and device buffers) and wf_env_step, every result checked against the
+wf_env_reset / wf_set_turbine_types interleaved with wf_step (host and device buffers) and wf_env_step, every result checked against the
 float64 oracle evaluated on the state the sequence should have produced (stale geometry, a stale pair table, a stale
 kernel variant or stale env state all show up as a mismatch).
 usage: python tests/tools/fuzz_api.py [n_sessions] [ops_per_session] [seed]
@@ -52,7 +52,7 @@ def run(n_sessions, n_ops, seed):
     def new_batch(small_hi=20):
         return int(rng.integers(4200, 9000)) if BIG else int(rng.integers(1, small_hi))
 
-    ncal = 0
+    ncal = ntyped = 0
     for sess in range(n_sessions):
         x, y = new_layout()
         B = new_batch()
@@ -65,6 +65,7 @@ def run(n_sessions, n_ops, seed):
         w = WfStep(x, y, env_batch=B, kernel_choice=dict(one_block=llg) if llg else None)
         resolve_on = False
         mp, model = None, {}
+        typed = None  # (definitions as the oracle takes them, definition of each turbine) while wf_set_turbine_types is in force
         envp = dict(yaw_lo=-40.0, yaw_hi=40.0, yaw_step=5.0, actuator_rate=0.3, dt=60.0, budget=0.1, load_coef=0.1, discrete=False)
         w.env_config(**envp)
         w.set_wind(8.0, 270.0)
@@ -79,6 +80,7 @@ def run(n_sessions, n_ops, seed):
         def oracle(yaw64):
             """reference of the farms `sub` (all of them unless FUZZ_API_BIG)"""
             ws, wd = w.get_wind()
+            mp = cur_mp()
             ws, wd, yaw64 = S(ws), S(wd), S(yaw64)
             if multi is None:
                 return c_oracle.farm_step_batch(x, y, ws, wd, yaw64, mp, margin=True), ws
@@ -94,16 +96,24 @@ def run(n_sessions, n_ops, seed):
                     out[k][idx] = v
             return out, ws
 
+        def cur_mp():
+            if typed is None:
+                return mp
+            import dataclasses
+
+            return dataclasses.replace(mp or ModelParams(), turbine_defs=typed[0], turbine_type_of=list(typed[1]))
+
         last_yaw = None
 
         def check(tag, got, ref):
-            nonlocal nbad, nflip, nchecks
+            nonlocal nbad, nflip, nchecks, ntyped
             nchecks += 1
+            ntyped += typed is not None
             got = {k: S(v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in got.items()}
             flags_now = S(w.risk_flags())
             r = worst(got, ref, flags_now)
             k = classify(r)
-            if resolve_on:  # the float64 re-solve is on: every farm strict, no flag left — anything else is a violation
+            if resolve_on or typed is not None:  # the float64 re-solve is on (several turbine definitions: it solves every farm): every farm strict, no flag left — anything else is a violation
                 e = parity.errors(got, ref)
                 if not parity.within(e, parity.TOL, x.size).all() or flags_now.any():
                     k = "BAD"
@@ -116,12 +126,13 @@ def run(n_sessions, n_ops, seed):
                 if os.environ.get("WF_FUZZ_DUMP"):  # the whole case, for a post-mortem against the oracle on a CPU
                     ws_, wd_ = w.get_wind()
                     np.savez(os.path.join(os.environ["WF_FUZZ_DUMP"], f"bad_{seed}_{sess}_{nchecks}.npz"), x=x, y=y, ws=ws_, wd=wd_,
-                             yaw=last_yaw, flags=w.risk_flags(), model=np.array(repr(model)), **{"got_" + k: v for k, v in got.items()})
+                             yaw=last_yaw, flags=w.risk_flags(), model=np.array(repr(model)), typed=np.array(repr(typed)),
+                             **{"got_" + k: v for k, v in got.items()})
 
         for _ in range(n_ops):
             op = rng.choice(["step", "step", "step_torch", "wind_shared", "wind_per_farm", "wind_device", "wind_sample", "series",
                              "series_step", "batch", "model", "layout", "env_step", "env_step", "env_reset", "env_config",
-                             "resolve", "kernel_choice", "layouts"])
+                             "resolve", "kernel_choice", "layouts", "turbine_types"])
             log.append(str(op))
             N = x.size
             if op in ("layout", "batch", "layouts"):
@@ -129,7 +140,29 @@ def run(n_sessions, n_ops, seed):
             if op in ("layout", "batch", "layouts", "wind_shared", "wind_per_farm", "wind_device", "wind_sample"):
                 w._series_left = 0  # any other way of setting the wind leaves series mode
                 w._ws_prev = None
-            if op == "resolve":  # float64 re-solve of the flagged farms on / off (wf_set_risk_resolve)
+            if op in ("layout", "model") and typed is not None:  # another turbine count invalidates the definitions; a model
+                w.set_turbine_types(None, None)                   # without them clears them (backend.set_model)
+                w.set_risk_resolve(1 if resolve_on else 0)
+                typed = None
+            if op == "turbine_types":  # several turbine definitions per farm on / off (wf_set_turbine_types)
+                if typed is None:
+                    base = ModelParams()
+                    k = float(rng.uniform(0.7, 0.95))
+                    d1 = dict(table_ct=[k * c for c in base.table_ct], table_cp=[0.8 * c for c in base.table_cp], TSR=float(rng.choice([7.0, 8.5])),
+                              pP=float(rng.choice([1.7, 2.0])), gen_eff=0.95)
+                    d2 = dict(table_ws=[0.0, 3.0, 9.0, 12.0, 25.0, 25.5], table_ct=[0.0, 0.85, 0.8, 0.45, 0.1, 0.0],
+                              table_cp=[0.0, 0.25, 0.46, 0.4, 0.05, 0.0], ref_density=1.2)
+                    defs = [{}, d1, d2][: int(rng.integers(2, 4))]
+                    tof = rng.integers(0, len(defs), N)
+                    w.set_turbine_types([{("tsr" if kk == "TSR" else kk): v for kk, v in d.items()} for d in defs], tof)
+                    typed = (defs, tof)
+                else:
+                    w.set_turbine_types(None, None)
+                    w.set_risk_resolve(1 if resolve_on else 0)
+                    typed = None
+            elif op == "resolve" and typed is not None:
+                log[-1] = "resolve(skipped)"  # (mode 0 is refused while definitions are set)
+            elif op == "resolve":  # float64 re-solve of the flagged farms on / off (wf_set_risk_resolve)
                 resolve_on = not resolve_on
                 w.set_risk_resolve(1 if resolve_on else 0)
             elif op == "kernel_choice":  # another kernel family for this handle; the wind has to be set again
@@ -255,7 +288,7 @@ def run(n_sessions, n_ops, seed):
                     nbad += 1
                     print("BAD reward", dict(session=sess, seed=seed, N=N, B=B, envp=envp), float(np.abs(S(got["reward"]) / r_ref - 1).max()), log[-12:], flush=True)
         w.close()
-    print(f"api fuzz{' (big batches: ' + str(ncal) + ' checks behind a kernel calibration)' if BIG else ''}: {n_sessions} sessions x {n_ops} ops, {nchecks} oracle checks: {nflip} threshold flips, {nbad} violations")
+    print(f"api fuzz{' (big batches: ' + str(ncal) + ' checks behind a kernel calibration)' if BIG else ''}: {n_sessions} sessions x {n_ops} ops, {nchecks} oracle checks ({ntyped} on farms of several turbine definitions): {nflip} threshold flips, {nbad} violations")
     return nflip, nbad
 
 

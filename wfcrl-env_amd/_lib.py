@@ -42,6 +42,13 @@ class ModelParams(C.Structure):
     ] + [(n, C.c_int) for n in _MODEL_SWITCHES]
 
 
+class TurbineDef(C.Structure):
+    """Mirror of `struct wf_turbine_def`."""
+
+    _fields_ = [("n_table", C.c_int), ("table_ws", C.POINTER(C.c_double)), ("table_ct", C.POINTER(C.c_double)),
+                ("table_cp", C.POINTER(C.c_double))] + [(n, C.c_double) for n in ("tsr", "pP", "gen_eff", "ref_density")]
+
+
 class EnvParams(C.Structure):
     """Mirror of `struct wf_env_params`."""
 
@@ -79,6 +86,8 @@ ABI = {
     "wf_set_stream": (C.c_int, [_P, _P, C.c_int]),
     "wf_get_stream": (_P, [_P]),
     "wf_set_model": (C.c_int, [_P, C.POINTER(ModelParams)]),
+    "wf_set_turbine_types": (C.c_int, [_P, C.c_int, C.POINTER(TurbineDef), C.POINTER(C.c_int)]),
+    "wf_get_turbine_types": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "wf_set_layout": (C.c_int, [_P, C.c_int, _P, _P]),
     "wf_set_batch": (C.c_int, [_P, C.c_int]),
     "wf_set_layouts": (C.c_int, [_P, C.c_int, _P, _P, _P]),

@@ -60,6 +60,7 @@ class WfStep:
             self.set_layout(np.asarray(xcoords[big], np.float64), np.asarray(ycoords[big], np.float64))
             self.set_batch(env_batch)
             self.set_layouts(xcoords, ycoords, layout_of)
+            self._apply_turbine_defs()
             if kernel_choice:
                 self.set_kernel_choice(**kernel_choice)
             return
@@ -73,13 +74,20 @@ class WfStep:
                 raise ValueError("layout_of needs 2-D coordinates [n_layouts][num_turbines]")
             self.set_layout(*xy)
             self.set_batch(env_batch)
+        self._apply_turbine_defs()
         if kernel_choice:  # keyword arguments of set_kernel_choice: which kernels may serve this handle
             self.set_kernel_choice(**kernel_choice)
 
     # -- configuration ---------------------------------------------------------------------------
     def set_model(self, model: dict):
+        """Model constants + the power_thrust_table (keys of default_model()).  Two more keys describe a farm of SEVERAL
+        turbine definitions (set_turbine_types): `turbine_defs`, `turbine_type_of`."""
         base = default_model()
         model = dict(model)
+        self._turbine_defs = model.pop("turbine_defs", None)
+        self._turbine_type_of = model.pop("turbine_type_of", None)
+        if (self._turbine_defs is None) != (self._turbine_type_of is None):
+            raise ValueError("turbine_defs and turbine_type_of come together")
         for k in ("alpha", "beta", "ka", "kb"):  # one gauss set given: the deflection model follows it (as in the template)
             if k in model and "defl_" + k not in model:
                 model["defl_" + k] = model[k]
@@ -101,6 +109,52 @@ class WfStep:
         dp = C.POINTER(C.c_double)
         p.table_ws, p.table_ct, p.table_cp = tws.ctypes.data_as(dp), tct.ctypes.data_as(dp), tcp.ctypes.data_as(dp)
         check(self._lib.wf_set_model(self._h, C.byref(p)), self._h)
+        self._model = base
+        if self.num_turbines:
+            self._apply_turbine_defs()
+
+    def _apply_turbine_defs(self):
+        if getattr(self, "_turbine_defs", None) is not None:
+            self.set_turbine_types(self._turbine_defs, self._turbine_type_of)
+        elif self.turbine_types():
+            self.set_turbine_types(None, None)
+
+    def set_turbine_types(self, defs, type_of):
+        """Several turbine definitions per farm (include/wfstep.h: wf_set_turbine_types; farm.turbine_type of a FLORIS case is
+        a list): `defs` = up to 4 dicts with any of table_ws / table_ct / table_cp / tsr / pP / gen_eff / ref_density (missing:
+        the model's value), `type_of[num_turbines]` the definition of each turbine.  The definitions share the rotor.  Every
+        farm is then solved by the float64 kernels on every step (risk_resolve() reports 2).  None / [] clears them."""
+        if not defs:
+            check(self._lib.wf_set_turbine_types(self._h, 0, None, None), self._h)
+            return
+        base = getattr(self, "_model", None) or default_model()
+        allowed = {"table_ws", "table_ct", "table_cp", "tsr", "pP", "gen_eff", "ref_density"}
+        arr = (_lib.TurbineDef * len(defs))()
+        keep = []
+        dp = C.POINTER(C.c_double)
+        for k, d in enumerate(defs):
+            bad = set(d) - allowed
+            if bad:
+                raise ValueError(f"turbine definition {k}: {sorted(bad)} cannot differ between the definitions of one farm "
+                                 f"(allowed: {sorted(allowed)})")
+            cols = [np.ascontiguousarray(d.get(c, base[c]), dtype=np.float64) for c in ("table_ws", "table_ct", "table_cp")]
+            if not (len(cols[0]) == len(cols[1]) == len(cols[2])):
+                raise ValueError("power_thrust_table columns must have equal length")
+            keep.append(cols)
+            arr[k].n_table = len(cols[0])
+            arr[k].table_ws, arr[k].table_ct, arr[k].table_cp = (c.ctypes.data_as(dp) for c in cols)
+            for n in ("tsr", "pP", "gen_eff", "ref_density"):
+                setattr(arr[k], n, float(d.get(n, base[n])))
+        t = np.ascontiguousarray(type_of, dtype=np.int32)
+        if t.shape != (self.num_turbines,):
+            raise ValueError("turbine_type_of: one definition index per turbine of the layout")
+        check(self._lib.wf_set_turbine_types(self._h, len(defs), arr, t.ctypes.data_as(C.POINTER(C.c_int))), self._h)
+
+    def turbine_types(self) -> int:
+        """Number of turbine definitions in force (0: the model's single one)."""
+        n = C.c_int(0)
+        check(self._lib.wf_get_turbine_types(self._h, C.byref(n)), self._h)
+        return int(n.value)
 
     def set_layout(self, xcoords, ycoords):
         x = np.ascontiguousarray(xcoords, dtype=np.float64)

@@ -107,6 +107,7 @@ int wf_destroy(wf_handle* h) {
   DeviceGuard guard(h->device);
   hipStreamSynchronize(h->stream);
   free_batch(h);
+  hipFree(h->d_tab64_mt); hipFree(h->d_type_consts); hipFree(h->d_type_of);
   hipFree(h->d_tab); hipFree(h->d_tab64); hipFree(h->d_lx); hipFree(h->d_ly); hipFree(h->d_centre); hipFree(h->d_layout_of);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
   hipStreamDestroy(h->own_stream);
@@ -302,13 +303,15 @@ int wf_set_risk_guard(wf_handle* h, double rel_band) {
 int wf_set_risk_resolve(wf_handle* h, int mode) {
   if (!h) return WF_E_INVALID;
   if (mode < 0 || mode > 2) return fail(h, WF_E_INVALID, "risk resolve mode must be 0 (off), 1 (flagged farms) or 2 (every farm)");
+  if (!h->types.empty() && mode == 0)  // (1 is kept for when the definitions are cleared; 2 is what runs meanwhile)
+    return fail(h, WF_E_INVALID, "several turbine definitions (wf_set_turbine_types): the float32 kernels know one table, mode 0 cannot be served");
   h->resolve_mode = mode;
   return WF_OK;
 }
 
 int wf_get_risk_resolve(wf_handle* h, int* mode) {
   if (!h || !mode) return WF_E_INVALID;
-  *mode = h->resolve_mode;
+  *mode = h->types.empty() ? h->resolve_mode : 2;
   return WF_OK;
 }
 

@@ -755,7 +755,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   // the farms with WF_RISK_THRUST_UNITY — a thrust coefficient above 0.995, where float32 carries no bound at all
   // (wf_kernel_common.h: table_ct) — and that only when the handle's thrust table gets there (nrel_5MW does not: nothing
   // is enqueued for it).
-  const int mode = h->resolve_mode;
+  const int mode = h->types.empty() ? h->resolve_mode : 2;  // (several turbine definitions: the float64 kernels solve every farm)
   int mask = mode == 1 ? 0xF : 0;
   if (mode == 0) {
     double ct_max = 0.0;
@@ -795,6 +795,11 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
     ra.yaw_state = ea->yaw_state; ra.reward = ea->reward; ra.ws_prev = ea->ws_prev; ra.load_coef = ea->load_coef;
   }
   h->rconsts.N = h->N;
+  if (!h->types.empty()) {
+    ra.tab64 = h->d_tab64_mt; ra.n_types = (int)h->types.size(); ra.type_of = h->d_type_of; ra.type_consts = h->d_type_consts;
+    WF_HIP(h, wfk_launch_resolve_mt(&h->rconsts, &ra, h->B, 1, h->d_flags_raw, h->n_cu, h->stream));
+    return WF_OK;
+  }
   WF_HIP(h, wfk_launch_resolve(&h->rconsts, &ra, h->B, mode == 2 ? 1 : 0, h->d_flags_raw, h->n_cu, h->stream));
   return WF_OK;
 }

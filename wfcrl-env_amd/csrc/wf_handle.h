@@ -194,6 +194,17 @@ struct wf_handle {
   int res_parity = 0;          // which of the two counters the last step with a re-solve used
   bool res_last = false;       // the last step had a re-solve behind it (its list, counter and raw flags are current)
   int res_mask = 0;            // nonzero only while launch_step enqueues the real launch: WF_RISK_* bits that put a farm on the list
+  // several turbine definitions per farm (wf_set_turbine_types): every farm is solved by the float64 kernels of
+  // wf_resolve_mt.hip, whatever resolve_mode says
+  struct TurbineType {
+    std::vector<double> ws, ct, cp;
+    double tsr, pP, gen_eff, ref_density;
+  };
+  std::vector<TurbineType> types;  // empty: the one definition of `model`
+  std::vector<int> type_of;        // [N] definition of each turbine, caller's order
+  double* d_tab64_mt = nullptr;    // [n_types][3][WF_TABLE_PAD]
+  double* d_type_consts = nullptr; // [n_types][1 + WF_TYPE_CONSTS]
+  int* d_type_of = nullptr;        // [N]
 };
 
 namespace wfi {

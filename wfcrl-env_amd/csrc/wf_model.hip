@@ -240,6 +240,32 @@ int build_consts(wf_handle* h) {
   hipError_t e = hipMemcpyAsync(h->d_tab, &t, sizeof(WfTables), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) return fail(h, WF_E_HIP, std::string("table upload: ") + hipGetErrorString(e));
+  if (!h->types.empty()) {  // several turbine definitions (wf_set_turbine_types): their float64 tables and scalars
+    const int nt = (int)h->types.size();
+    if ((int)h->type_of.size() != h->N)
+      return fail(h, WF_E_INVALID, "wf_set_turbine_types was given for another turbine count than the layout's: set the definitions again");
+    std::vector<double> tabs((size_t)nt * 3 * WF_TABLE_PAD, 0.0), tc((size_t)nt * (1 + WF_TYPE_CONSTS));
+    for (int k = 0; k < nt; ++k) {
+      const wf_handle::TurbineType& ty = h->types[k];
+      double* tb = tabs.data() + (size_t)k * 3 * WF_TABLE_PAD;
+      for (size_t i = 0; i < ty.ws.size(); ++i) {
+        tb[i] = ty.ws[i]; tb[WF_TABLE_PAD + i] = ty.ct[i];
+        tb[2 * WF_TABLE_PAD + i] = 0.5 * area * ty.cp[i] * ty.gen_eff * ty.ws[i] * ty.ws[i] * ty.ws[i];  // [A.4], as pwv above
+      }
+      double* c1 = tc.data() + (size_t)k * (1 + WF_TYPE_CONSTS);
+      c1[0] = (double)ty.ws.size(); c1[1] = 1.0 / ty.tsr; c1[2] = ty.pP / 3.0;
+      c1[3] = std::pow(m.air_density / ty.ref_density, 1.0 / 3.0); c1[4] = ty.ref_density;
+    }
+    hipError_t et = hipSuccess;
+    if (!h->d_tab64_mt) et = hipMalloc(&h->d_tab64_mt, sizeof(double) * WF_MAX_TYPES * 3 * WF_TABLE_PAD);
+    if (et == hipSuccess && !h->d_type_consts) et = hipMalloc(&h->d_type_consts, sizeof(double) * WF_MAX_TYPES * (1 + WF_TYPE_CONSTS));
+    if (et == hipSuccess) { hipFree(h->d_type_of); h->d_type_of = nullptr; et = hipMalloc(&h->d_type_of, sizeof(int) * (size_t)h->N); }
+    if (et == hipSuccess) et = hipMemcpyAsync(h->d_tab64_mt, tabs.data(), sizeof(double) * tabs.size(), hipMemcpyHostToDevice, h->stream);
+    if (et == hipSuccess) et = hipMemcpyAsync(h->d_type_consts, tc.data(), sizeof(double) * tc.size(), hipMemcpyHostToDevice, h->stream);
+    if (et == hipSuccess) et = hipMemcpyAsync(h->d_type_of, h->type_of.data(), sizeof(int) * (size_t)h->N, hipMemcpyHostToDevice, h->stream);
+    if (et == hipSuccess) et = hipStreamSynchronize(h->stream);
+    if (et != hipSuccess) return fail(h, WF_E_HIP, std::string("turbine definitions upload: ") + hipGetErrorString(et));
+  }
   h->model_dirty = false;
   return WF_OK;
 }
@@ -318,6 +344,52 @@ int wf_set_model(wf_handle* h, const wf_model_params* p) {
     apply_kernel_pick(h, h->N, h->B, nullptr);
     h->wind_count = 0; h->shared_dir = false; h->n_groups = 0; h->grid_step = 0.0; h->series_T = 0;
   }
+  return WF_OK;
+}
+
+
+static_assert(WF_MAX_TYPES == WF_MAX_TURBINE_TYPES, "wf_resolve.h and include/wfstep.h disagree");
+
+int wf_set_turbine_types(wf_handle* h, int n_types, const wf_turbine_def* defs, const int* type_of) {
+  if (!h) return WF_E_INVALID;
+  if (n_types == 0) {  // back to the one definition of the model
+    h->types.clear(); h->type_of.clear();
+    return WF_OK;
+  }
+  if (h->N <= 0) return fail(h, WF_E_INVALID, "wf_set_layout must be called first (the definitions are given per turbine)");
+  if (n_types < 1 || n_types > WF_MAX_TURBINE_TYPES || !defs || !type_of)
+    return fail(h, WF_E_INVALID, "turbine definitions: 1..WF_MAX_TURBINE_TYPES of them and a definition index per turbine");
+  std::vector<wf_handle::TurbineType> types((size_t)n_types);
+  for (int k = 0; k < n_types; ++k) {
+    const wf_turbine_def& d = defs[k];
+    if (d.n_table < 2 || d.n_table > WF_MAX_TABLE - 1 || !d.table_ws || !d.table_ct || !d.table_cp)
+      return fail(h, WF_E_INVALID, "turbine definition: power_thrust_table needs 2..63 entries");
+    const double positive[] = {d.tsr, d.pP, d.gen_eff, d.ref_density};
+    for (double v : positive)
+      if (!(v > 0.0) || !std::isfinite(v)) return fail(h, WF_E_INVALID, "turbine definition: TSR, pP, generator_efficiency and ref_density_cp_ct must be finite and > 0");
+    for (int i = 0; i < d.n_table; ++i) {
+      if (!std::isfinite(d.table_ws[i]) || !std::isfinite(d.table_ct[i]) || !std::isfinite(d.table_cp[i]) || d.table_ct[i] < 0.0 ||
+          d.table_cp[i] < 0.0)
+        return fail(h, WF_E_INVALID, "turbine definition: power_thrust_table entries must be finite and non-negative");
+      if (i && !(d.table_ws[i] > d.table_ws[i - 1])) return fail(h, WF_E_INVALID, "turbine definition: table wind speeds must be strictly ascending");
+    }
+    wf_handle::TurbineType& ty = types[(size_t)k];
+    ty.ws.assign(d.table_ws, d.table_ws + d.n_table);
+    ty.ct.assign(d.table_ct, d.table_ct + d.n_table);
+    ty.cp.assign(d.table_cp, d.table_cp + d.n_table);
+    ty.tsr = d.tsr; ty.pP = d.pP; ty.gen_eff = d.gen_eff; ty.ref_density = d.ref_density;
+  }
+  for (int t = 0; t < h->N; ++t)
+    if (type_of[t] < 0 || type_of[t] >= n_types) return fail(h, WF_E_INVALID, "turbine definitions: a turbine's index is outside 0..n_types-1");
+  h->types.swap(types);
+  h->type_of.assign(type_of, type_of + h->N);
+  h->model_dirty = true;  // (uploaded with the model constants before the next step)
+  return WF_OK;
+}
+
+int wf_get_turbine_types(wf_handle* h, int* n_types) {
+  if (!h || !n_types) return WF_E_INVALID;
+  *n_types = (int)h->types.size();
   return WF_OK;
 }
 

@@ -48,4 +48,14 @@ struct WfResolveArgs {
   float* reward;           // [B] or null
   const double* ws_prev;   // [B] or null
   float load_coef;
+  // several turbine definitions per farm (wf_set_turbine_types; read by the kernels of wf_resolve_mt.hip only, where tab64 is
+  // [n_types][3][WF_TABLE_PAD])
+  int n_types;
+  const int* type_of;         // [N] definition of each turbine, caller's order
+  const double* type_consts;  // [n_types][1 + WF_TYPE_CONSTS]: table entries, then 1 / TSR, pP / 3, (air / ref density)^(1/3), ref density
 };
+#define WF_TYPE_CONSTS 4
+#define WF_MAX_TYPES 4  // == WF_MAX_TURBINE_TYPES (include/wfstep.h)
+
+extern "C" hipError_t wfk_launch_resolve_mt(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags, int n_cu,
+                                            hipStream_t s);

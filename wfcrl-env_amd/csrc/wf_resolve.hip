@@ -21,6 +21,33 @@
 #include "wf_resolve.h"
 #include "wf_f64_math.h"
 
+// Several turbine definitions per farm (include/wfstep.h: wf_set_turbine_types): this file is compiled a second time with
+// RES_MT = 1 (wf_resolve_mt.hip) into kernels that take a turbine's thrust / power table, TSR, pP and reference density from
+// the definition the turbine belongs to.  The definitions share the rotor (diameter, hub height), so the geometry constants
+// stay per handle; what differs enters at two places only — the source's thrust coefficient and wake-rotation circulation,
+// and the turbine's power.  The build without definitions (RES_MT = 0) is the code it always was: the macros below expand
+// to the single table.
+#ifndef RES_MT
+#define RES_MT 0
+#endif
+#if RES_MT
+#define RES_NT WF_MAX_TYPES
+#define wf_list_all_kernel wf_list_all_mt_kernel
+#define wf_resolve_kernel wf_resolve_mt_kernel
+#define wf_resolve4_kernel wf_resolve4_mt_kernel
+#define wfk_launch_resolve wfk_launch_resolve_mt
+#define RES_TY(t) (reinterpret_cast<const int*>(res_dyn + (t) * RES_TS + 35)[0])  // (the record's first padding word)
+#define RES_TOFS(ty) ((ty) * WF_TABLE_PAD)
+#define RES_TN(S, ty) ((S).ty_n[ty])
+#define RES_TC(S, k, ty, single) ((S).ty_c[ty][k])
+#else
+#define RES_NT 1
+#define RES_TY(t) 0
+#define RES_TOFS(ty) 0
+#define RES_TN(S, ty) ((S).c.n_table)
+#define RES_TC(S, k, ty, single) (single)
+#endif
+
 namespace {
 
 
@@ -134,8 +161,12 @@ struct SrcShared {  // what a source leaves for the two passes over its targets
 };
 struct ResShared {
   WfResolveConsts c;
-  double tws[WF_TABLE_PAD], tct[WF_TABLE_PAD], tpw[WF_TABLE_PAD];
-  double tcs[WF_TABLE_PAD], tps[WF_TABLE_PAD];  // segment slopes of the thrust / power columns (one division per segment and launch)
+  double tws[RES_NT * WF_TABLE_PAD], tct[RES_NT * WF_TABLE_PAD], tpw[RES_NT * WF_TABLE_PAD];
+  double tcs[RES_NT * WF_TABLE_PAD], tps[RES_NT * WF_TABLE_PAD];  // segment slopes of the thrust / power columns (one division per segment and launch)
+#if RES_MT
+  double ty_c[RES_NT][WF_TYPE_CONSTS];  // per definition: 1 / TSR, pP / 3, (air / ref density)^(1/3), ref density
+  int ty_n[RES_NT];                     // table entries
+#endif
   double ws, wd, Uinf, Uinit[3];
   double dec_a[3];  // 4 nu_k ws / Uinf: decay_k = eps^2 / (dec_a[k] dx + eps^2)  [A.3-4]
   int N, n_pad, veer_on, mcore;
@@ -181,11 +212,12 @@ RES_SRC_FN void res_source_begin(int i) {
   }
   const double m3m = m3 * (1.0 / 9.0);
   const double ubar = __any(!(m3m > 1.0e-6)) ? cbrt_any(m3m) : cbrt_pos(m3m);
-  double ct_tab = interp_fill_uniform(ubar, c.n_table, R.tws, R.tct, R.tcs, 0.0001, 0.9999);
+  [[maybe_unused]] const int ty = RES_TY(i);
+  double ct_tab = interp_fill_uniform(ubar, RES_TN(R, ty), R.tws + RES_TOFS(ty), R.tct + RES_TOFS(ty), R.tcs + RES_TOFS(ty), 0.0001, 0.9999);
   ct_tab = fmin(fmax(ct_tab, 0.0001), 0.9999);
   const double ct = ct_tab * cg;
   const double ai = 0.5 * rcp64(cg) * (1.0 - sqrt_nn(1.0 - ct * cg));
-  const double G_wr = (0.25 * kTwoPi) * c.D * (ai - ai * ai) * ubar * c.inv_TSR;
+  const double G_wr = (0.25 * kTwoPi) * c.D * (ai - ai * ai) * ubar * RES_TC(R, 0, ty, c.inv_TSR);
   const double gam_top = (kTwoPi / 16.0) * c.D * c.vel_top * R.Uinf * ct;
   const double gam_bot = (kTwoPi / 16.0) * c.D * c.vel_bot * R.Uinf * ct;
   const double sc = sg * cg;
@@ -419,8 +451,9 @@ RES_PASS_FN void res_deficit_pass(int i) {
 // ---- outputs [A.4] of one turbine (sorted index t, caller's index o) from the farm's state in LDS ----
 // (tb: the turbine's record in LDS; the nine rotor-grid velocities are kept in registers: one root per grid point)
 __device__ __forceinline__ void res_turbine_outputs(const WfResolveConsts& c, const WfResolveArgs& a, const double* tb,
-                                                    size_t oo, bool real, const double* Uinit, double wd, double cg_t, const double* tws,
-                                                    const double* tpw, const double* tps, double& psum, double& lsum) {
+                                                    size_t oo, bool real, const double* Uinit, double wd, double cg_t, int n_tab,
+                                                    const double* tws, const double* tpw, const double* tps, double pP3,
+                                                    double dens_cbrt, double rho_ref, double& psum, double& lsum) {
   double u[9], m3 = 0.0, mu = 0.0, mv = 0.0, mw = 0.0;
   bool small = true;
 #pragma unroll
@@ -448,8 +481,8 @@ __device__ __forceinline__ void res_turbine_outputs(const WfResolveConsts& c, co
   }
   const double m3m = m3 * (1.0 / 9.0);
   const double wsp = __any(!(m3m > 1.0e-6)) ? cbrt_any(m3m) : cbrt_pos(m3m);
-  const double veff = c.dens_cbrt * (wsp * POW_F64(cg_t, c.pP3));
-  const double pw = c.rho_ref * interp_fill(veff, c.n_table, tws, tpw, tps, 0.0, 0.0);
+  const double veff = dens_cbrt * (wsp * POW_F64(cg_t, pP3));
+  const double pw = rho_ref * interp_fill(veff, n_tab, tws, tpw, tps, 0.0, 0.0);
   const double l0 = (tb[32] + tb[33] + tb[34]) * (1.0 / 3.0);
   const double l1 = sqrt_nn(su * (1.0 / 9.0)), l2 = sqrt_nn(sv * (1.0 / 9.0)), l3 = sqrt_nn(sw * (1.0 / 9.0));
   psum += real ? pw : 0.0;
@@ -469,8 +502,10 @@ RES_PASS_FN void res_outputs(const WfResolveArgs& a, int b, size_t gofs) {
   const int n_real = a.n_real ? a.n_real[b] : N;  // turbines the farm really has (padded layouts)
   for (int t = lane; t < N; t += 64) {
     const int o = a.gidx[gofs + t];
-    res_turbine_outputs(c, a, res_dyn + t * RES_TS, (size_t)b * N + o, o < n_real, R.Uinit, R.wd, RES_CG(t), R.tws, R.tpw, R.tps,
-                        psum, lsum);  // (a placeholder of a padded layout: zeros out, nothing into the reward)
+    [[maybe_unused]] const int ty = RES_TY(t);
+    res_turbine_outputs(c, a, res_dyn + t * RES_TS, (size_t)b * N + o, o < n_real, R.Uinit, R.wd, RES_CG(t), RES_TN(R, ty),
+                        R.tws + RES_TOFS(ty), R.tpw + RES_TOFS(ty), R.tps + RES_TOFS(ty), RES_TC(R, 1, ty, c.pP3),
+                        RES_TC(R, 2, ty, c.dens_cbrt), RES_TC(R, 3, ty, c.rho_ref), psum, lsum);  // (a placeholder of a padded layout: zeros out, nothing into the reward)
   }
   if (a.reward) {  // reference simple_env.py:78-84 on the float64 values
 #pragma unroll
@@ -485,7 +520,40 @@ RES_PASS_FN void res_outputs(const WfResolveArgs& a, int b, size_t gofs) {
   }
 }
 
-#ifdef WF_RES_STAMP  // debug build (tools/res_stamps.py): wave cycles per phase, summed over the launch
+// the table columns (and their segment slopes) of every definition -> LDS, by all `nthreads` threads of the block
+template <class Shared>
+__device__ __forceinline__ void res_stage_tables(Shared& S, const WfResolveConsts& c_arg, const WfResolveArgs& a_arg, int tid, int nthreads) {
+#if RES_MT
+  const int n_types = a_arg.n_types;
+  for (int k = tid; k < n_types; k += nthreads) {
+    S.ty_n[k] = (int)a_arg.type_consts[k * (WF_TYPE_CONSTS + 1)];
+    for (int j = 0; j < WF_TYPE_CONSTS; ++j) S.ty_c[k][j] = a_arg.type_consts[k * (WF_TYPE_CONSTS + 1) + 1 + j];
+  }
+#else
+  const int n_types = 1;
+#endif
+  for (int ty = 0; ty < n_types; ++ty) {
+    const double* tb = a_arg.tab64 + (size_t)ty * 3 * WF_TABLE_PAD;
+#if RES_MT
+    const int n = (int)a_arg.type_consts[ty * (WF_TYPE_CONSTS + 1)];
+#else
+    const int n = c_arg.n_table;
+#endif
+    for (int k = tid; k < n; k += nthreads) {
+      const int d = RES_TOFS(ty) + k;
+      S.tws[d] = tb[k];
+      S.tct[d] = tb[WF_TABLE_PAD + k];
+      S.tpw[d] = tb[2 * WF_TABLE_PAD + k];
+      if (k + 1 < n) {  // segment slopes (scipy interp1d: slope * (x - x_lo) + y_lo)
+        const double dxk = tb[k + 1] - tb[k];
+        S.tcs[d] = (tb[WF_TABLE_PAD + k + 1] - tb[WF_TABLE_PAD + k]) / dxk;
+        S.tps[d] = (tb[2 * WF_TABLE_PAD + k + 1] - tb[2 * WF_TABLE_PAD + k]) / dxk;
+      }
+    }
+  }
+}
+
+#if defined(WF_RES_STAMP) && !RES_MT  // debug build (tools/res_stamps.py): wave cycles per phase, summed over the launch
 __device__ unsigned long long wf_res_stamp[8];
 #define RES_T(v) const unsigned long long v = __builtin_readcyclecounter()
 #define RES_ACC(k, a, b) st_acc[k] += (b) - (a)
@@ -501,16 +569,7 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
     R.a = a_arg;
     R.N = N; R.n_pad = n_pad; R.veer_on = c_arg.sin2_veer != 0.0; R.mcore = c_arg.mirror_core;
   }
-  for (int k = lane; k < c_arg.n_table; k += 64) {
-    R.tws[k] = a_arg.tab64[k];
-    R.tct[k] = a_arg.tab64[WF_TABLE_PAD + k];
-    R.tpw[k] = a_arg.tab64[2 * WF_TABLE_PAD + k];
-    if (k + 1 < c_arg.n_table) {  // segment slopes (scipy interp1d: slope * (x - x_lo) + y_lo)
-      const double dxk = a_arg.tab64[k + 1] - a_arg.tab64[k];
-      R.tcs[k] = (a_arg.tab64[WF_TABLE_PAD + k + 1] - a_arg.tab64[WF_TABLE_PAD + k]) / dxk;
-      R.tps[k] = (a_arg.tab64[2 * WF_TABLE_PAD + k + 1] - a_arg.tab64[2 * WF_TABLE_PAD + k]) / dxk;
-    }
-  }
+  res_stage_tables(R, c_arg, a_arg, lane, 64);
   const int n_list = *a_arg.count;
   if (n_list < min_count) return;  // (few enough farms for one residency of the four-wave kernel below: it serves them)
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
@@ -536,6 +595,9 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
       if (__any(fabs(g) > 45.0)) sincos_any(g * kDeg, sg, cg);  // (never an admissible yaw command)
       else sincos_small(g * kDeg, sg, cg);
       RES_XS(t) = a.gx[gofs + t]; RES_YS(t) = a.gy[gofs + t]; RES_CG(t) = cg; RES_SG(t) = sg; RES_GR(t) = g * kDeg;
+#if RES_MT
+      reinterpret_cast<int*>(res_dyn + t * RES_TS + 35)[0] = a.type_of[a.gidx[gofs + t]];
+#endif
 #pragma unroll 1
       for (int q = 0; q < 27; ++q) res_dyn[t * RES_TS + 5 + q] = 0.0;
       for (int j = 0; j < 3; ++j) res_dyn[t * RES_TS + 32 + j] = c_arg.amb;
@@ -616,8 +678,12 @@ struct Fin4Shared {  // the source-only constants of deflection, deficit and wak
 };
 struct Res4Shared {
   WfResolveConsts c;
-  double tws[WF_TABLE_PAD], tct[WF_TABLE_PAD], tpw[WF_TABLE_PAD];
-  double tcs[WF_TABLE_PAD], tps[WF_TABLE_PAD];  // segment slopes of the thrust / power columns
+  double tws[RES_NT * WF_TABLE_PAD], tct[RES_NT * WF_TABLE_PAD], tpw[RES_NT * WF_TABLE_PAD];
+  double tcs[RES_NT * WF_TABLE_PAD], tps[RES_NT * WF_TABLE_PAD];  // segment slopes of the thrust / power columns
+#if RES_MT
+  double ty_c[RES_NT][WF_TYPE_CONSTS];
+  int ty_n[RES_NT];
+#endif
   double ws, wd, Uinf, Uinit[3];
   double dec_a[3];  // 4 nu_k ws / Uinf
   WfResolveArgs a;  // the launch arguments (read from here inside the farm loop)
@@ -653,11 +719,12 @@ RES_SRC_FN void res4_source_begin(int tid, int i) {
   }
   const double m3m = m3 * (1.0 / 9.0);
   const double ubar = __any(!(m3m > 1.0e-6)) ? cbrt_any(m3m) : cbrt_pos(m3m);
-  double ct_tab = interp_fill_uniform(ubar, c.n_table, R4.tws, R4.tct, R4.tcs, 0.0001, 0.9999);
+  [[maybe_unused]] const int ty = RES_TY(i);
+  double ct_tab = interp_fill_uniform(ubar, RES_TN(R4, ty), R4.tws + RES_TOFS(ty), R4.tct + RES_TOFS(ty), R4.tcs + RES_TOFS(ty), 0.0001, 0.9999);
   ct_tab = fmin(fmax(ct_tab, 0.0001), 0.9999);
   const double ct = ct_tab * cg;
   const double ai = 0.5 * rcp64(cg) * (1.0 - sqrt_nn(1.0 - ct * cg));
-  const double G_wr = (0.25 * kTwoPi) * c.D * (ai - ai * ai) * ubar * c.inv_TSR;
+  const double G_wr = (0.25 * kTwoPi) * c.D * (ai - ai * ai) * ubar * RES_TC(R4, 0, ty, c.inv_TSR);
   const double gam_top = (kTwoPi / 16.0) * c.D * c.vel_top * R4.Uinf * ct;
   const double gam_bot = (kTwoPi / 16.0) * c.D * c.vel_bot * R4.Uinf * ct;
   const double sc = sg * cg;
@@ -924,8 +991,10 @@ RES_PASS_FN void res4_outputs(int tid, const WfResolveArgs& a, int b, size_t gof
   const int n_real = a.n_real ? a.n_real[b] : N;  // turbines the farm really has (padded layouts)
   for (int t = tid; t < N; t += 256) {
     const int o = a.gidx[gofs + t];
-    res_turbine_outputs(c, a, res_dyn + t * RES_TS, (size_t)b * N + o, o < n_real, R4.Uinit, R4.wd, RES4_CG(t), R4.tws, R4.tpw,
-                        R4.tps, psum, lsum);
+    [[maybe_unused]] const int ty = RES_TY(t);
+    res_turbine_outputs(c, a, res_dyn + t * RES_TS, (size_t)b * N + o, o < n_real, R4.Uinit, R4.wd, RES4_CG(t), RES_TN(R4, ty),
+                        R4.tws + RES_TOFS(ty), R4.tpw + RES_TOFS(ty), R4.tps + RES_TOFS(ty), RES_TC(R4, 1, ty, c.pP3),
+                        RES_TC(R4, 2, ty, c.dens_cbrt), RES_TC(R4, 3, ty, c.rho_ref), psum, lsum);
   }
   if (a.reward) {  // reference simple_env.py:78-84 on the float64 values
 #pragma unroll
@@ -952,16 +1021,7 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
     R4.a = a_arg;
     R4.N = N; R4.n_pad = n_pad; R4.veer_on = c_arg.sin2_veer != 0.0; R4.mcore = c_arg.mirror_core;
   }
-  for (int k = tid; k < c_arg.n_table; k += 256) {
-    R4.tws[k] = a_arg.tab64[k];
-    R4.tct[k] = a_arg.tab64[WF_TABLE_PAD + k];
-    R4.tpw[k] = a_arg.tab64[2 * WF_TABLE_PAD + k];
-    if (k + 1 < c_arg.n_table) {  // segment slopes (scipy interp1d: slope * (x - x_lo) + y_lo)
-      const double dxk = a_arg.tab64[k + 1] - a_arg.tab64[k];
-      R4.tcs[k] = (a_arg.tab64[WF_TABLE_PAD + k + 1] - a_arg.tab64[WF_TABLE_PAD + k]) / dxk;
-      R4.tps[k] = (a_arg.tab64[2 * WF_TABLE_PAD + k + 1] - a_arg.tab64[2 * WF_TABLE_PAD + k]) / dxk;
-    }
-  }
+  res_stage_tables(R4, c_arg, a_arg, tid, 256);
   const int n_list = *a_arg.count;
   if (n_list > max_count) return;  // the one-wave-per-farm kernel serves counts beyond one residency of this one
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
@@ -986,6 +1046,9 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
       if (__any(fabs(g) > 45.0)) sincos_any(g * kDeg, sg, cg);  // (never an admissible yaw command)
       else sincos_small(g * kDeg, sg, cg);
       RES4_XS(t) = a.gx[gofs + t]; RES4_YS(t) = a.gy[gofs + t]; RES4_CG(t) = cg; RES4_SG(t) = sg; RES4_GR(t) = g * kDeg;
+#if RES_MT
+      reinterpret_cast<int*>(res_dyn + t * RES_TS + 35)[0] = a.type_of[a.gidx[gofs + t]];
+#endif
 #pragma unroll 1
       for (int q = 0; q < 27; ++q) res_dyn[t * RES_TS + 5 + q] = 0.0;
       for (int j = 0; j < 3; ++j) res_dyn[t * RES_TS + 32 + j] = c_arg.amb;
@@ -1029,7 +1092,7 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
 }
 
 
-#ifdef WF_RES_STAMP
+#if defined(WF_RES_STAMP) && !RES_MT
 extern "C" int wfk_res_stamps(unsigned long long* out, int reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res_stamp), sizeof(wf_res_stamp));
   if (e == hipSuccess && reset) {

@@ -109,10 +109,36 @@ def load_case_yaml(path_or_dict) -> dict:
         raise UnsupportedCaseError("exactly one wind speed and one wind direction per case (as the reference uses)")
     if flow.get("heterogenous_inflow_config") or flow.get("heterogeneous_inflow_config"):
         raise UnsupportedCaseError("heterogeneous inflow is not implemented")
+    # farm.turbine_type is a list (case.yaml:27-28): one entry for every turbine, or one entry per turbine.  Distinct entries
+    # become the backend's turbine definitions (include/wfstep.h: wf_set_turbine_types) as long as they share the rotor.
     ttypes = farm.get("turbine_type", ["nrel_5MW"])
-    if any(t != ttypes[0] for t in ttypes):
-        raise UnsupportedCaseError("mixed turbine types are not implemented")
-    model = _turbine_fields(ttypes[0])
+    n_turb = len(farm["layout_x"])
+    if len(ttypes) not in (1, n_turb):
+        raise UnsupportedCaseError("farm.turbine_type needs one entry, or one per turbine")
+    distinct = []
+    type_of = []
+    for t in ttypes:
+        if t not in distinct:
+            distinct.append(t)
+        type_of.append(distinct.index(t))
+    fields = [_turbine_fields(t) for t in distinct]
+    model = dict(fields[0])
+    if len(distinct) > 1:
+        per_def = ("table_ws", "table_ct", "table_cp", "tsr", "pP", "gen_eff", "ref_density")
+        nrel = {"rotor_diameter": 126.0, "hub_height": 90.0, "pT": 1.88}  # what a library name stands for in the shared fields
+        for k, f in enumerate(fields[1:], 1):
+            for name in ("rotor_diameter", "hub_height"):
+                if f.get(name, nrel[name]) != fields[0].get(name, nrel[name]):
+                    raise UnsupportedCaseError(f"turbine definitions of one farm must share {name} (definition {k} differs): "
+                                               "the rotor grid and the vortex geometry are per farm")
+        if len(distinct) > 4:
+            raise UnsupportedCaseError("at most 4 distinct turbine definitions per farm")
+        # a definition that leaves a per-definition field out means FLORIS' nrel_5MW value there, not definition 0's
+        from .backend import default_model
+
+        dflt = default_model()
+        model["turbine_defs"] = [{k: f.get(k, dflt[k]) for k in per_def} for f in fields]
+        model["turbine_type_of"] = type_of if len(ttypes) > 1 else [0] * n_turb
     ref_h = float(flow.get("reference_wind_height", -1))
     hub = model.get("hub_height", 90.0)
     if ref_h != -1 and ref_h != hub:
