@@ -689,7 +689,7 @@ struct Res4Shared {
   WfResolveArgs a;  // the launch arguments (read from here inside the farm loop)
   double red[4][2];
   int N, n_pad, veer_on, mcore;
-  Src4Shared s[4];
+  Src4Shared s[2];  // by stage parity: wave 3 writes the NEXT source's copy while the others still read this one's
   Fin4Shared f;
   double own[18];  // V (0..8) and W (9..17) of the source's own turbine after its transverse pass (see res4_transverse_pass)
 };
@@ -704,11 +704,17 @@ __shared__ Res4Shared R4;
 #define RES4_TIE(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(t)])
 #define RES4_CNT(j, t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(1 + (j)) * R4.n_pad + (t)])  // overlap count of column j
 
-// ---- the source's state and circulations [A.3-1, A.3-2, A.3-4]: every wave, into its own copy ----
+// ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
+// Wave 3 only, one source AHEAD (round 5): source i + 1's rotor speed, thrust and circulations need its turbine's deficits
+// (final after the deficit pass of source i) and transverse velocities (final after the transverse pass of source i), so
+// wave 3 — idle during the turbulence pass of stage i — derives them there, into the other parity's copy; the block barrier
+// that ends the stage publishes them.  Before, every wave derived them at the START of stage i + 1: a cube root, a table
+// probe, a root and two reciprocals of pure latency on each of the farm's N stages.  The three column TIs of the source are
+// NOT final at that point (the turbulence pass is writing them): wave 3 snapshots them at the start of the stage proper
+// (res4_source_chain), ahead of the barrier behind which the recovery and the deficit pass read them.
 RES_SRC_FN void res4_source_begin(int tid, int i) {
   RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const int wave = tid >> 6;
   const double cg = RES4_CG(i), sg = RES4_SG(i);
   double m3 = 0.0, vs = 0.0;
 #pragma unroll
@@ -729,9 +735,8 @@ RES_SRC_FN void res4_source_begin(int tid, int i) {
   const double gam_bot = (kTwoPi / 16.0) * c.D * c.vel_bot * R4.Uinf * ct;
   const double sc = sg * cg;
   if ((tid & 63) == 0) {
-    Src4Shared& s = R4.s[wave];
+    Src4Shared& s = R4.s[i & 1];
     s.x_i = RES4_XS(i); s.y_i = RES4_YS(i); s.ct = ct; s.ai = ai; s.ubar = ubar; s.Vmean = vs * (1.0 / 9.0);
-    s.TIs[0] = RES4_ST(27, i); s.TIs[1] = RES4_ST(28, i); s.TIs[2] = RES4_ST(29, i);
     s.Gt = sc * gam_top * (1.0 / kTwoPi); s.Gb = -sc * gam_bot * (1.0 / kTwoPi); s.Gw = G_wr * (1.0 / kTwoPi);
     s.first_tv = RES4_TIE(i);
     // secondary steering [A.3-2]: the three means on the source's own grid are geometry constants
@@ -752,7 +757,7 @@ RES_SRC_FN void res4_source_begin(int tid, int i) {
 RES_PASS_FN void res4_transverse_pass(int tid, int i, int j) {
   RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const Src4Shared& s = R4.s[tid >> 6];
+  const Src4Shared& s = R4.s[i & 1];
   const int lane = tid & 63, N = R4.N;
   const double x_i = s.x_i, y_i = s.y_i, Gt = s.Gt, Gb = s.Gb, Gw = s.Gw;
   const double qd = c.off[2], neps = c.num_eps, twoHH = 2.0 * c.HH, eps2 = c.eps2, ieps2 = c.inv_eps2;
@@ -814,7 +819,8 @@ RES_PASS_FN void res4_transverse_pass(int tid, int i, int j) {
 RES_SRC_FN void res4_source_chain(int tid, int i) {
   RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const Src4Shared& s0 = R4.s[tid >> 6];
+  Src4Shared& s0 = R4.s[i & 1];
+  if ((tid & 63) < 3) s0.TIs[tid & 63] = RES4_ST(27 + (tid & 63), i);  // (final since the barrier that ended the previous stage)
   const double cg = RES4_CG(i), sg = RES4_SG(i), ct = s0.ct, D = c.D;
   double val = s0.val;
   val = fmin(fmax(val, -1.0), 1.0);
@@ -851,7 +857,7 @@ RES_SRC_FN double res4_recovery(int tid, int i) {
   RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
   const int wave = tid >> 6;
-  const Src4Shared& s0 = R4.s[wave];
+  const Src4Shared& s0 = R4.s[i & 1];
   double vsum = 0.0, wsum = 0.0;
 #pragma unroll
   for (int q = 0; q < 9; ++q) { vsum += R4.own[q]; wsum += R4.own[9 + q]; }
@@ -874,7 +880,7 @@ RES_SRC_FN double res4_recovery(int tid, int i) {
 RES_PASS_FN void res4_deficit_pass(int tid, int i, int j, double dTI) {
   RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const Src4Shared& s = R4.s[tid >> 6];
+  const Src4Shared& s = R4.s[i & 1];
   const Fin4Shared& f = R4.f;
   const int lane = tid & 63, N = R4.N;
   const bool veer_on = R4.veer_on != 0;
@@ -961,7 +967,7 @@ RES_PASS_FN void res4_deficit_pass(int tid, int i, int j, double dTI) {
 RES_PASS_FN void res4_turbulence_pass(int tid, int i, int j) {
   RES_PHASE_FENCE;
   const WfResolveConsts& c = R4.c;
-  const Src4Shared& s = R4.s[tid >> 6];
+  const Src4Shared& s = R4.s[i & 1];
   const int lane = tid & 63, N = R4.N;
   const double x_i = s.x_i, y_i = s.y_i, D = c.D, ch_pref = R4.f.ch_pref;
   for (int base = i + 1; base < N; base += 64) {
@@ -1060,13 +1066,14 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
       RES4_TIE(t) = f;
     }
     __syncthreads();
+    if ((tid >> 6) == 3) res4_source_begin(tid, 0);
+    __syncthreads();
     for (int i = 0; i < N; ++i) {
       // (the thread index is made opaque once per source: everything derived from it — wave, lane, a dozen LDS addresses per
       // phase — is recomputed where it is used instead of being hoisted out of this loop and held, or spilled, across it)
       int tq = tid;
       asm volatile("" : "+v"(tq));
       const int wq = tq >> 6;
-      res4_source_begin(tq, i);
       if (wq < 3) {
         if (R4.c.sw_tv) res4_transverse_pass(tq, i, wq);
         else if ((tq & 63) < 3) {  // (no transverse velocities: the side buffer holds the unchanged — zero — state)
@@ -1083,6 +1090,7 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
         if (wq < 3) res4_deficit_pass(tq, i, wq, dTI);
         __syncthreads();
         if (wq < 3) res4_turbulence_pass(tq, i, wq);
+        else res4_source_begin(tq, i + 1);  // (see there: the next source's state, beside the turbulence pass)
       }
       __syncthreads();
     }
