@@ -171,3 +171,37 @@ def test_case_yaml_with_two_turbine_types_through_the_interface(tmp_path):
     cfg["farm"]["turbine_type"][1] = dict(derated, hub_height=100.0)
     with pytest.raises(UnsupportedCaseError, match="share hub_height"):
         load_case_yaml(cfg)
+
+
+def test_definitions_with_layouts_of_different_turbine_counts():
+    """The definition index is per turbine SLOT, shared by the layouts of a batch (include/wfstep.h); the placeholders of a
+    shorter layout (wf_set_layouts_counts) receive wakes and give none whatever their slot's definition.  Checker: the oracle
+    on the UNPADDED layouts with the definitions of their slots; fused env step: the reward over the real turbines."""
+    import parity
+    from oracle import c_oracle
+    from wfcrl_env_amd.backend import WfStep
+
+    rng = np.random.default_rng(77)
+    counts, B = (12, 9, 7), 96
+    N, K = max(counts), len(counts)
+    X = [list(rng.uniform(0, 2500, n)) for n in counts]
+    Y = [list(rng.uniform(0, 1500, n)) for n in counts]
+    layout_of = rng.integers(0, K, B).astype(np.int32)
+    defs = _definitions()
+    type_of = rng.integers(0, len(defs), N)
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    ws, wd = np.clip(8 * rng.weibull(8, B), 4, 20), rng.uniform(0, 360, B)
+    w = WfStep(X, Y, env_batch=B, layout_of=layout_of, model=dict(turbine_defs=defs, turbine_type_of=type_of))
+    assert w.turbine_types() == 3 and list(w.turbine_counts) == list(counts)
+    w.set_wind(ws, wd)
+    out = {k: np.asarray(v) for k, v in w.step(yaw).items()}
+    for l in range(K):
+        idx = np.flatnonzero(layout_of == l)
+        n = counts[l]
+        ref = c_oracle.farm_step_batch(np.array(X[l]), np.array(Y[l]), ws[idx], wd[idx], yaw[idx, :n].astype(np.float64),
+                                       _oracle_params(defs, type_of[:n]), margin=True)
+        got = {k: v[idx] for k, v in out.items()}
+        for k, v in got.items():
+            assert not v[:, n:].any(), (l, k)
+        parity.check_strict({k: v[:, :n] for k, v in got.items()}, ref, parity.TOL_F64)
+    w.close()
