@@ -61,15 +61,16 @@ constexpr int kNumFamilies = 6, kNumRoundsN = 5;
 const int kRoundsN[kNumRoundsN] = {32, 48, 64, 80, 91};
 // [family][N index][blocks per CU - 1]
 // (N = 32, 48, 64: the first N turbines of HornsRev2 at 263 deg; N = 80, 91: HornsRev1 / HornsRev2 at 270 deg, the
-// BASELINE configs — profiles/r03_v34_rounds_table.txt, r03_v34_batch_sweep_fine.txt, measured with the far-pair skip of pass 2
+// BASELINE configs — profiles/r05_rounds_table.txt (re-measured on round 5's kernels: one-slot families in their two-wave build
+// up to two blocks per CU; rounds 3-4: r03_v34_rounds_table.txt), r03_v34_batch_sweep_fine.txt, measured with the far-pair skip of pass 2
 // (wf_kernels_ll.hip: WF_LL_FAR_SKIP), whose yield depends on layout and direction; layouts move these by up to 10 %)
 const double kRoundsMs[kNumFamilies][kNumRoundsN][3] = {
-    {{0.094, 0.118, 0.0}, {0.124, 0.148, 0.187}, {0.166, 0.210, 0.0}, {0.230, 0.288, 0.0}, {0.304, 0.366, 0.0}},            // slot (8x4, 16x3, 16x4, 16x5, 16x6)
-    {{0.088, 0.110, 0.143}, {0.152, 0.192, 0.247}, {0.228, 0.284, 0.363}, {0.337, 0.413, 0.530}, {0.418, 0.506, 0.641}},  // 8x1
-    {{0.117, 0.156, 0.0}, {0.210, 0.271, 0.0}, {0.326, 0.414, 0.0}, {0.473, 0.600, 0.0}, {0.600, 0.777, 0.0}},            // 4x2
-    {{0.126, 0.166, 0.215}, {0.227, 0.296, 0.379}, {0.353, 0.438, 0.591}, {0.515, 0.623, 0.812}, {0.637, 0.800, 1.081}},  // 4x1
-    {{0.183, 0.255, 0.0}, {0.346, 0.472, 0.0}, {0.551, 0.768, 0.0}, {0.796, 1.030, 0.0}, {1.025, 1.409, 0.0}},            // 2x2
-    {{0.066, 0.085, 0.109}, {0.110, 0.141, 0.183}, {0.164, 0.207, 0.263}, {0.230, 0.288, 0.365}, {0.290, 0.352, 0.448}}};  // 16x1
+    {{0.088, 0.112, 0.0}, {0.115, 0.145, 0.187}, {0.156, 0.204, 0.0}, {0.210, 0.274, 0.0}, {0.279, 0.345, 0.0}},            // slot (8x4, 16x3, 16x4, 16x5, 16x6)
+    {{0.089, 0.117, 0.157}, {0.162, 0.212, 0.282}, {0.234, 0.301, 0.393}, {0.308, 0.390, 0.517}, {0.391, 0.490, 0.648}},  // 8x1
+    {{0.124, 0.163, 0.0}, {0.216, 0.281, 0.0}, {0.314, 0.398, 0.0}, {0.428, 0.535, 0.0}, {0.537, 0.666, 0.0}},            // 4x2
+    {{0.129, 0.172, 0.250}, {0.215, 0.283, 0.389}, {0.310, 0.405, 0.565}, {0.421, 0.535, 0.767}, {0.514, 0.650, 0.946}},  // 4x1
+    {{0.179, 0.250, 0.0}, {0.307, 0.432, 0.0}, {0.454, 0.648, 0.0}, {0.622, 0.856, 0.0}, {0.798, 1.026, 0.0}},            // 2x2
+    {{0.068, 0.090, 0.122}, {0.116, 0.151, 0.198}, {0.171, 0.224, 0.292}, {0.228, 0.296, 0.386}, {0.287, 0.361, 0.474}}};  // 16x1
 // A partial round behind full ones overlaps with their tail: its cost relative to the same round on an idle chip, by
 // (blocks per CU it reaches, resident blocks per CU of the family) — fitted on profiles/r03_batch_sweep_fine.txt
 const double kTailFactor[2][3] = {{0.80, 0.95, 0.0}, {0.62, 0.79, 0.86}};  // [per_cu - 2][tail blocks per CU - 1]
@@ -191,8 +192,8 @@ int pick_ll(const wf_handle* h, int N, int B) {  // returns (G << 4) | S, 0 = ke
     int mix_unused;
     double t = family_estimate(h, fi, N, B, &mix_unused);
     // G = 16 runs neck and neck with the register-slot kernel up to two blocks per CU (0.290 against 0.294 ms at
-    // HornsRev1 x 8192, either way round from layout to layout): it has to win by 4 % — its case is the third block
-    if (f.code == ((16 << 4) | 1)) t *= 1.04;
+    // HornsRev1 x 8192, either way round from layout to layout): there it has to win by 4 % — its case is the third block
+    if (f.code == ((16 << 4) | 1) && (long)B <= 2l * h->n_cu * f.farms_per_block) t *= 1.04;
     if (t < t_best) { t_best = t; best = f.code; }
   }
   return best;
@@ -838,10 +839,12 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
     // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
     // fields above would describe) is enqueued behind it for the directions that have one
     const int ll_s = tab ? h->ll_S : ll_fly_S(h), ll_g = tab ? h->ll_G : ll_fly_G(h);
-    WF_HIP(h, wfk_ll_func_attributes(ll_g, ll_s, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, veer ? 1 : 0, &a));
     info->lanes_per_env = ll_g; info->slots_per_lane = ll_s;
     info->envs_per_block = wfk_ll_farms_per_block(ll_g); info->threads_per_block = 256;
     info->grid_blocks = (int)(((h->n_groups > 0 ? (size_t)h->n_slots : (size_t)h->B) + info->envs_per_block - 1) / info->envs_per_block);
+    const int ll_blocks = info->mixed_main_farms ? info->mixed_main_farms / info->envs_per_block : info->grid_blocks;
+    WF_HIP(h, wfk_ll_func_attributes(ll_g, ll_s, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, veer ? 1 : 0,
+                                     (tab && ll_s == 1 && ll_blocks <= 2 * h->n_cu) ? 1 : 0, &a));
   }
   info->vgprs = a.numRegs;
   info->lds_bytes = (int)a.sharedSizeBytes; info->scratch_bytes = (int)a.localSizeBytes;

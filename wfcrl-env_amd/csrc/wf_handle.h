@@ -60,7 +60,7 @@ extern "C" hipError_t wfk_launch_step_ll(int G, int S, const WfConsts* c, const 
                                          float* o_wd, float* load, int B, const WfEnvArgs* env, const float* ll_tab,
                                          const int* cross_tie, float* src_log, size_t log_records,
                                          const WfGroupArgs* grp, hipStream_t s);
-extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, int veer, hipFuncAttributes* a);
+extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, int veer, int occ2, hipFuncAttributes* a);
 extern "C" hipError_t wfk_launch_fill(int n, double* a, hipStream_t s);  // a[1..n) = a[0]
 extern "C" hipError_t wfk_sort_tmp_bytes(int B, size_t* bytes);
 extern "C" hipError_t wfk_sort_by_direction(int B, int n_slots, const double* wd, float* keys, int* vals, void* tmp, size_t tmp_bytes,

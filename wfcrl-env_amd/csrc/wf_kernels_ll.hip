@@ -188,8 +188,13 @@ __device__ unsigned long long wf_ll_stamp[16];
 // Waves per SIMD the register allocator is asked to make room for: three with one slot (first version of the kernel,
 // G = 8: 2 -> 1.87 ms, 3 -> 1.60 ms, 4 -> 2.9 ms with 168 B of spills; G = 4: 3 -> 1.24 ms, 4 -> 1.35 ms with 96 B of
 // scratch; HornsRev1 x 65536), two with two slots (54 state registers).
-template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB, bool VEER = false>
-__global__ __launch_bounds__(64 * WPB, (S == 1 ? 3 : 2) * 4 / WPB) void wf_step_ll_kernel(
+// OCC2 (one-slot families on the table path): the same kernel compiled for TWO waves per SIMD instead of three.  Since the
+// hot records go through LDS (round 5) the one-slot shapes spill 22-36 registers at the 168 of three waves per SIMD and carry a
+// private segment; at 200 registers they do not, and a batch that reaches no third block per CU anyway runs 3-9 % faster from
+// this build (profiles/r05_s1_occ2_ab.txt).  launch_ll picks by the launch's blocks per CU; the three-wave build keeps the
+// batches whose third block is its whole point.
+template <int G, int S, bool UWS, bool TAB, bool MC1, int WPB, bool VEER = false, bool OCC2 = false>
+__global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) void wf_step_ll_kernel(
     const WfConsts c, const WfTables* __restrict__ tab, const int* __restrict__ gidx, const double* __restrict__ ws_in,
     const double* __restrict__ wd_in, int wind_stride, const float* __restrict__ yaw_in, float* __restrict__ o_power,
     float* __restrict__ o_ws, float* __restrict__ o_wd, float* __restrict__ o_load, int B, const WfEnvArgs ea,
@@ -1235,6 +1240,16 @@ static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* g
   if constexpr (TAB) {
     if (wind_stride == 0) fn = (const void*)&wf_step_ll_kernel<G, S, true, TAB, MC1, kLLWaves, VEER>;
   }
+  if constexpr (TAB && S == 1 && MC1 && !VEER) {  // no third block per CU in this launch: the spill-free two-wave build
+    static const int n_cu = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+      return n;
+    }();
+    if (n_cu > 0 && grid <= 2 * n_cu)
+      fn = wind_stride == 0 ? (const void*)&wf_step_ll_kernel<G, S, true, TAB, MC1, kLLWaves, VEER, true>
+                            : (const void*)&wf_step_ll_kernel<G, S, false, TAB, MC1, kLLWaves, VEER, true>;
+  }
   return hipLaunchKernel(fn, dim3(grid), dim3(64 * kLLWaves), args, dyn_lds, s);
 }
 
@@ -1306,7 +1321,8 @@ extern "C" hipError_t wfk_launch_step_ll_fly(int G, int S, const WfConsts* c, co
   return hipErrorInvalidValue;
 }
 
-extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, int veer, hipFuncAttributes* a) {
+// (occ2: the launch reaches no third block per CU — launch_ll then takes the two-wave build of a one-slot family)
+extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int table, int veer, int occ2, hipFuncAttributes* a) {
 #define WF_LL_ATTR_VEER(G_, S_) hipFuncGetAttributes(a, shared_speed ? (const void*)&wf_step_ll_kernel<G_, S_, true, true, true, kLLWaves, true> : (const void*)&wf_step_ll_kernel<G_, S_, false, true, true, kLLWaves, true>)
   if (veer) {
     if (!table) return (G == 4 && S == 2) ? hipFuncGetAttributes(a, (const void*)&wf_step_ll_kernel<4, 2, false, false, true, kLLWaves, true>) : hipErrorInvalidValue;
@@ -1323,6 +1339,12 @@ extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int
     WF_LL_DISPATCH(4, 1, WF_LL_ATTR_FLY);
     WF_LL_DISPATCH(8, 1, WF_LL_ATTR_FLY);
     return hipErrorInvalidValue;
+  }
+#define WF_LL_ATTR_OCC2(G_, S_) hipFuncGetAttributes(a, shared_speed ? (const void*)&wf_step_ll_kernel<G_, S_, true, true, true, kLLWaves, false, true> : (const void*)&wf_step_ll_kernel<G_, S_, false, true, true, kLLWaves, false, true>)
+  if (occ2) {
+    WF_LL_DISPATCH(4, 1, WF_LL_ATTR_OCC2);
+    WF_LL_DISPATCH(8, 1, WF_LL_ATTR_OCC2);
+    WF_LL_DISPATCH(16, 1, WF_LL_ATTR_OCC2);
   }
   WF_LL_DISPATCH(4, 1, WF_LL_ATTR);
   WF_LL_DISPATCH(8, 1, WF_LL_ATTR);

@@ -755,11 +755,6 @@ RES_SRC_FN void res4_source_begin(int tid, int i, double m3m) {
     // secondary steering [A.3-2]: the three means on the source's own grid are geometry constants
     const double v_top = gam_top * c.k_top, v_bot = -gam_bot * c.k_bot, v_core = G_wr * c.k_core;
     s.val = 2.0 * (s.Vmean - v_core) * rcp64(v_top + v_bot);
-#ifdef RES_DEBUG
-    if (tid == 0 && blockIdx.x == 0 && i < 2)
-      printf("dbg i=%d cg=%g sg=%g m3m=%g ubar=%g ct_tab=%g ct=%g ai=%g Gwr=%g gam_top=%g Gt=%g val=%g tws0=%g tws1=%g tct1=%g tcs1=%g n_table=%d invTSR=%g invD=%g ieps2=%g Uinf=%g dec_a0=%g x=%g y=%g TI=%g\n",
-             i, cg, sg, m3m, ubar, ct_tab, ct, ai, G_wr, gam_top, s.Gt, s.val, R4.tws[0], R4.tws[1], R4.tct[1], R4.tcs[1], c.n_table, c.inv_TSR, c.inv_D, c.inv_eps2, R4.Uinf, R4.dec_a[0], s.x_i, s.y_i, s.TIs[0]);
-#endif
   }
 }
 
