@@ -844,7 +844,7 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
     info->grid_blocks = (int)(((h->n_groups > 0 ? (size_t)h->n_slots : (size_t)h->B) + info->envs_per_block - 1) / info->envs_per_block);
     const int ll_blocks = info->mixed_main_farms ? info->mixed_main_farms / info->envs_per_block : info->grid_blocks;
     WF_HIP(h, wfk_ll_func_attributes(ll_g, ll_s, h->wind_count == 1 ? 1 : 0, tab ? 1 : 0, veer ? 1 : 0,
-                                     (tab && ll_s == 1 && ll_blocks <= 2 * h->n_cu) ? 1 : 0, &a));
+                                     (ll_s == 1 && ll_blocks <= 2 * h->n_cu) ? 1 : 0, &a));
   }
   info->vgprs = a.numRegs;
   info->lds_bytes = (int)a.sharedSizeBytes; info->scratch_bytes = (int)a.localSizeBytes;

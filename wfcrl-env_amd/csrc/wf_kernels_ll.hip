@@ -1240,7 +1240,7 @@ static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* g
   if constexpr (TAB) {
     if (wind_stride == 0) fn = (const void*)&wf_step_ll_kernel<G, S, true, TAB, MC1, kLLWaves, VEER>;
   }
-  if constexpr (TAB && S == 1 && MC1 && !VEER) {  // no third block per CU in this launch: the spill-free two-wave build
+  if constexpr (S == 1 && (MC1 || !TAB) && !VEER) {  // no third block per CU in this launch: the spill-free two-wave build
     static const int n_cu = [] {
       int dev = 0, n = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -1333,7 +1333,12 @@ extern "C" hipError_t wfk_ll_func_attributes(int G, int S, int shared_speed, int
   }
 #define WF_LL_ATTR(G_, S_) hipFuncGetAttributes(a, shared_speed ? (const void*)&wf_step_ll_kernel<G_, S_, true, true, true, kLLWaves> : (const void*)&wf_step_ll_kernel<G_, S_, false, true, true, kLLWaves>)
 #define WF_LL_ATTR_FLY(G_, S_) hipFuncGetAttributes(a, (const void*)&wf_step_ll_kernel<G_, S_, false, false, true, kLLWaves>)
+#define WF_LL_ATTR_FLY_OCC2(G_, S_) hipFuncGetAttributes(a, (const void*)&wf_step_ll_kernel<G_, S_, false, false, true, kLLWaves, false, true>)
   if (!table) {
+    if (occ2) {
+      WF_LL_DISPATCH(4, 1, WF_LL_ATTR_FLY_OCC2);
+      WF_LL_DISPATCH(8, 1, WF_LL_ATTR_FLY_OCC2);
+    }
     WF_LL_DISPATCH(4, 2, WF_LL_ATTR_FLY);
     WF_LL_DISPATCH(2, 2, WF_LL_ATTR_FLY);
     WF_LL_DISPATCH(4, 1, WF_LL_ATTR_FLY);
