@@ -1,0 +1,32 @@
+"""GPU box: where a stage of the FOUR-wave float64 kernel goes (a -DWF_RES_STAMP build, tools/res4_stamps.sh): work and
+barrier wait per phase for a column wave (wave 0) and for the scalar wave (wave 3), cycles per source stage."""
+import ctypes as C, json, os, sys
+os.environ.setdefault("WF_RISK_RESOLVE", "0")
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wfcrl_env_amd.backend import WfStep
+from wfcrl_env_amd import _lib
+lib = _lib.load()
+L = json.load(open(os.path.join(ROOT, "wfcrl-env_amd", "environments", "layouts.json")))
+tc = L["Turb_TCRWP_"]
+L["Turb16_TCRWP_"] = {"num_turbines": 16, "xcoords": tc["xcoords"][:16], "ycoords": tc["ycoords"][:16]}
+for name, B, per_farm in (("Ablaincourt_", 4096, True), ("Turb16_TCRWP_", 16384, True), ("Ormonde_", 8192, False), ("HornsRev1_", 16384, True), ("HornsRev2_", 16384, False)):
+    l = L[name]; N = l["num_turbines"]
+    rng = np.random.default_rng(1)
+    yaw = torch.from_numpy(rng.uniform(-30, 30, (B, N)).astype(np.float32)).cuda()
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    if per_farm: w.set_wind(np.clip(8 * rng.weibull(8, B), 3, 28), rng.normal(270, 20, B) % 360)
+    else: w.set_wind(8.0, 263.0)
+    w.set_risk_resolve(1)
+    out = w.step(yaw); w.sync()
+    buf = (C.c_ulonglong * 16)()
+    lib.wfk_res4_stamps(buf, 1)
+    w.step(yaw, out); w.sync()
+    lib.wfk_res4_stamps(buf, 0)
+    v = list(buf); n = max(v[12], 1)
+    print(f"{name} N={N}: {n} farms re-solved by the four-wave kernel ({w.resolve_stats()['n_resolved']} flagged); cycles per source stage")
+    for wv, nm in ((0, "column wave 0"), (6, "scalar wave 3")):
+        x = [v[wv + k] / n / N for k in range(6)]
+        print(f"  {nm}: phase 1 work {x[0]:6.0f} wait {x[1]:6.0f} | phase 2 work {x[2]:6.0f} wait {x[3]:6.0f} | phase 3 work {x[4]:6.0f} wait {x[5]:6.0f} | sum {sum(x):6.0f}")
+    w.close()

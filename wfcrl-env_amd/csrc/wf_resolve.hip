@@ -555,11 +555,19 @@ __device__ __forceinline__ void res_stage_tables(Shared& S, const WfResolveConst
 
 #if defined(WF_RES_STAMP) && !RES_MT  // debug build (tools/res_stamps.py): wave cycles per phase, summed over the launch
 __device__ unsigned long long wf_res_stamp[8];
+// the four-wave kernel (tools/res4_stamps.py): [wave 0 | wave 3][work phase 1, wait 1, work 2, wait 2, work 3, wait 3], then farms
+__device__ unsigned long long wf_res4_stamp[16];
+#define RES4_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define RES4_ACC(k, a, b) st4[k] += (b) - (a)
 #define RES_T(v) const unsigned long long v = __builtin_readcyclecounter()
 #define RES_ACC(k, a, b) st_acc[k] += (b) - (a)
 #else
 #define RES_T(v)
 #define RES_ACC(k, a, b)
+#endif
+#if !defined(WF_RES_STAMP) || RES_MT
+#define RES4_T(v)
+#define RES4_ACC(k, a, b)
 #endif
 __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a_arg, int n_pad, int min_count) {
   const int lane = threadIdx.x;
@@ -1076,12 +1084,16 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
     __syncthreads();
     if ((tid >> 6) == 3) res4_source_begin(tid, 0, res4_rotor_m3(0));
     __syncthreads();
+#if defined(WF_RES_STAMP) && !RES_MT
+    unsigned long long st4[6] = {0, 0, 0, 0, 0, 0};
+#endif
     for (int i = 0; i < N; ++i) {
       // (the thread index is made opaque once per source: everything derived from it — wave, lane, a dozen LDS addresses per
       // phase — is recomputed where it is used instead of being hoisted out of this loop and held, or spilled, across it)
       int tq = tid;
       asm volatile("" : "+v"(tq));
       const int wq = tq >> 6;
+      RES4_T(p0);
       if (wq < 3) {
         if (R4.c.sw_tv) res4_transverse_pass(tq, i, wq);
         else if ((tq & 63) < 3) {  // (no transverse velocities: the side buffer holds the unchanged — zero — state)
@@ -1092,7 +1104,9 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
       } else {
         res4_source_chain(tq, i);
       }
+      RES4_T(p1);
       __syncthreads();
+      RES4_T(p2);
       double dTI = 0.0, m3_spec = 0.0;
       if (wq < 3) dTI = res4_recovery(tq, i);
       if (i + 1 < N) {
@@ -1102,16 +1116,30 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
           m3_spec = res4_rotor_m3(i + 1);
           res4_source_begin(tq, i + 1, m3_spec);
         }
+        RES4_T(p3);
         __syncthreads();
+        RES4_T(p4);
+        RES4_ACC(2, p2, p3); RES4_ACC(3, p3, p4);
         if (wq < 3) {
           res4_turbulence_pass(tq, i, wq);
         } else {  // (... and confirmed, or derived again, beside the turbulence pass)
           const double m3_now = res4_rotor_m3(i + 1);
           if (__double_as_longlong(m3_now) != __double_as_longlong(m3_spec)) res4_source_begin(tq, i + 1, m3_now);
         }
+        RES4_T(p5);
+        RES4_ACC(4, p4, p5);
       }
+      RES4_T(p6);
       __syncthreads();
+      RES4_T(p7);
+      RES4_ACC(0, p0, p1); RES4_ACC(1, p1, p2); RES4_ACC(5, p6, p7);
     }
+#if defined(WF_RES_STAMP) && !RES_MT
+    if ((tid & 63) == 0 && ((tid >> 6) == 0 || (tid >> 6) == 3)) {
+      for (int k = 0; k < 6; ++k) atomicAdd(&wf_res4_stamp[((tid >> 6) ? 6 : 0) + k], st4[k]);
+      if (tid == 0) atomicAdd(&wf_res4_stamp[12], 1ull);
+    }
+#endif
     res4_outputs(tid, a, b, gofs);
     if (tid == 0) a.flags[b] = 0;
   }
@@ -1124,6 +1152,17 @@ extern "C" int wfk_res_stamps(unsigned long long* out, int reset) {
   if (e == hipSuccess && reset) {
     unsigned long long z[8] = {};
     e = hipMemcpyToSymbol(HIP_SYMBOL(wf_res_stamp), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
+
+#if defined(WF_RES_STAMP) && !RES_MT
+extern "C" int wfk_res4_stamps(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res4_stamp), sizeof(wf_res4_stamp));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[16] = {};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(wf_res4_stamp), z, sizeof(z));
   }
   return (int)e;
 }
