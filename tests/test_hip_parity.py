@@ -1514,3 +1514,33 @@ def test_mixed_launch_for_a_batch_just_beyond_whole_rounds(layouts):
     assert np.array_equal(o1["power"][:M], out["power"][:M])  # the family's share: the same kernel, the same bits
     assert np.abs(o1["power"][M:] / np.maximum(out["power"][M:], 1e3) - out["power"][M:] / np.maximum(out["power"][M:], 1e3)).max() < 2e-4
     w1.close()
+
+
+def test_one_slot_families_run_their_two_wave_build_when_no_third_block_per_cu(layouts):
+    """Round 5: the one-slot one-block kernels exist in two builds — three waves per SIMD (168 registers: they spill since the
+    hot records go through LDS) for launches that reach a third block per CU, two waves per SIMD (no spill, no private segment)
+    for all others (wf_kernels_ll.hip: OCC2; launch_ll picks by the launch's blocks per CU).  kernel_info reports the build that
+    runs; both are held to the oracle."""
+    import parity
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    x, y, N = l["xcoords"], l["ycoords"], 80
+    for B, per_farm, want_scratch in ((8192, False, False), (12288, False, True), (8192, True, False)):
+        rng = np.random.default_rng(B + per_farm)
+        yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+        w = WfStep(x, y, env_batch=B, kernel_choice=dict(one_block="16" if not per_farm else "8", calibrate=False))
+        if per_farm:
+            ws, wd = np.clip(8 * rng.weibull(8, B), 3, 28), rng.normal(270, 20, B) % 360
+        else:
+            ws, wd = 8.0, 263.0
+        w.set_wind(ws, wd)
+        info = w.kernel_info()
+        assert info["one_block_kernel"] == 1 and info["slots_per_lane"] == 1 and info["pair_table"] == (0 if per_farm else 1)
+        assert (info["scratch_bytes"] > 0) == want_scratch, info
+        assert info["vgprs"] == 168 if want_scratch else 168 < info["vgprs"] <= 256, info
+        out = w.step(yaw)
+        idx = np.arange(0, B, 61)
+        ref = _oracle(x, y, ws if not per_farm else ws[idx], wd if not per_farm else wd[idx], yaw[idx])
+        parity.check({k: v[idx] for k, v in out.items()}, ref, w.risk_flags()[idx], max_flagged_frac=0.1)
+        w.close()
