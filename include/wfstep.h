@@ -201,6 +201,9 @@ int wf_sync(wf_handle* h);
  *                       Such farms are ALWAYS solved again in float64 and the flag cleared, in every wf_set_risk_resolve
  *                       mode (round 5; round 4 exempted them from every bound on the float32-only path): a caller never
  *                       sees this flag after a step, only in wf_get_resolve_stats' raw flags.
+ *   WF_RISK_NEGATIVE_SPEED a rotor-grid speed that is not positive: summed deficits beyond 1 in an unphysically tight farm
+ *                       (the reference keeps computing there, and so does this path).  The cube mean of mixed-sign speeds
+ *                       cancels: float32 keeps about 1e-5 of the rotor wind speed of such a turbine (round-5 fuzz).
  * Farms with flag 0 match the float64 path within the parity tolerances (power 1e-4 of max(P, 1 kW), wind speed 5e-5,
  * direction 3e-4 deg, TI 5e-6).  By default (wf_set_risk_resolve mode 1) the flagged farms are solved again in float64 behind
  * every step and no flag is left.  A FLAGGED farm left in float32 (mode 0, the opt-out) may differ by the bounded signature of
@@ -220,6 +223,7 @@ int wf_sync(wf_handle* h);
 #define WF_RISK_POWER_KNEE 2
 #define WF_RISK_THRUST_RAMP 4
 #define WF_RISK_THRUST_UNITY 8
+#define WF_RISK_NEGATIVE_SPEED 16
 int wf_set_risk_guard(wf_handle* h, double rel_band); /* default 2e-5 (20 x the float32 deficit error measured at the
                                                          threshold); 0 disables WF_RISK_OVERLAP */
 int wf_get_risk_flags(wf_handle* h, int* flags, int on_device);

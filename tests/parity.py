@@ -37,6 +37,7 @@ LARGE_FARM_FACTOR = 3.0  # N > 128, see above
 # genuine flip, float64 margin 9.8e-6 — fuzz_api seed 802, session 15
 FLAGGED_BOUND = dict(power=1e-1, ws=2e-2, wd=0.1, ti=2e-2, std=5e-2)
 RISK_OVERLAP, RISK_POWER_KNEE, RISK_THRUST_RAMP = 1, 2, 4
+RISK_NEGATIVE_SPEED = 16  # a rotor-grid speed <= 0 (unphysically tight farm): float32 keeps ~1e-5 of that turbine's wind speed
 RISK_THRUST_UNITY = 8  # Ct > 0.995 (user tables): never left in float32 — re-solved in float64 in every mode, so never seen after a step
 # A flag only excuses what its event can move (round 3; tests/tools/flag_stats.py on 10 x 4096 farms,
 # profiles/r03_flag_stats.txt): a farm flagged for the power knee ALONE has a wind field as good as an unflagged farm's —
@@ -81,6 +82,22 @@ def flagged_within(e, flags, n_turbines):
     return ok
 
 
+def _ws_scale(ws_ref, B):
+    """What a wind-speed error is measured against: the speed itself (at least 0.1 m/s) — except on a turbine whose rotor-mean
+    speed is NOT POSITIVE.  An unphysically tight farm (summed deficits beyond 1 behind a thrust table clipped at 0.9999: round-5
+    fuzz, case 5041 / 1720) leaves such a rotor the small difference u = U_inf - W of two numbers of free-stream size, the
+    reference keeps computing, and a relative deviation of 6e-7 in W — float64 device kernel against the oracle — shows as
+    5e-5 of |u|.  There the error is measured against the farm's largest speed (the free stream), which is what the
+    deficits are accurate to; nothing changes for a turbine in a physical state."""
+    w = np.asarray(ws_ref, dtype=np.float64)
+    scale = np.maximum(np.abs(w), 0.1)
+    neg = w <= 0.0
+    if neg.any():
+        free = np.abs(w).reshape(B, -1).max(axis=1).reshape((B,) + (1,) * (w.ndim - 1))
+        scale = np.where(neg, np.maximum(free, 0.1), scale)
+    return scale
+
+
 def errors(got, ref):
     """Per-farm worst errors (B,) of each output family."""
     g = {k: np.asarray(v.cpu().numpy() if hasattr(v, "cpu") else v, dtype=np.float64) for k, v in got.items()
@@ -97,7 +114,7 @@ def errors(got, ref):
     return dict(
         **extra,
         power=(np.abs(g["power"] - ref["power"]) / np.maximum(ref["power"], 1e3)).reshape(B, -1).max(axis=1),
-        ws=(np.abs(g["wind_speed"] - ref["wind_speed"]) / np.maximum(ref["wind_speed"], 0.1)).reshape(B, -1).max(axis=1),
+        ws=(np.abs(g["wind_speed"] - ref["wind_speed"]) / _ws_scale(ref["wind_speed"], B)).reshape(B, -1).max(axis=1),
         wd=np.abs(g["wind_direction"] - ref["wind_direction"]).reshape(B, -1).max(axis=1),
         ti=np.abs(g["load"][..., 0] - ref["load"][..., 0]).reshape(B, -1).max(axis=1),
         # relative to max(1e-4, 2e-5 U) per farm, expressed on the 1e-4 scale of TOL["std"]

@@ -1544,3 +1544,37 @@ def test_one_slot_families_run_their_two_wave_build_when_no_third_block_per_cu(l
         ref = _oracle(x, y, ws if not per_farm else ws[idx], wd if not per_farm else wd[idx], yaw[idx])
         parity.check({k: v[idx] for k, v in out.items()}, ref, w.risk_flags()[idx], max_flagged_frac=0.1)
         w.close()
+
+
+def test_negative_rotor_speed_keeps_the_reference_turbulence_floor():
+    """Round-5 fuzz, case 5041 / 1720 (tests/golden/negative_rotor_speed_case.npz: the case's inputs): a 7 x 3 farm at 1.6 D
+    behind a thrust table clipped at 0.9999 drives one rotor's mean speed NEGATIVE; FLORIS keeps computing — the yaw-added
+    mixing term I_tot / ubar turns negative there and takes the turbine's TI to -0.56, which the solver's
+    maximum(sqrt(ti_added^2 + ambient^2), TI) over ALL turbines at the end of the same source step lifts back to ambient
+    (oracle: 0.04).  Every kernel family stored TI + dTI unlifted.  Float32 kernels (both families), the flagged-farm re-solve
+    and the float64 kernels on every farm against the oracle."""
+    import parity
+    from oracle.floris_gch_numpy import ModelParams
+    from wfcrl_env_amd.backend import WfStep
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "negative_rotor_speed_case.npz"))
+    model = eval(str(d["model"]))
+    ren = {"rotor_diameter": "D", "hub_height": "HH"}
+    mp = ModelParams(**{ren.get(k, k): v for k, v in model.items()})
+    x, y, yaw = d["x"], d["y"], d["yaw"]
+    ws, wd = float(d["ws"][0]), float(d["wd"][0])
+    ref = _oracle(x, y, ws, wd, yaw, mp)
+    assert ref["wind_speed"].min() < -1.0 and np.isclose(ref["load"][..., 0].min(), 0.04)  # the regime, and FLORIS' floor
+    for choice, mode in ((dict(slot=(32, 4), one_block="4"), 0), (dict(slot=(32, 4), one_block=False), 0), (dict(one_block="2x2"), 1), (None, 2)):
+        w = WfStep(x, y, env_batch=yaw.shape[0], model=dict(model), kernel_choice=choice)
+        w.set_risk_resolve(mode)
+        w.set_wind(ws, wd)
+        out = w.step(yaw)
+        if mode == 0:
+            parity.check(out, ref, w.risk_flags(), max_flagged_frac=1.0)
+        else:
+            # (TOL also for the float64 kernels: the rotor with the negative mean is the difference of two free-stream-sized
+            # numbers, and the kernels' combined deficit sits 6e-7 from the oracle's — parity._ws_scale)
+            parity.check_strict(out, ref, parity.TOL)
+        assert np.abs(np.asarray(out["load"])[..., 0] - ref["load"][..., 0]).max() < 1e-5
+        w.close()

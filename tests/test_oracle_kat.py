@@ -264,3 +264,27 @@ def test_thrust_ramp_is_ill_conditioned_in_float64():
 def test_overlap_flip_case_sits_on_the_threshold():
     i, ref = _regime("overlap_flip")
     assert ref["margin"][0] < 1e-6
+
+
+def test_negative_rotor_speed_regime_of_the_oracles():
+    """tests/golden/negative_rotor_speed_case.npz (round-5 fuzz, case 5041 / 1720): a rotor whose mean speed goes NEGATIVE behind
+    a thrust table clipped at 0.9999.  FLORIS keeps computing; the mixing term takes that turbine's TI below zero and the
+    solver's maximum(sqrt(ti_added^2 + ambient^2), TI) over all turbines lifts it back to ambient within the same source step.
+    Both restatements do exactly that and agree."""
+    import os
+
+    from conftest import ROOT
+    from oracle import c_oracle
+    from oracle import floris_gch_numpy as fn
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "negative_rotor_speed_case.npz"))
+    model = eval(str(d["model"]))
+    ren = {"rotor_diameter": "D", "hub_height": "HH"}
+    mp = fn.ModelParams(**{ren.get(k, k): v for k, v in model.items()})
+    yaw = d["yaw"][[1, 3]].astype(np.float64)
+    a = fn.farm_step_batch(d["x"], d["y"], d["ws"], d["wd"], yaw, mp)
+    b = c_oracle.farm_step_batch(d["x"], d["y"], d["ws"], d["wd"], yaw, mp)
+    for k in a:
+        assert np.abs(a[k] - b[k]).max() <= 1e-9 * max(1.0, np.abs(a[k]).max()), k
+    assert a["wind_speed"].min() < -2.0                      # the regime
+    assert abs(a["load"][..., 0].min() - 0.04) < 1e-15       # ... and the floor the reference's maximum() leaves

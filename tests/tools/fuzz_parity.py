@@ -171,6 +171,9 @@ def run(n_cases, seed, only=-1, resolve=False):
                 print(k, dict(case=case, N=N, G=G, S=S, LL=w.kernel_info()["one_block_kernel"] and llg, B=B, mode=mode, wd0=wd0, ws0=ws0,
                               model={a: (b if not isinstance(b, list) else f"<{len(b)} values, max {max(b):.4f}>") for a, b in model.items()},
                               table=w.kernel_info()["pair_table"]), r, flush=True)
+            if only >= 0 and os.environ.get("WF_FUZZ_DUMP"):  # the whole case, for a post-mortem (tools/replay_fuzz_case.py)
+                np.savez(os.path.join(os.environ["WF_FUZZ_DUMP"], f"case_{seed}_{case}_{mode}_{int(ws[-1] * 1000)}.npz"), x=x, y=y, ws=ws, wd=wd, yaw=yaw,
+                         model=np.array(repr(model)), choice=np.array(repr(choice)), flags=flags, **{"got_" + k_: np.asarray(v_) for k_, v_ in got.items()})
             if only >= 0:
                 np.set_printoptions(linewidth=220, precision=5, suppress=True)
                 p = np.abs(got["power"].astype(np.float64) - ref["power"]) / np.maximum(ref["power"], 1e3)

@@ -133,6 +133,7 @@ struct WfGroupArgs {
 #define WF_RISK_POWER_KNEE 2
 #define WF_RISK_THRUST_RAMP 4
 #define WF_RISK_THRUST_UNITY 8
+#define WF_RISK_NEGATIVE_SPEED 16
 
 // Pair-coefficient table (shared wind only): for source i and target t (sorted indices) the
 // transverse-velocity contribution is linear in the source's circulations.  The tip vortices' circulations share

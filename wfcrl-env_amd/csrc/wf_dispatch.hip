@@ -757,7 +757,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   // (wf_kernel_common.h: table_ct) — and that only when the handle's thrust table gets there (nrel_5MW does not: nothing
   // is enqueued for it).
   const int mode = h->types.empty() ? h->resolve_mode : 2;  // (several turbine definitions: the float64 kernels solve every farm)
-  int mask = mode == 1 ? 0xF : 0;
+  int mask = mode == 1 ? 0x1F : 0;
   if (mode == 0) {
     double ct_max = 0.0;
     for (double v : h->tct) ct_max = v > ct_max ? v : ct_max;

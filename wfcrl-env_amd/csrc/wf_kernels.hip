@@ -719,7 +719,11 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const float dTI = c.gch_gain * Imix;  // gch_gain is 0 with enable_yaw_added_recovery off
       if (lane == src) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) st.TI[0][j] += dTI;
+        // (FLORIS ends every source step with TI = maximum(sqrt(ti_added^2 + ambient^2), TI) over ALL turbines — for the source's
+        // own turbine that is max(ambient, TI + dTI): a no-op unless its rotor-mean speed is NEGATIVE (an unphysically tight farm
+        // behind a thrust table clipped at 0.9999), where I_tot / ubar and with it dTI turn negative; the deficit pass below
+        // still sees TI + dTI, as the reference's does.  Round-5 fuzz, case 5041/1720: TI -0.565 against 0.04.)
+        for (int j = 0; j < 3; ++j) st.TI[0][j] = fmaxf(st.TI[0][j] + dTI, amb0);
       }
       sc.sy0v = c.sz0v * cg;
       if constexpr (VEER) sc.sy0v *= c.cos_veer;
@@ -972,6 +976,13 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
           su = fmaf(du, du, su); sv = fmaf(dv, dv, sv); sw = fmaf(dw, dw, sw);
         }
         const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
+        {  // a rotor-grid speed that is not positive (an unphysically tight farm: summed deficits beyond 1; the reference keeps
+           // computing): the cube mean of mixed-sign speeds cancels, float32 keeps 1e-5 of it at best
+          float umin = U[0];
+#pragma unroll
+          for (int q = 1; q < 9; ++q) umin = fminf(umin, U[q]);
+          if (!(umin > 0.0f)) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_NEGATIVE_SPEED);
+        }
         const float cy = L.cg[eiw][t];
         const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cy));
         float pslope;

@@ -859,7 +859,9 @@ __global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) vo
       X.dTI = c.gch_gain * Imix;
       if (lane == src) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) TI[ps][j] += X.dTI;
+        // (the stored TI: max(ambient, TI + dTI), as FLORIS' maximum over all turbines at the end of the source step leaves it —
+        // see wf_kernels.hip; the passes of this source go on with TI + dTI)
+        for (int j = 0; j < 3; ++j) TI[ps][j] = fmaxf(TI[ps][j] + X.dTI, amb0);
       }
       Sc.sy0v = c.sz0v * cg;
       if constexpr (VEER) Sc.sy0v *= c.cos_veer;
@@ -1153,6 +1155,12 @@ __global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) vo
         su = fmaf(du, du, su); sv = fmaf(dv, dv, sv); sw = fmaf(dw, dw, sw);
       }
       const float wsp = fcbrt_pos(m3 * (1.0f / 9.0f));
+      {  // (a rotor-grid speed that is not positive: WF_RISK_NEGATIVE_SPEED, see wf_kernels.hip)
+        float umin = U[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) umin = fminf(umin, U[k]);
+        if (!(umin > 0.0f)) atomicOr(&risk_lds[wave][eiw], (unsigned)WF_RISK_NEGATIVE_SPEED);
+      }
       const float veff = c.dens_f * wsp * fexp2(c.pw * flog2(cg_t[p]));
       float pslope;
       const float pwr = c.rho * table_pw(c, T, veff, pslope);

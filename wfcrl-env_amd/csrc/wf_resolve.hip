@@ -327,7 +327,9 @@ RES_SRC_FN void res_source_finish(int i) {
   const double sM = sqrt_pos(M0);
   const double sz0v = D * 0.5 * sqrt_pos((ct * rcp64(2.0 * (1.0 - s_c))) * i1sc);
   const int lane = res_tid();
-  if (lane < 3) RES_ST(27 + lane, i) = s0.TIs[lane] + dTI;
+  // (stored: max(ambient, TI + dTI) — FLORIS' maximum(sqrt(ti_added^2 + ambient^2), TI) over all turbines at the end of the
+  // source step lifts a TI that a NEGATIVE rotor-mean speed drove below ambient; the deficit pass goes on with TI + dTI)
+  if (lane < 3) RES_ST(27 + lane, i) = fmax(s0.TIs[lane] + dTI, c.amb);
   if (lane == 0) {
     SrcShared& s = R.s;
     s.dTI = dTI; s.cgd = cgd; s.s_cc = s_cc; s.s_c = s_c; s.th0 = th0; s.tan_th0 = tan_th0; s.M0 = M0;
@@ -882,7 +884,7 @@ RES_SRC_FN double res4_recovery(int tid, int i) {
   const double vbar = vsum * (1.0 / 9.0), wbar = wsum * (1.0 / 9.0);
   const double I_tot = sqrt_nn((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) * rcp64(ubar);
   const double dTI = c.sw_yar ? c.gch_gain * (I_tot - I) : 0.0;
-  if (wave < 3 && (tid & 63) == 0) RES4_ST(27 + wave, i) = s0.TIs[wave] + dTI;
+  if (wave < 3 && (tid & 63) == 0) RES4_ST(27 + wave, i) = fmax(s0.TIs[wave] + dTI, c.amb);  // (stored: see res_source_finish)
   if (wave < 3 && (tid & 63) < 3) {  // commit the source's own column (nothing reads it before the next barrier)
     const int q = wave * 3 + (tid & 63);
     RES4_ST(9 + q, i) = R4.own[q];
