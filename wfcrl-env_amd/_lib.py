@@ -18,6 +18,8 @@ WF_OK = 0
 WF_RISK_OVERLAP = 1     # a deficit within the guard band of the overlap threshold (include/wfstep.h)
 WF_RISK_POWER_KNEE = 2  # a turbine on a steep segment (cut-in / cut-out) of the power table
 WF_RISK_THRUST_RAMP = 4  # a turbine on the cut-in ramp / cut-out drop of the thrust table (v |dCt/dv| > 5)
+WF_RISK_THRUST_UNITY = 8  # a thrust coefficient above 0.995 (user tables): always re-solved in float64, only seen in the raw flags
+WF_RISK_NEGATIVE_SPEED = 16  # a rotor-grid speed that is not positive (an unphysically tight farm)
 WF_E = {-1: "WF_E_INVALID", -2: "WF_E_UNSUPPORTED", -3: "WF_E_NODEVICE", -4: "WF_E_HIP", -5: "WF_E_NOMEM"}
 
 _MODEL_DOUBLES = (
