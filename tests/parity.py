@@ -86,8 +86,9 @@ def _ws_scale(ws_ref, B):
     """What a wind-speed error is measured against: the speed itself (at least 0.1 m/s) — except on a turbine whose rotor-mean
     speed is NOT POSITIVE.  An unphysically tight farm (summed deficits beyond 1 behind a thrust table clipped at 0.9999: round-5
     fuzz, case 5041 / 1720) leaves such a rotor the small difference u = U_inf - W of two numbers of free-stream size, the
-    reference keeps computing, and a relative deviation of 6e-7 in W — float64 device kernel against the oracle — shows as
-    5e-5 of |u|.  There the error is measured against the farm's largest speed (the free stream), which is what the
+    reference keeps computing, and a relative deviation of 6e-7 in W — float64 device kernel against the oracle: two orders
+    of summation of an amplitude 1 - sqrt(1 - Ct' D^2 / (8 sigma_y sigma_z)) that sits at the clip of its root at Ct = 0.9999,
+    profiles/r05_f64_deviation_probe.txt — shows as 5e-5 of |u|.  There the error is measured against the farm's largest speed (the free stream), which is what the
     deficits are accurate to; nothing changes for a turbine in a physical state."""
     w = np.asarray(ws_ref, dtype=np.float64)
     scale = np.maximum(np.abs(w), 0.1)
