@@ -601,6 +601,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const int i = blk * G + li;
       if (TAB && i + 1 < N) stage_row(i + 1);  // lands in the other buffer while this source is processed
       // ---- A. the source's state (slot 0 of lane `li` of the group) ------------------------
+      __builtin_amdgcn_s_setprio(3);  // (the per-source scalar phases are latency chains: ahead of the other wave's passes, wf_kernels_ll.hip)
       float vsum = 0.0f;
 #pragma unroll
       for (int q = 0; q < 9; ++q) vsum += st.V[0][q];
@@ -626,6 +627,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const float cg = L.cg[eiw][i], sg = L.sg[eiw][i];
 
       // ---- C. pass 1: transverse velocities on every target at or downstream of the source --
+      __builtin_amdgcn_s_setprio(0);
       const float rho_tab = (TAB && Gwt != 0.0f) ? Gy * frcp(Gwt) : 0.0f;  // (apply_tab's ratio form)
       float vbar = 0.0f, wbar = 0.0f;  // mean (V,W) of the SOURCE after its own contribution
 #pragma unroll
@@ -665,6 +667,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       wbar = __shfl(wbar, src) * (1.0f / 9.0f);
 
       // ---- B2. steering + deflection constants [A.3-2, A.3-3] (kept out of pass 1's live range) ----
+      __builtin_amdgcn_s_setprio(3);
       // secondary steering
       // (c.sw_steer is 1, or 0 with enable_secondary_steering off: the deflection model then sees the commanded yaw)
       float val = c.sw_steer * (Vmean - Gwr * c.ks_core) * frcp(gt * c.ks_top - gb * c.ks_bot);
@@ -748,6 +751,7 @@ __global__ __launch_bounds__(64 * WPB, (min_blocks_per_cu<G, S, TAB, WPB>())) vo
       const ColConsts k0 = col_consts(TIs[0], TIs[0] + dTI);
 
       // ---- E. pass 2: deflection, deficit, SOSFS, wake-added turbulence ----------------------
+      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int p = 0; p < S; ++p) {
         if (p > 0 && p >= live) break;

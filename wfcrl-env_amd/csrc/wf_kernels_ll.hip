@@ -755,6 +755,10 @@ __global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) vo
     auto own_source = [&](auto PS, int i, const float* recs) {
       constexpr int ps = decltype(PS)::value;
       const int src = gbase + ((i - first_own) - ps * G);  // owner lane
+      // The own-source step is a dependent chain (~4 300 cycles of latency); the SIMD's other wave is usually in its replay,
+      // which is throughput: with equal priority the two alternate and every instruction of the chain also waits for its turn.
+      // Raised priority for the chain: HornsRev1 x 65 536 0.902 -> 0.861 ms on one box (profiles/r05_setprio_ab.txt).
+      __builtin_amdgcn_s_setprio(3);
       WF_T(so_0);
       // A. the source's state
       float vsum = 0.0f;
@@ -934,6 +938,7 @@ __global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) vo
       });
       WF_T(so_5);
       WF_ACC(10, so_4, so_5);
+      __builtin_amdgcn_s_setprio(0);
     };
 
     for (int cq = 0; cq < n_chunks; ++cq, ++q) {
