@@ -1044,6 +1044,9 @@ __global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) vo
             });
           };
           ColdRec cold_b = {};
+          // (the deficit pass waits for its cold records: ahead of the other wave's transverse pass and outputs, behind its
+          // own-source chain — HornsRev1 x 65 536 another -2.4 %, profiles/r05_setprio_ab.txt)
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
           while (near_bits) {
             const int k0 = __builtin_ctzll(near_bits) / GS;
@@ -1054,6 +1057,7 @@ __global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) vo
             near_bits &= near_bits - 1ull;
             near_step(k1, cold_b, cold_nx);
           }
+          __builtin_amdgcn_s_setprio(0);
         }
       } else {
         // a wind per farm: the pair geometry comes from the farm's own float64 coordinates (the source's travel with its
