@@ -35,3 +35,18 @@ class OracleStep:
 class OracleFlorisInterface(HipFlorisInterface):
     def _make_backend(self, xcoords, ycoords, device_id, model):
         return OracleStep(xcoords, ycoords)
+
+
+class OracleStep64(OracleStep):
+    """The same stand-in handing back float64 (no float32 device surface in between): what the reference's
+    FLORIS object hands its interface.  Used where host-side arithmetic is compared at 1e-12."""
+
+    def step(self, yaw, out=None):
+        self.calls += 1
+        yaw = np.asarray(yaw, np.float32).reshape(self.env_batch, self.num_turbines).astype(np.float64)
+        return dict(c_oracle.farm_step_batch(self.x, self.y, self.ws, self.wd, yaw, nthreads=1))
+
+
+class OracleFlorisInterface64(HipFlorisInterface):
+    def _make_backend(self, xcoords, ycoords, device_id, model):
+        return OracleStep64(xcoords, ycoords)
