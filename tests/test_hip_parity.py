@@ -1516,6 +1516,35 @@ def test_mixed_launch_for_a_batch_just_beyond_whole_rounds(layouts):
     w1.close()
 
 
+def test_mixed_off_after_a_calibrated_mixed_handle_is_one_launch(layouts):
+    """the process-wide calibration cache was keyed without `mixed`: a handle created with mixed=False AFTER a
+    default handle of the same configuration had calibrated a mixed launch inherited the split (two launches, against the
+    header's "0: always one launch").  Neither handle forces `one_block`, so both go through the calibration and its cache."""
+    import torch
+
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["HornsRev1_"]
+    N, B = 80, 69632
+    rng = np.random.default_rng(697)
+    yaw = torch.from_numpy(rng.uniform(-30, 30, (B, N)).astype(np.float32)).cuda()
+    w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+    w.set_wind(8.0, 270.0)
+    w.step(yaw); w.sync()  # calibrates (and caches) this configuration
+    first = w.calibration()
+    info = w.kernel_info()
+    w.close()
+    w1 = WfStep(l["xcoords"], l["ycoords"], env_batch=B, kernel_choice=dict(mixed=False))
+    w1.set_wind(8.0, 270.0)
+    o1 = w1.step(yaw); w1.sync()
+    assert w1.kernel_info()["mixed_main_farms"] == 0, (info, first, w1.kernel_info())
+    assert w1.calibration()["mixed_main_farms"] == 0
+    idx = np.concatenate([rng.choice(B, 32, replace=False), [65535, 65536, B - 1]])
+    ref = _oracle(l["xcoords"], l["ycoords"], 8.0, 270.0, yaw.cpu().numpy()[idx])
+    _check(dict({k: v.cpu().numpy()[idx] for k, v in o1.items()}, flags=w1.risk_flags()[idx]), ref)
+    w1.close()
+
+
 def test_one_slot_families_run_their_two_wave_build_when_no_third_block_per_cu(layouts):
     """Round 5: the one-slot one-block kernels exist in two builds — three waves per SIMD (168 registers: they spill since the
     hot records go through LDS) for launches that reach a third block per CU, two waves per SIMD (no spill, no private segment)

@@ -60,6 +60,15 @@ def _rel(a, b, floor=1e-30):
     return float(np.max(np.abs(np.asarray(a, float) - b) / np.maximum(np.abs(b), floor)))
 
 
+def reward_tol(sc, want, rel):
+    """|d reward| allowed for a relative error `rel` of the UNSHAPED reward: a percentage shaper (rewards.py:24-46) turns
+    r into (r - ref) / ref, which divides the error by the small difference it reports."""
+    kind = sc["shaper"][0]
+    if kind == "DoNothingReward":
+        return rel * max(abs(want), 1e-3)
+    return rel * abs(want + 1.0) * (2.0 if kind == "StepPercentage" else 1.0) + 1e-15
+
+
 def replay_central(env, z, name, meta, tol, yaw_exact=True):
     sc = meta["scenario"]
     g = lambda k: z[f"{name}/{k}"]
@@ -90,7 +99,7 @@ def replay_central(env, z, name, meta, tol, yaw_exact=True):
         assert isinstance(r, np.ndarray) and r.shape == (1,)
         check_obs(obs, t + 1, meta["obs_dtypes_step"])
         want_r = g("reward")[t]
-        worst["reward"] = max(worst.get("reward", 0), abs(float(r[0]) - want_r) / max(abs(want_r), 1e-3))
+        worst["reward"] = max(worst.get("reward", 0), abs(float(r[0]) - want_r) / reward_tol(sc, want_r, 1.0))
         worst["power"] = max(worst.get("power", 0), float(np.max(np.abs(info["power"] - g("power")[t]) / np.maximum(g("power")[t], 1e-3))))
         worst["load"] = max(worst.get("load", 0), float(np.abs(info["load"] - g("load")[t]).max()))
     assert bool(g("truncated")[-1])
@@ -115,7 +124,7 @@ def replay_aec(env, z, name, meta, tol):
         worst["ws"] = max(worst["ws"], abs(float(o["wind_speed"]) - g("obs_wind_speed")[i]) / g("obs_wind_speed")[i])
         worst["wd"] = max(worst["wd"], abs(float(o["wind_direction"]) - g("obs_wind_direction")[i]))
         want_r = g("reward")[i]
-        worst["reward"] = max(worst["reward"], abs(float(np.ravel(r)[0]) - want_r) / max(abs(want_r), 1e-3))
+        worst["reward"] = max(worst["reward"], abs(float(np.ravel(r)[0]) - want_r) / reward_tol(sc, want_r, 1.0))
         assert bool(term) == bool(g("terminated")[i]) and bool(trunc) == bool(g("truncated")[i]), (name, i)
         wp = g("info_power")[i]
         assert ("power" in info) == bool(np.isfinite(wp)), (name, i)
@@ -229,7 +238,7 @@ def test_vec_env_reproduces_reference_trace(traces, name):
             assert np.array_equal(obs["yaw"][b].cpu().numpy(), g("obs_yaw")[t + 1]), (name, t)  # incl. the gate's effect
             assert bool(trunc[b]) == bool(g("truncated")[t]) and not bool(term[b])
             want_r = g("reward")[t]
-            assert abs(float(rew[b]) - want_r) <= 3e-5 * max(abs(want_r), 1e-3), (name, t, float(rew[b]), want_r)
+            assert abs(float(rew[b]) - want_r) <= reward_tol(sc, want_r, 3e-5), (name, t, float(rew[b]), want_r)
             assert np.allclose(info["power"][b].cpu().numpy(), g("power")[t], rtol=1e-4, atol=1e-7)
             assert np.abs(info["load"][b].cpu().numpy() - g("load")[t]).max() < 1e-4
             assert np.abs(obs["wind_speed"][b].cpu().numpy() / g("obs_wind_speed")[t + 1] - 1).max() <= 5e-5
@@ -271,7 +280,7 @@ def test_vec_aec_env_reproduces_reference_trace(traces, name):
         assert np.abs(f(o["wind_speed"]) / g("obs_wind_speed")[i] - 1).max() <= 5e-5
         assert np.abs(f(o["wind_direction"]) - g("obs_wind_direction")[i]).max() <= 3e-4
         want_r = g("reward")[i]
-        assert np.abs(f(r) - want_r).max() <= 3e-5 * max(abs(want_r), 1e-3), (name, i, f(r), want_r)
+        assert np.abs(f(r) - want_r).max() <= reward_tol(sc, want_r, 3e-5), (name, i, f(r), want_r)
         assert bool(np.all(f(term) == g("terminated")[i])) and bool(np.all(f(trunc) == g("truncated")[i])), (name, i)
         if np.all(f(trunc) != 0) or np.all(f(term) != 0):
             env.step(None)

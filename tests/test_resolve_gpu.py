@@ -488,3 +488,94 @@ def test_thrust_coefficient_near_one_is_never_left_in_float32(kernel, monkeypatc
         parity.check_strict({k: v[unity] for k, v in out0.items()}, {k: v[unity] for k, v in ref.items()})
         parity.check(out0, ref, fl0, max_flagged_frac=1.0)
     w.close()
+
+
+def _level_stats(reset=True):
+    import ctypes as C
+
+    from wfcrl_env_amd import _lib
+
+    buf = (C.c_ulonglong * 8)()
+    _lib.load().wfk_res_level_stats(buf, 1 if reset else 0)
+    return dict(zip(("farms", "repeated_without_levels", "level_stages", "sources_in_levels", "sequential_stages"), list(buf)))
+
+
+@pytest.mark.parametrize("name", ["HornsRev1_", "HornsRev2_", "Turb_TCRWP_", "Turb16_Row5_", "Ormonde_", "WMR_"])
+@pytest.mark.parametrize("wind", ["270", "287.5", "per_farm"])
+def test_level_stages_are_the_sequential_solve_bit_for_bit(layouts, name, wind):
+    """Round 6 (csrc/wf_resolve.hip: Lvl4Shared): consecutive sources that put no deficit on each other are solved as ONE
+    stage of the four-wave kernel.  Every sum is still taken in source order, so the outputs must be the same BITS as with
+    every source a stage of its own (wfk_set_resolve_levels(0)); no farm may have failed a level's check; the levels must
+    have been used where the layout has them; and the result is the CPU oracle's at TOL_F64 like every float64 solve."""
+    import parity
+    from wfcrl_env_amd import _lib
+    from wfcrl_env_amd.backend import WfStep
+
+    lib = _lib.load()
+    l = layouts[name]
+    x, y, N = l["xcoords"], l["ycoords"], l["num_turbines"]
+    B = 96
+    rng = np.random.default_rng(zlib.crc32(f"levels/{name}/{wind}".encode()))
+    yaw = rng.uniform(-40, 40, (B, N)).astype(np.float32)
+    if wind == "per_farm":
+        ws, wd = _wind(rng, B, "per_env")
+    else:
+        ws, wd = np.array([9.0]), np.array([float(wind)])
+    outs, stats = [], []
+    try:
+        for on in (1, 0):
+            lib.wfk_set_resolve_levels(on)
+            w = WfStep(x, y, env_batch=B)
+            w.set_risk_resolve(2)
+            w.set_wind(ws, wd)
+            _level_stats()
+            outs.append({k: v.copy() for k, v in w.step(yaw).items()})
+            stats.append(_level_stats())
+            w.close()
+    finally:
+        lib.wfk_set_resolve_levels(1)
+    on, off = stats
+    assert on["farms"] == B and off["farms"] == B and off["level_stages"] == 0 and off["sequential_stages"] == B * N
+    assert on["repeated_without_levels"] == 0  # (the geometric rule is a heuristic: a failure is not an error, but none is expected here)
+    assert on["sources_in_levels"] + on["sequential_stages"] == B * N
+    if name.startswith("HornsRev"):
+        assert on["sources_in_levels"] >= 0.5 * B * N, on  # grid farms: most sources stand in columns
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k].view(np.uint32), outs[1][k].view(np.uint32)), k
+    parity.check_strict(outs[0], _oracle(x, y, ws, wd, yaw), parity.TOL_F64)
+
+
+def test_a_failed_level_check_falls_back_to_the_sequential_solve(layouts):
+    """The rule that admits turbines to a level is geometric (8.6 wake widths apart); the guarantee is the check at the end
+    of the stage.  A model whose wakes grow twenty times faster than the rule assumes (ka, kb of a user's case.yaml) makes
+    members reach each other: such farms must be solved again without levels and still be the oracle's."""
+    import parity
+    from oracle.floris_gch_numpy import ModelParams
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["Turb16_Row5_"]
+    x, y, N = l["xcoords"], l["ycoords"], l["num_turbines"]
+    B = 64
+    rng = np.random.default_rng(99)
+    yaw = rng.uniform(-25, 25, (B, N)).astype(np.float32)
+    ws, wd = np.array([9.0]), np.array([283.0])
+    outs = {}
+    for wide in (False, True):
+        model = dict(ambient_ti=0.06)
+        mp = ModelParams()
+        if wide:  # the level rule prices the growth rate at TI = 0.3: an ambient TI of 0.9 triples it
+            model = dict(ambient_ti=0.9)
+            mp = ModelParams(ambient_ti=0.9)
+        w = WfStep(x, y, env_batch=B, model=model)
+        w.set_risk_resolve(2)
+        w.set_wind(ws, wd)
+        _level_stats()
+        out = w.step(yaw)
+        st = _level_stats()
+        parity.check_strict(out, _oracle(x, y, ws, wd, yaw, mp), parity.TOL_F64)
+        outs[wide] = st
+        w.close()
+    assert outs[False]["repeated_without_levels"] == 0 and outs[False]["level_stages"] > 0
+    # ... and at three times the assumed growth rate the members of Turb16_Row5's columns do reach each other at 283 deg: every
+    # farm failed a check, was solved again stage by stage — and is the oracle's (asserted above)
+    assert outs[True]["farms"] == B and outs[True]["repeated_without_levels"] == B, outs[True]

@@ -11,6 +11,6 @@ F="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function -Wno-un
 mkdir -p build/alt
 /opt/rocm/bin/hipcc $F "$@" -c -o build/alt/ll_$name.o wfcrl-env_amd/csrc/wf_kernels_ll.hip
 C=wfcrl-env_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o build/alt/lib_$name.so $C/wf_kernels_1.o $C/wf_kernels_2.o build/alt/ll_$name.o $C/wf_resolve.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o build/alt/lib_$name.so $C/wf_kernels_1.o $C/wf_kernels_2.o build/alt/ll_$name.o $C/wf_resolve.o $C/wf_resolve4.o $C/wf_resolve4_mt.o \
   $C/wf_abi.o $C/wf_model.o $C/wf_dispatch.o $C/wf_groups.o $C/wf_wind_abi.o $C/wf_env_abi.o $C/wf_sort.o
 echo built build/alt/lib_$name.so

@@ -22,11 +22,28 @@ for name, B, per_farm in (("Ablaincourt_", 4096, True), ("Turb16_TCRWP_", 16384,
     out = w.step(yaw); w.sync()
     buf = (C.c_ulonglong * 16)()
     lib.wfk_res4_stamps(buf, 1)
+    lib.wfk_res4_level_stamps((C.c_ulonglong * 20)(), 1)
+    lib.wfk_res_level_stats((C.c_ulonglong * 8)(), 1)
     w.step(yaw, out); w.sync()
     lib.wfk_res4_stamps(buf, 0)
     v = list(buf); n = max(v[12], 1)
-    print(f"{name} N={N}: {n} farms re-solved by the four-wave kernel ({w.resolve_stats()['n_resolved']} flagged); cycles per source stage")
+    stq = (C.c_ulonglong * 8)()
+    lib.wfk_res_level_stats(stq, 0)
+    n_seq = max(1, list(stq)[4])
+    print(f"{name} N={N}: {n} farms re-solved by the four-wave kernel ({w.resolve_stats()['n_resolved']} flagged); cycles per SEQUENTIAL source stage ({n_seq} of them)")
     for wv, nm in ((0, "column wave 0"), (6, "scalar wave 3")):
-        x = [v[wv + k] / n / N for k in range(6)]
+        x = [v[wv + k] / n_seq for k in range(6)]
         print(f"  {nm}: phase 1 work {x[0]:6.0f} wait {x[1]:6.0f} | phase 2 work {x[2]:6.0f} wait {x[3]:6.0f} | phase 3 work {x[4]:6.0f} wait {x[5]:6.0f} | sum {sum(x):6.0f}")
+    lb = (C.c_ulonglong * 20)()
+    lib.wfk_res4_level_stamps(lb, 1)
+    lv = list(lb)
+    st = (C.c_ulonglong * 8)()
+    lib.wfk_res_level_stats(st, 1)
+    st = list(st)
+    if st[2]:
+        nm = ("tv members", "wait", "chain", "tv rest", "wait", "deficit", "wait", "turb|check+begin", "wait", "-")
+        print(f"  level stages: {st[2]} covering {st[3]} sources ({st[3] / st[2]:.1f} per stage), {st[4]} sequential stages; cycles per LEVEL stage")
+        for wv, nmw in ((0, "wave 0"), (10, "wave 3")):
+            x = [lv[wv + k] / st[2] for k in range(10)]
+            print(f"    {nmw}: " + " | ".join(f"{nm[k]} {x[k]:6.0f}" for k in range(10)) + f" | sum {sum(x):6.0f}  (per source {sum(x) * st[2] / st[3]:6.0f})")
     w.close()

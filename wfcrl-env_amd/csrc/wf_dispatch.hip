@@ -425,7 +425,7 @@ int launch_step_f32(wf_handle* h, const float* yaw, float* power, float* wspd, f
     size_t log_records = 0;
     if ((rc = ensure_log(h, slots, &log_records)) != WF_OK) return rc;
     // mixed launch (mix_candidate above): the family keeps its whole rounds, the farms [M, B) go to wf_step_kernel behind it
-    const int M = (h->mix_main > 0 && h->mix_main < h->B && h->n_groups == 0) ? h->mix_main : 0;
+    const int M = (h->choice.mixed != 0 && h->mix_main > 0 && h->mix_main < h->B && h->n_groups == 0) ? h->mix_main : 0;  // (mixed == 0: always ONE launch, include/wfstep.h)
     if (M) { ga.env_base = 0; ga.env_end = M; }
     if (h->ll_ties != 1)
       WF_HIP(h, wfk_launch_step_ll(h->ll_G, h->ll_S, &h->consts, h->d_tab, h->d_gidx, h->d_ws, h->d_wd, wstride, yaw, power, wspd, wdir,
@@ -498,10 +498,11 @@ static bool calibration_due(const wf_handle* h) {
 // ---- process-wide cache of calibration results ----
 struct CalibKey {
   int device, N, B, n_cu, far_skip;
+  int mixed, slot_G, slot_S;  // (a handle created with mixed = 0, or with a forced register-slot shape, must not inherit the split / the timing of one without)
   unsigned long long layout_hash, model_hash;
   bool operator<(const CalibKey& o) const {
-    return std::tie(device, N, B, n_cu, far_skip, layout_hash, model_hash) <
-           std::tie(o.device, o.N, o.B, o.n_cu, o.far_skip, o.layout_hash, o.model_hash);
+    return std::tie(device, N, B, n_cu, far_skip, mixed, slot_G, slot_S, layout_hash, model_hash) <
+           std::tie(o.device, o.N, o.B, o.n_cu, o.far_skip, o.mixed, o.slot_G, o.slot_S, o.layout_hash, o.model_hash);
   }
 };
 struct CalibVal {
@@ -520,6 +521,7 @@ static unsigned long long fnv(const void* p, size_t n, unsigned long long hsh = 
 static CalibKey calib_key(const wf_handle* h) {
   CalibKey k{};
   k.device = h->device; k.N = h->N; k.B = h->B; k.n_cu = h->n_cu; k.far_skip = h->choice.far_skip;
+  k.mixed = h->choice.mixed != 0; k.slot_G = h->choice.slot_G; k.slot_S = h->choice.slot_S;
   k.layout_hash = fnv(h->ly.data(), sizeof(double) * h->ly.size(), fnv(h->lx.data(), sizeof(double) * h->lx.size()));
   const wf_model_params& m = h->model;  // every scalar up to the table (the pointers behind it are this handle's own copies)
   unsigned long long mh = fnv(&m, offsetof(wf_model_params, n_table));
@@ -697,7 +699,7 @@ int calibrate_now(wf_handle* h, const float* yaw, float* power, float* wspd, flo
         WF_HIP(h, hipStreamSynchronize(h->stream));
         apply_family(h, cv.code, code0);
       }
-      h->calib_code = cv.code; h->calib_done = true; h->mix_main = cv.mix_main;
+      h->calib_code = cv.code; h->calib_done = true; h->mix_main = h->choice.mixed == 0 ? 0 : cv.mix_main;
       for (int k = 0; k < 8; ++k) h->calib_ms[k] = cv.ms[k];
     } else {
       if ((rc = calibrate_families(h, yaw, power, wspd, wdir, load, probe)) != WF_OK) return rc;
@@ -777,7 +779,12 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   h->res_mask = mask;
   int rc = launch_step_f32(h, yaw, power, wspd, wdir, load, ea);
   h->res_mask = 0;
-  if (rc != WF_OK) return rc;
+  if (rc != WF_OK) {
+    //  a launch that failed before any kernel was enqueued has not zeroed the other counter: both are cleared, so
+    // that no later step appends behind a stale count
+    if (mask && h->d_res_count) hipMemsetAsync(h->d_res_count, 0, sizeof(int) * 2, h->stream);
+    return rc;
+  }
   if (mode == 0 && !mask) return WF_OK;
   WfResolveArgs ra{};
   ra.tab64 = h->d_tab64; ra.list = h->d_res_list; ra.count = h->d_res_count + h->res_parity; ra.flags = h->d_flags;
@@ -834,7 +841,7 @@ int wf_get_kernel_info(wf_handle* h, wf_kernel_info* info) {
   const bool ll_fly = !tab && h->wind_count == h->B && h->B > 1 && h->n_groups == 0 && h->ll_G && wfk_ll_has_fly(ll_fly_G(h), ll_fly_S(h)) && h->choice.fly_one_block != 0 &&
                       h->fly_calib != 2;
   info->one_block_kernel = ((tab && h->ll_G && !(h->tab_slot && h->n_groups == 0)) || ll_fly) ? 1 : 0;
-  info->mixed_main_farms = (tab && info->one_block_kernel && !ll_fly && h->n_groups == 0 && h->mix_main > 0 && h->mix_main < h->B) ? h->mix_main : 0;
+  info->mixed_main_farms = (tab && info->one_block_kernel && !ll_fly && h->n_groups == 0 && h->choice.mixed != 0 && h->mix_main > 0 && h->mix_main < h->B) ? h->mix_main : 0;
   if (info->one_block_kernel) {
     // what serves every wind direction without an x' tie across a block boundary; wf_step_kernel (the variant the
     // fields above would describe) is enqueued behind it for the directions that have one
@@ -919,7 +926,7 @@ int wf_get_calibration(wf_handle* h, int* code, float* family_ms) {
 
 int wf_get_mixed_launch(wf_handle* h, int* main_farms, float* mixed_ms) {
   if (!h) return WF_E_INVALID;
-  if (main_farms) *main_farms = (h->mix_main > 0 && h->mix_main < h->B) ? h->mix_main : 0;
+  if (main_farms) *main_farms = (h->choice.mixed != 0 && h->mix_main > 0 && h->mix_main < h->B) ? h->mix_main : 0;
   if (mixed_ms) *mixed_ms = h->calib_ms[6];
   return WF_OK;
 }

@@ -28,10 +28,12 @@ __device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x
 // actually waiting for").  Now the kernel waits where the data is needed: wf_dma_wait() in front of the chunk's closing barrier.
 // (Compiler-issued loads that are waited for in between may wait for an older transfer with them — in-order counter — never
 // for too little.)  agent: sc1, served by the L2 past the vector L1.
+// (the LDS base reaches M0 through an "{m0}"-constrained operand — ADVICE r5: the compiler owns M0 too (movrel / s_set_gpr_idx,
+// its own LDS-DMA and GWS builtins), so it writes the register itself and knows what it holds; clobber lists may not name M0)
 __device__ __forceinline__ void lds_dma16(const void* g, void* l, bool agent) {
   const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)l);
-  if (agent) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "s"(la) : "memory");
-  else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory");
+  if (agent) asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "{m0}"(la) : "memory");
+  else asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "{m0}"(la) : "memory");
 }
 __device__ __forceinline__ void wf_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

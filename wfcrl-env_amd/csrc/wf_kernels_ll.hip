@@ -1258,11 +1258,14 @@ static hipError_t launch_ll(const WfConsts* c, const WfTables* tab, const int* g
     if (wind_stride == 0) fn = (const void*)&wf_step_ll_kernel<G, S, true, TAB, MC1, kLLWaves, VEER>;
   }
   if constexpr (S == 1 && (MC1 || !TAB) && !VEER) {  // no third block per CU in this launch: the spill-free two-wave build
-    static const int n_cu = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-      return n;
-    }();
+    // CU count of the CURRENT device (the handle's: launch_step_f32 runs under WF_ON_DEVICE), cached per device — not once per
+    // instantiation from whichever device launched first: wf_get_kernel_info decides with the handle's own count
+    static int n_cu_of[64] = {};
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      n_cu = n_cu_of[dev];
+      if (n_cu == 0 && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n_cu_of[dev] = n_cu;
+    }
     if (n_cu > 0 && grid <= 2 * n_cu)
       fn = wind_stride == 0 ? (const void*)&wf_step_ll_kernel<G, S, true, TAB, MC1, kLLWaves, VEER, true>
                             : (const void*)&wf_step_ll_kernel<G, S, false, TAB, MC1, kLLWaves, VEER, true>;

@@ -8,14 +8,26 @@
 // unconditional: the flagged farms are compacted on the device (no host round trip) and solved again in float64, the
 // comparison taken exactly as FLORIS takes it, and their outputs overwritten.
 //
-// Mapping: one farm per workgroup, one thread per (sorted) target turbine, the turbine's state — 9 wake deficits, 9 V,
-// 9 W, 3 column TIs, all float64 — in registers for the whole solve; sources i = 0 .. N-1 in sorted order, the source's
-// rotor means broadcast through LDS (two barriers per source: its state, then its transverse velocities including its
-// own contribution, which the yaw-added recovery [A.3-5] needs before the deficit [A.3-6]).  The per-source constants
-// are derived redundantly by every thread.  Persistent blocks walk the compacted farm list.
+// Two kernels, chosen on the device by the number of flagged farms (wfk_launch_resolve):
+//   wf_resolve4_kernel  one farm per 256-thread block, up to two blocks per CU (half a residency of the chip: the re-solve is
+//                       then ONE farm's latency).  The farm's state — per sorted turbine 9 sums of squared deficits, 9 V, 9 W,
+//                       3 column TIs, float64 — lives in LDS, turbine-major; a lane is not tied to a turbine.  A SEQUENTIAL
+//                       stage solves one source: waves 0-2 take a rotor-grid column each (transverse pass; deflection / deficit
+//                       pass; turbulence pass — three block barriers), wave 3 the source-only chain of steering, deflection and
+//                       deficit constants beside the transverse pass, and the NEXT source's rotor speed, thrust and circulations
+//                       beside the other two passes (speculated from the deficit sums, confirmed by a bit comparison).  A LEVEL
+//                       stage (round 6: Lvl4Shared) solves three to eight consecutive sources that put no deficit on each
+//                       other at once, every (source, target, column) pair in its own lane, the sums still taken in source order.
+//   wf_resolve_kernel   one farm per WAVE (64-thread blocks, one per SIMD), the same state in LDS, no block barrier inside the
+//                       solve: a third more farms per CU and second than the four-wave kernel, at 2.2 x its latency — for
+//                       lists beyond half a residency, and for mode 2 at any batch beyond it.
+// Per-source constants are derived once per farm and handed to the pair passes through LDS; every phase of a stage starts
+// behind a compiler barrier and is free of calls and spills (no private segment: tests/test_abi.py).
 // Only exactness-preserving algebra is used (vortex core 1 - exp(-(y^2+z^2)/eps^2) with the z factor a constant);
 // sums are taken in a different order than NumPy takes them: results agree with the CPU oracle to ~1e-13 relative.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "wf_device.h"
 #include "wf_resolve.h"
@@ -30,12 +42,24 @@
 #ifndef RES_MT
 #define RES_MT 0
 #endif
+// The file is compiled in two PARTS (round 6): 1 = the one-wave-per-farm kernel, the list kernel and the launch logic, under
+// the default flags; 2 = the four-wave kernel (wf_resolve4.hip, wf_resolve4_mt.hip) WITHOUT machine LICM — hoisted out of the
+// stage loop, the ~50 float64 literals of its phases held a register pair each across the whole solve (256 VGPRs, 60-90
+// spilled SGPRs, and with the level stages a private segment); rematerialised where they are used the kernel needs 128.  The
+// one-wave kernel loses 10-30 % without the hoisting (profiles/r06_levels_ab.txt), hence two translation units.
+#ifndef RES_PART
+#define RES_PART 1
+#endif
+#define WF_RES_GRID_PER_CU 4  // persistent one-wave blocks per CU: one per SIMD (WF_RES_OCC)
 #if RES_MT
 #define RES_NT WF_MAX_TYPES
 #define wf_list_all_kernel wf_list_all_mt_kernel
 #define wf_resolve_kernel wf_resolve_mt_kernel
 #define wf_resolve4_kernel wf_resolve4_mt_kernel
 #define wfk_launch_resolve wfk_launch_resolve_mt
+#if RES_PART == 2
+#define wfk_launch_resolve4 wfk_launch_resolve4_mt
+#endif
 #define RES_TY(t) (reinterpret_cast<const int*>(res_dyn + (t) * RES_TS + 35)[0])  // (the record's first padding word)
 #define RES_TOFS(ty) ((ty) * WF_TABLE_PAD)
 #define RES_TN(S, ty) ((S).ty_n[ty])
@@ -80,6 +104,7 @@ __device__ inline double interp_fill_uniform(double xq, int n, const double* xs,
 
 }  // namespace
 
+#if RES_PART == 1
 // every farm -> list, count = B; raw = copy of the flags as the float32 kernels raised them (mode 2: the flagged-farms list of
 // modes 0 / 1 is written by the step kernels themselves, wf_device.h: WfGroupArgs::res_list)
 __global__ void wf_list_all_kernel(const int* __restrict__ flags, int B, int* __restrict__ list, int* __restrict__ count,
@@ -91,6 +116,7 @@ __global__ void wf_list_all_kernel(const int* __restrict__ flags, int B, int* __
   list[b] = b;
 }
 
+#endif  // RES_PART == 1
 // The kernels below contain NO function call and no register spill: a kernel with a private segment (a stack for out-of-line
 // library routines, callee-saved register saves, spills) costs ~20 us per LAUNCH on this chip against ~2.6 us without one
 // (tools/ubench/scratch_switch.hip, profiles/r05_scratch_switch.txt) — two such launches behind every step were the whole
@@ -111,6 +137,12 @@ __device__ __forceinline__ int res_tid() {
   int t = threadIdx.x;
   asm volatile("" : "+v"(t));
   return t;
+}
+// a literal the compiler must materialise where it is used: hoisted out of the stage loop, every float64 literal of every
+// phase holds a register pair across the whole solve (~50 pairs), and the allocator spills them instead of rematerialising
+__device__ __forceinline__ double res_lit(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
 }
 #define LOG_F64(x) log_any(x)
 #define POW_F64(x, y) pow_any(x, y)
@@ -153,6 +185,7 @@ __device__ __forceinline__ int res_tid() {
 // Beyond 4 farms per CU the persistent blocks take their next farm: 3 rounds of 0.8 ms for 3000 farms against 3.9 ms before.
 #define WF_RES_OCC 1
 #endif
+#if RES_PART == 1
 struct SrcShared {  // what a source leaves for the two passes over its targets
   double x_i, y_i, ct, ai, ubar, Vmean, TIs[3], dTI;
   double Gt, Gb, Gw;  // circulations / (2 pi): top, bottom, wake rotation (commanded yaw)
@@ -174,6 +207,7 @@ struct ResShared {
   SrcShared s;
 };
 __shared__ ResShared R;
+#endif  // RES_PART == 1
 extern __shared__ double res_dyn[];  // per sorted turbine: x', y', cos / sin / radians of the commanded yaw, the 30 state values; then the int arrays
 // Turbine-major (round 5; rounds 3-4: one array per quantity at stride n_pad): a quantity of turbine t is at a CONSTANT offset
 // from t's record, so a phase's dozens of state addresses are one base plus immediates — with the run-time stride the compiler
@@ -191,14 +225,13 @@ extern __shared__ double res_dyn[];  // per sorted turbine: x', y', cos / sin / 
 #define RES_ST(q, t) res_dyn[(t) * RES_TS + 5 + (q)]  // wake2 q = 0..8, V 9..17, W 18..26, TI 27..29
 #define RES_TIE(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R.n_pad)[(t)])
 
-// ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
-// (the source-only phases stay out of line: inlined, the loop body carries their live ranges across the calls — 5.18
-// against 4.78 ms per step with 1394 farms re-solved)
 #if RES_SRC_INLINE
 #define RES_SRC_FN __device__ __forceinline__
 #else
 #define RES_SRC_FN __device__ __noinline__
 #endif
+#if RES_PART == 1
+// ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
 RES_SRC_FN void res_source_begin(int i) {
   RES_PHASE_FENCE;
   const WfResolveConsts& c = R.c;
@@ -450,6 +483,7 @@ RES_PASS_FN void res_deficit_pass(int i) {
   }
 }
 
+#endif  // RES_PART == 1
 // ---- outputs [A.4] of one turbine (sorted index t, caller's index o) from the farm's state in LDS ----
 // (tb: the turbine's record in LDS; the nine rotor-grid velocities are kept in registers: one root per grid point)
 __device__ __forceinline__ void res_turbine_outputs(const WfResolveConsts& c, const WfResolveArgs& a, const double* tb,
@@ -495,6 +529,7 @@ __device__ __forceinline__ void res_turbine_outputs(const WfResolveConsts& c, co
   if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = real ? make_float4((float)l0, (float)l1, (float)l2, (float)l3) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
+#if RES_PART == 1
 // ---- outputs [A.4] in the caller's turbine order; the farm's reward ----
 RES_PASS_FN void res_outputs(const WfResolveArgs& a, int b, size_t gofs) {
   RES_PHASE_FENCE;
@@ -522,6 +557,7 @@ RES_PASS_FN void res_outputs(const WfResolveArgs& a, int b, size_t gofs) {
   }
 }
 
+#endif  // RES_PART == 1
 // the table columns (and their segment slopes) of every definition -> LDS, by all `nthreads` threads of the block
 template <class Shared>
 __device__ __forceinline__ void res_stage_tables(Shared& S, const WfResolveConsts& c_arg, const WfResolveArgs& a_arg, int tid, int nthreads) {
@@ -570,7 +606,13 @@ __device__ unsigned long long wf_res4_stamp[16];
 #if !defined(WF_RES_STAMP) || RES_MT
 #define RES4_T(v)
 #define RES4_ACC(k, a, b)
+#define RES4_LACC(k, a, b)
+#else
+// level stages (tools/res4_stamps.py): [wave 0 | wave 3][transverse of the members, wait, chain, transverse of the rest, wait, deficit, wait, turbulence | check + next begin, wait]
+__device__ unsigned long long wf_res4_lstamp[20];
+#define RES4_LACC(k, a, b) stl[k] += (b) - (a)
 #endif
+#if RES_PART == 1
 __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfResolveConsts c_arg, const WfResolveArgs a_arg, int n_pad, int min_count) {
   const int lane = threadIdx.x;
   const int N = c_arg.N;
@@ -650,12 +692,13 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
   }
 }
 
+#endif  // RES_PART == 1
+#if RES_PART == 2
 // ---------------------------------------------------------------------------------------------------------------------
 // The same solve with FOUR waves per farm, for flagged counts that fit one residency of the chip (<= kRes4MaxFarms): there
 // the re-solve is pure latency — one farm's 80-stage chain, whatever the count — and spreading a source step over four
 // waves shortens it (HornsRev1: 1.04 -> 0.73 ms per farm).  Both kernels are enqueued behind the compaction; each reads
 // the count on the device and the one it is not meant for returns at once.
-#define WF_RES_GRID_PER_CU 4  // persistent one-wave blocks per CU: one per SIMD (WF_RES_OCC)
 #ifndef WF_RES4_OCC
 #define WF_RES4_OCC 2          // blocks per CU the register allocator makes room for (256 VGPRs: the inlined source step fits without a spill; at 3 or 4 it spills 57 / 113 values and the kernel gets a private segment)
 #endif
@@ -686,6 +729,41 @@ struct Src4Shared {  // what res4_source_begin leaves (one copy per wave)
 struct Fin4Shared {  // the source-only constants of deflection, deficit and wake-added turbulence (written by wave 3)
   double cgd, s_cc, s_c, th0, tan_th0, M0, E0, sM, sz0d, sy0d, is0d, lnAB, sz0v, sy0v, snw, kdef, ch_pref, cgv;
 };
+// LEVELS (round 6).  Consecutive sources of the sort order that put no deficit and no turbulence on each other — the
+// turbines of a column of a grid farm, an x' tie group — need not wait for each other: their rotor speeds, thrusts and
+// circulations depend on the sources BEFORE the level only, and the one coupling that does run through the level (the
+// transverse velocities of member k at the rotors of the members behind it, which enter their steering and their
+// yaw-added recovery) is a sum whose terms are all known once the circulations are.  A level of L = 3 .. 8 members is
+// therefore ONE stage of five phases instead of L stages of three:
+//   begin       (wave 3, a member per lane)   rotor speed, thrust, circulations of every member
+//   transverse  (all waves)                   every (member, target, column) pair in its own lane: 64 / L targets per
+//                                             wave pass instead of the N - i of a single source (40 of 64 lanes on average
+//                                             at N = 80, 8 near the end of the farm)
+//   chain       (wave 3, a member per lane)   steering, recovery, deflection / deficit / turbulence constants
+//   deficit     (all waves)                   pairs as above
+//   turbulence  (waves 0-2)                   pairs; wave 3 checks the level and derives the next source's state
+// What a target receives from the members of a level is added in MEMBER ORDER (a lane holds one member's contribution;
+// the running sum travels from lane group to lane group), so every sum is taken in the order of the sequential solve: the
+// results are the SAME BITS as the sequential stages' (tests/test_resolve_gpu.py: levels on against levels off).
+// Which turbines may share a level is decided from the geometry alone (res4_level_lengths: laterally 8.6 wake widths
+// apart, where exp() has taken the deficit below half an ulp of the free stream) — a heuristic, not a proof: at the end of the
+// stage the mean cube of every member's rotor speeds is recomputed from the final deficit sums and compared bit for bit
+// with the one its state was derived from, and a member's column TIs must not have been raised by a member ahead of it.
+// A farm that fails the check is solved again without levels (never seen on the repo's layouts; counted, wfk_res_level_stats).
+#define RES_LMAX 8
+#ifndef RES4_SCHED_LIMIT
+#define RES4_SCHED_LIMIT 0  // the sequential stage's transverse pass: 0 all 14 reciprocal chains at once, 2 in two batches (8 + 6), 1 two at a time
+#endif
+#ifndef RES_LV_SCHED_LIMIT
+#define RES_LV_SCHED_LIMIT 2
+#endif
+struct Lvl4Shared {
+  Src4Shared s[RES_LMAX];
+  Fin4Shared f[RES_LMAX];
+  double m3[RES_LMAX], dTI[RES_LMAX], vtb[RES_LMAX], vcore[RES_LMAX];
+  double before[RES_LMAX][9];  // V of member m's rotor as source m finds it (after the members ahead of it)
+  double own[RES_LMAX][18];    // V, W of member m's rotor after its own transverse pass
+};
 struct Res4Shared {
   WfResolveConsts c;
   double tws[RES_NT * WF_TABLE_PAD], tct[RES_NT * WF_TABLE_PAD], tpw[RES_NT * WF_TABLE_PAD];
@@ -702,6 +780,10 @@ struct Res4Shared {
   Src4Shared s[2];  // by stage parity: wave 3 writes the NEXT source's copy while the others still read this one's
   Fin4Shared f;
   double own[18];  // V (0..8) and W (9..17) of the source's own turbine after its transverse pass (see res4_transverse_pass)
+  Lvl4Shared lv[2];  // a LEVEL stage's members (round 6, below), by level parity: wave 3 derives the NEXT level's members while the others still read this one's
+  double lvl_a, lvl_b;  // two turbines may share a level when |dy'| >= lvl_a + lvl_b dx' (or dx' == 0)
+  int levels_on, lv_fail;
+  int wp_tv, wp_df, wp_tb;  // next wave pass of a level stage's pair passes (the waves draw them: whoever is free takes the next)
 };
 __shared__ Res4Shared R4;
 
@@ -713,6 +795,9 @@ __shared__ Res4Shared R4;
 #define RES4_ST(q, t) res_dyn[(t) * RES_TS + 5 + (q)]  // wake2 q = 0..8, V 9..17, W 18..26, TI 27..29
 #define RES4_TIE(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(t)])
 #define RES4_CNT(j, t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(1 + (j)) * R4.n_pad + (t)])  // overlap count of column j
+#define RES4_LVL(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[4 * R4.n_pad + (t)])  // members of the level that starts at t (1: a sequential stage)
+#define RES4_LCNT(m, j, t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(5 + (m) * 3 + (j)) * R4.n_pad + (t)])  // overlap count of member m, column j
+#define RES4_DYN_INTS (5 + 3 * RES_LMAX)
 
 // ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
 // Wave 3 only, one source AHEAD (round 5): source i + 1's rotor speed, thrust and circulations need its turbine's deficits
@@ -749,8 +834,9 @@ RES_SRC_FN void res4_source_begin(int tid, int i, double m3m) {
   for (int q = 0; q < 9; ++q) vs += RES4_ST(9 + q, i);
   const double ubar = __any(!(m3m > 1.0e-6)) ? cbrt_any(m3m) : cbrt_pos(m3m);
   [[maybe_unused]] const int ty = RES_TY(i);
-  double ct_tab = interp_fill_uniform(ubar, RES_TN(R4, ty), R4.tws + RES_TOFS(ty), R4.tct + RES_TOFS(ty), R4.tcs + RES_TOFS(ty), 0.0001, 0.9999);
-  ct_tab = fmin(fmax(ct_tab, 0.0001), 0.9999);
+  const double lo_ct = res_lit(0.0001), hi_ct = res_lit(0.9999);
+  double ct_tab = interp_fill_uniform(ubar, RES_TN(R4, ty), R4.tws + RES_TOFS(ty), R4.tct + RES_TOFS(ty), R4.tcs + RES_TOFS(ty), lo_ct, hi_ct);
+  ct_tab = fmin(fmax(ct_tab, lo_ct), hi_ct);
   const double ct = ct_tab * cg;
   const double ai = 0.5 * rcp64(cg) * (1.0 - sqrt_nn(1.0 - ct * cg));
   const double G_wr = (0.25 * kTwoPi) * c.D * (ai - ai * ai) * ubar * RES_TC(R4, 0, ty, c.inv_TSR);
@@ -815,7 +901,7 @@ RES_PASS_FN void res4_transverse_pass(int tid, int i, int j) {
         Bw[m - 2] += Gw * (tr - tm);
       }
       // (above two waves per SIMD the 14 interleaved reciprocal chains of a column would not fit the registers)
-      if (RES_SCHED_LIMIT && (m & 1)) __builtin_amdgcn_sched_barrier(0);
+      if (RES4_SCHED_LIMIT == 2 ? (m == 3) : (RES4_SCHED_LIMIT && (m & 1))) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1005,6 +1091,447 @@ RES_PASS_FN void res4_turbulence_pass(int tid, int i, int j) {
   }
 }
 
+// ======================================================================================================================
+// LEVEL stages (see Lvl4Shared).  Lane layout of the pair passes: T = 64 / L targets per wave pass, lane = ks T + tl —
+// member ks of the level on target (chunk base + tl); lanes beyond L T idle.
+#define RES4_LV_LANES(L)                                        \
+  const int lane = tid & 63, T = 64 / (L);                      \
+  int ks = 0;                                                   \
+  _Pragma("unroll") for (int q_ = 1; q_ < RES_LMAX; ++q_) ks += (lane >= q_ * T) ? 1 : 0; \
+  const int tl = lane - ks * T;                                 \
+  const bool member = ks < (L);                                 \
+  const int km = member ? ks : 0
+
+// ---- begin: rotor speed, thrust, induction, circulations of every member (wave 3, member m in lane m) ----
+RES_SRC_FN void res4_level_begin(int tid, Lvl4Shared& lv, int i0, int L) {
+  RES_PHASE_FENCE;
+  const WfResolveConsts& c = R4.c;
+  const int m = tid & 63;
+  const bool act = m < L;
+  const int i = i0 + (act ? m : 0);
+  const double m3m = res4_rotor_m3(i);
+  const double cg = RES4_CG(i), sg = RES4_SG(i);
+  double ubar = cbrt_pos(act && m3m > 1.0e-6 ? m3m : 1.0);
+  if (__any(act && !(m3m > 1.0e-6))) {  // (the routine the sequential stage would have taken for THIS member: same bits)
+    const double ua = cbrt_any(m3m);
+    ubar = (m3m > 1.0e-6) ? ubar : ua;
+  }
+  [[maybe_unused]] const int ty = RES_TY(i);
+  const double lo_ct = res_lit(0.0001), hi_ct = res_lit(0.9999);
+  double ct_tab = interp_fill(ubar, RES_TN(R4, ty), R4.tws + RES_TOFS(ty), R4.tct + RES_TOFS(ty), R4.tcs + RES_TOFS(ty), lo_ct, hi_ct);
+  ct_tab = fmin(fmax(ct_tab, lo_ct), hi_ct);
+  const double ct = ct_tab * cg;
+  const double ai = 0.5 * rcp64(cg) * (1.0 - sqrt_nn(1.0 - ct * cg));
+  const double G_wr = (0.25 * kTwoPi) * c.D * (ai - ai * ai) * ubar * RES_TC(R4, 0, ty, c.inv_TSR);
+  const double gam_top = (kTwoPi / 16.0) * c.D * c.vel_top * R4.Uinf * ct;
+  const double gam_bot = (kTwoPi / 16.0) * c.D * c.vel_bot * R4.Uinf * ct;
+  const double sc = sg * cg;
+  if (act) {
+    Src4Shared& s = lv.s[m];
+    s.x_i = RES4_XS(i); s.y_i = RES4_YS(i); s.ct = ct; s.ai = ai; s.ubar = ubar;
+    s.Gt = sc * gam_top * (1.0 / kTwoPi); s.Gb = -sc * gam_bot * (1.0 / kTwoPi); s.Gw = G_wr * (1.0 / kTwoPi);
+    s.first_tv = RES4_TIE(i);
+    const double v_top = gam_top * c.k_top, v_bot = -gam_bot * c.k_bot, v_core = G_wr * c.k_core;
+    lv.vtb[m] = v_top + v_bot; lv.vcore[m] = v_core;
+    lv.m3[m] = m3m;
+  }
+}
+
+// ---- 4. transverse velocities: every (member, target, column) pair; what a target receives is added in member order ----
+RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, int part) {
+  RES_PHASE_FENCE;
+  const WfResolveConsts& c = R4.c;
+  RES4_LV_LANES(L);
+  const int wave = tid >> 6, N = R4.N;
+  const Src4Shared& s = lv.s[km];
+  const double x_i = s.x_i, y_i = s.y_i, Gt = s.Gt, Gb = s.Gb, Gw = s.Gw;
+  const int first = s.first_tv, tmin = lv.s[0].first_tv;
+  const double qd = c.off[2], neps = c.num_eps, twoHH = 2.0 * c.HH, eps2 = c.eps2, ieps2 = c.inv_eps2;
+  const bool mcore = R4.mcore != 0;
+  // part 1: the chunks that hold the level's own members (the chain waits for them), a fixed share per wave; part 2: all
+  // other chunks, drawn from a counter — wave 3 joins when its chain is done
+  const int n_ch = (N - tmin + T - 1) / T, c0 = (i0 - tmin) / T, c1 = (i0 + L - 1 - tmin) / T, n_own = c1 - c0 + 1;
+  const int n_wp = part == 1 ? 3 * n_own : 3 * (n_ch - n_own);
+  for (int wp_s = wave;; wp_s += 4) {
+    int wp = wp_s;
+    if (part != 1) {
+      if (lane == 0) wp = atomicAdd(&R4.wp_tv, 1);
+      wp = __builtin_amdgcn_readfirstlane(wp);
+    }
+    if (wp >= n_wp) break;
+    int ch = wp / 3;
+    if (part == 1) ch += c0;
+    else if (ch >= c0) ch += n_own;
+    const int j = wp % 3, t = tmin + ch * T + tl;
+    const bool valid_t = member && t < N;
+    const bool active = valid_t && t >= first;
+    const int tt = t < N ? t : N - 1;
+    double cv[3] = {0.0, 0.0, 0.0}, cw[3] = {0.0, 0.0, 0.0};
+    if (active) {
+      const double dx = RES4_XS(tt) - x_i, y_t = RES4_YS(tt);
+      double dec[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dec[k] = eps2 * rcp64(fma(R4.dec_a[k], dx, eps2));
+      const double yL = (y_t + c.off[j] - y_i) + neps;
+      const double yL2 = yL * yL;
+      const double Ey = exp_lean(-yL2 * ieps2);
+      double Av[3] = {0.0, 0.0, 0.0}, Bw[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int m = 0; m < 7; ++m) {
+        const double zc = (double)(m - 3) * qd + neps, zm = zc + twoHH;
+        const double tr = (1.0 - Ey * c.ezc[m]) * rcp64(yL2 + zc * zc);
+        double tm = rcp64(yL2 + zm * zm);
+        if (mcore) tm *= 1.0 - Ey * c.ezm7[m];
+        const double pr = zc * tr, pm = zm * tm;
+        if (m <= 2) {
+          Av[m] += Gt * pr - Gb * pm;
+          Bw[m] += Gt * tr - Gb * tm;
+        }
+        if (m >= 4) {
+          Av[m - 4] += Gb * pr - Gt * pm;
+          Bw[m - 4] += Gb * tr - Gt * tm;
+        }
+        if (m >= 2 && m <= 4) {
+          Av[m - 2] += Gw * (pr - pm);
+          Bw[m - 2] += Gw * (tr - tm);
+        }
+        if (RES_LV_SCHED_LIMIT == 2 ? (m == 3) : (RES_LV_SCHED_LIMIT && (m & 1))) __builtin_amdgcn_sched_barrier(0);  // (the reciprocal chains in two batches — 8, then 6 — instead of all 14 at once: the lane bookkeeping of a level needs a few registers)
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double w = -yL * Bw[k] * dec[k];
+        cv[k] = Av[k] * dec[k];
+        cw[k] = (w < 0.0) ? 0.0 : w;  // quirk (5) [A.6]
+      }
+    }
+    // the running sums, member by member: lane group ks takes them from group ks - 1 and adds its own term
+    double pv[3], pw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { pv[k] = RES4_ST(9 + j * 3 + k, tt); pw[k] = RES4_ST(18 + j * 3 + k, tt); }
+    const int mt = t - i0;  // the target as a member of this level (0 .. L - 1), if it is one
+    if (valid_t && ks == 0 && mt == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) lv.before[0][j * 3 + k] = pv[k];
+    }
+    if (active && ks == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { pv[k] = pv[k] + cv[k]; pw[k] = pw[k] + cw[k]; }
+    }
+    for (int sidx = 1; sidx < L; ++sidx) {
+      double rv[3], rw[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { rv[k] = __shfl_up(pv[k], T); rw[k] = __shfl_up(pw[k], T); }
+      if (ks == sidx) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pv[k] = active ? rv[k] + cv[k] : rv[k]; pw[k] = active ? rw[k] + cw[k] : rw[k]; }
+      }
+    }
+    if (valid_t) {
+      if (mt >= 1 && mt < L && ks == mt - 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lv.before[mt][j * 3 + k] = pv[k];
+      }
+      if (mt >= 0 && mt < L && ks == mt) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lv.own[mt][j * 3 + k] = pv[k]; lv.own[mt][9 + j * 3 + k] = pw[k]; }
+      }
+      if (ks == L - 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { RES4_ST(9 + j * 3 + k, tt) = pv[k]; RES4_ST(18 + j * 3 + k, tt) = pw[k]; }
+      }
+    }
+  }
+}
+
+// ---- 2, 5 and the source-only part of 3 + 6 + 8 of every member (wave 3, member m in lane m): steering from the
+// transverse velocities the member finds at its rotor, yaw-added recovery from the ones it leaves there ----
+RES_SRC_FN void res4_level_chain(int tid, Lvl4Shared& lv, int i0, int L) {
+  RES_PHASE_FENCE;
+  const WfResolveConsts& c = R4.c;
+  const int m = tid & 63;
+  const bool act = m < L;
+  const int mm = act ? m : 0, i = i0 + mm;
+  Src4Shared& s0 = lv.s[mm];
+  double TIs[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) TIs[j] = RES4_ST(27 + j, i);  // (final: no member ahead may raise them — checked in the turbulence pass)
+  double vs = 0.0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) vs += lv.before[mm][q];
+  const double Vmean = vs * (1.0 / 9.0);
+  const double cg = RES4_CG(i), sg = RES4_SG(i), ct = s0.ct, D = c.D, ubar = s0.ubar;
+  double val = 2.0 * (Vmean - lv.vcore[mm]) * rcp64(lv.vtb[mm]);
+  val = fmin(fmax(val, -1.0), 1.0);
+  double asv = asin_small(val);
+  if (__any(act && fabs(val) > 0.3)) {  // (per member the routine its sequential stage would take)
+    const double aa = asin_any(val);
+    asv = fabs(val) > 0.3 ? aa : asv;
+  }
+  const double g_off = c.sw_steer ? 0.5 * asv : 0.0;
+  const double c2d = sqrt_nn(fmax(1.0 - val * val, 0.0)), cd = sqrt_pos(0.5 * (1.0 + c2d)), sd = 0.5 * val * rcp64(cd);
+  const double cgd = c.sw_steer ? cg * cd - sg * sd : cg;
+  const double gd_rad = -(RES4_GR(i) + g_off);
+  const double s_cc = sqrt_nn(1.0 - ct * cgd), s_c = sqrt_nn(1.0 - ct);
+  const double th0 = c.dm * (0.3 * gd_rad * rcp64(cgd)) * (1.0 - s_cc);
+  double tan_th0 = tan_small(th0);
+  if (__any(act && fabs(th0) > 0.5)) {
+    const double ta = tan_any(th0);
+    tan_th0 = fabs(th0) > 0.5 ? ta : tan_th0;
+  }
+  const double C0 = 1.0 - s_c;
+  const double M0 = C0 * (2.0 - C0);
+  const double i1sc = rcp64(1.0 + s_c);
+  const double sz0d = D * 0.5 * sqrt_pos((ct * cgd * rcp64(2.0 * (1.0 - s_cc))) * i1sc);
+  const double sy0d = sz0d * cgd * c.cos_veer;
+  const double sM = sqrt_pos(M0);
+  const double sz0v = D * 0.5 * sqrt_pos((ct * rcp64(2.0 * (1.0 - s_c))) * i1sc);
+  // 5. yaw-added recovery [A.3-5]
+  double vsum = 0.0, wsum = 0.0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { vsum += lv.own[mm][q]; wsum += lv.own[mm][9 + q]; }
+  const double I = TIs[0];
+  const double k_tke = (ubar * I) * (ubar * I) * 1.5;
+  const double vbar = vsum * (1.0 / 9.0), wbar = wsum * (1.0 / 9.0);
+  const double I_tot = sqrt_nn((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) * rcp64(ubar);
+  const double dTI = c.sw_yar ? c.gch_gain * (I_tot - I) : 0.0;
+  const double ch_pref = c.ch_constant * POW_F64(s0.ai, c.ch_ai) * c.ch_amb_pow;
+  if (act) {
+    Fin4Shared& f = lv.f[m];
+    f.cgd = cgd; f.s_cc = s_cc; f.s_c = s_c; f.th0 = th0; f.tan_th0 = tan_th0; f.M0 = M0;
+    f.E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
+    f.sM = sM; f.sz0d = sz0d; f.sy0d = sy0d; f.is0d = rcp64(sy0d * sz0d); f.lnAB = (1.6 + sM) * rcp64(1.6 - sM);
+    f.sz0v = sz0v; f.sy0v = sz0v * cg * c.cos_veer; f.snw = c.near_c * sqrt_pos(ct * 0.5); f.kdef = ct * cg * D * D * 0.125;
+    f.ch_pref = ch_pref;
+    f.cgv = cg;
+    s0.Vmean = Vmean; s0.val = val;
+    lv.dTI[m] = dTI;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      s0.TIs[j] = TIs[j];
+      RES4_ST(27 + j, i) = fmax(TIs[j] + dTI, c.amb);  // (stored: see res_source_finish)
+    }
+  }
+}
+
+// ---- 3 + 6 + 7: every (member, target behind it, column) pair; the squared deficits added in member order ----
+RES_PASS_FN void res4_level_deficit(int tid, Lvl4Shared& lv, int i0, int L) {
+  RES_PHASE_FENCE;
+  const WfResolveConsts& c = R4.c;
+  RES4_LV_LANES(L);
+  const int N = R4.N;
+  const Src4Shared& s = lv.s[km];
+  const Fin4Shared& f = lv.f[km];
+  const bool veer_on = R4.veer_on != 0;
+  const double x_i = s.x_i, y_i = s.y_i, dTI = lv.dTI[km];
+  const double q2 = c.off[2] * c.off[2];
+  const int k_src = i0 + km;
+  const int n_wp = 3 * ((N - i0 - 1 + T - 1) / T);
+  for (;;) {
+    int wp = 0;
+    if (lane == 0) wp = atomicAdd(&R4.wp_df, 1);
+    wp = __builtin_amdgcn_readfirstlane(wp);
+    if (wp >= n_wp) break;
+    const int j = wp % 3, t = i0 + 1 + (wp / 3) * T + tl;
+    const bool valid_t = member && t < N;
+    const bool active = valid_t && t > k_src;
+    const int tt = t < N ? t : N - 1;
+    double dU[3] = {0.0, 0.0, 0.0};
+    int cnt = 0;
+    if (active) {
+      // source-side constants of this column [A.3-3, A.3-6]
+      const double TIpre = s.TIs[j];
+      const double x0d_rel = c.D * f.cgd * (1.0 + f.s_cc) * rcp64(c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - f.s_c)));
+      const double x0d = x0d_rel + x_i;
+      const double ix0d_rel = rcp64(x0d_rel);
+      const double kyd = c.defl_ka * TIpre + c.defl_kb;
+      const double d0 = f.tan_th0 * x0d_rel;
+      const double pfar = f.th0 * f.E0 * (1.0 / 5.2) * sqrt_pos(f.sy0d * f.sz0d * rcp64(kyd * kyd * f.M0));
+      const double TIq = TIpre + dTI;
+      const double x0v_rel = c.D * f.cgv * (1.0 + f.s_c) * rcp64(c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - f.s_c)));
+      const double x0v = x0v_rel + x_i;
+      const double ix0v_rel = rcp64(x0v_rel);
+      const double kyv = c.ka * TIq + c.kb;
+      const double x_t = RES4_XS(tt), y_t = RES4_YS(tt);
+      const double dx = x_t - x_i;
+      const double lin = c.ad + c.bd * dx;
+      double d_near = (dx * ix0d_rel) * d0 + lin;
+      if (!(x_t <= x0d)) d_near = 0.0;
+      double d_far = 0.0;
+      if (x_t > x0d) {
+        const double sy = kyd * (x_t - x0d) + f.sy0d, sz = kyd * (x_t - x0d) + f.sz0d;
+        const double sg_ = sqrt_pos(sy * sz * f.is0d);
+        const double ln_arg = f.lnAB * (1.6 * sg_ - f.sM) * rcp64(1.6 * sg_ + f.sM);
+        d_far = d0 + pfar * LOG_F64(ln_arg) + lin;
+      }
+      const double delta = d_near + d_far;
+      double amp = 0.0, isy2 = 0.0, isz2 = 0.0, sy = 0.0, sz = 0.0;
+      bool on = false;
+      if (x_t > x_i + 0.1 && x_t < x0v) {
+        const double up = dx * ix0v_rel, dn = (x0v - x_t) * ix0v_rel;
+        sy = dn * f.snw + up * f.sy0v;
+        sz = dn * f.snw + up * f.sz0v;
+        on = true;
+      } else if (x_t >= x0v) {
+        sy = kyv * (x_t - x0v) + f.sy0v;
+        sz = kyv * (x_t - x0v) + f.sz0v;
+        on = true;
+      }
+      if (on) {
+        const double isy = rcp64(sy), isz = rcp64(sz);
+        double dd = 1.0 - f.kdef * isy * isz;
+        dd = fmin(fmax(dd, 0.0), 1.0);
+        amp = 1.0 - sqrt_nn(dd);
+        isy2 = 0.5 * isy * isy;
+        isz2 = 0.5 * isz * isz;
+      }
+      const double yy = (y_t + c.off[j]) - y_i - delta;
+      double def[3];
+      if (!veer_on) {
+        const double e1 = amp * exp_lean(-(yy * yy) * isy2);
+        const double e0 = e1 * exp_lean(-q2 * isz2);
+        def[0] = e0; def[1] = e1; def[2] = e0;
+      } else {
+        const double ca = c.cos2_veer * isy2 + c.sin2_veer * isz2;
+        const double cb = 0.5 * c.sin_2veer * (isz2 - isy2);
+        const double cc = c.sin2_veer * isy2 + c.cos2_veer * isz2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double zz = c.off[k];
+          def[k] = amp * exp_lean(-(ca * yy * yy - 2.0 * cb * yy * zz + cc * zz * zz));
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dU[k] = def[k] * R4.Uinit[k];
+        if (dU[k] > c.overlap_thr) ++cnt;  // the comparison as FLORIS takes it [A.3-8]
+      }
+    }
+    double p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = RES4_ST(j * 3 + k, tt);
+    if (active && ks == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p[k] = fma(dU[k], dU[k], p[k]);  // 7. SOSFS [A.3-7]
+    }
+    for (int sidx = 1; sidx < L; ++sidx) {
+      double r[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[k] = __shfl_up(p[k], T);
+      if (ks == sidx) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = active ? fma(dU[k], dU[k], r[k]) : r[k];
+      }
+    }
+    if (valid_t) {
+      RES4_LCNT(ks, j, tt) = cnt;
+      if (ks == L - 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) RES4_ST(j * 3 + k, tt) = p[k];
+      }
+    }
+  }
+}
+
+// ---- 8. Crespo-Hernandez + overlap gating of every (member, target behind it) pair, the three columns in the lane
+// (waves 0-2).  A target that is itself a member must not be touched by a member ahead of it: the check of the level ----
+RES_PASS_FN void res4_level_turbulence(int tid, Lvl4Shared& lv, int i0, int L) {
+  RES_PHASE_FENCE;
+  const WfResolveConsts& c = R4.c;
+  RES4_LV_LANES(L);
+  const int N = R4.N;
+  const Src4Shared& s = lv.s[km];
+  const double x_i = s.x_i, y_i = s.y_i, D = c.D, ch_pref = lv.f[km].ch_pref;
+  const int k_src = i0 + km;
+  const int n_ch = (N - i0 - 1 + T - 1) / T;
+  for (;;) {
+    int ch = 0;
+    if (lane == 0) ch = atomicAdd(&R4.wp_tb, 1);
+    ch = __builtin_amdgcn_readfirstlane(ch);
+    if (ch >= n_ch) break;
+    const int t = i0 + 1 + ch * T + tl;
+    const bool valid_t = member && t < N;
+    const bool active = valid_t && t > k_src;
+    const int tt = t < N ? t : N - 1;
+    const double x_t = RES4_XS(tt), y_t = RES4_YS(tt);
+    const bool reach = active && (x_t > x_i) && (x_t <= x_i + 15.0 * D);
+    bool gate[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gate[j] = reach && (fabs(y_i - (y_t + c.off[j])) < 2.0 * D);
+    double cand = 0.0;
+    if (gate[0] || gate[1] || gate[2]) {
+      const double dx = x_t - x_i;
+      const int cnt = RES4_LCNT(ks, 0, tt) + RES4_LCNT(ks, 1, tt) + RES4_LCNT(ks, 2, tt);
+      const double dxp = (dx <= 0.1) ? dx + 1.0 : dx;
+      double ti = ch_pref * POW_F64(dxp * c.inv_D, c.ch_down);
+      if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
+      const double ti_added = ((double)cnt * (1.0 / 9.0)) * ti;
+      cand = sqrt_pos(ti_added * ti_added + c.amb * c.amb);
+    }
+    const int mt = t - i0;
+    if (active && mt < L) {  // a member behind this one: its column TIs were read by its own chain already
+      const Src4Shared& st = lv.s[mt];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (gate[j] && cand > st.TIs[j]) R4.lv_fail = 1;
+    }
+    double p[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) p[j] = RES4_ST(27 + j, tt);
+    if (ks == 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) p[j] = (gate[j] && cand > p[j]) ? cand : p[j];
+    }
+    for (int sidx = 1; sidx < L; ++sidx) {
+      double r[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) r[j] = __shfl_up(p[j], T);
+      if (ks == sidx) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) p[j] = (gate[j] && cand > r[j]) ? cand : r[j];
+      }
+    }
+    if (valid_t && ks == L - 1 && mt >= L) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) RES4_ST(27 + j, tt) = p[j];
+    }
+  }
+}
+
+// ---- the check of a level (wave 3, member m in lane m): the deficit sums of every member as they stand now hold what
+// the members ahead of it added — the mean cube of its rotor speeds must be the one its state was derived from ----
+RES_SRC_FN void res4_level_check(int tid, Lvl4Shared& lv, int i0, int L) {
+  RES_PHASE_FENCE;
+  const int m = tid & 63;
+  const bool act = m >= 1 && m < L;
+  const double m3_now = res4_rotor_m3(i0 + (act ? m : 0));
+  if (act && __double_as_longlong(m3_now) != __double_as_longlong(lv.m3[m])) R4.lv_fail = 1;
+}
+
+// ---- which turbines may share a level (once per farm): from sorted turbine t on, as many as are pairwise either tied
+// in x' or laterally far enough apart; fewer than three are not worth a level stage (two sequential stages cost the same) ----
+RES_PASS_FN void res4_level_lengths(int tid, bool on) {
+  RES_PHASE_FENCE;
+  const int N = R4.N;
+  const double la = R4.lvl_a, lb = R4.lvl_b;
+  for (int t = tid; t < N; t += 256) {
+    int L = 1;
+    if (on) {
+      while (L < RES_LMAX && t + L < N) {
+        const int cnd = t + L;
+        const double xc = RES4_XS(cnd), yc = RES4_YS(cnd);
+        bool ok = true;
+        for (int k = t; k < cnd; ++k) {
+          const double dx = xc - RES4_XS(k), dy = fabs(yc - RES4_YS(k));
+          ok = ok && (dx == 0.0 || dy >= la + lb * dx);
+        }
+        if (!ok) break;
+        ++L;
+      }
+    }
+    RES4_LVL(t) = L >= 3 ? L : 1;
+  }
+}
+
 // ---- outputs [A.4] in the caller's turbine order; the farm's reward ----
 RES_PASS_FN void res4_outputs(int tid, const WfResolveArgs& a, int b, size_t gofs) {
   RES_PHASE_FENCE;
@@ -1037,34 +1564,61 @@ RES_PASS_FN void res4_outputs(int tid, const WfResolveArgs& a, int b, size_t gof
   }
 }
 
-__global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfResolveConsts c_arg, const WfResolveArgs a_arg, int n_pad, int max_count) {
+#if !RES_MT
+// [0] farms solved by the four-wave kernel, [1] of them solved a second time without levels (a level failed its check),
+// [2] level stages, [3] sources inside them, [4] sequential stages — since the library was loaded (wfk_res_level_stats)
+__device__ unsigned long long wf_res_lvl_stat[8];
+#endif
+#ifndef RES4_WAVES_ATTR
+#define RES4_WAVES_ATTR
+#endif
+__global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_kernel(const WfResolveConsts c_arg, const WfResolveArgs a_arg, int n_pad, int max_count, int levels) {
   const int tid = threadIdx.x;
   const int N = c_arg.N;
+  const int n_list = *a_arg.count;
+  if (n_list == 0 || n_list > max_count) return;  // nothing flagged (the common case: the launch costs its dispatch only) / the one-wave-per-farm kernel serves this count
   if (tid == 0) {
     R4.c = c_arg;
     R4.a = a_arg;
     R4.N = N; R4.n_pad = n_pad; R4.veer_on = c_arg.sin2_veer != 0.0; R4.mcore = c_arg.mirror_core;
+    // level rule (see Lvl4Shared): 8.6 standard deviations of a member's wake (exp(-37) of an amplitude <= 0.6 is below half an
+    // ulp of the free stream) — sigma <= sigma_0 + k_y dx, sigma_0 = D / sqrt(8) at the rotor whatever the thrust (near wake:
+    // near_wake_c D sqrt(Ct / 2)), the growth rate at a turbulence intensity of 0.3 — plus a quarter rotor of grid offsets and
+    // the wake's deflection (<= 0.1 D + 0.15 dx at 40 deg of yaw)
+    const double ky = fmax(c_arg.ka, c_arg.defl_ka) * 0.3 + fmax(c_arg.kb, c_arg.defl_kb);
+    const double s0 = fmax(0.35355339059327379 * c_arg.D, 0.70710678118654752 * c_arg.near_c);
+    R4.lvl_a = 0.35 * c_arg.D + 8.6 * s0;
+    R4.lvl_b = 8.6 * ky + 0.15;
+    R4.levels_on = levels && c_arg.sw_tv;
   }
   res_stage_tables(R4, c_arg, a_arg, tid, 256);
-  const int n_list = *a_arg.count;
-  if (n_list > max_count) return;  // the one-wave-per-farm kernel serves counts beyond one residency of this one
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
-    const int b = a_arg.list[li];
     __syncthreads();  // the constants are in place / the previous farm's last readers are done
     RES_PHASE_FENCE;
     const WfResolveArgs& a = R4.a;
-    size_t gofs = 0;
-    if (a.farm_group) gofs = (size_t)((a.farm_group[b] + a.shift) % a.mod) * N;
-    else gofs = (size_t)b * a.geom_stride;
-    const float* yaw_b = (a.yaw_state ? a.yaw_state : a.yaw_in) + (size_t)b * N;
     if (tid == 0) {
+      const int b = a_arg.list[li];
       const double ws = a.ws[(size_t)b * a.wind_stride];
       double wd = fmod(a.wd[(size_t)b * a.wind_stride], 360.0);  // reference interface.py:664 (Python's %)
       if (wd < 0.0) wd += 360.0;
-      R4.ws = ws; R4.wd = wd; R4.Uinf = ws * c_arg.uinf1;  // inflow [A.2]
-      for (int k = 0; k < 3; ++k) { R4.Uinit[k] = ws * c_arg.shearf[k]; R4.dec_a[k] = 4.0 * (c_arg.nu1[k] * ws) / R4.Uinf; }
+      R4.ws = ws; R4.wd = wd; R4.Uinf = ws * R4.c.uinf1;  // inflow [A.2]
+      for (int k = 0; k < 3; ++k) { R4.Uinit[k] = ws * R4.c.shearf[k]; R4.dec_a[k] = 4.0 * (R4.c.nu1[k] * ws) / R4.Uinf; }
     }
-    for (int t = tid; t < N; t += 256) {
+#if defined(WF_RES_STAMP) && !RES_MT
+    unsigned long long st4[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long stl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    [[maybe_unused]] unsigned n_lv = 0, n_lv_src = 0, n_seq = 0;
+    bool use_levels = true;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    {  // (the farm's index and geometry offset are derived again where they are needed — here and at the outputs — instead of
+       // being held across the solve: the stage loop has no register to spare)
+    const int b = a_arg.list[li];
+    const size_t gofs = a.farm_group ? (size_t)((a.farm_group[b] + a.shift) % a.mod) * N : (size_t)b * a.geom_stride;
+    const float* yaw_b = (a.yaw_state ? a.yaw_state : a.yaw_in) + (size_t)b * N;
+    int ti = tid;
+    asm volatile("" : "+v"(ti));  // (what is derived from it is derived per attempt, not held across the solve)
+    for (int t = ti; t < N; t += 256) {
       const double g = (double)yaw_b[a.gidx[gofs + t]];
       double sg, cg;
       if (__any(fabs(g) > 45.0)) sincos_any(g * kDeg, sg, cg);  // (never an admissible yaw command)
@@ -1075,26 +1629,72 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
 #endif
 #pragma unroll 1
       for (int q = 0; q < 27; ++q) res_dyn[t * RES_TS + 5 + q] = 0.0;
-      for (int j = 0; j < 3; ++j) res_dyn[t * RES_TS + 32 + j] = c_arg.amb;
+      for (int j = 0; j < 3; ++j) res_dyn[t * RES_TS + 32 + j] = R4.c.amb;
     }
+    }
+    int ti = tid;
+    asm volatile("" : "+v"(ti));
+    if (ti == 0) R4.lv_fail = 0;
     __syncthreads();
-    for (int t = tid; t < N; t += 256) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
+    for (int t = ti; t < N; t += 256) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
       int f = t;
       while (f > 0 && RES4_XS(f - 1) == RES4_XS(t)) --f;
       RES4_TIE(t) = f;
     }
+    res4_level_lengths(ti, use_levels && R4.levels_on);
     __syncthreads();
-    if ((tid >> 6) == 3) res4_source_begin(tid, 0, res4_rotor_m3(0));
+    int lp = 0;  // parity of the next level stage's record (R4.lv[lp]): whoever derives a level's members ahead writes there
+    if ((ti >> 6) == 3) {  // the first stage's source state(s)
+      if (RES4_LVL(0) > 1) res4_level_begin(ti, R4.lv[0], 0, RES4_LVL(0));
+      else res4_source_begin(ti, 0, res4_rotor_m3(0));
+    }
     __syncthreads();
-#if defined(WF_RES_STAMP) && !RES_MT
-    unsigned long long st4[6] = {0, 0, 0, 0, 0, 0};
-#endif
-    for (int i = 0; i < N; ++i) {
+    for (int i = 0; i < N;) {
       // (the thread index is made opaque once per source: everything derived from it — wave, lane, a dozen LDS addresses per
       // phase — is recomputed where it is used instead of being hoisted out of this loop and held, or spilled, across it)
       int tq = tid;
       asm volatile("" : "+v"(tq));
       const int wq = tq >> 6;
+      const int L = RES4_LVL(i);
+      if (L > 1) {  // ---- a level stage: sources i .. i + L - 1 at once (their states were derived a stage ahead) ----
+        Lvl4Shared& lv = R4.lv[lp];
+        RES4_T(l0);
+        if (tq == 0) { R4.wp_tv = 0; R4.wp_df = 0; R4.wp_tb = 0; }
+        res4_level_transverse(tq, lv, i, L, 1);  // the chunks that hold the members themselves
+        RES4_T(l1);
+        __syncthreads();
+        RES4_T(l2);
+        if (wq == 3) res4_level_chain(tq, lv, i, L);
+        RES4_T(l3);
+        res4_level_transverse(tq, lv, i, L, 2);  // every other target: waves 0-2 at once, wave 3 behind its chain
+        RES4_T(l4);
+        __syncthreads();
+        RES4_T(l5);
+        res4_level_deficit(tq, lv, i, L);
+        RES4_T(l6);
+        __syncthreads();
+        RES4_T(l7);
+        if (wq < 3) {
+          res4_level_turbulence(tq, lv, i, L);
+        } else {  // the level's check, and the state(s) of the next stage's source(s)
+          res4_level_check(tq, lv, i, L);
+          if (i + L < N) {
+            const int Ln = RES4_LVL(i + L);
+            if (Ln > 1) res4_level_begin(tq, R4.lv[lp ^ 1], i + L, Ln);
+            else res4_source_begin(tq, i + L, res4_rotor_m3(i + L));
+          }
+        }
+        RES4_T(l8);
+        __syncthreads();
+        RES4_T(l9);
+        RES4_LACC(0, l0, l1); RES4_LACC(1, l1, l2); RES4_LACC(2, l2, l3); RES4_LACC(3, l3, l4); RES4_LACC(4, l4, l5);
+        RES4_LACC(5, l5, l6); RES4_LACC(6, l6, l7); RES4_LACC(7, l7, l8); RES4_LACC(8, l8, l9);
+        ++n_lv; n_lv_src += L;
+        lp ^= 1;
+        i += L;
+        continue;
+      }
+      ++n_seq;
       RES4_T(p0);
       if (wq < 3) {
         if (R4.c.sw_tv) res4_transverse_pass(tq, i, wq);
@@ -1112,9 +1712,10 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
       double dTI = 0.0, m3_spec = 0.0;
       if (wq < 3) dTI = res4_recovery(tq, i);
       if (i + 1 < N) {
+        const int Ln = RES4_LVL(i + 1);  // (> 1: a level follows — its members' states are derived beside the turbulence pass, from the final sums)
         if (wq < 3) {
           res4_deficit_pass(tq, i, wq, dTI);
-        } else {  // (see res4_source_begin: the next source's state, speculated beside the deficit pass ...)
+        } else if (Ln == 1) {  // (see res4_source_begin: the next source's state, speculated beside the deficit pass ...)
           m3_spec = res4_rotor_m3(i + 1);
           res4_source_begin(tq, i + 1, m3_spec);
         }
@@ -1124,9 +1725,11 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
         RES4_ACC(2, p2, p3); RES4_ACC(3, p3, p4);
         if (wq < 3) {
           res4_turbulence_pass(tq, i, wq);
-        } else {  // (... and confirmed, or derived again, beside the turbulence pass)
+        } else if (Ln == 1) {  // (... and confirmed, or derived again, beside the turbulence pass)
           const double m3_now = res4_rotor_m3(i + 1);
           if (__double_as_longlong(m3_now) != __double_as_longlong(m3_spec)) res4_source_begin(tq, i + 1, m3_now);
+        } else {
+          res4_level_begin(tq, R4.lv[lp], i + 1, Ln);
         }
         RES4_T(p5);
         RES4_ACC(4, p4, p5);
@@ -1135,20 +1738,54 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) void wf_resolve4_kernel(const WfR
       __syncthreads();
       RES4_T(p7);
       RES4_ACC(0, p0, p1); RES4_ACC(1, p1, p2); RES4_ACC(5, p6, p7);
+      ++i;
     }
+    if (!(use_levels && R4.lv_fail)) break;  // (block-uniform: every thread reads the flag behind the stage's last barrier)
+    use_levels = false;  // a level failed its check: the farm once more, every source a stage of its own
+    __syncthreads();
+    }
+#if !RES_MT
+    if (tid == 0) {
+      atomicAdd(&wf_res_lvl_stat[0], 1ull);
+      if (!use_levels) atomicAdd(&wf_res_lvl_stat[1], 1ull);
+      atomicAdd(&wf_res_lvl_stat[2], (unsigned long long)n_lv);
+      atomicAdd(&wf_res_lvl_stat[3], (unsigned long long)n_lv_src);
+      atomicAdd(&wf_res_lvl_stat[4], (unsigned long long)n_seq);
+    }
+#endif
 #if defined(WF_RES_STAMP) && !RES_MT
     if ((tid & 63) == 0 && ((tid >> 6) == 0 || (tid >> 6) == 3)) {
       for (int k = 0; k < 6; ++k) atomicAdd(&wf_res4_stamp[((tid >> 6) ? 6 : 0) + k], st4[k]);
+      for (int k = 0; k < 10; ++k) atomicAdd(&wf_res4_lstamp[((tid >> 6) ? 10 : 0) + k], stl[k]);
       if (tid == 0) atomicAdd(&wf_res4_stamp[12], 1ull);
     }
 #endif
+    RES_PHASE_FENCE;
+    const int b = a_arg.list[li];
+    const size_t gofs = a.farm_group ? (size_t)((a.farm_group[b] + a.shift) % a.mod) * N : (size_t)b * a.geom_stride;
     res4_outputs(tid, a, b, gofs);
     if (tid == 0) a.flags[b] = 0;
   }
 }
 
+#if !RES_MT
+// level stages on (1, default; WF_RES_LEVELS seeds it) or off (0: every source a stage of its own — the A/B switch and the
+// other side of the bit-identity test, tests/test_resolve_gpu.py); shared with the build for several turbine definitions
+int g_res_levels = -1;
+extern "C" void wfk_set_resolve_levels(int on) { g_res_levels = on ? 1 : 0; }
+extern "C" int wfk_res_level_stats(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res_lvl_stat), sizeof(wf_res_lvl_stat));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(wf_res_lvl_stat), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
 
-#if defined(WF_RES_STAMP) && !RES_MT
+
+#endif  // RES_PART == 2
+#if defined(WF_RES_STAMP) && !RES_MT && RES_PART == 1
 extern "C" int wfk_res_stamps(unsigned long long* out, int reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res_stamp), sizeof(wf_res_stamp));
   if (e == hipSuccess && reset) {
@@ -1159,7 +1796,7 @@ extern "C" int wfk_res_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
-#if defined(WF_RES_STAMP) && !RES_MT
+#if defined(WF_RES_STAMP) && !RES_MT && RES_PART == 2
 extern "C" int wfk_res4_stamps(unsigned long long* out, int reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res4_stamp), sizeof(wf_res4_stamp));
   if (e == hipSuccess && reset) {
@@ -1168,8 +1805,48 @@ extern "C" int wfk_res4_stamps(unsigned long long* out, int reset) {
   }
   return (int)e;
 }
+extern "C" int wfk_res4_level_stamps(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res4_lstamp), sizeof(wf_res4_lstamp));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[20] = {};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(wf_res4_lstamp), z, sizeof(z));
+  }
+  return (int)e;
+}
 #endif
 
+#if RES_PART == 2
+#if RES_MT
+extern int g_res_levels;
+#endif
+// the four-wave kernel's launch (called by wfk_launch_resolve of part 1): how many farms one residency holds -> *max4_out;
+// launched when `launch` (the caller decides: always for a device-side count, for `all` when B fits)
+extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfResolveArgs* a, int B, int n_cu, int launch, int* max4_out,
+                                          hipStream_t s) {
+  const int n_pad = (c->N + 1) & ~1;  // (keeps the int arrays behind the doubles aligned)
+  const size_t dyn4 = sizeof(double) * RES_TS * (size_t)n_pad + sizeof(int) * RES4_DYN_INTS * (size_t)n_pad;
+  if (g_res_levels < 0) { const char* e = getenv("WF_RES_LEVELS"); g_res_levels = e ? atoi(e) : 1; }
+  const int levels = g_res_levels;
+  const size_t lds4 = dyn4 + sizeof(Res4Shared);
+  int per_cu = (int)((160 * 1024) / lds4);
+  if (per_cu > WF_RES4_OCC) per_cu = WF_RES4_OCC;
+  // (half a residency: with more farms than two per CU the four waves of a farm wait for issue slots more than they gain —
+  // HornsRev1: 322 farms 0.90 ms against 1.1 for the one-wave kernel, 680 farms 1.27 against 1.1)
+  const int max4 = per_cu >= 2 ? n_cu * 2 : (per_cu >= 1 ? n_cu * per_cu : 0);
+  *max4_out = max4;
+  if (!launch || max4 <= 0) return hipSuccess;
+  const int grid4 = B < max4 ? B : max4;
+  hipLaunchKernelGGL(wf_resolve4_kernel, dim3(grid4), dim3(256), dyn4, s, *c, *a, n_pad, max4, levels);
+  return hipGetLastError();
+}
+#endif  // RES_PART == 2
+
+#if RES_PART == 1
+#if RES_MT
+#define wfk_launch_resolve4 wfk_launch_resolve4_mt
+#endif
+extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfResolveArgs* a, int B, int n_cu, int launch, int* max4_out,
+                                          hipStream_t s);
 extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags,
                                          int n_cu, hipStream_t s) {
   hipError_t e = hipSuccess;
@@ -1178,22 +1855,15 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   // Which kernel serves the list depends on how many farms it holds, and that number exists on the device only (no host
-  // round trip): up to kRes4MaxFarms — one residency of the four-wave kernel at WF_RES4_OCC farms per CU, where the
-  // re-solve is a single farm's latency — the four-wave kernel, beyond it the one-wave kernel (four times the farms per
-  // residency, the same throughput per instruction without the redundant per-wave parts).  Both are enqueued; the one
-  // the count is not meant for returns at once.  With `all` the count is B and only the right one is launched.
-  const int n_pad = (c->N + 1) & ~1;  // (keeps the int arrays behind the doubles aligned)
-  const size_t dyn4 = sizeof(double) * RES_TS * (size_t)n_pad + sizeof(int) * 4 * (size_t)n_pad;
-  const size_t lds4 = dyn4 + sizeof(Res4Shared);
-  int per_cu = (int)((160 * 1024) / lds4);
-  if (per_cu > WF_RES4_OCC) per_cu = WF_RES4_OCC;
-  // (half a residency: with more farms than two per CU the four waves of a farm wait for issue slots more than they gain —
-  // HornsRev1: 322 farms 0.90 ms against 1.1 for the one-wave kernel, 680 farms 1.27 against 1.1)
-  const int max4 = per_cu >= 2 ? n_cu * 2 : (per_cu >= 1 ? n_cu * per_cu : 0);
+  // round trip): up to max4 — half a residency of the four-wave kernel, where the re-solve is a single farm's latency — the
+  // four-wave kernel, beyond it the one-wave kernel (four times the farms per residency, a third more farms per CU and
+  // second).  Both are enqueued; the one the count is not meant for returns at once (an empty list: both, 5 us each — folding
+  // them into one kernel would put four one-wave farms, 115 KB of LDS at N = 91, into every block and halve the four-wave
+  // residency).  With `all` the count is B and only the right one is launched.
+  int max4 = 0;
+  if ((e = wfk_launch_resolve4(c, a, B, n_cu, 0, &max4, s)) != hipSuccess) return e;
   if (max4 > 0 && (!all || B <= max4)) {
-    const int grid4 = B < max4 ? B : max4;
-    hipLaunchKernelGGL(wf_resolve4_kernel, dim3(grid4), dim3(256), dyn4, s, *c, *a, n_pad, max4);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = wfk_launch_resolve4(c, a, B, n_cu, 1, &max4, s)) != hipSuccess) return e;
   }
   if (!all || B > max4) {
     // persistent one-wave blocks over the compacted list: enough to fill the chip several times over, never more than farms
@@ -1201,6 +1871,7 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
     // for 8192 blocks that return at once, 7 us for 2048)
     // (every farm — B is known here — runs 27 % faster from a grid of 32 blocks per CU than from 8 persistent ones: 53.5 against
     // 73.7 ms at 65536 HornsRev1 farms, tools/gridab.sh; the flagged list is short and an empty launch should be cheap)
+    const int n_pad = (c->N + 1) & ~1;
     const int per_cu_grid = all ? 4 * WF_RES_GRID_PER_CU : WF_RES_GRID_PER_CU;
     const int grid = B < n_cu * per_cu_grid ? B : n_cu * per_cu_grid;
     const size_t dyn = sizeof(double) * RES_TS * (size_t)n_pad + sizeof(int) * (size_t)n_pad;
@@ -1208,3 +1879,4 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
   }
   return hipGetLastError();
 }
+#endif  // RES_PART == 1
