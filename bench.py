@@ -40,6 +40,32 @@ CONFIGS = {
 }
 
 
+def valu_practical_peak(info, shared_wind=True):
+    """The fp32 VALU ceiling for the kernel that ran (profiles/valu_practical.json: issue rates measured on this chip at the
+    kernel's waves per SIMD, mixed by the kernel's own static share of transcendental instructions), or None."""
+    try:
+        vp = json.load(open(os.path.join(ROOT, "profiles", "valu_practical.json")))
+    except Exception:
+        return None
+    G, S = info["lanes_per_env"], info["slots_per_lane"]
+    if info.get("one_block_kernel"):
+        want = f"ll_{G}x{S}_shared{1 if shared_wind else 0}_tab{1 if info.get('pair_table') else 0}_"
+    else:
+        want = f"slot_{G}x{S}_"
+    cands = [k for k in vp["kernels"] if k.startswith(want) and "veer1" not in k]
+    if not cands:
+        return None
+    k = vp["kernels"][sorted(cands, key=lambda n: ("mc1" not in n, "occ21" in n))[0]]
+    waves = max(2, min(4, 512 // max(1, info["vgprs"])))
+    r = vp[f"cycles_per_wave_instr_at_{waves}_waves_per_simd"]
+    share = k["transcendental_share"]
+    cyc = (1.0 - share) * r["plain_fp32"] + share * r["transcendental"]
+    peak = 64.0 * 256 * 4 * 2.4e9 / cyc
+    return {"peak": peak, "how": f"{waves} waves per SIMD: {r['plain_fp32']:.2f} cycles per plain fp32 wave-instruction, {r['transcendental']:.2f} per "
+                                 f"transcendental (measured, {vp['source_rates']}); {100 * share:.1f} % of the kernel's {k['valu_static']} static VALU "
+                                 f"instructions are transcendental -> {cyc:.2f} cycles per wave-instruction against the nominal 2"}
+
+
 def effective_cpus() -> int:
     """CPUs this process may actually use: affinity mask, capped by a cgroup CPU quota if there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -302,27 +328,41 @@ def main():
             env_id = {"Turb16_TCRWP_": "Turb16_TCRWP_Floris"}.get(layout_name, layout_name + "Floris")
             acts = [(torch.rand((B, N), device="cuda") * 10 - 5) for _ in range(8)]
             env_level = {}
-            # the env object as make() builds it by DEFAULT (fresh output tensors every step) and with reuse_buffers=True
-            # (two preallocated buffer sets used alternately: the opt-in for throughput loops)
-            for label, kw in (("default", {}), ("reuse_buffers", {"reuse_buffers": True})):
+            # the env object as make() builds it by DEFAULT (round 6: two preallocated output buffer sets used alternately, power in
+            # MW out of the kernel) and with reuse_buffers=False (fresh output tensors every step: the opt-out for callers that
+            # keep what a step returned)
+            for label, kw in (("default", {}), ("fresh_buffers", {"reuse_buffers": False})):
                 env = envs.make(env_id, env_batch=B, max_num_steps=10 ** 9, load_coef=0.1, log=False, **kw)
                 env.reset(seed=0, options={"wind_speed": 8.0, "wind_direction": 270.0})
                 for name, fn in (("step", env.step), ("step_light", env.step_light)):
                     for i in range(3):
                         fn(acts[i])
                     torch.cuda.synchronize()
+                    # steady-state rate of the asynchronous loop: events on the stream the env launches on (torch's current
+                    # stream, which the handle adopts), over enough steps that the loop's one-off costs (first launch, the final
+                    # host sync: ~0.5 ms, 3 % of a 20-step run) do not pass for per-step time; the wall clock is kept beside it
+                    n_it = max(args.steps, 100)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     t = time.perf_counter()
-                    for i in range(args.steps):
+                    e0.record()
+                    for i in range(n_it):
                         fn(acts[i % 8])
+                    e1.record()
                     torch.cuda.synchronize()
-                    ms = (time.perf_counter() - t) / args.steps * 1e3
-                    key = name if label == "reuse_buffers" else name + "_default_buffers"
-                    env_level[key] = {"ms_per_step": ms, "env_steps_per_sec": B / (ms * 1e-3), "over_kernel": ms / kern_ms - 1.0}
+                    wall_ms = (time.perf_counter() - t) / n_it * 1e3
+                    ms = e0.elapsed_time(e1) / n_it
+                    key = name + "_default_buffers" if label == "default" else name + "_fresh_buffers"
+                    env_level[key] = {"ms_per_step": ms, "env_steps_per_sec": B / (ms * 1e-3), "over_kernel": ms / kern_ms - 1.0,
+                                      "wall_ms_per_step": wall_ms, "steps_timed": n_it}
                 env.close()
+            # (rounds 4-5 printed the reuse_buffers=True env under "step" / "step_light": that env is the default now)
+            env_level["step"], env_level["step_light"] = env_level["step_default_buffers"], env_level["step_light_default_buffers"]
             env_level["what"] = (f'make("{env_id}", env_batch={B}).step / .step_light with device-resident random actions, '
-                                 "wall clock per step over the same number of steps (asynchronous launches, one sync at the end); "
-                                 "*_default_buffers: the env as make() builds it (outputs allocated per step); step / step_light: "
-                                 "reuse_buffers=True (outputs written into two preallocated buffer sets used alternately)")
+                                 "device time per step between two events on the launch stream over max(steps, 100) steps (asynchronous "
+                                 "launches; wall_ms_per_step: the same loop by the host clock, one sync at the end); "
+                                 "*_default_buffers: the env as make() builds it (since round 6: outputs written into two preallocated "
+                                 "buffer sets used alternately, power in MW out of the kernel); *_fresh_buffers: reuse_buffers=False "
+                                 "(outputs allocated per step); over_kernel: against the plain wf_step kernel of the headline")
         except Exception as e:  # pragma: no cover
             print(f"bench.py: env-level leg failed: {e}", file=sys.stderr)
 
@@ -399,6 +439,7 @@ def main():
     # analytic "useful work" fraction; it counted every downstream pair and overstated the work once the kernel began
     # to skip far pairs — withdrawn: only issued slots are reported.)
     valu_achieved = (cp["insts_valu"] * 64.0 / (kern_ms * 1e-3)) if cp else None
+    vp = valu_practical_peak(info, shared_wind=not args.per_env_wind)
 
     wl_wind = ("ws 8 m/s, wd(t) = 270 + 30 sin(2 pi t/200)" + (" + U(-10,10) per farm" if args.per_env_wind else " shared")
                if sweep else ("ws ~ U(6,12) m/s, wd ~ 270 + U(-10,10) per farm (fixed)" if args.per_env_wind else "ws 8 m/s, wd 270"))
@@ -423,6 +464,9 @@ def main():
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                         "traffic": cp["hbm_bytes"] if cp else None,
+                        # traffic / algorithmic bytes: what the kernel moves over what the path must move (the source log of the
+                        # one-block kernel: written once per source and farm, re-read by every later block in reach)
+                        "traffic_ratio": (cp["hbm_bytes"] / algo_bytes) if cp else None,
                         "traffic_source": cp["source"] if cp else None,
                         # what the number is: bytes the L2 requested from / sent to the fabric — an upper bound on HBM
                         # bytes (Infinity Cache hits are in it: rocprofv3 exposes no MALL counter on this box)
@@ -437,7 +481,17 @@ def main():
                              "frac_is": "ISSUED slots: SQ_INSTS_VALU x 64 lanes per launch / kernel time / (256 CU x 4 SIMD x 32 "
                                         "lanes x 2.4 GHz); idle lanes on the triangle and per-wave redundancy are in it",
                              "insts_valu_per_launch": cp["insts_valu"] if cp else None,
-                             "source": cp["source"] if cp else None}}
+                             "source": cp["source"] if cp else None,
+                             # the ceiling this chip reaches with the kernel's waves per SIMD and its own share of transcendentals
+                             # (measured issue rates: profiles/valu_practical.json, tools/valu_practical.py) — the nominal peak, one
+                             # wave-instruction per SIMD every 2 cycles, is not reachable at two waves per SIMD
+                             "practical_peak": vp["peak"] if vp else None,
+                             "frac_of_practical": (valu_achieved / vp["peak"]) if (cp and vp) else None,
+                             "practical_peak_how": vp["how"] if vp else None},
+           # which of the two roofs binds: the fraction of each the kernel reaches (fabric traffic over the HBM peak against issued
+           # VALU slots over the practical ceiling)
+           "binding_roof": (None if not (cp and vp) else
+                            ("valu" if valu_achieved / vp["peak"] >= cp["hbm_bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_COPY_GBS else "fabric"))}
     if other_leg is not None:
         res[f"{other_leg['mode']}_scaling"] = {
             "value": other_leg["total"] * args.steps / other_leg["elapsed"], "unit": "farm-steps/s",

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 6
+#define WF_ABI_VERSION 7
 
 /* status codes (0 = ok, negative = error; text via wf_last_error) */
 #define WF_OK 0
@@ -266,6 +266,11 @@ typedef struct wf_env_params {
 } wf_env_params;
 
 int wf_env_config(wf_handle* h, const wf_env_params* p);
+
+/* Unit of the `power` output of wf_env_step (ABI 7): 0 watts (default, as wf_step), 1 megawatts — what the reference's env hands
+ * out (info["power"] = powers / 1e6, wfcrl/mdp.py:284; wfcrl/simple_env.py:91): the float32 watts times 1e-6f, written by the
+ * step kernel itself instead of by a scaling pass over [B*N] behind every step.  wf_step and the reward are not affected. */
+int wf_env_set_power_unit(wf_handle* h, int megawatts);
 
 /* Zero yaw, accumulators and move counters (WindFarmMDP.reset, mdp.py:267-270). Wind: wf_set_wind. */
 int wf_env_reset(wf_handle* h);

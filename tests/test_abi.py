@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"libwfstep.so does not export {s}"
         assert s in _lib.ABI, f"ctypes binding table lacks {s}"
     assert set(_lib.ABI) == set(declared_symbols())
-    assert lib.wf_version() == 6
+    assert lib.wf_version() == 7
 
 
 def test_default_model_matches_oracle_defaults():

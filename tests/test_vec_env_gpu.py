@@ -446,3 +446,43 @@ def test_batched_aec_env_matches_B_reference_aec_envs(layouts, name, discrete):
         for k in o:
             assert torch.equal(venv.history[agent]["observation"][idx][k], o[k]), (agent, idx, k)
     venv.close()
+
+
+@pytest.mark.parametrize("name,B,gs", [("Turb16_Row5_", 64, None), ("HornsRev1_", 4096, None), ("HornsRev1_", 69632, None)])
+def test_env_step_writes_yaw_and_megawatts_itself(layouts, name, B, gs):
+    """Round 6 (ABI 7): the fused env step hands the new yaw to the caller's array as it writes the state (no device-to-device
+    copy behind the launch) and, with wf_env_set_power_unit(1), the power in MW — the float32 watts times 1e-6f, bit for bit what
+    the scaling pass it replaces produced (reference wfcrl/mdp.py:284: powers / 1e6).  Also under a wind per farm (flagged farms
+    re-solved in float64: the same unit) and on a batch served by a mixed launch (two kernels on disjoint farms)."""
+    import torch
+
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts[name]
+    N = l["num_turbines"]
+    rng = np.random.default_rng(B)
+    act = torch.from_numpy(rng.uniform(-6, 6, (B, N)).astype(np.float32)).cuda()
+    for wind in ("shared", "per_farm"):
+        if wind == "per_farm" and B > 10000:
+            continue
+        res = {}
+        for mw in (False, True):
+            w = WfStep(l["xcoords"], l["ycoords"], env_batch=B)
+            if wind == "shared":
+                w.set_wind(8.0, 270.0)
+            else:
+                r2 = np.random.default_rng(5)
+                w.set_wind(np.clip(8 * r2.weibull(8, B), 3, 28), r2.normal(270, 20, B) % 360)
+            w.env_config(load_coef=0.1, power_mw=mw)
+            w.env_reset()
+            w.env_step(act)
+            o = w.env_step(act)  # second transition: the state is not zero any more
+            st = w.env_get_state()
+            res[mw] = {k: v.cpu().numpy() for k, v in o.items()}
+            assert np.array_equal(res[mw]["yaw"], st["yaw"])  # the caller's array holds the state's new yaw
+            if wind == "per_farm" and B >= 4096:  # (flagged farms re-solved in float64: they carry the unit too)
+                assert w.resolve_stats()["n_resolved"] > 0
+            w.close()
+        assert np.array_equal(res[True]["power"], (res[False]["power"] * np.float32(1e-6)).astype(np.float32))
+        for k in ("yaw", "reward", "wind_speed", "wind_direction", "load"):
+            assert np.array_equal(res[True][k], res[False][k]), k

@@ -9,8 +9,8 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/fuzz_head.txt
 : > $O
-leg() { echo "## $*" >> $O; timeout ${LEG_TIMEOUT:-600} env "$@" 2>&1 | grep -v amdgpu.ids | grep -E "^BAD|^fuzz|^api|^env" | cut -c1-1500 >> $O; }
-S=${FUZZ_SCALE:-1}
+leg() { echo "## $*" >> $O; timeout ${LEG_TIMEOUT:-2400} env "$@" 2>&1 | grep -v amdgpu.ids | grep -E "^BAD|^fuzz|^api|^env|^family" | cut -c1-1500 >> $O; }
+S=${FUZZ_SCALE:-5}  # (round 6: the default is the scale that found round 5's only real defect; FUZZ_SCALE=1 for an interim record)
 leg python tests/tools/fuzz_parity.py $((500 * S)) 5011
 leg WF_FUZZ_RESOLVE=1 python tests/tools/fuzz_parity.py $((400 * S)) 5021
 leg WF_FUZZ_VEER=1 python tests/tools/fuzz_parity.py $((200 * S)) 5031
@@ -19,6 +19,7 @@ leg WF_FUZZ_SKIP=1 FUZZ_WS=2.5,26 WF_FUZZ_RESOLVE=1 python tests/tools/fuzz_pari
 leg python tests/tools/fuzz_api.py $((30 * S)) 50 5051
 leg FUZZ_API_BIG=1 python tests/tools/fuzz_api.py $((4 * S)) 40 5053
 leg python tests/tools/fuzz_env.py $((30 * S)) 5061
+leg python tests/tools/fuzz_families.py $((150 * S)) 5071
 python - <<'PY'
 import glob, hashlib, json, re, subprocess
 h = hashlib.sha256()
@@ -35,7 +36,8 @@ for line in open("gpurun_out/fuzz_head.txt"):
         m = re.search(r"(\d+) violations", line) or re.search(r"violations: (\d+)", line)
         if m:
             cur["summary"], cur["violations"] = line.strip(), int(m.group(1))
-json.dump({"sources_sha256": h.hexdigest(), "files": files, "legs": legs,
+import os
+json.dump({"sources_sha256": h.hexdigest(), "files": files, "fuzz_scale": int(os.environ.get("FUZZ_SCALE", "5")), "legs": legs,
            "violations_total": sum((l["violations"] if l["violations"] is not None else 10 ** 6) for l in legs),
            "legs_without_a_summary": [l["leg"] for l in legs if l["summary"] is None]},
           open("gpurun_out/fuzz_head.json", "w"), indent=1)

@@ -109,6 +109,7 @@ ABI = {
     "wf_wind_series_step": (C.c_int, [_P]),
     "wf_get_wind": (C.c_int, [_P, _P, _P, C.c_int]),
     "wf_env_config": (C.c_int, [_P, C.POINTER(EnvParams)]),
+    "wf_env_set_power_unit": (C.c_int, [_P, C.c_int]),
     "wf_env_reset": (C.c_int, [_P]),
     "wf_env_state": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),
     "wf_env_set_prev_wind": (C.c_int, [_P, _P, C.c_int]),

@@ -308,9 +308,11 @@ class WfStep:
 
     # -- fused env step ---------------------------------------------------------------
     def env_config(self, yaw_lo=-40.0, yaw_hi=40.0, yaw_step=5.0, actuator_rate=0.3, dt=60.0, budget=0.1,
-                   load_coef=0.1, discrete=False):
+                   load_coef=0.1, discrete=False, power_mw=False):
+        """power_mw: the `power` output of env_step in MW (include/wfstep.h: wf_env_set_power_unit) instead of W."""
         p = EnvParams(yaw_lo, yaw_hi, yaw_step, actuator_rate, dt, budget, load_coef, int(bool(discrete)))
         check(self._lib.wf_env_config(self._h, C.byref(p)), self._h)
+        check(self._lib.wf_env_set_power_unit(self._h, int(bool(power_mw))), self._h)
 
     def env_reset(self):
         check(self._lib.wf_env_reset(self._h), self._h)

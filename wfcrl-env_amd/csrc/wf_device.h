@@ -98,6 +98,11 @@ struct WfEnvArgs {
   float rate, dt, budget;          // ACTUATORS_RATE["yaw"] = 0.3 deg/s, case.dt, 0.1
   float load_coef;
   int discrete;
+  // round 6 (the two device-side copies a learner's step paid for): the new absolute yaw also goes to the caller's array as it is
+  // written to the state (null: not wanted / no transition — wf_env_step copies the state instead), and the power output may
+  // leave the kernel in MW, the unit the reference's env hands out (info["power"] = powers / 1e6, mdp.py:284)
+  float* yaw_out;
+  int power_mw;
 };
 
 // Grouped launch (one pair table + sorted geometry per distinct wind direction) and the per-farm risk

@@ -801,6 +801,7 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   ra.o_power = power; ra.o_ws = wspd; ra.o_wd = wdir; ra.o_load = load;
   if (ea) {
     ra.yaw_state = ea->yaw_state; ra.reward = ea->reward; ra.ws_prev = ea->ws_prev; ra.load_coef = ea->load_coef;
+    ra.power_mw = ea->power_mw;
   }
   h->rconsts.N = h->N;
   if (!h->types.empty()) {

@@ -14,6 +14,12 @@ int wf_env_config(wf_handle* h, const wf_env_params* p) {
   return WF_OK;
 }
 
+int wf_env_set_power_unit(wf_handle* h, int megawatts) {
+  if (!h) return WF_E_INVALID;
+  h->env_power_mw = megawatts ? 1 : 0;
+  return WF_OK;
+}
+
 static int env_alloc(wf_handle* h) {
   if (h->B <= 0) return fail(h, WF_E_INVALID, "wf_set_batch must be called first");
   if (h->d_env_yaw) return WF_OK;
@@ -90,10 +96,12 @@ int wf_env_step(wf_handle* h, const float* action, float* reward, float* yaw, fl
   // valid for one reward only — a second env step without a new tick normalises by the current wind again
   ea.ws_prev = (h->ws_prev_valid && h->d_ws_prev) ? h->d_ws_prev : nullptr;
   if (reward) h->ws_prev_valid = false;
+  ea.power_mw = h->env_power_mw;
   if (on_device) {
     ea.action = action; ea.reward = reward;
+    ea.yaw_out = action ? yaw : nullptr;  // (a transition writes the new yaw to the caller's array as it writes the state)
     if ((rc = launch_step(h, nullptr, power, wspd, wdir, load, &ea)) != WF_OK) return rc;
-    if (yaw) WF_HIP(h, hipMemcpyAsync(yaw, h->d_env_yaw, sizeof(float) * bn, hipMemcpyDeviceToDevice, h->stream));
+    if (yaw && !ea.yaw_out) WF_HIP(h, hipMemcpyAsync(yaw, h->d_env_yaw, sizeof(float) * bn, hipMemcpyDeviceToDevice, h->stream));
     return WF_OK;
   }
   if (!h->d_env_act) {

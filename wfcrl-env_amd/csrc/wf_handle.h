@@ -121,6 +121,7 @@ struct wf_handle {
   size_t cap_env = 0, cap_bn = 0;
   // fused env state
   wf_env_params env{-40.f, 40.f, 5.f, 0.3f, 60.f, 0.1f, 0.1f, 0};
+  int env_power_mw = 0;  // wf_env_set_power_unit: the power output of wf_env_step in MW
   float *d_env_yaw = nullptr, *d_env_acc = nullptr, *d_env_act = nullptr, *d_env_out = nullptr;  // out: reward[B] + yaw[BN]
   int* d_env_moves = nullptr;
   float *h_env_act = nullptr, *h_env_out = nullptr;

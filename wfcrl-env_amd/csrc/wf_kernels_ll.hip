@@ -323,6 +323,7 @@ __global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) vo
       if (okf) {
         ea.yaw_state[oi] = yw;
         ea.acc[oi] = acc;
+        if (ea.yaw_out) ea.yaw_out[oi] = yw;
       }
       o += 64;
       while (o >= N) { o -= N; ++f; }
@@ -1185,7 +1186,7 @@ __global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) vo
       lsum += real ? (l.x + l.y) + (l.z + l.w) : 0.0f;
       if (env_ok) {
         const size_t oo = yofs + o;
-        if (o_power) o_power[oo] = real ? pwr : 0.0f;
+        if (o_power) o_power[oo] = real ? (ea.power_mw ? pwr * 1.0e-6f : pwr) : 0.0f;
         if (o_ws) o_ws[oo] = real ? wsp : 0.0f;
         if (o_wd) o_wd[oo] = real ? wd - adir * (kRad2Deg / 9.0f) : 0.0f;
         if (o_load) reinterpret_cast<float4*>(o_load)[oo] = real ? l : make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -48,6 +48,7 @@ struct WfResolveArgs {
   float* reward;           // [B] or null
   const double* ws_prev;   // [B] or null
   float load_coef;
+  int power_mw;            // the power output in MW (float32 watts x 1e-6f, as the float32 kernels write it: WfEnvArgs::power_mw)
   // several turbine definitions per farm (wf_set_turbine_types; read by the kernels of wf_resolve_mt.hip only, where tab64 is
   // [n_types][3][WF_TABLE_PAD])
   int n_types;

@@ -523,7 +523,7 @@ __device__ __forceinline__ void res_turbine_outputs(const WfResolveConsts& c, co
   const double l1 = sqrt_nn(su * (1.0 / 9.0)), l2 = sqrt_nn(sv * (1.0 / 9.0)), l3 = sqrt_nn(sw * (1.0 / 9.0));
   psum += real ? pw : 0.0;
   lsum += real ? fabs(l0) + fabs(l1) + fabs(l2) + fabs(l3) : 0.0;
-  if (a.o_power) a.o_power[oo] = real ? (float)pw : 0.0f;
+  if (a.o_power) a.o_power[oo] = real ? (a.power_mw ? (float)pw * 1.0e-6f : (float)pw) : 0.0f;
   if (a.o_ws) a.o_ws[oo] = real ? (float)wsp : 0.0f;
   if (a.o_wd) a.o_wd[oo] = real ? (float)(dir * (1.0 / 9.0)) : 0.0f;
   if (a.o_load) reinterpret_cast<float4*>(a.o_load)[oo] = real ? make_float4((float)l0, (float)l1, (float)l2, (float)l3) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -30,7 +30,7 @@ class VecWindFarmEnv:
     def __init__(self, farm_case, controls: dict = None, env_batch: int = 1, continuous_control: bool = True,
                  reward_shaper=None, start_iter: int = 0, max_num_steps: int = 500, load_coef: float = 0.1,
                  device_id: int = 0, model: dict = None, return_torch: bool = True, backend=None,
-                 wind_sampling: str = "host", reuse_buffers: bool = False, wind_direction_step: float = None,
+                 wind_sampling: str = "host", reuse_buffers: bool = True, wind_direction_step: float = None,
                  actuation_budget: float = 0.1, kernel_choice: dict = None, risk_resolve: bool = None,
                  layouts: dict = None):
         controls = {"yaw": (-40, 40, 5)} if controls is None else dict(controls)
@@ -74,7 +74,7 @@ class VecWindFarmEnv:
             self.fi.set_layouts(layouts["xcoords"], layouts["ycoords"], layouts.get("layout_of"), layouts.get("counts"))
         self.fi.env_config(yaw_lo=spec[0], yaw_hi=spec[1], yaw_step=spec[2],
                            actuator_rate=WindFarmMDP.ACTUATORS_RATE["yaw"], dt=self.dt, budget=actuation_budget,
-                           load_coef=load_coef, discrete=not continuous_control)
+                           load_coef=load_coef, discrete=not continuous_control, power_mw=True)
         n = self.num_turbines
         # per-env spaces, identical to the reference's (mdp.py:108-153)
         if continuous_control:
@@ -110,10 +110,12 @@ class VecWindFarmEnv:
         self._num_iter = 0
         self._freewind = None
         self._shaper_ref = None
-        # reuse_buffers=True (opt-in, throughput loops): output tensors are preallocated and used alternately (torch path) —
-        # what step t returned stays valid until step t + 2 overwrites it: enough for (obs, next_obs) pairs, copy what must
-        # live longer (rollout storage, loggers).  The default allocates fresh tensors every step, as B reference envs
-        # would: nothing a caller keeps is ever overwritten.
+        # reuse_buffers=True (the DEFAULT since round 6; torch path): the output tensors of `step` / `step_light` are two
+        # preallocated sets used alternately — what step t returned stays valid until step t + 2 overwrites it: enough for
+        # (obs, next_obs) pairs; ALIASING: anything that must live longer (rollout storage, loggers, a list of observations)
+        # has to be copied (`.clone()`) by the caller, or the env built with reuse_buffers=False, which allocates fresh
+        # tensors every step as B reference envs would (+3 % per step on the headline batch).  The logged / AEC flavours
+        # (environments.make(..., log=True), Dec_*) keep what they return and therefore build their inner env without reuse.
         self.reuse_buffers = bool(reuse_buffers) and return_torch
         self._bufs = [{}, {}]
         self._flip = 0
@@ -272,19 +274,15 @@ class VecWindFarmEnv:
             import torch
 
             if buf is not None:
-                if "power_mw" not in buf:
-                    buf["power_mw"] = torch.empty_like(out["power"])
-                    buf.update(out)  # keep the tensors env_step allocated on first use
-                info = {"power": torch.mul(out["power"], 1e-6, out=buf["power_mw"]), "load": out["load"]}
-            else:
-                info = {"power": out["power"] * 1e-6, "load": out["load"]}
+                buf.update(out)  # keep the tensors env_step allocated on first use
+            info = {"power": out["power"], "load": out["load"]}  # (MW out of the kernel: wf_env_set_power_unit)
             if not self._const:
                 dev = out["reward"].device
                 self._const = {False: torch.zeros(self.num_envs, dtype=torch.bool, device=dev),
                                True: torch.ones(self.num_envs, dtype=torch.bool, device=dev)}
             trunc, term = self._const[bool(truncated)], self._const[False]
         else:
-            info = {"power": out["power"] * 1e-6, "load": out["load"]}
+            info = {"power": out["power"], "load": out["load"]}
             trunc = np.full(self.num_envs, bool(truncated))
             term = np.zeros(self.num_envs, bool)
         return self._obs(out), reward, term, trunc, info
