@@ -270,6 +270,11 @@ def main():
             w.sync()
         sync_ms = (time.perf_counter() - t1) / nsync * 1e3
         shards = [[rank, local_rank, lo, hi]]
+        ki = w.kernel_info()
+        # every rank's kernel, beside its shard (each handle times its kernel families itself, so two ranks may
+        # settle on different families for the same shard size — the line says so instead of quoting rank 0's only):
+        # [lanes per farm, slots per lane, one-block kernel, farms of a mixed launch's main part, VGPRs]
+        kern = [[ki["lanes_per_env"], ki["slots_per_lane"], ki["one_block_kernel"], ki["mixed_main_farms"], ki["vgprs"]]]
         if dist is not None:
             dev = "cuda" if backend == "nccl" else "cpu"
             t = torch.tensor([elapsed, kern_ms], device=dev, dtype=torch.float64)
@@ -279,8 +284,12 @@ def main():
             parts = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine)  # (bookkeeping for the JSON line, outside the timed region: not a data-path collective)
             shards = [[int(v) for v in p_] for p_ in parts]
+            mine_k = torch.tensor(kern[0], device=dev, dtype=torch.int64)
+            parts_k = [torch.empty_like(mine_k) for _ in range(world)]
+            dist.all_gather(parts_k, mine_k)
+            kern = [[int(v) for v in p_] for p_ in parts_k]
         return dict(mode=mode, B=B, total=total, elapsed=elapsed, kern_ms=kern_ms, sync_ms=sync_ms, w=w, ring=ring, out=out,
-                    shards=shards)
+                    shards=shards, shard_kernels=kern)
 
     main_leg = run_leg(args.scaling)
     other_leg = None
@@ -455,6 +464,10 @@ def main():
                       # which farms each rank stepped: [rank, device, first farm, one past the last] (contiguous blocks,
                       # wfcrl_env_amd/sharding.py: shard_bounds)
                       "shards": main_leg["shards"],
+                      # the kernel each rank's handle settled on, in the order of `shards`: [G, S, one-block kernel, main farms of a
+                      # mixed launch, VGPRs]; `kernel` below is rank 0's
+                      "shard_kernels": main_leg["shard_kernels"],
+                      "shard_kernels_agree": len({tuple(k[:4]) for k in main_leg["shard_kernels"]}) == 1,
                       "parallelism": f"env-shard x{world}" + (f" ({world} ranks sharing {ndev} GPU(s) over gloo: test mode)" if shared_devices else ""),
                       "kernel": (f"wf_step_ll_kernel<G={info['lanes_per_env']},S={info['slots_per_lane']}> (one target block at a time, source log)"
                                  if info.get("one_block_kernel") else

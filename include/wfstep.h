@@ -307,7 +307,7 @@ int wf_wind_sample(wf_handle* h, unsigned long long seed, const wf_wind_dist* di
  * layout / model and kept across resets, and every step takes the table path (about twice the throughput of a
  * continuous direction per farm).  It is a DIFFERENT wind process, not an approximation of the continuous one within the
  * parity tolerances: a 2-degree grid moves HornsRev1's farm power by 0.8 % in the median and 7.7 % at the 99th percentile
- * (profiles/r03_binning_error.txt).  Falls back to wf_wind_sample when K is too large for the batch (padding each group
+ * (profiles/archive/r03_binning_error.txt).  Falls back to wf_wind_sample when K is too large for the batch (padding each group
  * to whole blocks would cost more than it saves). */
 int wf_wind_sample_binned(wf_handle* h, unsigned long long seed, const wf_wind_dist* dist, double step_deg);
 

@@ -40,7 +40,7 @@ RISK_OVERLAP, RISK_POWER_KNEE, RISK_THRUST_RAMP = 1, 2, 4
 RISK_NEGATIVE_SPEED = 16  # a rotor-grid speed <= 0 (unphysically tight farm): float32 keeps ~1e-5 of that turbine's wind speed
 RISK_THRUST_UNITY = 8  # Ct > 0.995 (user tables): never left in float32 — re-solved in float64 in every mode, so never seen after a step
 # A flag only excuses what its event can move (round 3; tests/tools/flag_stats.py on 10 x 4096 farms,
-# profiles/r03_flag_stats.txt): a farm flagged for the power knee ALONE has a wind field as good as an unflagged farm's —
+# profiles/archive/r03_flag_stats.txt): a farm flagged for the power knee ALONE has a wind field as good as an unflagged farm's —
 # only the power read off the steep segment moves (1.3e-2 measured on the cut-out drop, condition number 2500) — and
 # a farm on the thrust ramp without an overlap flag stays within a few TOL (power 7.7e-4, ws 6.9e-5, wd 8.9e-4 deg
 # measured; TI 1.3e-5 on the fixture farm with 48 turbines on the ramp).

@@ -1,7 +1,7 @@
 """CPU (float64 oracle): what rounding every farm's wind direction to a grid does to the answer — the price of the binned
 reset sampling (wf_wind_sample_binned: about twice the throughput of a continuous direction per farm) —
 per layout and grid step, under the reference's reset distribution (wfcrl/mdp.py:237-258).
-  python tools/binning_error.py [B] > profiles/r03_binning_error.txt"""
+  python tools/binning_error.py [B] > profiles/archive/r03_binning_error.txt"""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box, LAST thing of a round (two rounds running the final kernel commits went out unfuzzed):
-# a short fuzz campaign on exactly the sources of HEAD — every leg of tools/fuzz_campaign_short.sh, plus one API-fuzz seed
+# a short fuzz campaign on exactly the sources of HEAD — the legs of tools/fuzz_campaign.sh (one seed each), with one API-fuzz seed
 # with batches beyond the latency regime, so that the handle's own kernel calibration (table path, on the fly, inside fused
 # env steps) fires in the middle of the sessions — and a record of WHAT was fuzzed: gpurun_out/fuzz_head.json =
 # {sha256 over csrc/*.hip, csrc/*.h, include/wfstep.h, totals per leg}.  Copy it to profiles/fuzz_head.json and commit:

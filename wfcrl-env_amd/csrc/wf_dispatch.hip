@@ -50,7 +50,7 @@ int pick_variant(const wf_handle* h, int N, int B) {
 // Rounds model.  A wave solves its 64 / G farms start to finish, so a launch runs in ROUNDS of (blocks the chip holds) x
 // (farms per block), and within a round the time depends on how many blocks share a CU (one wave per SIMD each).
 // Measured per family at 1, 2, 3 blocks per CU on one MI355X (256 CUs) for farms of 32, 48, 64, 80, 91 turbines
-// (tools/rounds_table.py -> profiles/r03_rounds_table.txt), ms; between the measured N the times are interpolated linearly in N (N + 1) / 2, the
+// (tools/rounds_table.py -> profiles/archive/r03_rounds_table.txt), ms; between the measured N the times are interpolated linearly in N (N + 1) / 2, the
 // number of (source, target) pairs, beyond them extrapolated the same way.  The number of CUs comes from the device
 // (a partitioned or smaller part has shorter rounds, the same time per round).
 //   code = (G << 4) | S of wf_step_ll_kernel, 0 = the register-slot kernel wf_step_kernel (its variant for N: pick_variant)
@@ -72,7 +72,7 @@ const double kRoundsMs[kNumFamilies][kNumRoundsN][3] = {
     {{0.179, 0.250, 0.0}, {0.307, 0.432, 0.0}, {0.454, 0.648, 0.0}, {0.622, 0.856, 0.0}, {0.798, 1.026, 0.0}},            // 2x2
     {{0.068, 0.090, 0.122}, {0.116, 0.151, 0.198}, {0.171, 0.224, 0.292}, {0.228, 0.296, 0.386}, {0.287, 0.361, 0.474}}};  // 16x1
 // A partial round behind full ones overlaps with their tail: its cost relative to the same round on an idle chip, by
-// (blocks per CU it reaches, resident blocks per CU of the family) — fitted on profiles/r03_batch_sweep_fine.txt
+// (blocks per CU it reaches, resident blocks per CU of the family) — fitted on profiles/archive/r03_batch_sweep_fine.txt
 const double kTailFactor[2][3] = {{0.80, 0.95, 0.0}, {0.62, 0.79, 0.86}};  // [per_cu - 2][tail blocks per CU - 1]
 
 // farms per block and resident blocks per CU of family fi for N turbines (the register-slot kernel's follow from its

@@ -31,9 +31,10 @@
 //     The two passes touch disjoint state and keep their own source order: bit for bit the result of one loop.
 //   * pair-table records are laid out per target block, [J][source i][target of J], so that the 64 records of a chunk
 //     (64 / (G S) consecutive sources of one block) are one contiguous 11-KiB piece, staged into a double-buffered LDS slab
-//     with global_load_lds_dwordx4 one chunk ahead (one __syncthreads() per chunk).  The compiler guards the first LDS read
-//     of an iteration with s_waitcnt vmcnt(0) — the chunk arrives by LDS-DMA, counted in vmcnt — so log prefetches are
-//     issued BEHIND the first LDS reads of an iteration and no load stays in flight across one.
+//     with global_load_lds_dwordx4 one chunk ahead (one __syncthreads() per chunk).  The transfers are issued by hand
+//     (lds_dma16, wf_kernel_common.h: inline assembly the compiler's wait-count bookkeeping does not see), so nothing is waited for
+//     at the first LDS read of an iteration any more (rounds 2-4: the builtin made every iteration start with s_waitcnt vmcnt(0));
+//     the kernel waits where the data is needed — wf_dma_wait() in front of the chunk's closing barrier and at a block's first chunk.
 //   * A wind per farm (TAB = false): no pair table — the transverse pass is evaluated on the fly from the farm's own float64
 //     coordinates (apply_fly), same log, one loop; wf_set_wind sorts the launch slots by direction so that the farms of a
 //     wave lie within a fraction of a degree and the wave-uniform skips take.
@@ -990,10 +991,8 @@ __global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) vo
           ColdRec cold_nx = {};
           if (near_bits) cold_nx = load_cold(i0 + (__builtin_ctzll(near_bits) / GS));
           // -- transverse pass: every logged source of the chunk, two per iteration (their hot records are one float4,
-          // fetched one iteration ahead, across chunk boundaries: started at the top of the block).  The compiler guards
-          // the first read of the staged chunk in an iteration with s_waitcnt vmcnt(0) (the chunk arrives by LDS-DMA,
-          // counted in vmcnt), so no load can stay in flight for longer than one iteration: two sources make that ~230
-          // instructions.  No lane mask: every real turbine of this block is at or downstream of an earlier block's
+          // staged into wave-private LDS by hand-issued LDS-DMA a chunk ahead: the loop holds no global load at all).  Two
+          // sources per iteration, ~230 instructions.  No lane mask: every real turbine of this block is at or downstream of an earlier block's
           // source (dx >= 0), and the lanes beyond N (last block only) carry all-zero records. --
           static_assert(GS % 2 == 0 && CH % 2 == 0, "logged sources come in pairs");
 #pragma unroll 1
@@ -1026,9 +1025,9 @@ __global__ __launch_bounds__(64 * WPB, ((S == 1 && !OCC2) ? 3 : 2) * 4 / WPB) vo
               exs[p] = *reinterpret_cast<const float4*>(buf + (k * GS + p * G + sub) * WF_PAIR_STRIDE + WF_PAIR_DX);
             asm volatile("" ::: "memory");
             // unconditional (the last near source re-reads its own record, which is in the cache): a conditional load leaves
-            // "keeps its value" on the other path, a register copy per float and iteration.  Behind the first LDS reads of the
-            // step: the compiler guards the first read of the staged chunk with s_waitcnt vmcnt(0) (the chunk arrives by
-            // LDS-DMA, counted in vmcnt), and a load issued before it would be waited for on the spot.
+            // "keeps its value" on the other path, a register copy per float and iteration.  (Issued behind the step's first LDS
+            // reads for historical reasons — rounds 2-4's builtin LDS-DMA made the compiler wait for every outstanding load there;
+            // with the hand-issued transfers the position no longer matters: measured equal either way, profiles/r05_hotlds_ablation.txt.)
 #ifdef WF_EXP_NOCOLD  // timing experiment only (wrong results): the deficit pass without its cold-record loads
             nxt = cold;
 #else

@@ -720,7 +720,7 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
 // The phases are separate NON-INLINED functions that talk through LDS (the per-source constants too): inlined into one
 // body the register allocator kept ~370 values live and spilled inside the source loop.
 // (History: a thread per turbine, state in registers, two __syncthreads per source, every wave re-deriving the source
-// constants: 1.95 ms for 1394 HornsRev1 farms; one wave per farm with the state in LDS: 1.37 ms; profiles/r03_*.)
+// constants: 1.95 ms for 1394 HornsRev1 farms; one wave per farm with the state in LDS: 1.37 ms; profiles/archive/r03_*.)
 struct Src4Shared {  // what res4_source_begin leaves (one copy per wave)
   double x_i, y_i, ct, ai, ubar, Vmean, val, TIs[3];
   double Gt, Gb, Gw;  // circulations / (2 pi): top, bottom, wake rotation (commanded yaw)
