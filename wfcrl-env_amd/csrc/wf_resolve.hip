@@ -1576,6 +1576,7 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
   const int tid = threadIdx.x;
   const int N = c_arg.N;
   const int n_list = *a_arg.count;
+  if (a_arg.hint && blockIdx.x == 0 && tid == 0) *a_arg.hint = n_list;  // (for the host's next decision, read without a sync)
   if (n_list == 0 || n_list > max_count) return;  // nothing flagged (the common case: the launch costs its dispatch only) / the one-wave-per-farm kernel serves this count
   if (tid == 0) {
     R4.c = c_arg;
@@ -1822,7 +1823,7 @@ extern int g_res_levels;
 // the four-wave kernel's launch (called by wfk_launch_resolve of part 1): how many farms one residency holds -> *max4_out;
 // launched when `launch` (the caller decides: always for a device-side count, for `all` when B fits)
 extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfResolveArgs* a, int B, int n_cu, int launch, int* max4_out,
-                                          hipStream_t s) {
+                                          int any_count, hipStream_t s) {
   const int n_pad = (c->N + 1) & ~1;  // (keeps the int arrays behind the doubles aligned)
   const size_t dyn4 = sizeof(double) * RES_TS * (size_t)n_pad + sizeof(int) * RES4_DYN_INTS * (size_t)n_pad;
   if (g_res_levels < 0) { const char* e = getenv("WF_RES_LEVELS"); g_res_levels = e ? atoi(e) : 1; }
@@ -1836,7 +1837,8 @@ extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfReso
   *max4_out = max4;
   if (!launch || max4 <= 0) return hipSuccess;
   const int grid4 = B < max4 ? B : max4;
-  hipLaunchKernelGGL(wf_resolve4_kernel, dim3(grid4), dim3(256), dyn4, s, *c, *a, n_pad, max4, levels);
+  // any_count: this launch is the only one behind the step — its persistent blocks walk a list of any length
+  hipLaunchKernelGGL(wf_resolve4_kernel, dim3(grid4), dim3(256), dyn4, s, *c, *a, n_pad, any_count ? 0x7fffffff : max4, levels);
   return hipGetLastError();
 }
 #endif  // RES_PART == 2
@@ -1846,9 +1848,9 @@ extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfReso
 #define wfk_launch_resolve4 wfk_launch_resolve4_mt
 #endif
 extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfResolveArgs* a, int B, int n_cu, int launch, int* max4_out,
-                                          hipStream_t s);
+                                          int any_count, hipStream_t s);
 extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags,
-                                         int n_cu, hipStream_t s) {
+                                         int n_cu, int recent_count, hipStream_t s) {
   hipError_t e = hipSuccess;
   if (all) {
     hipLaunchKernelGGL(wf_list_all_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a->flags, B, a->list, a->count, raw_flags);
@@ -1861,10 +1863,17 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
   // them into one kernel would put four one-wave farms, 115 KB of LDS at N = 91, into every block and halve the four-wave
   // residency).  With `all` the count is B and only the right one is launched.
   int max4 = 0;
-  if ((e = wfk_launch_resolve4(c, a, B, n_cu, 0, &max4, s)) != hipSuccess) return e;
+  if ((e = wfk_launch_resolve4(c, a, B, n_cu, 0, &max4, 0, s)) != hipSuccess) return e;
+  // ONE launch where the lists have been short (round 6).  recent_count: the length of a flagged list one or two steps back, as
+  // the four-wave kernel left it in host-visible memory (read without a sync: a hint, never a dependency) — while it stays within
+  // the four-wave kernel's range only that kernel is enqueued, with no upper bound (its persistent blocks walk a list of any
+  // length: a list that suddenly grows is served correctly, merely slower for that step), and an empty list costs one dispatch
+  // (4.9 us) instead of two (10.4).  Once lists beyond the range are seen both are enqueued as before.
+  const bool only4 = !all && max4 > 0 && recent_count >= 0 && recent_count <= max4;
   if (max4 > 0 && (!all || B <= max4)) {
-    if ((e = wfk_launch_resolve4(c, a, B, n_cu, 1, &max4, s)) != hipSuccess) return e;
+    if ((e = wfk_launch_resolve4(c, a, B, n_cu, 1, &max4, only4 ? 1 : 0, s)) != hipSuccess) return e;
   }
+  if (only4) return hipSuccess;
   if (!all || B > max4) {
     // persistent one-wave blocks over the compacted list: enough to fill the chip several times over, never more than farms
     // (two waves per SIMD hold 8 farms per CU; more blocks than that only cost launch time when the list is empty — 20 us
