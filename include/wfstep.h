@@ -204,6 +204,11 @@ int wf_sync(wf_handle* h);
  *   WF_RISK_NEGATIVE_SPEED a rotor-grid speed that is not positive: summed deficits beyond 1 in an unphysically tight farm
  *                       (the reference keeps computing there, and so does this path).  The cube mean of mixed-sign speeds
  *                       cancels: float32 keeps about 1e-5 of the rotor wind speed of such a turbine (round-5 fuzz).
+ *                       What the FLOAT64 kernels guarantee there (modes 1 / 2): the combined deficit of every rotor-grid point
+ *                       to 6e-7 relative (profiles/r05_f64_deviation_probe.txt: with Ct at 0.9999 the deficit amplitude sits at
+ *                       the clip of its square root, where two float64 orders of summation differ that much) — i.e. a wind
+ *                       speed error of 6e-7 of the FREE STREAM on such a turbine (5e-5 of |u| where u is the small difference
+ *                       of two free-stream-sized numbers), and the contract's tolerances everywhere else.
  * Farms with flag 0 match the float64 path within the parity tolerances (power 1e-4 of max(P, 1 kW), wind speed 5e-5,
  * direction 3e-4 deg, TI 5e-6).  By default (wf_set_risk_resolve mode 1) the flagged farms are solved again in float64 behind
  * every step and no flag is left.  A FLAGGED farm left in float32 (mode 0, the opt-out) may differ by the bounded signature of
