@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
 // waves shortens it (HornsRev1: 1.04 -> 0.73 ms per farm).  Both kernels are enqueued behind the compaction; each reads
 // the count on the device and the one it is not meant for returns at once.
 #ifndef WF_RES4_OCC
-#define WF_RES4_OCC 2          // blocks per CU the register allocator makes room for (256 VGPRs: the inlined source step fits without a spill; at 3 or 4 it spills 57 / 113 values and the kernel gets a private segment)
+#define WF_RES4_OCC 4          // blocks per CU the register allocator makes room for: 128 VGPRs since round 6 (without machine LICM the kernel needs no more — with it, at 256, only two blocks fitted a CU and a list beyond 512 farms needed a second round)
 #endif
 // One farm per 256-thread block.  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column TIs,
 // float64 — lives in LDS, structure-of-arrays over the sorted turbine index; a lane is not tied to a turbine: for source i
@@ -764,6 +764,16 @@ struct Lvl4Shared {
   double before[RES_LMAX][9];  // V of member m's rotor as source m finds it (after the members ahead of it)
   double own[RES_LMAX][18];    // V, W of member m's rotor after its own transverse pass
 };
+// The member-to-member hand-over of a pair pass's running sums goes through a wave-private LDS buffer (first version: a chain of
+// L - 1 ds_bpermute steps — 35-39 % of a level stage, profiles/r06_handover_ablation.txt): every lane leaves its term there,
+// and for each of the pass's three values ONE lane group (group k for value k; a level has at least three members) adds the L
+// terms of its target in member order — L reads issued at once and L dependent adds instead of L - 1 round trips through the
+// crossbar for all values at once.  The sums are the same sums in the same order: the same bits.  Laid out value-major
+// ([value][lane]: a lane's three terms are 512 bytes apart — side by side the compiler would merge two of them into a
+// ds_write_b128 that is 16-byte aligned for every other lane only, which this runtime does not serve: see RES_TS).
+#define RES_HAND_DOUBLES 3
+// (the terms are in LDS before any lane of the wave reads them: the wave's writes have completed, and the compiler keeps the order)
+#define RES_HAND_FENCE asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 struct Res4Shared {
   WfResolveConsts c;
   double tws[RES_NT * WF_TABLE_PAD], tct[RES_NT * WF_TABLE_PAD], tpw[RES_NT * WF_TABLE_PAD];
@@ -784,6 +794,7 @@ struct Res4Shared {
   double lvl_a, lvl_b;  // two turbines may share a level when |dy'| >= lvl_a + lvl_b dx' (or dx' == 0)
   int levels_on, lv_fail;
   int wp_tv, wp_df, wp_tb;  // next wave pass of a level stage's pair passes (the waves draw them: whoever is free takes the next)
+  double hand[4][64 * RES_HAND_DOUBLES];  // per wave: a term per lane and value (see RES_HAND_DOUBLES)
 };
 __shared__ Res4Shared R4;
 
@@ -796,8 +807,8 @@ __shared__ Res4Shared R4;
 #define RES4_TIE(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(t)])
 #define RES4_CNT(j, t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(1 + (j)) * R4.n_pad + (t)])  // overlap count of column j
 #define RES4_LVL(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[4 * R4.n_pad + (t)])  // members of the level that starts at t (1: a sequential stage)
-#define RES4_LCNT(m, j, t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(5 + (m) * 3 + (j)) * R4.n_pad + (t)])  // overlap count of member m, column j
-#define RES4_DYN_INTS (5 + 3 * RES_LMAX)
+#define RES4_LCNT(m, j, t) (reinterpret_cast<unsigned char*>(reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad) + 5 * R4.n_pad)[((m) * 3 + (j)) * R4.n_pad + (t)])  // overlap count (0 .. 3) of member m, column j: a byte each
+#define RES4_DYN_BYTES(n_pad) (sizeof(double) * RES_TS * (size_t)(n_pad) + sizeof(int) * 5 * (size_t)(n_pad) + 3 * RES_LMAX * (size_t)(n_pad))
 
 // ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
 // Wave 3 only, one source AHEAD (round 5): source i + 1's rotor speed, thrust and circulations need its turbine's deficits
@@ -1204,40 +1215,28 @@ RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, i
         cw[k] = (w < 0.0) ? 0.0 : w;  // quirk (5) [A.6]
       }
     }
-    // the running sums, member by member: lane group ks takes them from group ks - 1 and adds its own term
-    double pv[3], pw[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { pv[k] = RES4_ST(9 + j * 3 + k, tt); pw[k] = RES4_ST(18 + j * 3 + k, tt); }
+    // the running sums: every lane leaves its term in the wave's buffer; lane group k (k = 0, 1, 2) adds, for its target, the members'
+    // terms of value k in member order (see RES_HAND_DOUBLES), takes the snapshots a member's chain needs on the way, and stores
     const int mt = t - i0;  // the target as a member of this level (0 .. L - 1), if it is one
-    if (valid_t && ks == 0 && mt == 0) {
+    const unsigned long long amask = __ballot(active);
+    double* hb = R4.hand[wave];
+    const bool coll = ks < 3 && t < N;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) lv.before[0][j * 3 + k] = pv[k];
-    }
-    if (active && ks == 0) {
+    for (int half = 0; half < 2; ++half) {  // V, then W through the same buffer (the wave's LDS operations execute in order)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { pv[k] = pv[k] + cv[k]; pw[k] = pw[k] + cw[k]; }
-    }
-    for (int sidx = 1; sidx < L; ++sidx) {
-      double rv[3], rw[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { rv[k] = __shfl_up(pv[k], T); rw[k] = __shfl_up(pw[k], T); }
-      if (ks == sidx) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { pv[k] = active ? rv[k] + cv[k] : rv[k]; pw[k] = active ? rw[k] + cw[k] : rw[k]; }
-      }
-    }
-    if (valid_t) {
-      if (mt >= 1 && mt < L && ks == mt - 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) lv.before[mt][j * 3 + k] = pv[k];
-      }
-      if (mt >= 0 && mt < L && ks == mt) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { lv.own[mt][j * 3 + k] = pv[k]; lv.own[mt][9 + j * 3 + k] = pw[k]; }
-      }
-      if (ks == L - 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { RES4_ST(9 + j * 3 + k, tt) = pv[k]; RES4_ST(18 + j * 3 + k, tt) = pw[k]; }
+      for (int k = 0; k < 3; ++k) hb[k * 64 + lane] = half ? cw[k] : cv[k];
+      RES_HAND_FENCE;
+      if (coll) {
+        const int q = (half ? 18 : 9) + j * 3 + ks;
+        double p = RES4_ST(q, tt);
+        for (int sm = 0; sm < L; ++sm) {
+          const int sl = sm * T + tl;
+          const double term = hb[ks * 64 + sl];
+          if (!half && sm == mt) lv.before[mt][j * 3 + ks] = p;
+          if ((amask >> sl) & 1ull) p = p + term;
+          if (sm == mt) lv.own[mt][(half ? 9 : 0) + j * 3 + ks] = p;
+        }
+        RES4_ST(q, tt) = p;
       }
     }
   }
@@ -1406,28 +1405,20 @@ RES_PASS_FN void res4_level_deficit(int tid, Lvl4Shared& lv, int i0, int L) {
         if (dU[k] > c.overlap_thr) ++cnt;  // the comparison as FLORIS takes it [A.3-8]
       }
     }
-    double p[3];
+    const unsigned long long amask = __ballot(active);
+    double* hb = R4.hand[tid >> 6];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) p[k] = RES4_ST(j * 3 + k, tt);
-    if (active && ks == 0) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) p[k] = fma(dU[k], dU[k], p[k]);  // 7. SOSFS [A.3-7]
-    }
-    for (int sidx = 1; sidx < L; ++sidx) {
-      double r[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) r[k] = __shfl_up(p[k], T);
-      if (ks == sidx) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = active ? fma(dU[k], dU[k], r[k]) : r[k];
+    for (int k = 0; k < 3; ++k) hb[k * 64 + lane] = dU[k];
+    RES_HAND_FENCE;
+    if (valid_t) RES4_LCNT(ks, j, tt) = (unsigned char)cnt;
+    if (ks < 3 && t < N) {  // lane group k: the squared deficits of grid row k, added in member order — 7. SOSFS [A.3-7]
+      double p = RES4_ST(j * 3 + ks, tt);
+      for (int sm = 0; sm < L; ++sm) {
+        const int sl = sm * T + tl;
+        const double d = hb[ks * 64 + sl];
+        if ((amask >> sl) & 1ull) p = fma(d, d, p);
       }
-    }
-    if (valid_t) {
-      RES4_LCNT(ks, j, tt) = cnt;
-      if (ks == L - 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) RES4_ST(j * 3 + k, tt) = p[k];
-      }
+      RES4_ST(j * 3 + ks, tt) = p;
     }
   }
 }
@@ -1460,7 +1451,7 @@ RES_PASS_FN void res4_level_turbulence(int tid, Lvl4Shared& lv, int i0, int L) {
     double cand = 0.0;
     if (gate[0] || gate[1] || gate[2]) {
       const double dx = x_t - x_i;
-      const int cnt = RES4_LCNT(ks, 0, tt) + RES4_LCNT(ks, 1, tt) + RES4_LCNT(ks, 2, tt);
+      const int cnt = (int)RES4_LCNT(ks, 0, tt) + (int)RES4_LCNT(ks, 1, tt) + (int)RES4_LCNT(ks, 2, tt);
       const double dxp = (dx <= 0.1) ? dx + 1.0 : dx;
       double ti = ch_pref * POW_F64(dxp * c.inv_D, c.ch_down);
       if (isnan(ti) || (isinf(ti) && ti > 0)) ti = 0.0;
@@ -1474,25 +1465,21 @@ RES_PASS_FN void res4_level_turbulence(int tid, Lvl4Shared& lv, int i0, int L) {
       for (int j = 0; j < 3; ++j)
         if (gate[j] && cand > st.TIs[j]) R4.lv_fail = 1;
     }
-    double p[3];
+    unsigned long long gmask[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) p[j] = RES4_ST(27 + j, tt);
-    if (ks == 0) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) p[j] = (gate[j] && cand > p[j]) ? cand : p[j];
-    }
-    for (int sidx = 1; sidx < L; ++sidx) {
-      double r[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) r[j] = __shfl_up(p[j], T);
-      if (ks == sidx) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) p[j] = (gate[j] && cand > r[j]) ? cand : r[j];
+    for (int j = 0; j < 3; ++j) gmask[j] = __ballot(gate[j]);
+    double* hb = R4.hand[tid >> 6];
+    hb[lane] = cand;
+    RES_HAND_FENCE;
+    if (ks < 3 && t < N && mt >= L) {  // lane group j: column j's TI of a target behind the level, raised member by member
+      double p = RES4_ST(27 + ks, tt);
+      const unsigned long long gm = gmask[ks];
+      for (int sm = 0; sm < L; ++sm) {
+        const int sl = sm * T + tl;
+        const double cd = hb[sl];
+        if (((gm >> sl) & 1ull) && cd > p) p = cd;
       }
-    }
-    if (valid_t && ks == L - 1 && mt >= L) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) RES4_ST(27 + j, tt) = p[j];
+      RES4_ST(27 + ks, tt) = p;
     }
   }
 }
@@ -1825,15 +1812,19 @@ extern int g_res_levels;
 extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfResolveArgs* a, int B, int n_cu, int launch, int* max4_out,
                                           int any_count, hipStream_t s) {
   const int n_pad = (c->N + 1) & ~1;  // (keeps the int arrays behind the doubles aligned)
-  const size_t dyn4 = sizeof(double) * RES_TS * (size_t)n_pad + sizeof(int) * RES4_DYN_INTS * (size_t)n_pad;
+  const size_t dyn4 = (RES4_DYN_BYTES(n_pad) + 15) & ~(size_t)15;
   if (g_res_levels < 0) { const char* e = getenv("WF_RES_LEVELS"); g_res_levels = e ? atoi(e) : 1; }
   const int levels = g_res_levels;
   const size_t lds4 = dyn4 + sizeof(Res4Shared);
   int per_cu = (int)((160 * 1024) / lds4);
   if (per_cu > WF_RES4_OCC) per_cu = WF_RES4_OCC;
-  // (half a residency: with more farms than two per CU the four waves of a farm wait for issue slots more than they gain —
-  // HornsRev1: 322 farms 0.90 ms against 1.1 for the one-wave kernel, 680 farms 1.27 against 1.1)
-  const int max4 = per_cu >= 2 ? n_cu * 2 : (per_cu >= 1 ? n_cu * per_cu : 0);
+  // One residency: as many blocks per CU as LDS and registers hold (HornsRev1 / 2: three; up to 64 turbines: four).  (Rounds 3-5:
+  // at most two — the kernel had 256 VGPRs — and beyond them the one-wave kernel won: 680 farms 1.27 ms against 1.1.  At 128 VGPRs a
+  // list of 600-800 farms is ONE round of this kernel with every SIMD shared by 2-3 farms' waves: issue-bound float64 work, the idle
+  // slots of one farm's latency chain filled by another's; profiles/r06_res4_residency_ab.txt.)
+  static const int per_cu_cap = [] { const char* e = getenv("WF_RES4_PER_CU"); return e ? atoi(e) : WF_RES4_OCC; }();
+  if (per_cu > per_cu_cap) per_cu = per_cu_cap;
+  const int max4 = per_cu >= 1 ? n_cu * per_cu : 0;
   *max4_out = max4;
   if (!launch || max4 <= 0) return hipSuccess;
   const int grid4 = B < max4 ? B : max4;
