@@ -794,7 +794,7 @@ struct Res4Shared {
   double lvl_a, lvl_b;  // two turbines may share a level when |dy'| >= lvl_a + lvl_b dx' (or dx' == 0)
   int levels_on, lv_fail;
   int wp_tv, wp_df, wp_tb;  // next wave pass of a level stage's pair passes (the waves draw them: whoever is free takes the next)
-  double hand[4][64 * RES_HAND_DOUBLES];  // per wave: a term per lane and value (see RES_HAND_DOUBLES)
+  double hand[4][64 * RES_HAND_DOUBLES + 2];  // per wave: a term per lane and value (see RES_HAND_DOUBLES); [192] holds 0.0: the term of a member the level does not have
 };
 __shared__ Res4Shared R4;
 
@@ -1217,27 +1217,39 @@ RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, i
     }
     // the running sums: every lane leaves its term in the wave's buffer; lane group k (k = 0, 1, 2) adds, for its target, the members'
     // terms of value k in member order (see RES_HAND_DOUBLES), takes the snapshots a member's chain needs on the way, and stores
+    // (a pair the sequential solve does not visit — a target ahead of the member's tie group, a lane without a member — leaves
+    // +0.0: adding it changes no bit of a sum that started at +0.0)
     const int mt = t - i0;  // the target as a member of this level (0 .. L - 1), if it is one
-    const unsigned long long amask = __ballot(active);
     double* hb = R4.hand[wave];
     const bool coll = ks < 3 && t < N;
+    int slot[RES_LMAX];  // where member sm's term for this lane's target lies (the zero slot for members the level does not have)
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {  // V, then W through the same buffer (the wave's LDS operations execute in order)
+    for (int sm = 0; sm < RES_LMAX; ++sm) slot[sm] = sm < L ? ks * 64 + sm * T + tl : 64 * RES_HAND_DOUBLES;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // V, then W through the same buffer
 #pragma unroll
       for (int k = 0; k < 3; ++k) hb[k * 64 + lane] = half ? cw[k] : cv[k];
       RES_HAND_FENCE;
       if (coll) {
         const int q = (half ? 18 : 9) + j * 3 + ks;
         double p = RES4_ST(q, tt);
-        for (int sm = 0; sm < L; ++sm) {
-          const int sl = sm * T + tl;
-          const double term = hb[ks * 64 + sl];
-          if (!half && sm == mt) lv.before[mt][j * 3 + ks] = p;
-          if ((amask >> sl) & 1ull) p = p + term;
-          if (sm == mt) lv.own[mt][(half ? 9 : 0) + j * 3 + ks] = p;
+        double term[RES_LMAX];
+#pragma unroll
+        for (int sm = 0; sm < RES_LMAX; ++sm) term[sm] = hb[slot[sm]];
+        if (part == 1) {  // (the chunks that hold the members: the snapshots their chains need)
+#pragma unroll
+          for (int sm = 0; sm < RES_LMAX; ++sm) {
+            if (!half && sm == mt) lv.before[sm][j * 3 + ks] = p;
+            p = p + term[sm];
+            if (sm == mt) lv.own[sm][(half ? 9 : 0) + j * 3 + ks] = p;
+          }
+        } else {
+#pragma unroll
+          for (int sm = 0; sm < RES_LMAX; ++sm) p = p + term[sm];
         }
         RES4_ST(q, tt) = p;
       }
+      RES_HAND_FENCE;  // (the reads are through before the next terms overwrite the buffer)
     }
   }
 }
@@ -1405,21 +1417,21 @@ RES_PASS_FN void res4_level_deficit(int tid, Lvl4Shared& lv, int i0, int L) {
         if (dU[k] > c.overlap_thr) ++cnt;  // the comparison as FLORIS takes it [A.3-8]
       }
     }
-    const unsigned long long amask = __ballot(active);
     double* hb = R4.hand[tid >> 6];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) hb[k * 64 + lane] = dU[k];
+    for (int k = 0; k < 3; ++k) hb[k * 64 + lane] = dU[k];  // (+0.0 for a pair the sequential solve does not visit: fma(0, 0, p) is p)
     RES_HAND_FENCE;
     if (valid_t) RES4_LCNT(ks, j, tt) = (unsigned char)cnt;
     if (ks < 3 && t < N) {  // lane group k: the squared deficits of grid row k, added in member order — 7. SOSFS [A.3-7]
       double p = RES4_ST(j * 3 + ks, tt);
-      for (int sm = 0; sm < L; ++sm) {
-        const int sl = sm * T + tl;
-        const double d = hb[ks * 64 + sl];
-        if ((amask >> sl) & 1ull) p = fma(d, d, p);
-      }
+      double d[RES_LMAX];
+#pragma unroll
+      for (int sm = 0; sm < RES_LMAX; ++sm) d[sm] = hb[sm < L ? ks * 64 + sm * T + tl : 64 * RES_HAND_DOUBLES];
+#pragma unroll
+      for (int sm = 0; sm < RES_LMAX; ++sm) p = fma(d[sm], d[sm], p);
       RES4_ST(j * 3 + ks, tt) = p;
     }
+    RES_HAND_FENCE;
   }
 }
 
@@ -1465,22 +1477,20 @@ RES_PASS_FN void res4_level_turbulence(int tid, Lvl4Shared& lv, int i0, int L) {
       for (int j = 0; j < 3; ++j)
         if (gate[j] && cand > st.TIs[j]) R4.lv_fail = 1;
     }
-    unsigned long long gmask[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) gmask[j] = __ballot(gate[j]);
     double* hb = R4.hand[tid >> 6];
-    hb[lane] = cand;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) hb[j * 64 + lane] = gate[j] ? cand : 0.0;  // (0.0 never raises a TI: they start at the ambient one)
     RES_HAND_FENCE;
     if (ks < 3 && t < N && mt >= L) {  // lane group j: column j's TI of a target behind the level, raised member by member
       double p = RES4_ST(27 + ks, tt);
-      const unsigned long long gm = gmask[ks];
-      for (int sm = 0; sm < L; ++sm) {
-        const int sl = sm * T + tl;
-        const double cd = hb[sl];
-        if (((gm >> sl) & 1ull) && cd > p) p = cd;
-      }
+      double cd[RES_LMAX];
+#pragma unroll
+      for (int sm = 0; sm < RES_LMAX; ++sm) cd[sm] = hb[sm < L ? ks * 64 + sm * T + tl : 64 * RES_HAND_DOUBLES];
+#pragma unroll
+      for (int sm = 0; sm < RES_LMAX; ++sm) p = cd[sm] > p ? cd[sm] : p;
       RES4_ST(27 + ks, tt) = p;
     }
+    RES_HAND_FENCE;
   }
 }
 
@@ -1623,6 +1633,7 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
     int ti = tid;
     asm volatile("" : "+v"(ti));
     if (ti == 0) R4.lv_fail = 0;
+    if ((ti & 63) == 0) R4.hand[ti >> 6][64 * RES_HAND_DOUBLES] = 0.0;
     __syncthreads();
     for (int t = ti; t < N; t += 256) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
       int f = t;
