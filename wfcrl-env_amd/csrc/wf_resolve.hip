@@ -741,10 +741,11 @@ struct Fin4Shared {  // the source-only constants of deflection, deficit and wak
 //                                             at N = 80, 8 near the end of the farm)
 //   chain       (wave 3, a member per lane)   steering, recovery, deflection / deficit / turbulence constants
 //   deficit     (all waves)                   pairs as above
-//   turbulence  (waves 0-2)                   pairs; wave 3 checks the level and derives the next source's state
-// What a target receives from the members of a level is added in MEMBER ORDER (a lane holds one member's contribution;
-// the running sum travels from lane group to lane group), so every sum is taken in the order of the sequential solve: the
-// results are the SAME BITS as the sequential stages' (tests/test_resolve_gpu.py: levels on against levels off).
+//   turbulence  (waves 0-2)                   pairs, then the level's check (wave 0); wave 3 derives the next stage's state(s)
+// What a target receives from the members of a level is added in MEMBER ORDER (a lane holds one member's contribution and
+// leaves it in a wave-private LDS buffer; one lane group per value adds the members' terms of its target in order: see
+// RES_HAND_DOUBLES), so every sum is taken in the order of the sequential solve: the results are the SAME BITS as the
+// sequential stages' (tests/test_resolve_gpu.py: levels on against levels off).
 // Which turbines may share a level is decided from the geometry alone (res4_level_lengths: laterally 8.6 wake widths
 // apart, where exp() has taken the deficit below half an ulp of the free stream) — a heuristic, not a proof: at the end of the
 // stage the mean cube of every member's rotor speeds is recomputed from the final deficit sums and compared bit for bit
@@ -1236,12 +1237,18 @@ RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, i
         double term[RES_LMAX];
 #pragma unroll
         for (int sm = 0; sm < RES_LMAX; ++sm) term[sm] = hb[slot[sm]];
-        if (part == 1) {  // (the chunks that hold the members: the snapshots their chains need)
+        if (part == 1) {  // (the chunks that hold the members: the snapshots their chains need — picked from the running sums
+                          // by selects, not by a branch per member)
+          double bef = p, own = p;
 #pragma unroll
           for (int sm = 0; sm < RES_LMAX; ++sm) {
-            if (!half && sm == mt) lv.before[sm][j * 3 + ks] = p;
+            bef = sm == mt ? p : bef;
             p = p + term[sm];
-            if (sm == mt) lv.own[sm][(half ? 9 : 0) + j * 3 + ks] = p;
+            own = sm == mt ? p : own;
+          }
+          if (mt >= 0 && mt < L) {
+            if (!half) lv.before[mt][j * 3 + ks] = bef;
+            lv.own[mt][(half ? 9 : 0) + j * 3 + ks] = own;
           }
         } else {
 #pragma unroll
@@ -1675,8 +1682,8 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
         RES4_T(l7);
         if (wq < 3) {
           res4_level_turbulence(tq, lv, i, L);
-        } else {  // the level's check, and the state(s) of the next stage's source(s)
-          res4_level_check(tq, lv, i, L);
+          if (wq == 0) res4_level_check(tq, lv, i, L);  // (behind its share of the drawn turbulence passes: wave 3 is busy with the next states)
+        } else {  // the state(s) of the next stage's source(s)
           if (i + L < N) {
             const int Ln = RES4_LVL(i + L);
             if (Ln > 1) res4_level_begin(tq, R4.lv[lp ^ 1], i + L, Ln);
