@@ -229,8 +229,10 @@ int wf_sync(wf_handle* h);
 #define WF_RISK_THRUST_RAMP 4
 #define WF_RISK_THRUST_UNITY 8
 #define WF_RISK_NEGATIVE_SPEED 16
-int wf_set_risk_guard(wf_handle* h, double rel_band); /* default 2e-5 (20 x the float32 deficit error measured at the
-                                                         threshold); 0 disables WF_RISK_OVERLAP */
+int wf_set_risk_guard(wf_handle* h, double rel_band); /* default (chosen by wf_set_layout until this is called): 1e-5 for farms of up
+                                                         to 128 turbines — 5 x the narrowest band at which no unflagged farm of 4.3 M
+                                                         left the tolerances, profiles/r06_band_study.txt — and 2e-5 beyond (rounds
+                                                         4-5: 2e-5 throughout); 0 disables WF_RISK_OVERLAP */
 int wf_get_risk_flags(wf_handle* h, int* flags, int on_device);
 
 /* ---- Float64 re-solve: the 1e-4 contract without exemptions ------------------------------------------------

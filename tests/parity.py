@@ -163,7 +163,7 @@ def table_flag_conditions(ref, slack=0.05, near=2e-4):
     return cond(veff, tpw, "knee"), cond(wsd, tct, "ramp")
 
 
-def summarize(got, ref, flags, guard_rel=2e-5):
+def summarize(got, ref, flags, guard_rel=1e-5):
     """Classification of a batch: dict with
       n, n_flagged, n_bad_unflagged (must be 0), n_bad_flagged (beyond FLAGGED_BOUND: must be 0),
       n_mismatch_flagged (flagged farms outside TOL: the "flips"), n_spurious (WF_RISK_OVERLAP raised although the
@@ -223,7 +223,7 @@ def classify(s):
     return "flagged" if s["n_mismatch_flagged"] else "ok"
 
 
-def check(got, ref, flags, max_flagged_frac=0.05, guard_rel=2e-5):
+def check(got, ref, flags, max_flagged_frac=0.05, guard_rel=1e-5):
     """Assert the contract on a batch; returns the summary."""
     s = summarize(got, ref, flags, guard_rel)
     assert s["n_bad_unflagged"] == 0, ("unflagged farm outside the parity tolerances", s)

@@ -193,7 +193,7 @@ def test_risk_flags_mark_exactly_the_farms_near_the_threshold(layouts):
         assert not fl[ref["margin"] > 1.1 * band + 1e-4].any(), band
         if band >= 1e-3:
             assert fl.any()
-    w.set_risk_guard(2e-5)
+    w.set_risk_guard(1e-5)
     w.close()
 
 

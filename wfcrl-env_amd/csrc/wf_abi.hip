@@ -197,6 +197,7 @@ int wf_set_layout(wf_handle* h, int n, const double* x, const double* y) {
   }
   if (n != h->N) { free_batch(h); h->B = 0; }
   h->N = n; h->variant = v; h->wind_count = 0; h->shared_dir = false; h->model_dirty = true;
+  if (!h->guard_user) h->guard_rel = n > 128 ? 2.0e-5 : 1.0e-5;  // (wf_handle.h: guard_rel)
   reset_calibration(h);
   h->n_groups = 0; h->grid_step = 0.0;
   return WF_OK;
@@ -298,6 +299,7 @@ int wf_set_risk_guard(wf_handle* h, double rel_band) {
   if (!h) return WF_E_INVALID;
   if (!(rel_band >= 0.0) || !(rel_band < 0.5)) return fail(h, WF_E_INVALID, "risk guard band must be in [0, 0.5)");
   h->guard_rel = rel_band;
+  h->guard_user = true;
   h->consts.guard_inv = rel_band > 0.0 ? (float)(1.0 / rel_band) : 1125899906842624.0f;
   return WF_OK;
 }

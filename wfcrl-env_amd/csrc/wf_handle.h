@@ -110,12 +110,16 @@ struct wf_handle {
   double* d_gy = nullptr;                   // sorted y' (float64: the lateral gate is decided on it)
   int* d_gidx = nullptr;
   int* d_flags = nullptr;                   // [B] WF_RISK_* bits of the last step
-  double guard_rel = 2.0e-5;                // relative half-width of the overlap-threshold guard band.  Measured (round 4,
-                                            // tests/tools/band_study.py, the float64 device kernel as the checker): over 1.47 M
-                                            // farms — HornsRev1 under the reset distribution and over all speeds / directions,
-                                            // random fuzzer layouts — no unflagged farm leaves the tolerances down to a band of
-                                            // 1e-6, the first do at 5e-7: the float32 deficit at the threshold is good to
-                                            // ~1e-6.  2e-5 keeps a factor 20 over that (rounds 2-3: 5e-5)
+  double guard_rel = 1.0e-5;                // relative half-width of the overlap-threshold guard band.  Measured (tests/tools/
+                                            // band_study.py, the float64 device kernel as the checker; round 4: 1.47 M farms, round 6:
+                                            // 4.3 M — HornsRev1 / 2, TCRWP, Ablaincourt under the reset distribution, over all speeds
+                                            // and directions, under one shared wind; random fuzzer layouts up to 128 turbines,
+                                            // profiles/r06_band_study.txt): no unflagged farm leaves the tolerances down to a band
+                                            // of 2e-6; the first does at 1e-6 (1 of 524 288 TCRWP farms).  Round 6: 1e-5 up to 128
+                                            // turbines — 5 x the narrowest clean band, half the farms of rounds 4-5's 2e-5 to solve
+                                            // again in float64 — and 2e-5 beyond (float32 rounding is amplified along the deep rows
+                                            // of a 256-turbine grid, tests/parity.py: LARGE_FARM_FACTOR); wf_set_risk_guard overrides
+  bool guard_user = false;                  // wf_set_risk_guard was called: wf_set_layout leaves the band alone
   float *d_yaw = nullptr, *d_out = nullptr;  // staging for host callers: yaw [B*N], out [B*N*7]
   float *h_yaw = nullptr, *h_out = nullptr;  // pinned
   size_t cap_env = 0, cap_bn = 0;
