@@ -3,6 +3,7 @@
 #   (1) machine LICM on / off for the two parts of wf_resolve.hip (tools/build_alt_res.sh: lib_ship = the Makefile's choice,
 #       lib_res4licm = the four-wave kernel WITH machine LICM, lib_res1nolicm = the one-wave kernel WITHOUT it)
 #   (2) WF_RESOLVE_ONE_LAUNCH = 1 (shipped) / 0: one or two float64 dispatches behind a step
+#   (3) WF_RES4_PER_CU = 4 (shipped: as many as fit) / 3 / 2: residency of the four-wave float64 kernel -> gpurun_out/r06_res4_residency_ab.txt
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r06_nolicm_ab.txt; : > $O
 for l in ship res4licm res1nolicm; do
@@ -18,5 +19,10 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); e=d['extra']['headline_wind']
 print('ms_per_step %.4f  kernel %.4f  float32-only %.4f -> strict %.4f (%d farms re-solved)' % (d['ms_per_step'], d['roofline']['kernel_ms'], e['float32_only']['ms_per_step'], e['with_float64_resolve']['ms_per_step'], e['n_resolved']))" >> $O
   done
+done
+O=gpurun_out/r06_res4_residency_ab.txt; : > $O
+for pc in 4 3 2; do
+  echo "## WF_RES4_PER_CU=$pc (blocks of the four-wave float64 kernel per CU at most; 2 = rounds 3-5: lists beyond 512 farms go to the one-wave kernel)" >> $O
+  WF_RES4_PER_CU=$pc timeout 600 python tools/levels_ab.py 2>&1 | grep -v amdgpu.ids | grep "HornsRev2 x 16384\|cfg4\|cfg5" >> $O
 done
 cat gpurun_out/r06_one_launch_ab.txt
