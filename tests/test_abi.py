@@ -99,9 +99,9 @@ def test_pmc_index_points_at_committed_counter_files():
         assert "TCC_EA0_RDREQ_128B_sum" in pmc or ("FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc), key
         assert set(e["kernel"]) <= {"lanes_per_env", "slots_per_lane", "one_block_kernel", "pair_table"}, key
     head = idx["cfg4_B65536"]
-    assert head["file"].startswith("profiles/r05_") and head["kernel"] == dict(lanes_per_env=2, slots_per_lane=2, one_block_kernel=1, pair_table=1)
+    assert head["file"].startswith("profiles/r06_") and head["kernel"] == dict(lanes_per_env=2, slots_per_lane=2, one_block_kernel=1, pair_table=1)
     fly = idx["cfg4_per_env_wind_B65536"]  # (bench.py --per-env-wind quotes this one)
-    assert fly["file"].startswith("profiles/r05_") and fly["kernel"] == dict(lanes_per_env=2, slots_per_lane=2, one_block_kernel=1, pair_table=0)
+    assert fly["file"].startswith("profiles/r06_") and fly["kernel"] == dict(lanes_per_env=2, slots_per_lane=2, one_block_kernel=1, pair_table=0)
 
 
 def test_last_fuzz_campaign_ran_on_these_kernels():
