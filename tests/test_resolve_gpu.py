@@ -348,10 +348,10 @@ def test_float64_kernel_at_the_abi_turbine_limit():
 
 
 def test_both_float64_kernels_by_flagged_count(layouts):
-    """Which float64 kernel serves the flagged farms is decided on the device by their number: up to one residency of the
-    four-wave kernel (512 farms: two per CU on 256 CUs) it runs, beyond that the one-wave kernel.  Mode 2 (every farm)
-    at 400 and at 1500 farms exercises one and the other; both against the CPU oracle, and against each other bit for bit
-    on the farms they share."""
+    """Mode 2 (every farm): up to one residency of the four-wave kernel (Ormonde: four blocks per CU, 1024 farms) that kernel
+    runs, beyond it the one-wave kernel — 400 and 1500 farms exercise one and the other; both against the CPU oracle, and
+    against each other on the farms they share.  (Behind a step of modes 0 / 1 the four-wave kernel serves a list of any
+    length since round 6: test_a_flagged_list_longer_than_a_residency_is_one_kernels_work.)"""
     import parity
     from wfcrl_env_amd.backend import WfStep
 
@@ -579,3 +579,32 @@ def test_a_failed_level_check_falls_back_to_the_sequential_solve(layouts):
     # ... and at three times the assumed growth rate the members of Turb16_Row5's columns do reach each other at 283 deg: every
     # farm failed a check, was solved again stage by stage — and is the oracle's (asserted above)
     assert outs[True]["farms"] == B and outs[True]["repeated_without_levels"] == B, outs[True]
+
+
+def test_a_flagged_list_longer_than_a_residency_is_one_kernels_work(layouts):
+    """Round 6: ONE float64 launch behind a step — the four-wave kernel's persistent blocks walk a flagged list of any length
+    (rounds 3-5: lists beyond a residency went to the one-wave kernel, enqueued beside it).  A guard band of 1e-2 flags
+    thousands of Ormonde farms: every one must be re-solved (strict, flags cleared), by the four-wave kernel alone."""
+    import parity
+    from wfcrl_env_amd.backend import WfStep
+
+    l = layouts["Ormonde_"]
+    x, y, N = l["xcoords"], l["ycoords"], l["num_turbines"]
+    B = 8192
+    rng = np.random.default_rng(2468)
+    yaw = rng.uniform(-35, 35, (B, N)).astype(np.float32)
+    ws, wd = _wind(rng, B, "per_env")
+    w = WfStep(x, y, env_batch=B)
+    w.set_risk_guard(1e-2)
+    w.set_risk_resolve(1)
+    w.set_wind(ws, wd)
+    _level_stats()
+    out = w.step(yaw)
+    st = w.resolve_stats()
+    lv = _level_stats()
+    assert st["n_resolved"] > 1500 and not w.risk_flags().any(), st["n_resolved"]
+    assert lv["farms"] == st["n_resolved"]  # (the four-wave kernel's own count: it solved them all)
+    idx = np.concatenate([np.nonzero(st["raw_flags"])[0][:300], rng.choice(B, 100, replace=False)])
+    ref = _oracle(x, y, ws[idx], wd[idx], yaw[idx])
+    parity.check_strict({k: v[idx] for k, v in out.items()}, ref)
+    w.close()

@@ -773,10 +773,6 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
       WF_HIP(h, hipMalloc(&h->d_flags_raw, sizeof(int) * h->cap_env));
       WF_HIP(h, hipMemsetAsync(h->d_res_count, 0, sizeof(int) * 2, h->stream));
       h->res_parity = 0;
-      if (!h->h_res_hint && hipHostMalloc(&h->h_res_hint, sizeof(int), hipHostMallocMapped) == hipSuccess) {
-        *h->h_res_hint = 0;
-        if (hipHostGetDevicePointer((void**)&h->d_res_hint, h->h_res_hint, 0) != hipSuccess) h->d_res_hint = nullptr;
-      }
     }
   }
   h->res_last = mode != 0 || mask != 0;
@@ -793,10 +789,6 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   if (mode == 0 && !mask) return WF_OK;
   WfResolveArgs ra{};
   ra.tab64 = h->d_tab64; ra.list = h->d_res_list; ra.count = h->d_res_count + h->res_parity; ra.flags = h->d_flags;
-  ra.hint = h->d_res_hint;
-  // (a stale read is fine: the value only chooses between one and two dispatches, wfk_launch_resolve)
-  static const bool one_launch = [] { const char* e = getenv("WF_RESOLVE_ONE_LAUNCH"); return !e || atoi(e) != 0; }();  // (0: always both kernels — the A/B switch)
-  const int recent = (h->d_res_hint && one_launch) ? *(volatile int*)h->h_res_hint : -1;
   ra.gx = h->d_gx; ra.gy = h->d_gy; ra.gidx = h->d_gidx;
   ra.geom_stride = (h->wind_count == 1 || h->shared_dir) ? 0 : (size_t)h->N;
   ra.mod = 1;
@@ -815,10 +807,10 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   h->rconsts.N = h->N;
   if (!h->types.empty()) {
     ra.tab64 = h->d_tab64_mt; ra.n_types = (int)h->types.size(); ra.type_of = h->d_type_of; ra.type_consts = h->d_type_consts;
-    WF_HIP(h, wfk_launch_resolve_mt(&h->rconsts, &ra, h->B, 1, h->d_flags_raw, h->n_cu, -1, h->stream));
+    WF_HIP(h, wfk_launch_resolve_mt(&h->rconsts, &ra, h->B, 1, h->d_flags_raw, h->n_cu, h->stream));
     return WF_OK;
   }
-  WF_HIP(h, wfk_launch_resolve(&h->rconsts, &ra, h->B, mode == 2 ? 1 : 0, h->d_flags_raw, h->n_cu, recent, h->stream));
+  WF_HIP(h, wfk_launch_resolve(&h->rconsts, &ra, h->B, mode == 2 ? 1 : 0, h->d_flags_raw, h->n_cu, h->stream));
   return WF_OK;
 }
 

@@ -25,7 +25,7 @@
 #include "wf_resolve.h"
 
 extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags,
-                                         int n_cu, int recent_count, hipStream_t s);
+                                         int n_cu, hipStream_t s);
 extern "C" int wfk_num_variants();
 extern "C" void wfk_variant(int i, int* G, int* S, const void** fn);
 extern "C" int wfk_variant_has_table(int i);
@@ -196,8 +196,6 @@ struct wf_handle {
   WfResolveConsts rconsts{};
   double* d_tab64 = nullptr;   // [3][WF_TABLE_PAD] wind speed, Ct, power in float64
   int *d_res_list = nullptr, *d_res_count = nullptr, *d_flags_raw = nullptr;  // [B], [2] (used alternately: res_parity), [B]
-  int* h_res_hint = nullptr;   // pinned, device-visible: the length of a recent flagged list, written by the four-wave float64 kernel and
-  int* d_res_hint = nullptr;   // read by the host without a sync (WfResolveArgs::hint); its device-side address
   int res_parity = 0;          // which of the two counters the last step with a re-solve used
   bool res_last = false;       // the last step had a re-solve behind it (its list, counter and raw flags are current)
   int res_mask = 0;            // nonzero only while launch_step enqueues the real launch: WF_RISK_* bits that put a farm on the list

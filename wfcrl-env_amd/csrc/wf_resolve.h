@@ -34,8 +34,6 @@ struct WfResolveArgs {
   int* list;            // [B] compacted farm indices
   int* count;           // [1]
   int* flags;           // [B] WF_RISK_* of the float32 step; cleared for every farm solved here
-  int* hint;            // host-mapped int (or null): the four-wave kernel leaves the list's length there — read by the host WITHOUT
-                        // a sync before a later step, to decide whether the one-wave kernel is worth its dispatch (wfk_launch_resolve)
   const double *gx, *gy;  // sorted geometry (float64)
   const int* gidx;
   size_t geom_stride;   // N for a geometry per farm, 0 for a shared one (ignored when farm_group is set)
@@ -61,4 +59,4 @@ struct WfResolveArgs {
 #define WF_MAX_TYPES 4  // == WF_MAX_TURBINE_TYPES (include/wfstep.h)
 
 extern "C" hipError_t wfk_launch_resolve_mt(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags, int n_cu,
-                                            int recent_count, hipStream_t s);
+                                            hipStream_t s);

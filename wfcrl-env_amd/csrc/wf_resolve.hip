@@ -8,7 +8,8 @@
 // unconditional: the flagged farms are compacted on the device (no host round trip) and solved again in float64, the
 // comparison taken exactly as FLORIS takes it, and their outputs overwritten.
 //
-// Two kernels, chosen on the device by the number of flagged farms (wfk_launch_resolve):
+// Two kernels (wfk_launch_resolve: the four-wave kernel behind every step of modes 0 / 1, whatever the list's length; the one-wave
+// kernel for mode 2 — every farm — at batches beyond one residency of the other):
 //   wf_resolve4_kernel  one farm per 256-thread block, up to two blocks per CU (half a residency of the chip: the re-solve is
 //                       then ONE farm's latency).  The farm's state — per sorted turbine 9 sums of squared deficits, 9 V, 9 W,
 //                       3 column TIs, float64 — lives in LDS, turbine-major; a lane is not tied to a turbine.  A SEQUENTIAL
@@ -19,8 +20,8 @@
 //                       stage (round 6: Lvl4Shared) solves three to eight consecutive sources that put no deficit on each
 //                       other at once, every (source, target, column) pair in its own lane, the sums still taken in source order.
 //   wf_resolve_kernel   one farm per WAVE (64-thread blocks, one per SIMD), the same state in LDS, no block barrier inside the
-//                       solve: a third more farms per CU and second than the four-wave kernel, at 2.2 x its latency — for
-//                       lists beyond half a residency, and for mode 2 at any batch beyond it.
+//                       solve, no levels: a third more farms per CU and second than the four-wave kernel's SEQUENTIAL stages, at
+//                       2.2 x their latency (rounds 3-5 and the first half of round 6: the kernel for lists beyond one residency).
 // Per-source constants are derived once per farm and handed to the pair passes through LDS; every phase of a stage starts
 // behind a compiler barrier and is free of calls and spills (no private segment: tests/test_abi.py).
 // Only exactness-preserving algebra is used (vortex core 1 - exp(-(y^2+z^2)/eps^2) with the z factor a constant);
@@ -28,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <string>
 
 #include "wf_device.h"
 #include "wf_resolve.h"
@@ -1580,7 +1582,6 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
   const int tid = threadIdx.x;
   const int N = c_arg.N;
   const int n_list = *a_arg.count;
-  if (a_arg.hint && blockIdx.x == 0 && tid == 0) *a_arg.hint = n_list;  // (for the host's next decision, read without a sync)
   if (n_list == 0 || n_list > max_count) return;  // nothing flagged (the common case: the launch costs its dispatch only) / the one-wave-per-farm kernel serves this count
   if (tid == 0) {
     R4.c = c_arg;
@@ -1859,26 +1860,21 @@ extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfReso
 extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfResolveArgs* a, int B, int n_cu, int launch, int* max4_out,
                                           int any_count, hipStream_t s);
 extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags,
-                                         int n_cu, int recent_count, hipStream_t s) {
+                                         int n_cu, hipStream_t s) {
   hipError_t e = hipSuccess;
   if (all) {
     hipLaunchKernelGGL(wf_list_all_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a->flags, B, a->list, a->count, raw_flags);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  // Which kernel serves the list depends on how many farms it holds, and that number exists on the device only (no host
-  // round trip): up to max4 — half a residency of the four-wave kernel, where the re-solve is a single farm's latency — the
-  // four-wave kernel, beyond it the one-wave kernel (four times the farms per residency, a third more farms per CU and
-  // second).  Both are enqueued; the one the count is not meant for returns at once (an empty list: both, 5 us each — folding
-  // them into one kernel would put four one-wave farms, 115 KB of LDS at N = 91, into every block and halve the four-wave
-  // residency).  With `all` the count is B and only the right one is launched.
   int max4 = 0;
   if ((e = wfk_launch_resolve4(c, a, B, n_cu, 0, &max4, 0, s)) != hipSuccess) return e;
-  // ONE launch where the lists have been short (round 6).  recent_count: the length of a flagged list one or two steps back, as
-  // the four-wave kernel left it in host-visible memory (read without a sync: a hint, never a dependency) — while it stays within
-  // the four-wave kernel's range only that kernel is enqueued, with no upper bound (its persistent blocks walk a list of any
-  // length: a list that suddenly grows is served correctly, merely slower for that step), and an empty list costs one dispatch
-  // (4.9 us) instead of two (10.4).  Once lists beyond the range are seen both are enqueued as before.
-  const bool only4 = !all && max4 > 0 && recent_count >= 0 && recent_count <= max4;
+  // ONE launch behind a step (round 6): the four-wave kernel serves a flagged list of ANY length — its persistent blocks walk the
+  // list, up to max4 farms resident at once.  With level stages it is the faster kernel at every count (2 011 flagged HornsRev2
+  // farms: + 1.07 ms against the one-wave kernel's + 1.62, profiles/r06_four_wave_always_ab.txt), and an empty list costs one
+  // dispatch instead of two.  (Rounds 3-5 enqueued both kernels and let each read the count on the device; WF_RESOLVE_POLICY=both
+  // restores that for A/B runs.)  The one-wave kernel remains for mode 2 at batches beyond one residency (`all`).
+  static const bool both = [] { const char* e = getenv("WF_RESOLVE_POLICY"); return e && std::string(e) == "both"; }();
+  const bool only4 = !all && max4 > 0 && !both;
   if (max4 > 0 && (!all || B <= max4)) {
     if ((e = wfk_launch_resolve4(c, a, B, n_cu, 1, &max4, only4 ? 1 : 0, s)) != hipSuccess) return e;
   }
