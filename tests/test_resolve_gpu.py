@@ -348,13 +348,17 @@ def test_float64_kernel_at_the_abi_turbine_limit():
 
 
 def test_both_float64_kernels_by_flagged_count(layouts):
-    """Mode 2 (every farm): up to one residency of the four-wave kernel (Ormonde: four blocks per CU, 1024 farms) that kernel
-    runs, beyond it the one-wave kernel — 400 and 1500 farms exercise one and the other; both against the CPU oracle, and
-    against each other on the farms they share.  (Behind a step of modes 0 / 1 the four-wave kernel serves a list of any
-    length since round 6: test_a_flagged_list_longer_than_a_residency_is_one_kernels_work.)"""
+    """Mode 2 (every farm) on Ormonde: 400 farms fit one residency of the four-wave kernel; 1500 do not — since round 6 its
+    persistent blocks walk them all the same (farms of 16 turbines and more), and with the policy of rounds 3-5
+    (wfk_set_resolve_policy(1): "both", by the list's length) the one-wave kernel serves them.  All three against the CPU
+    oracle; the two four-wave runs bit for bit on the farms they share, the one-wave kernel at 2e-6 (another order of summation).
+    (Behind a step of modes 0 / 1 the four-wave kernel serves a list of any length:
+    test_a_flagged_list_longer_than_a_residency_is_one_kernels_work.)"""
     import parity
+    from wfcrl_env_amd import _lib
     from wfcrl_env_amd.backend import WfStep
 
+    lib = _lib.load()
     l = layouts["Ormonde_"]
     x, y, N = l["xcoords"], l["ycoords"], l["num_turbines"]
     rng = np.random.default_rng(1024)
@@ -362,16 +366,24 @@ def test_both_float64_kernels_by_flagged_count(layouts):
     yaw = rng.uniform(-35, 35, (Bmax, N)).astype(np.float32)
     ws, wd = _wind(rng, Bmax, "per_env")
     outs = {}
-    for B in (400, Bmax):
-        w = WfStep(x, y, env_batch=B)
-        w.set_risk_resolve(2)
-        w.set_wind(ws[:B], wd[:B])
-        outs[B] = {k: v.copy() for k, v in w.step(yaw[:B]).items()}
-        assert w.resolve_stats()["n_resolved"] == B
-        parity.check_strict(outs[B], _oracle(x, y, ws[:B], wd[:B], yaw[:B]), parity.TOL_F64)
-        w.close()
-    for k in outs[400]:
-        assert np.abs(outs[400][k].astype(np.float64) - outs[Bmax][k][:400]).max() <= 2e-6 * max(1.0, np.abs(outs[400][k]).max()), k
+    try:
+        for tag, B, both in (("four_400", 400, 0), ("four_1500", Bmax, 0), ("one_wave_1500", Bmax, 1)):
+            lib.wfk_set_resolve_policy(both)
+            w = WfStep(x, y, env_batch=B)
+            w.set_risk_resolve(2)
+            w.set_wind(ws[:B], wd[:B])
+            _level_stats()
+            outs[tag] = {k: v.copy() for k, v in w.step(yaw[:B]).items()}
+            st = _level_stats()
+            assert w.resolve_stats()["n_resolved"] == B
+            assert st["farms"] == (0 if both else B), (tag, st)  # (the four-wave kernel counts the farms it solves)
+            parity.check_strict(outs[tag], _oracle(x, y, ws[:B], wd[:B], yaw[:B]), parity.TOL_F64)
+            w.close()
+    finally:
+        lib.wfk_set_resolve_policy(0)
+    for k in outs["four_400"]:
+        assert np.array_equal(outs["four_400"][k].view(np.uint32), outs["four_1500"][k][:400].view(np.uint32)), k
+        assert np.abs(outs["four_1500"][k].astype(np.float64) - outs["one_wave_1500"][k]).max() <= 2e-6 * max(1.0, np.abs(outs["four_1500"][k]).max()), k
 
 
 def test_env_surface_switches(layouts):

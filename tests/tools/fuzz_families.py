@@ -67,8 +67,9 @@ def run(n_cases, seed):
         # float64: four-wave kernel with levels, without, and the one-wave kernel (a batch beyond the four-wave residency: the
         # case's farms repeated)
         f64 = {}
-        for name, lv, rep in (("f64_levels", 1, 1), ("f64_sequential", 0, 1), ("f64_one_wave", 1, (600 + B - 1) // B)):
+        for name, lv, rep in (("f64_levels", 1, 1), ("f64_sequential", 0, 1), ("f64_one_wave", 1, (1100 + B - 1) // B)):
             lib.wfk_set_resolve_levels(lv)
+            lib.wfk_set_resolve_policy(1 if name == "f64_one_wave" else 0)  # ("both": mode 2 beyond a residency on the one-wave kernel)
             Bt = B * rep
             w = WfStep(x, y, env_batch=Bt, model=dict(model) if model else None)
             w.set_risk_resolve(2)
@@ -77,6 +78,7 @@ def run(n_cases, seed):
             f64[name] = {k: np.asarray(v)[:B].copy() for k, v in o.items()}
             w.close()
         lib.wfk_set_resolve_levels(1)
+        lib.wfk_set_resolve_policy(0)
         bad = []
         for k in f64["f64_levels"]:
             if not np.array_equal(f64["f64_levels"][k].view(np.uint32), f64["f64_sequential"][k].view(np.uint32)):

@@ -27,6 +27,11 @@ for v in four both; do
   echo "## WF_RESOLVE_POLICY=$v" >> $O
   WF_RESOLVE_POLICY=$v timeout 600 python tools/levels_ab.py 2>&1 | grep -v amdgpu.ids >> $O
 done
+O=gpurun_out/r06_mode2_ab.txt; : > $O
+for v in four both; do
+  echo "## WF_RESOLVE_POLICY=$v (mode 2, every farm in float64: the four-wave kernel with levels for farms of 16 turbines and more / the one-wave kernel beyond a residency)" >> $O
+  WF_RESOLVE_POLICY=$v python tools/mode2_timing.py 2>&1 | grep -v amdgpu.ids >> $O
+done
 O=gpurun_out/r06_res4_residency_ab.txt; : > $O
 for pc in 4 3 2; do
   echo "## WF_RES4_PER_CU=$pc (blocks of the four-wave float64 kernel per CU at most; WF_RESOLVE_POLICY=both: lists beyond that residency go to the one-wave kernel, as in rounds 3-5 at 2)" >> $O

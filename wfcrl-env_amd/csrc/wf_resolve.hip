@@ -1682,8 +1682,8 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
         __syncthreads();
         RES4_T(l7);
         if (wq < 3) {
+          if (wq == 0) res4_level_check(tq, lv, i, L);  // (ahead of its share of the drawn turbulence passes: wave 3 is busy with the next states)
           res4_level_turbulence(tq, lv, i, L);
-          if (wq == 0) res4_level_check(tq, lv, i, L);  // (behind its share of the drawn turbulence passes: wave 3 is busy with the next states)
         } else {  // the state(s) of the next stage's source(s)
           if (i + L < N) {
             const int Ln = RES4_LVL(i + L);
@@ -1780,6 +1780,10 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
 // other side of the bit-identity test, tests/test_resolve_gpu.py); shared with the build for several turbine definitions
 int g_res_levels = -1;
 extern "C" void wfk_set_resolve_levels(int on) { g_res_levels = on ? 1 : 0; }
+// which kernels are enqueued (wfk_launch_resolve): 0 the four-wave kernel wherever it is the faster one (default), 1 "both" —
+// rounds 3-5's rule, by the list's length (WF_RESOLVE_POLICY=both seeds it; tests and A/B runs switch it here)
+int g_res_policy = -1;
+extern "C" void wfk_set_resolve_policy(int both) { g_res_policy = both ? 1 : 0; }
 extern "C" int wfk_res_level_stats(unsigned long long* out, int reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res_lvl_stat), sizeof(wf_res_lvl_stat));
   if (e == hipSuccess && reset) {
@@ -1857,6 +1861,7 @@ extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfReso
 #if RES_MT
 #define wfk_launch_resolve4 wfk_launch_resolve4_mt
 #endif
+extern int g_res_policy;
 extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfResolveArgs* a, int B, int n_cu, int launch, int* max4_out,
                                           int any_count, hipStream_t s);
 extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResolveArgs* a, int B, int all, int* raw_flags,
@@ -1873,9 +1878,14 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
   // farms: + 1.07 ms against the one-wave kernel's + 1.62, profiles/r06_four_wave_always_ab.txt), and an empty list costs one
   // dispatch instead of two.  (Rounds 3-5 enqueued both kernels and let each read the count on the device; WF_RESOLVE_POLICY=both
   // restores that for A/B runs.)  The one-wave kernel remains for mode 2 at batches beyond one residency (`all`).
-  static const bool both = [] { const char* e = getenv("WF_RESOLVE_POLICY"); return e && std::string(e) == "both"; }();
-  const bool only4 = !all && max4 > 0 && !both;
-  if (max4 > 0 && (!all || B <= max4)) {
+  if (g_res_policy < 0) { const char* e = getenv("WF_RESOLVE_POLICY"); g_res_policy = (e && std::string(e) == "both") ? 1 : 0; }
+  const bool both = g_res_policy == 1;
+  // mode 2 (every farm) at a batch beyond a residency: the four-wave kernel too where farms have levels to offer — 16 turbines
+  // and more (HornsRev1 x 65536: 43.2 -> 25.9 ms, HornsRev2 25.4 -> 18.0, Ormonde 14.5 -> 11.5; a 7-turbine row in line with the
+  // wind has none and is 25 % faster on the one-wave kernel: profiles/r06_mode2_ab.txt)
+  const bool all4 = all && c->N >= 16 && !both;
+  const bool only4 = (!all || all4) && max4 > 0 && !both;
+  if (max4 > 0 && (!all || B <= max4 || all4)) {
     if ((e = wfk_launch_resolve4(c, a, B, n_cu, 1, &max4, only4 ? 1 : 0, s)) != hipSuccess) return e;
   }
   if (only4) return hipSuccess;
