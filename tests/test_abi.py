@@ -148,3 +148,25 @@ def test_float64_kernels_have_no_private_segment(tmp_path):
         assert "s_swappc_b64" not in text  # no out-of-line call anywhere in the file
     mk = open(os.path.join(src, "Makefile")).read()
     assert "SETRES = -mllvm -disable-machine-licm" in mk and "$(SETRES) -c -o $@ wf_resolve4.hip" in mk  # (what this test compiled is what ships)
+
+
+def test_practical_valu_ceiling_data_serves_the_headline_kernel():
+    """bench.py's valu_roofline.practical_peak comes from profiles/valu_practical.json: measured issue rates at the
+    kernel's waves per SIMD, mixed by the kernel's own share of transcendentals (tools/valu_practical.py).  The file must hold the
+    headline kernel, with a share and rates that make sense, and bench.py must find it."""
+    import json
+    import os
+    import sys
+
+    from conftest import ROOT
+
+    vp = json.load(open(os.path.join(ROOT, "profiles", "valu_practical.json")))
+    k = vp["kernels"]["ll_2x2_shared1_tab1_mc1_veer0_occ20"]
+    assert k["valu_static"] > 4000 and 0.03 < k["transcendental_share"] < 0.2
+    r = vp["cycles_per_wave_instr_at_2_waves_per_simd"]
+    assert 2.0 < r["plain_fp32"] < 5.0 and 6.0 < r["transcendental"] < 12.0
+    sys.path.insert(0, ROOT)
+    import bench
+
+    got = bench.valu_practical_peak(dict(lanes_per_env=2, slots_per_lane=2, one_block_kernel=1, pair_table=1, vgprs=248))
+    assert got and 3.0e13 < got["peak"] < 7.864e13  # below the nominal peak, above half of it
