@@ -509,7 +509,7 @@ def _level_stats(reset=True):
 
     buf = (C.c_ulonglong * 8)()
     _lib.load().wfk_res_level_stats(buf, 1 if reset else 0)
-    return dict(zip(("farms", "repeated_without_levels", "level_stages", "sources_in_levels", "sequential_stages"), list(buf)))
+    return dict(zip(("farms", "repeated_without_levels", "level_stages", "sources_in_levels", "sequential_stages", "farms_with_helper_waves"), list(buf)))
 
 
 @pytest.mark.parametrize("name", ["HornsRev1_", "HornsRev2_", "Turb_TCRWP_", "Turb16_Row5_", "Ormonde_", "WMR_"])
@@ -555,6 +555,99 @@ def test_level_stages_are_the_sequential_solve_bit_for_bit(layouts, name, wind):
     for k in outs[0]:
         assert np.array_equal(outs[0][k].view(np.uint32), outs[1][k].view(np.uint32)), k
     parity.check_strict(outs[0], _oracle(x, y, ws, wd, yaw), parity.TOL_F64)
+
+
+def _helper_farms():
+    import ctypes as C
+
+    from wfcrl_env_amd import _lib
+
+    buf = (C.c_ulonglong * 8)()
+    _lib.load().wfk_res_level_stats(buf, 1)
+    return int(buf[0]), int(buf[5])
+
+
+@pytest.mark.parametrize("name", ["HornsRev2_", "Ormonde_", "Turb16_Row5_"])
+def test_helper_waves_leave_the_bits_alone(layouts, name):
+    """Round 6 (csrc/wf_resolve.hip: HELPER WAVES): a launch of 512 threads gives a farm's block four more waves for the pair
+    passes of its level stages.  The sums are taken in member order whoever computes the terms: with the helper waves on every
+    launch (wfk_set_resolve_helpers(2)) and on none (0) the outputs are the same BITS, and the farms were solved the way asked."""
+    from wfcrl_env_amd import _lib
+    from wfcrl_env_amd.backend import WfStep
+
+    lib = _lib.load()
+    l = layouts[name]
+    x, y, N = l["xcoords"], l["ycoords"], l["num_turbines"]
+    B = 160
+    rng = np.random.default_rng(zlib.crc32(f"helpers/{name}".encode()))
+    yaw = rng.uniform(-40, 40, (B, N)).astype(np.float32)
+    ws, wd = _wind(rng, B, "per_env")
+    outs = []
+    try:
+        for mode in (2, 0):
+            lib.wfk_set_resolve_helpers(mode)
+            w = WfStep(x, y, env_batch=B)
+            w.set_risk_resolve(2)
+            w.set_wind(ws, wd)
+            _helper_farms()
+            outs.append({k: v.copy() for k, v in w.step(yaw).items()})
+            farms, helped = _helper_farms()
+            assert farms == B and helped == (B if mode else 0), (mode, farms, helped)
+            w.close()
+    finally:
+        lib.wfk_set_resolve_helpers(1)
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k].view(np.uint32), outs[1][k].view(np.uint32)), k
+
+
+def test_the_launch_width_follows_the_length_of_the_previous_list(layouts):
+    """The flagged list's length is known on the device only; the host picks the width of the float64 launch — 512 threads with
+    helper waves for a short list, 256 for a long one — from the length the PREVIOUS launch found (wf_resolve.h: seen_host).  The
+    first launch of a handle is a narrow one; behind a short list the next is wide; behind a long list narrow again.  Which width
+    ran changes no bit: every step's outputs are compared with a handle that never uses the helper waves."""
+    from wfcrl_env_amd import _lib
+    from wfcrl_env_amd.backend import WfStep
+
+    lib = _lib.load()
+    l = layouts["HornsRev2_"]
+    x, y, N = l["xcoords"], l["ycoords"], l["num_turbines"]
+    B = 4096
+    rng = np.random.default_rng(20260)
+    yaw = rng.uniform(-30, 30, (B, N)).astype(np.float32)
+    ws, wd = _wind(rng, B, "per_env")
+    w = WfStep(x, y, env_batch=B)
+    w.set_risk_resolve(1)
+    w.set_wind(ws, wd)
+    ref = WfStep(x, y, env_batch=B)
+    ref.set_risk_resolve(1)
+    ref.set_wind(ws, wd)
+    seen = []
+    try:
+        for band in (1.0e-5, 1.0e-5, 3.0e-3, 3.0e-3, 1.0e-5, 1.0e-5):
+            w.set_risk_guard(band)
+            ref.set_risk_guard(band)
+            lib.wfk_set_resolve_helpers(1)
+            _helper_farms()
+            o = {k: v.copy() for k, v in w.step(yaw).items()}
+            w.sync()
+            farms, helped = _helper_farms()
+            assert farms == w.resolve_stats()["n_resolved"]
+            seen.append((farms, helped))
+            lib.wfk_set_resolve_helpers(0)
+            o_ref = ref.step(yaw)
+            for k in o:
+                assert np.array_equal(o[k].view(np.uint32), o_ref[k].view(np.uint32)), (band, k)
+    finally:
+        lib.wfk_set_resolve_helpers(1)
+        w.close()
+        ref.close()
+    (f0, h0), (f1, h1), (f2, h2), (f3, h3), (f4, h4), (f5, h5) = seen
+    assert 0 < f0 <= 320 and f1 == f0 and f2 > 512 and f3 == f2 and f4 == f0, seen
+    assert h0 == 0          # nothing known yet: narrow
+    assert h1 == f1         # behind a short list: wide, the helper waves at work
+    assert h2 == 0          # a long list met by a wide launch: the helper waves have returned
+    assert h3 == 0 and h4 == 0  # behind a long list: narrow (whatever the list turns out to be)
+    assert h5 == f5         # ... and wide again behind the short one
 
 
 def test_a_failed_level_check_falls_back_to_the_sequential_solve(layouts):

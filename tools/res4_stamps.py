@@ -23,6 +23,7 @@ for name, B, per_farm in (("Ablaincourt_", 4096, True), ("Turb16_TCRWP_", 16384,
     buf = (C.c_ulonglong * 16)()
     lib.wfk_res4_stamps(buf, 1)
     lib.wfk_res4_level_stamps((C.c_ulonglong * 20)(), 1)
+    lib.wfk_res4_fn_stamps((C.c_ulonglong * 16)(), 1)
     lib.wfk_res_level_stats((C.c_ulonglong * 8)(), 1)
     w.step(yaw, out); w.sync()
     lib.wfk_res4_stamps(buf, 0)
@@ -46,4 +47,11 @@ for name, B, per_farm in (("Ablaincourt_", 4096, True), ("Turb16_TCRWP_", 16384,
         for wv, nmw in ((0, "wave 0"), (10, "wave 3")):
             x = [lv[wv + k] / st[2] for k in range(10)]
             print(f"    {nmw}: " + " | ".join(f"{nm[k]} {x[k]:6.0f}" for k in range(10)) + f" | sum {sum(x):6.0f}  (per source {sum(x) * st[2] / st[3]:6.0f})")
+        fb = (C.c_ulonglong * 16)()
+        lib.wfk_res4_fn_stamps(fb, 1)
+        fv = list(fb)
+        for part in (1, 2):  # thread 0's transverse passes: cycles per pass inside the function
+            o = (part - 1) * 4; npass = max(1, fv[o + 3])
+            print(f"    transverse part {part}, wave 0: {fv[o + 3]} passes ({fv[o + 3] / st[2]:.2f} per stage) | to the first pass {fv[o] / st[2]:6.0f} per stage | "
+                  f"terms {fv[o + 1] / npass:6.0f} | hand-over {fv[o + 2] / npass:6.0f} per pass")
     w.close()

@@ -15,6 +15,8 @@ void free_batch(wf_handle* h) {
   h->sort_tmp_bytes = h->dir_perm_cap = 0; h->dir_slots = 0;
   hipFree(h->d_res_list); hipFree(h->d_res_count); hipFree(h->d_flags_raw);
   h->d_res_list = h->d_res_count = h->d_flags_raw = nullptr;
+  if (h->h_res_seen) (void)hipHostFree(h->h_res_seen);
+  h->h_res_seen = nullptr;
   h->d_flags = h->d_farm_tie = nullptr;
   hipFree(h->d_yaw); hipFree(h->d_out);
   hipFree(h->d_env_yaw); hipFree(h->d_env_acc); hipFree(h->d_env_act); hipFree(h->d_env_out); hipFree(h->d_env_moves);

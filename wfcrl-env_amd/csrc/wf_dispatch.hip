@@ -769,9 +769,12 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   if (mode != 0 || mask) {
     if (!h->d_res_list) {
       WF_HIP(h, hipMalloc(&h->d_res_list, sizeof(int) * h->cap_env));
-      WF_HIP(h, hipMalloc(&h->d_res_count, sizeof(int) * 2));
+      WF_HIP(h, hipMalloc(&h->d_res_count, sizeof(int) * 3));
       WF_HIP(h, hipMalloc(&h->d_flags_raw, sizeof(int) * h->cap_env));
-      WF_HIP(h, hipMemsetAsync(h->d_res_count, 0, sizeof(int) * 2, h->stream));
+      WF_HIP(h, hipMemsetAsync(h->d_res_count, 0, sizeof(int) * 3, h->stream));
+      // the flagged list's length as the float64 kernel last found it (wf_resolve.h: seen_host): unknown yet -> "long"
+      if (!h->h_res_seen) WF_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_res_seen), sizeof(int), hipHostMallocDefault));
+      *h->h_res_seen = 0x7fffffff;
       h->res_parity = 0;
     }
   }
@@ -789,6 +792,9 @@ int launch_step(wf_handle* h, const float* yaw, float* power, float* wspd, float
   if (mode == 0 && !mask) return WF_OK;
   WfResolveArgs ra{};
   ra.tab64 = h->d_tab64; ra.list = h->d_res_list; ra.count = h->d_res_count + h->res_parity; ra.flags = h->d_flags;
+  // a launch with helper waves where the previous one found a farm per CU or so (a hint: the results are the same bits either way)
+  ra.seen_host = h->h_res_seen; ra.seen_dev = h->d_res_count + 2;
+  ra.wide_hint = h->h_res_seen && *const_cast<volatile int*>(h->h_res_seen) <= (h->n_cu * 5) / 4 ? 1 : 0;
   ra.gx = h->d_gx; ra.gy = h->d_gy; ra.gidx = h->d_gidx;
   ra.geom_stride = (h->wind_count == 1 || h->shared_dir) ? 0 : (size_t)h->N;
   ra.mod = 1;

@@ -195,7 +195,8 @@ struct wf_handle {
                                // the same modes — nothing forces mode 2)
   WfResolveConsts rconsts{};
   double* d_tab64 = nullptr;   // [3][WF_TABLE_PAD] wind speed, Ct, power in float64
-  int *d_res_list = nullptr, *d_res_count = nullptr, *d_flags_raw = nullptr;  // [B], [2] (used alternately: res_parity), [B]
+  int *d_res_list = nullptr, *d_res_count = nullptr, *d_flags_raw = nullptr;  // [B], [2] (used alternately: res_parity) + [1] (shadow of h_res_seen), [B]
+  int* h_res_seen = nullptr;   // pinned host int: the length of the flagged list as the float64 kernel last found it
   int res_parity = 0;          // which of the two counters the last step with a re-solve used
   bool res_last = false;       // the last step had a re-solve behind it (its list, counter and raw flags are current)
   int res_mask = 0;            // nonzero only while launch_step enqueues the real launch: WF_RISK_* bits that put a farm on the list

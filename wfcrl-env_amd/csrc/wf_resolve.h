@@ -33,6 +33,9 @@ struct WfResolveArgs {
   const double* tab64;  // [3][WF_TABLE_PAD]: wind speed, Ct, power (1/2 A Cp eta ws^3)
   int* list;            // [B] compacted farm indices
   int* count;           // [1]
+  int* seen_host;       // pinned host int, or null: the four-wave kernel leaves the list's length there for the NEXT launch's choice of width
+  int* seen_dev;        // its shadow in device memory (the host copy is written when the length changes only)
+  int wide_hint;        // the caller expects a short list (from seen_host): a launch with helper waves
   int* flags;           // [B] WF_RISK_* of the float32 step; cleared for every farm solved here
   const double *gx, *gy;  // sorted geometry (float64)
   const int* gidx;

@@ -609,9 +609,14 @@ __device__ unsigned long long wf_res4_stamp[16];
 #define RES4_T(v)
 #define RES4_ACC(k, a, b)
 #define RES4_LACC(k, a, b)
+#define RES4_FT(v)
+#define RES4_FACC(k, a, b)
 #else
 // level stages (tools/res4_stamps.py): [wave 0 | wave 3][transverse of the members, wait, chain, transverse of the rest, wait, deficit, wait, turbulence | check + next begin, wait]
 __device__ unsigned long long wf_res4_lstamp[20];
+__device__ unsigned long long wf_res4_fstamp[16];  // inside the level's transverse pass (thread 0): per part {prologue, terms, hand-over, passes}
+#define RES4_FT(v) const unsigned long long v = __builtin_readcyclecounter()
+#define RES4_FACC(k, a, b) if (tid == 0) atomicAdd(&wf_res4_fstamp[k], (b) - (a))
 #define RES4_LACC(k, a, b) stl[k] += (b) - (a)
 #endif
 #if RES_PART == 1
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
 // waves shortens it (HornsRev1: 1.04 -> 0.73 ms per farm).  Both kernels are enqueued behind the compaction; each reads
 // the count on the device and the one it is not meant for returns at once.
 #ifndef WF_RES4_OCC
-#define WF_RES4_OCC 4          // blocks per CU the register allocator makes room for: 128 VGPRs since round 6 (without machine LICM the kernel needs no more — with it, at 256, only two blocks fitted a CU and a list beyond 512 farms needed a second round)
+#define WF_RES4_OCC 4          // waves per SIMD the register allocator makes room for (four 4-wave blocks, or two blocks with their helper waves, per CU): 128 VGPRs since round 6 (without machine LICM the kernel needs no more — with it, at 256, only two 4-wave blocks fitted a CU and a list beyond 512 farms needed a second round)
 #endif
 // One farm per 256-thread block.  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column TIs,
 // float64 — lives in LDS, structure-of-arrays over the sorted turbine index; a lane is not tied to a turbine: for source i
@@ -754,18 +759,34 @@ struct Fin4Shared {  // the source-only constants of deflection, deficit and wak
 // with the one its state was derived from, and a member's column TIs must not have been raised by a member ahead of it.
 // A farm that fails the check is solved again without levels (never seen on the repo's layouts; counted, wfk_res_level_stats).
 #define RES_LMAX 8
+#define RES4_MAX_WAVES 8  // four waves with roles + four helper waves (level stages of a short list)
 #ifndef RES4_SCHED_LIMIT
 #define RES4_SCHED_LIMIT 0  // the sequential stage's transverse pass: 0 all 14 reciprocal chains at once, 2 in two batches (8 + 6), 1 two at a time
 #endif
 #ifndef RES_LV_SCHED_LIMIT
 #define RES_LV_SCHED_LIMIT 2
 #endif
-struct Lvl4Shared {
+struct Lvl4Shared {  // what res4_level_begin leaves: written a stage AHEAD, hence two copies (R4.lv, by level parity)
   Src4Shared s[RES_LMAX];
+  double m3[RES_LMAX], vtb[RES_LMAX], vcore[RES_LMAX];
+  // the lane layout of the level's pair passes (RES4_LV_LANES), divided out once: targets per wave pass (64 / L), the first target
+  // of the transverse passes and their chunks — all, the first that holds a member, how many hold members — and the chunks of the
+  // deficit / turbulence passes
+  int T, tmin, n_ch_tv, c0, n_own, n_ch_df;
+};
+struct Col4Shared {  // the deflection / deficit constants of ONE rotor-grid column of a member [A.3-3, A.3-6]: they depend on the
+  double x0d, ix0d_rel, kyd, d0, pfar, x0v, ix0v_rel, kyv;  // column's TI — derived once by the chain, not by every pair pass
+};
+struct Lvl4Work {  // what the level stage itself writes and reads (one copy: a stage's last barrier lies between its readers and the next level's writers)
   Fin4Shared f[RES_LMAX];
-  double m3[RES_LMAX], dTI[RES_LMAX], vtb[RES_LMAX], vcore[RES_LMAX];
-  double before[RES_LMAX][9];  // V of member m's rotor as source m finds it (after the members ahead of it)
-  double own[RES_LMAX][18];    // V, W of member m's rotor after its own transverse pass
+  double dTI[RES_LMAX];
+  union {  // (the chain has read the sums by the time it writes the columns' constants: one wave, in program order)
+    struct {
+      double before[RES_LMAX][9];  // V of member m's rotor as source m finds it (after the members ahead of it)
+      double own[RES_LMAX][18];    // V, W of member m's rotor after its own transverse pass
+    };
+    Col4Shared col[RES_LMAX][3];
+  };
 };
 // The member-to-member hand-over of a pair pass's running sums goes through a wave-private LDS buffer (first version: a chain of
 // L - 1 ds_bpermute steps — 35-39 % of a level stage, profiles/r06_handover_ablation.txt): every lane leaves its term there,
@@ -777,6 +798,8 @@ struct Lvl4Shared {
 #define RES_HAND_DOUBLES 3
 // (the terms are in LDS before any lane of the wave reads them: the wave's writes have completed, and the compiler keeps the order)
 #define RES_HAND_FENCE asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// (measured in round 6: as a compiler barrier alone — the LDS serves a wave's instructions in the order they were issued — the
+// results are the same bits and the time is the same; the wait is kept)
 struct Res4Shared {
   WfResolveConsts c;
   double tws[RES_NT * WF_TABLE_PAD], tct[RES_NT * WF_TABLE_PAD], tpw[RES_NT * WF_TABLE_PAD];
@@ -788,16 +811,18 @@ struct Res4Shared {
   double ws, wd, Uinf, Uinit[3];
   double dec_a[3];  // 4 nu_k ws / Uinf
   WfResolveArgs a;  // the launch arguments (read from here inside the farm loop)
-  double red[4][2];
+  double red[RES4_MAX_WAVES][2];
   int N, n_pad, veer_on, mcore;
+  int nw;  // waves at work on the block's farm: 4, or 8 with the helper waves of a short list (see wf_resolve4_kernel)
   Src4Shared s[2];  // by stage parity: wave 3 writes the NEXT source's copy while the others still read this one's
   Fin4Shared f;
   double own[18];  // V (0..8) and W (9..17) of the source's own turbine after its transverse pass (see res4_transverse_pass)
   Lvl4Shared lv[2];  // a LEVEL stage's members (round 6, below), by level parity: wave 3 derives the NEXT level's members while the others still read this one's
+  Lvl4Work lw;
   double lvl_a, lvl_b;  // two turbines may share a level when |dy'| >= lvl_a + lvl_b dx' (or dx' == 0)
   int levels_on, lv_fail;
   int wp_tv, wp_df, wp_tb;  // next wave pass of a level stage's pair passes (the waves draw them: whoever is free takes the next)
-  double hand[4][64 * RES_HAND_DOUBLES + 2];  // per wave: a term per lane and value (see RES_HAND_DOUBLES); [192] holds 0.0: the term of a member the level does not have
+  double hand[RES4_MAX_WAVES][64 * RES_HAND_DOUBLES + 2];  // per wave: a term per lane and value (see RES_HAND_DOUBLES); [192] holds 0.0: the term of a member the level does not have
 };
 __shared__ Res4Shared R4;
 
@@ -808,10 +833,11 @@ __shared__ Res4Shared R4;
 #define RES4_GR(t) res_dyn[(t) * RES_TS + 4]
 #define RES4_ST(q, t) res_dyn[(t) * RES_TS + 5 + (q)]  // wake2 q = 0..8, V 9..17, W 18..26, TI 27..29
 #define RES4_TIE(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(t)])
-#define RES4_CNT(j, t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(1 + (j)) * R4.n_pad + (t)])  // overlap count of column j
-#define RES4_LVL(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[4 * R4.n_pad + (t)])  // members of the level that starts at t (1: a sequential stage)
-#define RES4_LCNT(m, j, t) (reinterpret_cast<unsigned char*>(reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad) + 5 * R4.n_pad)[((m) * 3 + (j)) * R4.n_pad + (t)])  // overlap count (0 .. 3) of member m, column j: a byte each
-#define RES4_DYN_BYTES(n_pad) (sizeof(double) * RES_TS * (size_t)(n_pad) + sizeof(int) * 5 * (size_t)(n_pad) + 3 * RES_LMAX * (size_t)(n_pad))
+#define RES4_LVL(t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[R4.n_pad + (t)])  // members of the level that starts at t (1: a sequential stage)
+// (the overlap counts live from a stage's deficit pass to its turbulence pass: a sequential stage's and a level stage's share the space)
+#define RES4_CNT(j, t) (reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad)[(2 + (j)) * R4.n_pad + (t)])  // overlap count of column j
+#define RES4_LCNT(m, j, t) (reinterpret_cast<unsigned char*>(reinterpret_cast<int*>(res_dyn + RES_TS * R4.n_pad) + 2 * R4.n_pad)[((m) * 3 + (j)) * R4.n_pad + (t)])  // overlap count (0 .. 3) of member m, column j: a byte each
+#define RES4_DYN_BYTES(n_pad) (sizeof(double) * RES_TS * (size_t)(n_pad) + sizeof(int) * 2 * (size_t)(n_pad) + 3 * RES_LMAX * (size_t)(n_pad))
 
 // ---- the source's state and circulations [A.3-1, A.3-2, A.3-4] ----
 // Wave 3 only, one source AHEAD (round 5): source i + 1's rotor speed, thrust and circulations need its turbine's deficits
@@ -1109,7 +1135,7 @@ RES_PASS_FN void res4_turbulence_pass(int tid, int i, int j) {
 // LEVEL stages (see Lvl4Shared).  Lane layout of the pair passes: T = 64 / L targets per wave pass, lane = ks T + tl —
 // member ks of the level on target (chunk base + tl); lanes beyond L T idle.
 #define RES4_LV_LANES(L)                                        \
-  const int lane = tid & 63, T = 64 / (L);                      \
+  const int lane = tid & 63, T = lv.T;                          \
   int ks = 0;                                                   \
   _Pragma("unroll") for (int q_ = 1; q_ < RES_LMAX; ++q_) ks += (lane >= q_ * T) ? 1 : 0; \
   const int tl = lane - ks * T;                                 \
@@ -1148,31 +1174,45 @@ RES_SRC_FN void res4_level_begin(int tid, Lvl4Shared& lv, int i0, int L) {
     const double v_top = gam_top * c.k_top, v_bot = -gam_bot * c.k_bot, v_core = G_wr * c.k_core;
     lv.vtb[m] = v_top + v_bot; lv.vcore[m] = v_core;
     lv.m3[m] = m3m;
+    if (m == 0) {
+      // (64 / L from a table, the quotients by T through a float reciprocal: turbine indices are far below 2^20 and T <= 21 — the
+      // half added before the multiplication is worth more than any rounding; four integer divisions would be ~ 600 cycles of this
+      // wave's chain)
+      const int T = (int)((0x08090A0C10152040ull >> (8 * (L - 1))) & 0xFF), tmin = s.first_tv, N = R4.N;
+      const float iT = __frcp_rn((float)T);
+      const int c0 = (int)(((float)(i0 - tmin) + 0.5f) * iT);
+      lv.T = T; lv.tmin = tmin; lv.n_ch_tv = (int)(((float)(N - tmin + T - 1) + 0.5f) * iT); lv.c0 = c0;
+      lv.n_own = (int)(((float)(i0 + L - 1 - tmin) + 0.5f) * iT) - c0 + 1;
+      lv.n_ch_df = (int)(((float)(N - i0 - 1 + T - 1) + 0.5f) * iT);
+    }
   }
 }
 
 // ---- 4. transverse velocities: every (member, target, column) pair; what a target receives is added in member order ----
 RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, int part) {
   RES_PHASE_FENCE;
+  RES4_FT(f0);
   const WfResolveConsts& c = R4.c;
   RES4_LV_LANES(L);
   const int wave = tid >> 6, N = R4.N;
   const Src4Shared& s = lv.s[km];
   const double x_i = s.x_i, y_i = s.y_i, Gt = s.Gt, Gb = s.Gb, Gw = s.Gw;
-  const int first = s.first_tv, tmin = lv.s[0].first_tv;
+  const int first = s.first_tv, tmin = lv.tmin;
   const double qd = c.off[2], neps = c.num_eps, twoHH = 2.0 * c.HH, eps2 = c.eps2, ieps2 = c.inv_eps2;
   const bool mcore = R4.mcore != 0;
   // part 1: the chunks that hold the level's own members (the chain waits for them), a fixed share per wave; part 2: all
   // other chunks, drawn from a counter — wave 3 joins when its chain is done
-  const int n_ch = (N - tmin + T - 1) / T, c0 = (i0 - tmin) / T, c1 = (i0 + L - 1 - tmin) / T, n_own = c1 - c0 + 1;
+  const int n_ch = lv.n_ch_tv, c0 = lv.c0, n_own = lv.n_own;
   const int n_wp = part == 1 ? 3 * n_own : 3 * (n_ch - n_own);
-  for (int wp_s = wave;; wp_s += 4) {
+  const int nw = R4.nw;
+  for (int wp_s = wave;; wp_s += nw) {
     int wp = wp_s;
     if (part != 1) {
       if (lane == 0) wp = atomicAdd(&R4.wp_tv, 1);
       wp = __builtin_amdgcn_readfirstlane(wp);
     }
     if (wp >= n_wp) break;
+    RES4_FT(f1);
     int ch = wp / 3;
     if (part == 1) ch += c0;
     else if (ch >= c0) ch += n_own;
@@ -1222,6 +1262,7 @@ RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, i
     // terms of value k in member order (see RES_HAND_DOUBLES), takes the snapshots a member's chain needs on the way, and stores
     // (a pair the sequential solve does not visit — a target ahead of the member's tie group, a lane without a member — leaves
     // +0.0: adding it changes no bit of a sum that started at +0.0)
+    RES4_FT(f2);
     const int mt = t - i0;  // the target as a member of this level (0 .. L - 1), if it is one
     double* hb = R4.hand[wave];
     const bool coll = ks < 3 && t < N;
@@ -1249,8 +1290,8 @@ RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, i
             own = sm == mt ? p : own;
           }
           if (mt >= 0 && mt < L) {
-            if (!half) lv.before[mt][j * 3 + ks] = bef;
-            lv.own[mt][(half ? 9 : 0) + j * 3 + ks] = own;
+            if (!half) R4.lw.before[mt][j * 3 + ks] = bef;
+            R4.lw.own[mt][(half ? 9 : 0) + j * 3 + ks] = own;
           }
         } else {
 #pragma unroll
@@ -1260,6 +1301,9 @@ RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, i
       }
       RES_HAND_FENCE;  // (the reads are through before the next terms overwrite the buffer)
     }
+    RES4_FT(f3);
+    RES4_FACC((part - 1) * 4 + 1, f1, f2); RES4_FACC((part - 1) * 4 + 2, f2, f3); RES4_FACC((part - 1) * 4 + 3, f0, f0 + 1);
+    if (wp_s == wave) RES4_FACC((part - 1) * 4, f0, f1);
   }
 }
 
@@ -1277,7 +1321,7 @@ RES_SRC_FN void res4_level_chain(int tid, Lvl4Shared& lv, int i0, int L) {
   for (int j = 0; j < 3; ++j) TIs[j] = RES4_ST(27 + j, i);  // (final: no member ahead may raise them — checked in the turbulence pass)
   double vs = 0.0;
 #pragma unroll
-  for (int q = 0; q < 9; ++q) vs += lv.before[mm][q];
+  for (int q = 0; q < 9; ++q) vs += R4.lw.before[mm][q];
   const double Vmean = vs * (1.0 / 9.0);
   const double cg = RES4_CG(i), sg = RES4_SG(i), ct = s0.ct, D = c.D, ubar = s0.ubar;
   double val = 2.0 * (Vmean - lv.vcore[mm]) * rcp64(lv.vtb[mm]);
@@ -1308,7 +1352,7 @@ RES_SRC_FN void res4_level_chain(int tid, Lvl4Shared& lv, int i0, int L) {
   // 5. yaw-added recovery [A.3-5]
   double vsum = 0.0, wsum = 0.0;
 #pragma unroll
-  for (int q = 0; q < 9; ++q) { vsum += lv.own[mm][q]; wsum += lv.own[mm][9 + q]; }
+  for (int q = 0; q < 9; ++q) { vsum += R4.lw.own[mm][q]; wsum += R4.lw.own[mm][9 + q]; }
   const double I = TIs[0];
   const double k_tke = (ubar * I) * (ubar * I) * 1.5;
   const double vbar = vsum * (1.0 / 9.0), wbar = wsum * (1.0 / 9.0);
@@ -1316,7 +1360,7 @@ RES_SRC_FN void res4_level_chain(int tid, Lvl4Shared& lv, int i0, int L) {
   const double dTI = c.sw_yar ? c.gch_gain * (I_tot - I) : 0.0;
   const double ch_pref = c.ch_constant * POW_F64(s0.ai, c.ch_ai) * c.ch_amb_pow;
   if (act) {
-    Fin4Shared& f = lv.f[m];
+    Fin4Shared& f = R4.lw.f[m];
     f.cgd = cgd; f.s_cc = s_cc; f.s_c = s_c; f.th0 = th0; f.tan_th0 = tan_th0; f.M0 = M0;
     f.E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
     f.sM = sM; f.sz0d = sz0d; f.sy0d = sy0d; f.is0d = rcp64(sy0d * sz0d); f.lnAB = (1.6 + sM) * rcp64(1.6 - sM);
@@ -1324,12 +1368,37 @@ RES_SRC_FN void res4_level_chain(int tid, Lvl4Shared& lv, int i0, int L) {
     f.ch_pref = ch_pref;
     f.cgv = cg;
     s0.Vmean = Vmean; s0.val = val;
-    lv.dTI[m] = dTI;
+    R4.lw.dTI[m] = dTI;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       s0.TIs[j] = TIs[j];
       RES4_ST(27 + j, i) = fmax(TIs[j] + dTI, c.amb);  // (stored: see res_source_finish)
     }
+  }
+  // ... and the constants of each member's three columns, a (member, column) pair per lane: the expressions of the sequential
+  // stage's deficit pass (res4_deficit_pass) on the same values — every pair pass of the level would otherwise derive them again
+  // (five reciprocals and a root of its ~ 30)
+  RES_HAND_FENCE;
+  {
+    const int l = tid & 63, m2 = l / 3, j2 = l - 3 * m2;
+    const bool act2 = l < 3 * L;
+    const int mq = act2 ? m2 : 0;
+    const Fin4Shared& f = R4.lw.f[mq];
+    const double TIpre = lv.s[mq].TIs[j2], x_i = lv.s[mq].x_i;
+    const double x0d_rel = c.D * f.cgd * (1.0 + f.s_cc) * rcp64(c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - f.s_c)));
+    const double kyd = c.defl_ka * TIpre + c.defl_kb;
+    const double TIq = TIpre + R4.lw.dTI[mq];
+    const double x0v_rel = c.D * f.cgv * (1.0 + f.s_c) * rcp64(c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - f.s_c)));
+    Col4Shared cs;
+    cs.x0d = x0d_rel + x_i;
+    cs.ix0d_rel = rcp64(x0d_rel);
+    cs.kyd = kyd;
+    cs.d0 = f.tan_th0 * x0d_rel;
+    cs.pfar = f.th0 * f.E0 * (1.0 / 5.2) * sqrt_pos(f.sy0d * f.sz0d * rcp64(kyd * kyd * f.M0));
+    cs.x0v = x0v_rel + x_i;
+    cs.ix0v_rel = rcp64(x0v_rel);
+    cs.kyv = c.ka * TIq + c.kb;
+    if (act2) R4.lw.col[mq][j2] = cs;
   }
 }
 
@@ -1340,12 +1409,12 @@ RES_PASS_FN void res4_level_deficit(int tid, Lvl4Shared& lv, int i0, int L) {
   RES4_LV_LANES(L);
   const int N = R4.N;
   const Src4Shared& s = lv.s[km];
-  const Fin4Shared& f = lv.f[km];
+  const Fin4Shared& f = R4.lw.f[km];
   const bool veer_on = R4.veer_on != 0;
-  const double x_i = s.x_i, y_i = s.y_i, dTI = lv.dTI[km];
+  const double x_i = s.x_i, y_i = s.y_i;
   const double q2 = c.off[2] * c.off[2];
   const int k_src = i0 + km;
-  const int n_wp = 3 * ((N - i0 - 1 + T - 1) / T);
+  const int n_wp = 3 * lv.n_ch_df;
   for (;;) {
     int wp = 0;
     if (lane == 0) wp = atomicAdd(&R4.wp_df, 1);
@@ -1358,19 +1427,10 @@ RES_PASS_FN void res4_level_deficit(int tid, Lvl4Shared& lv, int i0, int L) {
     double dU[3] = {0.0, 0.0, 0.0};
     int cnt = 0;
     if (active) {
-      // source-side constants of this column [A.3-3, A.3-6]
-      const double TIpre = s.TIs[j];
-      const double x0d_rel = c.D * f.cgd * (1.0 + f.s_cc) * rcp64(c.sqrt2 * (4.0 * c.defl_alpha * TIpre + 2.0 * c.defl_beta * (1.0 - f.s_c)));
-      const double x0d = x0d_rel + x_i;
-      const double ix0d_rel = rcp64(x0d_rel);
-      const double kyd = c.defl_ka * TIpre + c.defl_kb;
-      const double d0 = f.tan_th0 * x0d_rel;
-      const double pfar = f.th0 * f.E0 * (1.0 / 5.2) * sqrt_pos(f.sy0d * f.sz0d * rcp64(kyd * kyd * f.M0));
-      const double TIq = TIpre + dTI;
-      const double x0v_rel = c.D * f.cgv * (1.0 + f.s_c) * rcp64(c.sqrt2 * (4.0 * c.alpha * TIq + 2.0 * c.beta * (1.0 - f.s_c)));
-      const double x0v = x0v_rel + x_i;
-      const double ix0v_rel = rcp64(x0v_rel);
-      const double kyv = c.ka * TIq + c.kb;
+      // source-side constants of this column [A.3-3, A.3-6] (res4_level_chain)
+      const Col4Shared& cs = R4.lw.col[km][j];
+      const double x0d = cs.x0d, ix0d_rel = cs.ix0d_rel, kyd = cs.kyd, d0 = cs.d0, pfar = cs.pfar;
+      const double x0v = cs.x0v, ix0v_rel = cs.ix0v_rel, kyv = cs.kyv;
       const double x_t = RES4_XS(tt), y_t = RES4_YS(tt);
       const double dx = x_t - x_i;
       const double lin = c.ad + c.bd * dx;
@@ -1452,9 +1512,9 @@ RES_PASS_FN void res4_level_turbulence(int tid, Lvl4Shared& lv, int i0, int L) {
   RES4_LV_LANES(L);
   const int N = R4.N;
   const Src4Shared& s = lv.s[km];
-  const double x_i = s.x_i, y_i = s.y_i, D = c.D, ch_pref = lv.f[km].ch_pref;
+  const double x_i = s.x_i, y_i = s.y_i, D = c.D, ch_pref = R4.lw.f[km].ch_pref;
   const int k_src = i0 + km;
-  const int n_ch = (N - i0 - 1 + T - 1) / T;
+  const int n_ch = lv.n_ch_df;
   for (;;) {
     int ch = 0;
     if (lane == 0) ch = atomicAdd(&R4.wp_tb, 1);
@@ -1519,7 +1579,7 @@ RES_PASS_FN void res4_level_lengths(int tid, bool on) {
   RES_PHASE_FENCE;
   const int N = R4.N;
   const double la = R4.lvl_a, lb = R4.lvl_b;
-  for (int t = tid; t < N; t += 256) {
+  for (int t = tid < 256 ? tid : N; t < N; t += 256) {
     int L = 1;
     if (on) {
       while (L < RES_LMAX && t + L < N) {
@@ -1546,7 +1606,7 @@ RES_PASS_FN void res4_outputs(int tid, const WfResolveArgs& a, int b, size_t gof
   const int N = R4.N;
   double psum = 0.0, lsum = 0.0;
   const int n_real = a.n_real ? a.n_real[b] : N;  // turbines the farm really has (padded layouts)
-  for (int t = tid; t < N; t += 256) {
+  for (int t = tid < 256 ? tid : N; t < N; t += 256) {  // (the four waves with roles: a helper wave has none here)
     const int o = a.gidx[gofs + t];
     [[maybe_unused]] const int ty = RES_TY(t);
     res_turbine_outputs(c, a, res_dyn + t * RES_TS, (size_t)b * N + o, o < n_real, R4.Uinit, R4.wd, RES4_CG(t), RES_TN(R4, ty),
@@ -1559,7 +1619,7 @@ RES_PASS_FN void res4_outputs(int tid, const WfResolveArgs& a, int b, size_t gof
       psum += __shfl_xor(psum, w);
       lsum += __shfl_xor(lsum, w);
     }
-    if ((tid & 63) == 0) { R4.red[tid >> 6][0] = psum; R4.red[tid >> 6][1] = lsum; }
+    if ((tid & 63) == 0 && tid < 256) { R4.red[tid >> 6][0] = psum; R4.red[tid >> 6][1] = lsum; }
     __syncthreads();
     if (tid == 0) {
       double ps = 0.0, ls = 0.0;
@@ -1572,18 +1632,43 @@ RES_PASS_FN void res4_outputs(int tid, const WfResolveArgs& a, int b, size_t gof
 
 #if !RES_MT
 // [0] farms solved by the four-wave kernel, [1] of them solved a second time without levels (a level failed its check),
-// [2] level stages, [3] sources inside them, [4] sequential stages — since the library was loaded (wfk_res_level_stats)
+// [2] level stages, [3] sources inside them, [4] sequential stages, [5] farms solved with the helper waves at work — since the
+// library was loaded (wfk_res_level_stats)
 __device__ unsigned long long wf_res_lvl_stat[8];
 #endif
 #ifndef RES4_WAVES_ATTR
 #define RES4_WAVES_ATTR
 #endif
-__global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_kernel(const WfResolveConsts c_arg, const WfResolveArgs a_arg, int n_pad, int max_count, int levels) {
+// HELPER WAVES (round 6).  A short list — a farm per CU or so: the 8-GPU share of a sweep, 39 farms — leaves every SIMD to ONE wave,
+// and a float64 chain at one wave per SIMD leaves every other issue slot empty.  A launch of 512 threads gives the block four more
+// waves (4-7) that take their share of a level stage's pair passes: the passes are drawn from counters, so more waves simply draw
+// faster.  They have no part in a sequential stage (its three phases are one wave pass per column) beyond its barriers.  The sums
+// are taken in member order whoever computes the terms: the same bits either way (tests/test_resolve_gpu.py).
+// The list's length is known on the device only, and a long list is better served by 256-thread blocks, three or four to a CU, than
+// by two wide ones (2 011 HornsRev2 farms: + 1.06 ms against + 1.25): the host picks the width from the length the PREVIOUS launch
+// found (seen_host; the first launch is a narrow one).  Should a wide launch meet a list beyond two blocks per CU after all, waves
+// 4-7 return at once (the registers of a wave that has ended are NOT handed to a new block while its block lives — measured: + 1.64
+// — so this is damage control for one step, not a way to launch).
+__global__ __launch_bounds__(64 * RES4_MAX_WAVES, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_kernel(const WfResolveConsts c_arg, const WfResolveArgs a_arg, int n_pad, int max_count, int levels, int helpers_max) {
   const int tid = threadIdx.x;
   const int N = c_arg.N;
   const int n_list = *a_arg.count;
-  if (n_list == 0 || n_list > max_count) return;  // nothing flagged (the common case: the launch costs its dispatch only) / the one-wave-per-farm kernel serves this count
+  // the list's length for the host, which picks the NEXT launch's width by it (wfk_launch_resolve4) — written when it changes only:
+  // the store goes to pinned host memory
+  // (on the path that returns and, below, behind the copies of the arguments: a store ahead of them makes the compiler copy the
+  // whole argument block to scratch first)
+  const bool tell = blockIdx.x == 0 && tid == 0 && a_arg.seen_host != nullptr;
+  if (n_list == 0 || n_list > max_count) {  // nothing flagged (the common case: the launch costs its dispatch only) / the one-wave-per-farm kernel serves this count
+    if (tell && *a_arg.seen_dev != n_list) {
+      *a_arg.seen_dev = n_list;
+      __hip_atomic_store(a_arg.seen_host, n_list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  const bool helpers = blockDim.x > 256 && n_list <= helpers_max;
+  if (tid >= 256 && !helpers) return;  // (ahead of the first barrier: a wave that has ended is not waited for)
   if (tid == 0) {
+    R4.nw = helpers ? RES4_MAX_WAVES : 4;
     R4.c = c_arg;
     R4.a = a_arg;
     R4.N = N; R4.n_pad = n_pad; R4.veer_on = c_arg.sin2_veer != 0.0; R4.mcore = c_arg.mirror_core;
@@ -1596,8 +1681,12 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
     R4.lvl_a = 0.35 * c_arg.D + 8.6 * s0;
     R4.lvl_b = 8.6 * ky + 0.15;
     R4.levels_on = levels && c_arg.sw_tv;
+    if (tell && *R4.a.seen_dev != n_list) {
+      *R4.a.seen_dev = n_list;
+      __hip_atomic_store(R4.a.seen_host, n_list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
-  res_stage_tables(R4, c_arg, a_arg, tid, 256);
+  res_stage_tables(R4, c_arg, a_arg, tid < 256 ? tid : 0x40000000, 256);
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
     __syncthreads();  // the constants are in place / the previous farm's last readers are done
     RES_PHASE_FENCE;
@@ -1624,7 +1713,7 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
     const float* yaw_b = (a.yaw_state ? a.yaw_state : a.yaw_in) + (size_t)b * N;
     int ti = tid;
     asm volatile("" : "+v"(ti));  // (what is derived from it is derived per attempt, not held across the solve)
-    for (int t = ti; t < N; t += 256) {
+    for (int t = ti < 256 ? ti : N; t < N; t += 256) {
       const double g = (double)yaw_b[a.gidx[gofs + t]];
       double sg, cg;
       if (__any(fabs(g) > 45.0)) sincos_any(g * kDeg, sg, cg);  // (never an admissible yaw command)
@@ -1643,7 +1732,7 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
     if (ti == 0) R4.lv_fail = 0;
     if ((ti & 63) == 0) R4.hand[ti >> 6][64 * RES_HAND_DOUBLES] = 0.0;
     __syncthreads();
-    for (int t = ti; t < N; t += 256) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
+    for (int t = ti < 256 ? ti : N; t < N; t += 256) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
       int f = t;
       while (f > 0 && RES4_XS(f - 1) == RES4_XS(t)) --f;
       RES4_TIE(t) = f;
@@ -1661,7 +1750,7 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
       // phase — is recomputed where it is used instead of being hoisted out of this loop and held, or spilled, across it)
       int tq = tid;
       asm volatile("" : "+v"(tq));
-      const int wq = tq >> 6;
+      const int wq = __builtin_amdgcn_readfirstlane(tq >> 6);  // (the wave: uniform, and known to be — the branches on it are scalar ones)
       const int L = RES4_LVL(i);
       if (L > 1) {  // ---- a level stage: sources i .. i + L - 1 at once (their states were derived a stage ahead) ----
         Lvl4Shared& lv = R4.lv[lp];
@@ -1681,7 +1770,7 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
         RES4_T(l6);
         __syncthreads();
         RES4_T(l7);
-        if (wq < 3) {
+        if (wq != 3) {
           if (wq == 0) res4_level_check(tq, lv, i, L);  // (ahead of its share of the drawn turbulence passes: wave 3 is busy with the next states)
           res4_level_turbulence(tq, lv, i, L);
         } else {  // the state(s) of the next stage's source(s)
@@ -1702,6 +1791,13 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
         continue;
       }
       ++n_seq;
+      if (wq >= 4) {  // a helper wave: the stage's barriers only
+        __syncthreads();
+        if (i + 1 < N) __syncthreads();
+        __syncthreads();
+        ++i;
+        continue;
+      }
       RES4_T(p0);
       if (wq < 3) {
         if (R4.c.sw_tv) res4_transverse_pass(tq, i, wq);
@@ -1758,6 +1854,7 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
       atomicAdd(&wf_res_lvl_stat[2], (unsigned long long)n_lv);
       atomicAdd(&wf_res_lvl_stat[3], (unsigned long long)n_lv_src);
       atomicAdd(&wf_res_lvl_stat[4], (unsigned long long)n_seq);
+      if (R4.nw > 4) atomicAdd(&wf_res_lvl_stat[5], 1ull);
     }
 #endif
 #if defined(WF_RES_STAMP) && !RES_MT
@@ -1780,6 +1877,8 @@ __global__ __launch_bounds__(256, WF_RES4_OCC) RES4_WAVES_ATTR void wf_resolve4_
 // other side of the bit-identity test, tests/test_resolve_gpu.py); shared with the build for several turbine definitions
 int g_res_levels = -1;
 extern "C" void wfk_set_resolve_levels(int on) { g_res_levels = on ? 1 : 0; }
+int g_res_helpers = -1;  // helper waves (WF_RES4_HELPERS / wfk_set_resolve_helpers): 0 never, 1 on lists expected to be short, 2 on every launch
+extern "C" void wfk_set_resolve_helpers(int mode) { g_res_helpers = mode < 0 ? 0 : mode > 2 ? 2 : mode; }
 // which kernels are enqueued (wfk_launch_resolve): 0 the four-wave kernel wherever it is the faster one (default), 1 "both" —
 // rounds 3-5's rule, by the list's length (WF_RESOLVE_POLICY=both seeds it; tests and A/B runs switch it here)
 int g_res_policy = -1;
@@ -1816,6 +1915,14 @@ extern "C" int wfk_res4_stamps(unsigned long long* out, int reset) {
   }
   return (int)e;
 }
+extern "C" int wfk_res4_fn_stamps(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res4_fstamp), sizeof(wf_res4_fstamp));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[16] = {};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(wf_res4_fstamp), z, sizeof(z));
+  }
+  return e == hipSuccess ? 0 : -1;
+}
 extern "C" int wfk_res4_level_stamps(unsigned long long* out, int reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_res4_lstamp), sizeof(wf_res4_lstamp));
   if (e == hipSuccess && reset) {
@@ -1828,10 +1935,11 @@ extern "C" int wfk_res4_level_stamps(unsigned long long* out, int reset) {
 
 #if RES_PART == 2
 #if RES_MT
-extern int g_res_levels;
+extern int g_res_levels, g_res_helpers;
 #endif
 // the four-wave kernel's launch (called by wfk_launch_resolve of part 1): how many farms one residency holds -> *max4_out;
-// launched when `launch` (the caller decides: always for a device-side count, for `all` when B fits)
+// launched when `launch & 1` (the caller decides: always for a device-side count, for `all` when B fits); `launch & 2`: the list
+// is every farm of the batch (its length is known: B)
 extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfResolveArgs* a, int B, int n_cu, int launch, int* max4_out,
                                           int any_count, hipStream_t s) {
   const int n_pad = (c->N + 1) & ~1;  // (keeps the int arrays behind the doubles aligned)
@@ -1840,6 +1948,17 @@ extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfReso
   const int levels = g_res_levels;
   const size_t lds4 = dyn4 + sizeof(Res4Shared);
   int per_cu = (int)((160 * 1024) / lds4);
+  {  // ... as the runtime counts it (LDS is handed out in granules: three blocks of 53 872 bytes do NOT fit 160 KB), asked once per size
+    static int occ4[2048];  // (blocks of 256 threads per CU) + 1; the same value whoever writes it
+    if (n_pad < 2048) {
+      if (occ4[n_pad] == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wf_resolve4_kernel, 256, dyn4) != hipSuccess) { (void)hipGetLastError(); nb = per_cu; }
+        occ4[n_pad] = nb + 1;
+      }
+      if (occ4[n_pad] - 1 < per_cu) per_cu = occ4[n_pad] - 1;
+    }
+  }
   if (per_cu > WF_RES4_OCC) per_cu = WF_RES4_OCC;
   // One residency: as many blocks per CU as LDS and registers hold (HornsRev1 / 2: three; up to 64 turbines: four).  (Rounds 3-5:
   // at most two — the kernel had 256 VGPRs — and beyond them the one-wave kernel won: 680 farms 1.27 ms against 1.1.  At 128 VGPRs a
@@ -1847,12 +1966,20 @@ extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfReso
   // slots of one farm's latency chain filled by another's; profiles/r06_res4_residency_ab.txt.)
   static const int per_cu_cap = [] { const char* e = getenv("WF_RES4_PER_CU"); return e ? atoi(e) : WF_RES4_OCC; }();
   if (per_cu > per_cu_cap) per_cu = per_cu_cap;
+  // helper waves (see the kernel): a launch of 512 threads where the list is expected to be short; two such blocks fit a CU
+  if (g_res_helpers < 0) { const char* e = getenv("WF_RES4_HELPERS"); g_res_helpers = e ? atoi(e) : 1; }
+  static const int helpers_max_env = [] { const char* e = getenv("WF_RES4_HELPERS_MAX"); return e ? atoi(e) : -1; }();  // (experiments)
+  const int helpers_max = !g_res_helpers ? 0 : helpers_max_env >= 0 ? helpers_max_env : 2 * n_cu;
+  // 0 never, 1 by what is known of the list (every farm: B; flagged farms: the caller's hint from the previous launch), 2 always
+  const bool wide = helpers_max > 0 && (g_res_helpers == 2 || ((launch & 2) ? B <= helpers_max : a->wide_hint != 0));
+  if (wide && per_cu > 2) per_cu = 2;
   const int max4 = per_cu >= 1 ? n_cu * per_cu : 0;
   *max4_out = max4;
-  if (!launch || max4 <= 0) return hipSuccess;
+  if (!(launch & 1) || max4 <= 0) return hipSuccess;
   const int grid4 = B < max4 ? B : max4;
   // any_count: this launch is the only one behind the step — its persistent blocks walk a list of any length
-  hipLaunchKernelGGL(wf_resolve4_kernel, dim3(grid4), dim3(256), dyn4, s, *c, *a, n_pad, any_count ? 0x7fffffff : max4, levels);
+  hipLaunchKernelGGL(wf_resolve4_kernel, dim3(grid4), dim3(wide ? 64 * RES4_MAX_WAVES : 256), dyn4, s, *c, *a, n_pad,
+                     any_count ? 0x7fffffff : max4, levels, helpers_max);
   return hipGetLastError();
 }
 #endif  // RES_PART == 2
@@ -1872,7 +1999,7 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   int max4 = 0;
-  if ((e = wfk_launch_resolve4(c, a, B, n_cu, 0, &max4, 0, s)) != hipSuccess) return e;
+  if ((e = wfk_launch_resolve4(c, a, B, n_cu, all ? 2 : 0, &max4, 0, s)) != hipSuccess) return e;
   // ONE launch behind a step (round 6): the four-wave kernel serves a flagged list of ANY length — its persistent blocks walk the
   // list, up to max4 farms resident at once.  With level stages it is the faster kernel at every count (2 011 flagged HornsRev2
   // farms: + 1.07 ms against the one-wave kernel's + 1.62, profiles/r06_four_wave_always_ab.txt), and an empty list costs one
@@ -1886,7 +2013,7 @@ extern "C" hipError_t wfk_launch_resolve(const WfResolveConsts* c, const WfResol
   const bool all4 = all && c->N >= 16 && !both;
   const bool only4 = (!all || all4) && max4 > 0 && !both;
   if (max4 > 0 && (!all || B <= max4 || all4)) {
-    if ((e = wfk_launch_resolve4(c, a, B, n_cu, 1, &max4, only4 ? 1 : 0, s)) != hipSuccess) return e;
+    if ((e = wfk_launch_resolve4(c, a, B, n_cu, all ? 3 : 1, &max4, only4 ? 1 : 0, s)) != hipSuccess) return e;
   }
   if (only4) return hipSuccess;
   if (!all || B > max4) {
