@@ -780,6 +780,7 @@ struct Col4Shared {  // the deflection / deficit constants of ONE rotor-grid col
 struct Lvl4Work {  // what the level stage itself writes and reads (one copy: a stage's last barrier lies between its readers and the next level's writers)
   Fin4Shared f[RES_LMAX];
   double dTI[RES_LMAX];
+  double i1sc[RES_LMAX], iubar[RES_LMAX];  // 1 / (1 + sqrt(1 - Ct)), 1 / rotor speed: from the chain's first part to its second
   union {  // (the chain has read the sums by the time it writes the columns' constants: one wave, in program order)
     struct {
       double before[RES_LMAX][9];  // V of member m's rotor as source m finds it (after the members ahead of it)
@@ -822,6 +823,8 @@ struct Res4Shared {
   double lvl_a, lvl_b;  // two turbines may share a level when |dy'| >= lvl_a + lvl_b dx' (or dx' == 0)
   int levels_on, lv_fail;
   int wp_tv, wp_df, wp_tb;  // next wave pass of a level stage's pair passes (the waves draw them: whoever is free takes the next)
+  int mem_done;  // wave passes over the chunks that hold the level's members that are through (the chain waits for all 3 n_own)
+  int chain_done;  // the level's chain is through: its constants are in LDS (the deficit passes wait for it)
   double hand[RES4_MAX_WAVES][64 * RES_HAND_DOUBLES + 2];  // per wave: a term per lane and value (see RES_HAND_DOUBLES); [192] holds 0.0: the term of a member the level does not have
 };
 __shared__ Res4Shared R4;
@@ -1205,6 +1208,7 @@ RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, i
   const int n_ch = lv.n_ch_tv, c0 = lv.c0, n_own = lv.n_own;
   const int n_wp = part == 1 ? 3 * n_own : 3 * (n_ch - n_own);
   const int nw = R4.nw;
+  int n_mine = 0;
   for (int wp_s = wave;; wp_s += nw) {
     int wp = wp_s;
     if (part != 1) {
@@ -1212,6 +1216,7 @@ RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, i
       wp = __builtin_amdgcn_readfirstlane(wp);
     }
     if (wp >= n_wp) break;
+    ++n_mine;
     RES4_FT(f1);
     int ch = wp / 3;
     if (part == 1) ch += c0;
@@ -1305,6 +1310,66 @@ RES_PASS_FN void res4_level_transverse(int tid, Lvl4Shared& lv, int i0, int L, i
     RES4_FACC((part - 1) * 4 + 1, f1, f2); RES4_FACC((part - 1) * 4 + 2, f2, f3); RES4_FACC((part - 1) * 4 + 3, f0, f0 + 1);
     if (wp_s == wave) RES4_FACC((part - 1) * 4, f0, f1);
   }
+  // part 1: this wave's passes over the members' chunks are in LDS (the fence above): counted for wave 3, whose chain waits for
+  // all of them — no barrier: the other waves go straight on to the other chunks (part 2)
+  if (part == 1 && n_mine > 0 && lane == 0) atomicAdd(&R4.mem_done, n_mine);
+}
+
+// wave 3, ahead of its chain: until every pass over the members' chunks is through.  (Bounded: a count that never arrives —
+// it always does: the passes are a fixed share of waves that are running — sends the farm to the sequential solve, like a
+// failed check, instead of hanging the block.)
+RES_SRC_FN void res4_level_wait_members(Lvl4Shared& lv) {
+  const int n1 = 3 * lv.n_own;
+  int it = 0;
+  while (__hip_atomic_load(&R4.mem_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n1 && it < (1 << 20)) {
+    __builtin_amdgcn_s_sleep(1);
+    ++it;
+  }
+  if (it >= (1 << 20)) R4.lv_fail = 1;
+  RES_HAND_FENCE;
+}
+// every wave, between its last transverse pass and its first deficit pass: until wave 3's chain has left the members' constants
+// (as a rule it has, long ago — the transverse passes take longer than the chain; no barrier: whoever runs out of transverse
+// passes starts on the deficit passes while the others finish theirs — the two kinds of pass touch different sums)
+RES_SRC_FN void res4_level_wait_chain() {
+  int it = 0;
+  while (__hip_atomic_load(&R4.chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 && it < (1 << 20)) {
+    __builtin_amdgcn_s_sleep(1);
+    ++it;
+  }
+  if (it >= (1 << 20)) R4.lv_fail = 1;
+  RES_HAND_FENCE;
+}
+
+// ---- the part of a member's chain that needs nothing but its state (res4_level_begin): wave 3 derives it WHILE the other waves
+// are on the transverse passes over the members' chunks — the roots and reciprocals that do not depend on the steering, and the
+// Crespo-Hernandez prefactor (a pow): a quarter of the chain's instructions off the stage's critical path ----
+RES_SRC_FN void res4_level_chain_pre(int tid, Lvl4Shared& lv, int i0, int L) {
+  RES_PHASE_FENCE;
+  const WfResolveConsts& c = R4.c;
+  const int m = tid & 63;
+  const bool act = m < L;
+  const int mm = act ? m : 0, i = i0 + mm;
+  const Src4Shared& s0 = lv.s[mm];
+  const double cg = RES4_CG(i), ct = s0.ct, D = c.D;
+  const double s_c = sqrt_nn(1.0 - ct);
+  const double C0 = 1.0 - s_c;
+  const double M0 = C0 * (2.0 - C0);
+  const double i1sc = rcp64(1.0 + s_c);
+  const double sM = sqrt_pos(M0);
+  const double sz0v = D * 0.5 * sqrt_pos((ct * rcp64(2.0 * (1.0 - s_c))) * i1sc);
+  const double ch_pref = c.ch_constant * POW_F64(s0.ai, c.ch_ai) * c.ch_amb_pow;
+  if (act) {
+    Fin4Shared& f = R4.lw.f[m];
+    f.s_c = s_c; f.M0 = M0;
+    f.E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
+    f.sM = sM; f.lnAB = (1.6 + sM) * rcp64(1.6 - sM);
+    f.sz0v = sz0v; f.sy0v = sz0v * cg * c.cos_veer; f.snw = c.near_c * sqrt_pos(ct * 0.5); f.kdef = ct * cg * D * D * 0.125;
+    f.ch_pref = ch_pref;
+    f.cgv = cg;
+    R4.lw.i1sc[m] = i1sc;
+    R4.lw.iubar[m] = rcp64(s0.ubar);
+  }
 }
 
 // ---- 2, 5 and the source-only part of 3 + 6 + 8 of every member (wave 3, member m in lane m): steering from the
@@ -1335,20 +1400,16 @@ RES_SRC_FN void res4_level_chain(int tid, Lvl4Shared& lv, int i0, int L) {
   const double c2d = sqrt_nn(fmax(1.0 - val * val, 0.0)), cd = sqrt_pos(0.5 * (1.0 + c2d)), sd = 0.5 * val * rcp64(cd);
   const double cgd = c.sw_steer ? cg * cd - sg * sd : cg;
   const double gd_rad = -(RES4_GR(i) + g_off);
-  const double s_cc = sqrt_nn(1.0 - ct * cgd), s_c = sqrt_nn(1.0 - ct);
+  const double s_cc = sqrt_nn(1.0 - ct * cgd);
   const double th0 = c.dm * (0.3 * gd_rad * rcp64(cgd)) * (1.0 - s_cc);
   double tan_th0 = tan_small(th0);
   if (__any(act && fabs(th0) > 0.5)) {
     const double ta = tan_any(th0);
     tan_th0 = fabs(th0) > 0.5 ? ta : tan_th0;
   }
-  const double C0 = 1.0 - s_c;
-  const double M0 = C0 * (2.0 - C0);
-  const double i1sc = rcp64(1.0 + s_c);
+  const double i1sc = R4.lw.i1sc[mm];  // (res4_level_chain_pre)
   const double sz0d = D * 0.5 * sqrt_pos((ct * cgd * rcp64(2.0 * (1.0 - s_cc))) * i1sc);
   const double sy0d = sz0d * cgd * c.cos_veer;
-  const double sM = sqrt_pos(M0);
-  const double sz0v = D * 0.5 * sqrt_pos((ct * rcp64(2.0 * (1.0 - s_c))) * i1sc);
   // 5. yaw-added recovery [A.3-5]
   double vsum = 0.0, wsum = 0.0;
 #pragma unroll
@@ -1356,17 +1417,12 @@ RES_SRC_FN void res4_level_chain(int tid, Lvl4Shared& lv, int i0, int L) {
   const double I = TIs[0];
   const double k_tke = (ubar * I) * (ubar * I) * 1.5;
   const double vbar = vsum * (1.0 / 9.0), wbar = wsum * (1.0 / 9.0);
-  const double I_tot = sqrt_nn((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) * rcp64(ubar);
+  const double I_tot = sqrt_nn((2.0 / 3.0) * 0.5 * (2.0 * k_tke + vbar * vbar + wbar * wbar)) * R4.lw.iubar[mm];
   const double dTI = c.sw_yar ? c.gch_gain * (I_tot - I) : 0.0;
-  const double ch_pref = c.ch_constant * POW_F64(s0.ai, c.ch_ai) * c.ch_amb_pow;
   if (act) {
     Fin4Shared& f = R4.lw.f[m];
-    f.cgd = cgd; f.s_cc = s_cc; f.s_c = s_c; f.th0 = th0; f.tan_th0 = tan_th0; f.M0 = M0;
-    f.E0 = C0 * C0 - c.e0c1 * C0 + c.e0c2;
-    f.sM = sM; f.sz0d = sz0d; f.sy0d = sy0d; f.is0d = rcp64(sy0d * sz0d); f.lnAB = (1.6 + sM) * rcp64(1.6 - sM);
-    f.sz0v = sz0v; f.sy0v = sz0v * cg * c.cos_veer; f.snw = c.near_c * sqrt_pos(ct * 0.5); f.kdef = ct * cg * D * D * 0.125;
-    f.ch_pref = ch_pref;
-    f.cgv = cg;
+    f.cgd = cgd; f.s_cc = s_cc; f.th0 = th0; f.tan_th0 = tan_th0;
+    f.sz0d = sz0d; f.sy0d = sy0d; f.is0d = rcp64(sy0d * sz0d);
     s0.Vmean = Vmean; s0.val = val;
     R4.lw.dTI[m] = dTI;
 #pragma unroll
@@ -1729,7 +1785,7 @@ __global__ __launch_bounds__(64 * RES4_MAX_WAVES, WF_RES4_OCC) RES4_WAVES_ATTR v
     }
     int ti = tid;
     asm volatile("" : "+v"(ti));
-    if (ti == 0) R4.lv_fail = 0;
+    if (ti == 0) { R4.lv_fail = 0; R4.wp_tv = 0; R4.mem_done = 0; R4.chain_done = 0; }
     if ((ti & 63) == 0) R4.hand[ti >> 6][64 * RES_HAND_DOUBLES] = 0.0;
     __syncthreads();
     for (int t = ti < 256 ? ti : N; t < N; t += 256) {  // start of the turbine's x' tie group (sorted order: ties are contiguous)
@@ -1755,21 +1811,31 @@ __global__ __launch_bounds__(64 * RES4_MAX_WAVES, WF_RES4_OCC) RES4_WAVES_ATTR v
       if (L > 1) {  // ---- a level stage: sources i .. i + L - 1 at once (their states were derived a stage ahead) ----
         Lvl4Shared& lv = R4.lv[lp];
         RES4_T(l0);
-        if (tq == 0) { R4.wp_tv = 0; R4.wp_df = 0; R4.wp_tb = 0; }
+        // (the pass counters and flags are zeroed a barrier before they are used: wp_tv, mem_done and chain_done behind the
+        // previous level stage's deficit passes or at the farm's start, wp_df and wp_tb here)
+        if (tq == 0) { R4.wp_df = 0; R4.wp_tb = 0; }
         res4_level_transverse(tq, lv, i, L, 1);  // the chunks that hold the members themselves
         RES4_T(l1);
-        __syncthreads();
+        if (wq == 3) {
+          res4_level_chain_pre(tq, lv, i, L);
+          res4_level_wait_members(lv);  // (no barrier: the waves without a member chunk are on the other chunks already)
+        }
         RES4_T(l2);
-        if (wq == 3) res4_level_chain(tq, lv, i, L);
+        if (wq == 3) {
+          res4_level_chain(tq, lv, i, L);
+          RES_HAND_FENCE;  // (the chain's constants are in LDS ...)
+          if ((tq & 63) == 0) __hip_atomic_store(&R4.chain_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (... before the flag is)
+        }
         RES4_T(l3);
-        res4_level_transverse(tq, lv, i, L, 2);  // every other target: waves 0-2 at once, wave 3 behind its chain
+        res4_level_transverse(tq, lv, i, L, 2);  // every other target: whoever is free, wave 3 behind its chain
         RES4_T(l4);
-        __syncthreads();
+        res4_level_wait_chain();
         RES4_T(l5);
         res4_level_deficit(tq, lv, i, L);
         RES4_T(l6);
         __syncthreads();
         RES4_T(l7);
+        if (tq == 0) { R4.wp_tv = 0; R4.mem_done = 0; R4.chain_done = 0; }
         if (wq != 3) {
           if (wq == 0) res4_level_check(tq, lv, i, L);  // (ahead of its share of the drawn turbulence passes: wave 3 is busy with the next states)
           res4_level_turbulence(tq, lv, i, L);
