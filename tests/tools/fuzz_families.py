@@ -2,8 +2,8 @@
 
 Every kernel family that can hold a random farm solves the SAME case: register-slot variants wf_step_kernel<G,S>, the
 one-block families wf_step_ll_kernel<G,S> (4x1, 8x1, 16x1, 4x2, 2x2) on the pair-table path and on the fly, and the float64
-kernels (mode 2: the four-wave kernel with level stages, the same without levels, the one-wave kernel at a batch beyond the
-four-wave residency).  Then they are compared WITH EACH OTHER:
+kernels (mode 2: the four-wave kernel with level stages and its helper waves, the same without levels on four waves, the
+one-wave kernel at a batch beyond the four-wave residency).  Then they are compared WITH EACH OTHER:
   * float32 family against float32 family on the farms neither flags: 2 x TOL (each is within TOL of the truth);
   * every float32 family against the float64 kernel on the farms it does not flag: TOL;
   * the float64 kernel with and without level stages: bit for bit; the one-wave float64 kernel against the four-wave one: 2e-6.
@@ -69,6 +69,7 @@ def run(n_cases, seed):
         f64 = {}
         for name, lv, rep in (("f64_levels", 1, 1), ("f64_sequential", 0, 1), ("f64_one_wave", 1, (1100 + B - 1) // B)):
             lib.wfk_set_resolve_levels(lv)
+            lib.wfk_set_resolve_helpers(2 if name == "f64_levels" else 0)  # (levels with the helper waves at work / four waves only)
             lib.wfk_set_resolve_policy(1 if name == "f64_one_wave" else 0)  # ("both": mode 2 beyond a residency on the one-wave kernel)
             Bt = B * rep
             w = WfStep(x, y, env_batch=Bt, model=dict(model) if model else None)
@@ -78,6 +79,7 @@ def run(n_cases, seed):
             f64[name] = {k: np.asarray(v)[:B].copy() for k, v in o.items()}
             w.close()
         lib.wfk_set_resolve_levels(1)
+        lib.wfk_set_resolve_helpers(1)
         lib.wfk_set_resolve_policy(0)
         bad = []
         for k in f64["f64_levels"]:
