@@ -363,6 +363,28 @@ def main():
                     key = name + "_default_buffers" if label == "default" else name + "_fresh_buffers"
                     env_level[key] = {"ms_per_step": ms, "env_steps_per_sec": B / (ms * 1e-3), "over_kernel": ms / kern_ms - 1.0,
                                       "wall_ms_per_step": wall_ms, "steps_timed": n_it}
+                if label == "default":
+                    # the plain wf_step kernel ON THE ENV'S OWN YAW STATE (the loop's small angles behind the budget gate are a
+                    # costlier solve than the headline's random walk): what the env step adds to the kernel, like for like
+                    try:
+                        yaw_env = torch.as_tensor(env.fi.env_get_state(as_torch=True)["yaw"]).to(torch.float32).reshape(B, N).contiguous()
+                        ws_e, wd_e = env.fi.get_wind()
+                        w2 = WfStep(lay["xcoords"], lay["ycoords"], env_batch=B)
+                        w2.set_wind(ws_e, wd_e)
+                        o2 = w2.step(yaw_env)
+                        for _ in range(3):
+                            w2.step(yaw_env, o2)
+                        w2.sync()
+                        w2.timing_begin()
+                        for _ in range(n_it):
+                            w2.step(yaw_env, o2)
+                        same_ms = w2.timing_end() / n_it
+                        w2.close()
+                        env_level["kernel_on_env_state_ms"] = same_ms
+                        for k2 in ("step_default_buffers", "step_light_default_buffers"):
+                            env_level[k2]["over_kernel_same_state"] = env_level[k2]["ms_per_step"] / same_ms - 1.0
+                    except Exception as e:  # pragma: no cover
+                        print(f"bench.py: same-state kernel leg failed: {e}", file=sys.stderr)
                 env.close()
             # (rounds 4-5 printed the reuse_buffers=True env under "step" / "step_light": that env is the default now)
             env_level["step"], env_level["step_light"] = env_level["step_default_buffers"], env_level["step_light_default_buffers"]
@@ -371,7 +393,9 @@ def main():
                                  "launches; wall_ms_per_step: the same loop by the host clock, one sync at the end); "
                                  "*_default_buffers: the env as make() builds it (since round 6: outputs written into two preallocated "
                                  "buffer sets used alternately, power in MW out of the kernel); *_fresh_buffers: reuse_buffers=False "
-                                 "(outputs allocated per step); over_kernel: against the plain wf_step kernel of the headline")
+                                 "(outputs allocated per step); over_kernel: against the plain wf_step kernel of the headline (random-walk yaw); "
+                                 "over_kernel_same_state: against the plain wf_step kernel timed on the env loop's own yaw state and wind "
+                                 "(kernel_on_env_state_ms) — what the env step adds, like for like")
         except Exception as e:  # pragma: no cover
             print(f"bench.py: env-level leg failed: {e}", file=sys.stderr)
 
