@@ -35,6 +35,8 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     assert d["power_rel_err"]["contract"] in ("ok", "flagged") and d["power_rel_err"]["max_unflagged"] <= 1e-4
     assert d["env_level"]["step"]["env_steps_per_sec"] > 0 and d["env_level"]["step_light"]["ms_per_step"] > 0
+    # the env step beside the plain kernel on the env loop's own yaw state (round 6)
+    assert d["env_level"]["kernel_on_env_state_ms"] > 0 and "over_kernel_same_state" in d["env_level"]["step"]
 
 
 def test_two_ranks_self_launched_strong_and_weak():
