@@ -10,15 +10,17 @@
 //
 // Two kernels (wfk_launch_resolve: the four-wave kernel behind every step of modes 0 / 1, whatever the list's length; the one-wave
 // kernel for mode 2 — every farm — at batches beyond one residency of the other):
-//   wf_resolve4_kernel  one farm per 256-thread block, up to two blocks per CU (half a residency of the chip: the re-solve is
-//                       then ONE farm's latency).  The farm's state — per sorted turbine 9 sums of squared deficits, 9 V, 9 W,
+//   wf_resolve4_kernel  one farm per block: four waves with roles, up to four such blocks per CU — or, on a short list (the
+//                       re-solve is then ONE farm's latency), a 512-thread launch whose four more HELPER waves share the pair
+//                       passes of the level stages.  The farm's state — per sorted turbine 9 sums of squared deficits, 9 V, 9 W,
 //                       3 column TIs, float64 — lives in LDS, turbine-major; a lane is not tied to a turbine.  A SEQUENTIAL
 //                       stage solves one source: waves 0-2 take a rotor-grid column each (transverse pass; deflection / deficit
 //                       pass; turbulence pass — three block barriers), wave 3 the source-only chain of steering, deflection and
 //                       deficit constants beside the transverse pass, and the NEXT source's rotor speed, thrust and circulations
 //                       beside the other two passes (speculated from the deficit sums, confirmed by a bit comparison).  A LEVEL
 //                       stage (round 6: Lvl4Shared) solves three to eight consecutive sources that put no deficit on each
-//                       other at once, every (source, target, column) pair in its own lane, the sums still taken in source order.
+//                       other at once, every (source, target, column) pair in its own lane, the sums still taken in source
+//                       order; its phases hand over through LDS counters and flags, two block barriers per stage.
 //   wf_resolve_kernel   one farm per WAVE (64-thread blocks, one per SIMD), the same state in LDS, no block barrier inside the
 //                       solve, no levels: a third more farms per CU and second than the four-wave kernel's SEQUENTIAL stages, at
 //                       2.2 x their latency (rounds 3-5 and the first half of round 6: the kernel for lists beyond one residency).
@@ -702,14 +704,14 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
 #endif  // RES_PART == 1
 #if RES_PART == 2
 // ---------------------------------------------------------------------------------------------------------------------
-// The same solve with FOUR waves per farm, for flagged counts that fit one residency of the chip (<= kRes4MaxFarms): there
-// the re-solve is pure latency — one farm's 80-stage chain, whatever the count — and spreading a source step over four
-// waves shortens it (HornsRev1: 1.04 -> 0.73 ms per farm).  Both kernels are enqueued behind the compaction; each reads
-// the count on the device and the one it is not meant for returns at once.
+// The same solve with FOUR waves per farm (built in round 3 for flagged counts within one residency of the chip: there the
+// re-solve is pure latency — one farm's 80-stage chain, whatever the count — and spreading a source step over four waves
+// shortens it; since round 6, with level stages, the kernel for a flagged list of ANY length: its persistent blocks walk the
+// list, and it is the only launch behind a step — wfk_launch_resolve).
 #ifndef WF_RES4_OCC
 #define WF_RES4_OCC 4          // waves per SIMD the register allocator makes room for (four 4-wave blocks, or two blocks with their helper waves, per CU): 128 VGPRs since round 6 (without machine LICM the kernel needs no more — with it, at 256, only two 4-wave blocks fitted a CU and a list beyond 512 farms needed a second round)
 #endif
-// One farm per 256-thread block.  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column TIs,
+// One farm per block (256 threads: the four waves below; 512 on a short list: four helper waves besides, see the kernel).  The farm's state — per turbine 9 sums of squared deficits, 9 V, 9 W, 3 column TIs,
 // float64 — lives in LDS, structure-of-arrays over the sorted turbine index; a lane is not tied to a turbine: for source i
 // the lanes take the turbines the source can reach, t = first + lane (first = the start of the source's x' tie group for
 // the transverse velocities [A.3-4], i + 1 for deficit and wake-added turbulence), 64 at a time, so the triangle of the
@@ -722,8 +724,9 @@ __global__ __launch_bounds__(64, WF_RES_OCC) void wf_resolve_kernel(const WfReso
 //              Crespo-Hernandez prefactor) BESIDE the transverse pass, which does not need it;
 //   all waves  the source's state and circulations (redundantly: each wave keeps its own copy, no barrier) and the
 //              yaw-added recovery once the transverse velocities of all three columns are in.
-// Three block barriers per source: after the transverse pass / the constant chain; after the deficit pass (the overlap
-// count of a turbine is the sum of its three columns' counts, exchanged through LDS); after the turbulence update.
+// Three block barriers per source (a SEQUENTIAL stage; level stages: below): after the transverse pass / the constant chain; after
+// the deficit pass (the overlap count of a turbine is the sum of its three columns' counts, exchanged through LDS); after the
+// turbulence update.
 // The phases are separate NON-INLINED functions that talk through LDS (the per-source constants too): inlined into one
 // body the register allocator kept ~370 values live and spilled inside the source loop.
 // (History: a thread per turbine, state in registers, two __syncthreads per source, every wave re-deriving the source
@@ -742,13 +745,20 @@ struct Fin4Shared {  // the source-only constants of deflection, deficit and wak
 // transverse velocities of member k at the rotors of the members behind it, which enter their steering and their
 // yaw-added recovery) is a sum whose terms are all known once the circulations are.  A level of L = 3 .. 8 members is
 // therefore ONE stage of five phases instead of L stages of three:
-//   begin       (wave 3, a member per lane)   rotor speed, thrust, circulations of every member
+//   begin       (wave 3, a member per lane)   rotor speed, thrust, circulations of every member — a stage AHEAD, beside the
+//                                             previous stage's turbulence passes
 //   transverse  (all waves)                   every (member, target, column) pair in its own lane: 64 / L targets per
 //                                             wave pass instead of the N - i of a single source (40 of 64 lanes on average
-//                                             at N = 80, 8 near the end of the farm)
-//   chain       (wave 3, a member per lane)   steering, recovery, deflection / deficit / turbulence constants
-//   deficit     (all waves)                   pairs as above
-//   turbulence  (waves 0-2)                   pairs, then the level's check (wave 0); wave 3 derives the next stage's state(s)
+//                                             at N = 80, 8 near the end of the farm); first the chunks that hold the members
+//                                             themselves (a fixed share per wave), then the others (drawn from a counter)
+//   chain       (wave 3, a member per lane)   steering, recovery, deflection / deficit / turbulence constants, the columns'
+//                                             constants: what needs only the members' states while the member chunks are in
+//                                             work, the rest behind a COUNT of their finished passes (no barrier)
+//   deficit     (all waves)                   pairs as above, behind the chain's FLAG (no barrier: a wave that runs out of
+//                                             transverse passes starts here while others finish theirs); a block barrier after
+//   turbulence  (all waves but 3)             pairs, the level's check first (wave 0); wave 3 derives the next stage's
+//                                             state(s); the stage's second block barrier
+// (helper waves 4-7 of a 512-thread launch take part in every "all waves" above.)
 // What a target receives from the members of a level is added in MEMBER ORDER (a lane holds one member's contribution and
 // leaves it in a wave-private LDS buffer; one lane group per value adds the members' terms of its target in order: see
 // RES_HAND_DOUBLES), so every sum is taken in the order of the sequential solve: the results are the SAME BITS as the
@@ -2026,7 +2036,7 @@ extern "C" hipError_t wfk_launch_resolve4(const WfResolveConsts* c, const WfReso
     }
   }
   if (per_cu > WF_RES4_OCC) per_cu = WF_RES4_OCC;
-  // One residency: as many blocks per CU as LDS and registers hold (HornsRev1 / 2: three; up to 64 turbines: four).  (Rounds 3-5:
+  // One residency: as many blocks per CU as LDS and registers hold (HornsRev1 / 2: three; up to 51 turbines: four).  (Rounds 3-5:
   // at most two — the kernel had 256 VGPRs — and beyond them the one-wave kernel won: 680 farms 1.27 ms against 1.1.  At 128 VGPRs a
   // list of 600-800 farms is ONE round of this kernel with every SIMD shared by 2-3 farms' waves: issue-bound float64 work, the idle
   // slots of one farm's latency chain filled by another's; profiles/r06_res4_residency_ab.txt.)
