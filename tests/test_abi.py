@@ -104,6 +104,18 @@ def test_pmc_index_points_at_committed_counter_files():
     assert fly["file"].startswith("profiles/r06_") and fly["kernel"] == dict(lanes_per_env=2, slots_per_lane=2, one_block_kernel=1, pair_table=0)
 
 
+def test_pure_python_turbine_defaults_are_the_librarys():
+    """`simul_utils.load_case_yaml` fills the per-definition fields a turbine definition leaves out from plain Python
+    data (`_nrel5mw.py`), so that parsing a case file needs no native library; the data must be the library's own defaults."""
+    from wfcrl_env_amd._nrel5mw import NREL_5MW_DEFINITION
+    from wfcrl_env_amd.backend import default_model
+
+    lib = default_model()
+    assert set(NREL_5MW_DEFINITION) == {"table_ws", "table_ct", "table_cp", "tsr", "pP", "gen_eff", "ref_density"}
+    for k, v in NREL_5MW_DEFINITION.items():
+        assert v == lib[k], k
+
+
 def test_last_fuzz_campaign_ran_on_these_kernels():
     """the round closes on a FUZZED head.  tools/round_close.sh (GPU box) runs the short fuzz campaign and
     records the sha256 of the kernel / host sources it ran on in profiles/fuzz_head.json; any later change of csrc/*.hip,

@@ -133,10 +133,10 @@ def load_case_yaml(path_or_dict) -> dict:
                                                "the rotor grid and the vortex geometry are per farm")
         if len(distinct) > 4:
             raise UnsupportedCaseError("at most 4 distinct turbine definitions per farm")
-        # a definition that leaves a per-definition field out means FLORIS' nrel_5MW value there, not definition 0's
-        from .backend import default_model
+        # a definition that leaves a per-definition field out means FLORIS' nrel_5MW value there, not definition 0's (plain
+        # Python data: parsing a case file needs no native library)
+        from ._nrel5mw import NREL_5MW_DEFINITION as dflt
 
-        dflt = default_model()
         model["turbine_defs"] = [{k: f.get(k, dflt[k]) for k in per_def} for f in fields]
         model["turbine_type_of"] = type_of if len(ttypes) > 1 else [0] * n_turb
     ref_h = float(flow.get("reference_wind_height", -1))
